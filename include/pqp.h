@@ -1,0 +1,169 @@
+/*
+ * pqp.h — C ABI of the MI355X-native batched path-QP engine (libpqp_hip.so).
+ *
+ * Drop-in boundary for the ONE hot path of LiJiangnanBit/path_optimizer_2: assembling and solving
+ * the Frenet path QP behind PathOptimizer::optimizePath / BaseSolver.  Every entry point cites the
+ * reference interface it replaces (file:line relative to the reference tree).
+ *
+ *   reference                                                     this ABI
+ *   ------------------------------------------------------------  ---------------------------------
+ *   BaseSolver::BaseSolver            src/solver/base_solver.cpp:15-39   pqp_path_sizes / pqp_path_pattern
+ *   BaseSolver::setCost               src/solver/base_solver.cpp:119-148 pqp_path_assemble (P diagonal)
+ *   BaseSolver::setConstraints        src/solver/base_solver.cpp:150-261 pqp_path_assemble (A values, l, u)
+ *   BaseSolver::getSoftBounds         src/solver/base_solver.cpp:290-295 (inside the assemble kernel)
+ *   BaseSolver::solve                 src/solver/base_solver.cpp:56-95   pqp_path_solve (warm = 0, passes = 0)
+ *   BaseSolver::updateProblemFormulationAndSolve      :97-117            pqp_path_solve (warm = 1, lin = input)
+ *   BaseSolver::getOptimizedPath      src/solver/base_solver.cpp:263-288 (unpack, fused into the solve kernel)
+ *   PathOptimizer::optimizePath       src/path_optimizer.cpp:124-161     pqp_path_solve (passes = 1)
+ *   OsqpEigen::Solver initSolver/solve (third party, called at base_solver.cpp:87-88,110)
+ *                                                                 the ADMM loop inside the solve kernel
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all reals are IEEE fp64, all indices int32.
+ *   - every function returns 0 on success or a negative pqp_error; nothing throws across the ABI.
+ *   - `*_device` entry points take DEVICE pointers and enqueue on the handle's HIP stream without
+ *     synchronising; pqp_sync() waits.  The non-suffixed entry points take HOST pointers, copy in,
+ *     run, copy out and synchronise (that is what the C++ BaseSolver shim uses with batch = 1).
+ *   - the handle owns all device memory and its stream; callers own every buffer they pass; no
+ *     caller pointer is retained after a call returns (device entry points: after pqp_sync()).
+ *   - a handle is single-owner and not re-entrant; use one handle per GPU / host thread.
+ *   - there is NO CPU fallback: if no HIP device is usable, pqp_create fails with PQP_ERR_NO_DEVICE.
+ *
+ * Array layouts (C-contiguous, fp64) — AoS per waypoint, the way State/SlState vectors are walked
+ * (reference include/data_struct/data_struct.hpp:14-32,74-93):
+ *   ref    [batch][n][5]   s, k, heading, x, y          ReferencePath::getReferenceStates()
+ *   lin    [batch][n][3]   l, d_heading, k              input_path_ (the linearisation point); NULL =>
+ *                                                       (0, 0, k_ref) as path_optimizer.cpp:128-137
+ *   bounds [batch][n][6]   front lb, ub, rear lb, ub, center lb, ub      ReferencePath::getBounds()
+ *   scal   [batch][6]      init_error[0], init_error[1], start_state.k, target_state.heading,
+ *                          blocked (0/1: ReferencePath::isBlocked()!=nullptr), max_steering_angle
+ *   out    [batch][n][7]   x, y, heading, l, d_heading, k, d_k           the SlState fields
+ *                                                       getOptimizedPath fills (s, v, a stay 0 there)
+ */
+#ifndef PQP_H_
+#define PQP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PQP_REF_STRIDE 5
+#define PQP_LIN_STRIDE 3
+#define PQP_BOUNDS_STRIDE 6
+#define PQP_SCAL_STRIDE 6
+#define PQP_OUT_STRIDE 7
+
+typedef enum pqp_error {
+    PQP_OK = 0,
+    PQP_ERR_INVALID = -1,      /* bad argument (null pointer, n or batch out of range)            */
+    PQP_ERR_NO_DEVICE = -2,    /* no usable HIP device: the product path has no CPU fallback      */
+    PQP_ERR_HIP = -3,          /* a HIP runtime call failed; see pqp_last_error()                 */
+    PQP_ERR_CAPACITY = -4      /* batch / n exceed what the handle was created for                */
+} pqp_error;
+
+/* Per-QP termination status written to status[batch] (osqp-eigen collapses this to bool). */
+typedef enum pqp_status {
+    PQP_STATUS_UNSOLVED = 0,
+    PQP_STATUS_SOLVED = 1,         /* both residual tests passed                       -> solve() == true  */
+    PQP_STATUS_MAX_ITER = 2,       /* max_iter reached                                  -> solve() == false */
+    PQP_STATUS_NUMERICAL = 3       /* NaN/Inf in the iterates                           -> solve() == false */
+} pqp_status;
+
+/* The scalars the path reads.  Defaults (pqp_default_params) are the reference's gflags defaults
+ * (src/config/planning_flags.cpp) and the constants hard-coded in base_solver.cpp. */
+typedef struct pqp_params {
+    /* car / planning flags */
+    double front_length;              /* planning_flags.cpp:20   3.9   */
+    double rear_length;               /* planning_flags.cpp:18  -1.0   */
+    double wheel_base;                /* planning_flags.cpp:16   2.5   */
+    double expected_safety_margin;    /* planning_flags.cpp:95   0.6   */
+    double precise_planning_length;   /* planning_flags.cpp:114  30.0  */
+    int32_t constraint_end_heading;   /* planning_flags.cpp:98   1     */
+    int32_t rough_constraints_far_away; /* planning_flags.cpp:112 0    */
+    /* constants of base_solver.cpp */
+    double weight_l;                  /* :123  0    */
+    double weight_kappa;              /* :124  20   */
+    double weight_dkappa;             /* :125  100  */
+    double weight_slack;              /* :126  10   */
+    double end_l_bound;               /* :250-251  1.0   */
+    double end_psi_tol;               /* :257-258  0.087 */
+    double end_psi_max;               /* :256  70 deg    */
+    double min_clearance;             /* :292  0.1       */
+    /* solver settings (OSQP names; base_solver.cpp:59-62 sets eps to 2e-3, the rest are OSQP defaults) */
+    double eps_abs;
+    double eps_rel;
+    double rho;                       /* 0.1   */
+    double sigma;                     /* 1e-6  */
+    double alpha;                     /* 1.6   */
+    int32_t max_iter;                 /* 4000  */
+    int32_t scaling;                  /* 10 Ruiz passes */
+    int32_t adaptive_rho;             /* 1     */
+    int32_t adaptive_rho_interval;    /* 100 (OSQP's "auto" value without wall-clock profiling) */
+    double adaptive_rho_tolerance;    /* 5     */
+    int32_t check_termination;        /* 25    */
+    int32_t reserved;
+} pqp_params;
+
+typedef struct pqp_sizes {
+    int32_t n, state, control, precise, slack, vars, cons, nnz_a, nnz_p;
+} pqp_sizes;
+
+typedef struct pqp_handle pqp_handle;
+
+void pqp_default_params(pqp_params* p);
+const char* pqp_last_error(void);
+const char* pqp_version(void);
+
+/* One handle per GPU.  max_batch / max_n size the device workspaces (they grow on demand). */
+int pqp_create(pqp_handle** h, const pqp_params* params, int device, int max_batch, int max_n);
+int pqp_destroy(pqp_handle* h);
+int pqp_set_params(pqp_handle* h, const pqp_params* params);
+int pqp_get_stream(pqp_handle* h, void** hip_stream);   /* hipStream_t */
+int pqp_sync(pqp_handle* h);
+
+/* BaseSolver ctor (base_solver.cpp:15-39): problem sizes.  `s` = the n arclengths of the path
+ * (only read when rough_constraints_far_away), may be NULL otherwise.  Pure integer host function. */
+int pqp_path_sizes(const pqp_params* params, int n, const double* s, pqp_sizes* out);
+
+/* Value-independent sparsity of A in CSC order (17N-5 slots when precise == n) and the columns of
+ * the diagonal P, in the REFERENCE variable / row numbering (base_solver.cpp:154-209,127-143).
+ * Computed by a HIP kernel.  rows[nnz_a], colptr[vars+1], pcols[nnz_p] are HOST buffers. */
+int pqp_path_pattern(pqp_handle* h, int n, int precise, int32_t* rows, int32_t* colptr, int32_t* pcols);
+
+/* setCost + setConstraints for a batch: values in the pattern's order.
+ *   a_val [batch][nnz_a]   p_val [batch][nnz_p]   lower/upper [batch][cons]
+ * All QPs of one call share n and `precise`.  Host-pointer and device-pointer variants. */
+int pqp_path_assemble(pqp_handle* h, int batch, int n, int precise, const double* ref, const double* lin,
+                      const double* bounds, const double* scal,
+                      double* a_val, double* p_val, double* lower, double* upper);
+int pqp_path_assemble_device(pqp_handle* h, int batch, int n, int precise, const double* ref,
+                             const double* lin, const double* bounds, const double* scal,
+                             double* a_val, double* p_val, double* lower, double* upper);
+
+/* Assemble + ADMM solve + unpack, `passes` re-linearised warm re-solves fused in one launch
+ * (PathOptimizer::optimizePath == passes 1).
+ *   warm == 0: cold start (BaseSolver::solve).  warm == 1: start from the primal/dual/rho the handle
+ *   kept from its previous pqp_path_solve* call with the same batch and n
+ *   (BaseSolver::updateProblemFormulationAndSolve: pass the previous output as `lin`).
+ *   status[batch], iters[batch] (total ADMM iterations over all passes) may be NULL.
+ *   info (may be NULL) [batch][4]: primal residual, dual residual, final rho, iterations of last pass. */
+int pqp_path_solve(pqp_handle* h, int batch, int n, const double* ref, const double* lin,
+                   const double* bounds, const double* scal, int passes, int warm,
+                   double* out, int32_t* status, int32_t* iters, double* info);
+int pqp_path_solve_device(pqp_handle* h, int batch, int n, const double* ref, const double* lin,
+                          const double* bounds, const double* scal, int passes, int warm,
+                          double* out, int32_t* status, int32_t* iters, double* info);
+
+/* Primal / dual solution of the handle's last solve in the REFERENCE numbering (OsqpEigen::Solver::
+ * getSolution(), base_solver.cpp:89,112): x [batch][vars], y [batch][cons].  HOST buffers; either may be NULL. */
+int pqp_path_get_solution(pqp_handle* h, int batch, int n, int precise, double* x, double* y);
+
+/* GPU time (ms, hipEvent) of the handle's last solve / assemble launch. */
+int pqp_last_kernel_ms(pqp_handle* h, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PQP_H_ */

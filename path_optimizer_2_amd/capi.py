@@ -1,0 +1,192 @@
+"""ctypes binding of the C ABI in include/pqp.h (libpqp_hip.so).
+
+Python is plumbing here (tests, bench, smoke); the product is the shared library.  There is no CPU
+fallback: if the library or a HIP device is missing, loading / pqp_create fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpqp_hip.so")
+
+
+class PqpParams(C.Structure):
+    _fields_ = [
+        ("front_length", C.c_double), ("rear_length", C.c_double), ("wheel_base", C.c_double),
+        ("expected_safety_margin", C.c_double), ("precise_planning_length", C.c_double),
+        ("constraint_end_heading", C.c_int32), ("rough_constraints_far_away", C.c_int32),
+        ("weight_l", C.c_double), ("weight_kappa", C.c_double), ("weight_dkappa", C.c_double),
+        ("weight_slack", C.c_double), ("end_l_bound", C.c_double), ("end_psi_tol", C.c_double),
+        ("end_psi_max", C.c_double), ("min_clearance", C.c_double),
+        ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("rho", C.c_double), ("sigma", C.c_double),
+        ("alpha", C.c_double), ("max_iter", C.c_int32), ("scaling", C.c_int32),
+        ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32),
+        ("adaptive_rho_tolerance", C.c_double), ("check_termination", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class PqpSizes(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("n", "state", "control", "precise", "slack", "vars", "cons", "nnz_a", "nnz_p")]
+
+
+EXPORTS = [
+    "pqp_default_params", "pqp_last_error", "pqp_version", "pqp_create", "pqp_destroy", "pqp_set_params",
+    "pqp_get_stream", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
+    "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_get_solution",
+    "pqp_last_kernel_ms",
+]
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libpqp_hip.so and declare the prototypes.  Raises OSError if it was not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise OSError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
+    lib.pqp_default_params.argtypes = [C.POINTER(PqpParams)]
+    lib.pqp_default_params.restype = None
+    lib.pqp_last_error.restype = C.c_char_p
+    lib.pqp_version.restype = C.c_char_p
+    lib.pqp_create.argtypes = [C.POINTER(vp), C.POINTER(PqpParams), C.c_int, C.c_int, C.c_int]
+    lib.pqp_destroy.argtypes = [vp]
+    lib.pqp_set_params.argtypes = [vp, C.POINTER(PqpParams)]
+    lib.pqp_get_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.pqp_sync.argtypes = [vp]
+    lib.pqp_path_sizes.argtypes = [C.POINTER(PqpParams), C.c_int, vp, C.POINTER(PqpSizes)]
+    lib.pqp_path_pattern.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+    for name in ("pqp_path_assemble", "pqp_path_assemble_device"):
+        getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    for name in ("pqp_path_solve", "pqp_path_solve_device"):
+        getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.pqp_path_get_solution.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    lib.pqp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def default_params(lib=None, **over):
+    lib = lib or load_library()
+    p = PqpParams()
+    lib.pqp_default_params(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(a))      # raw device pointer (e.g. torch.Tensor.data_ptr())
+
+
+class PqpError(RuntimeError):
+    pass
+
+
+class Handle:
+    """Thin RAII wrapper over pqp_handle (one per GPU)."""
+
+    def __init__(self, params=None, device=0, max_batch=1024, max_n=128):
+        self.lib = load_library()
+        self.params = params or default_params(self.lib)
+        self._h = C.c_void_p()
+        self._check(self.lib.pqp_create(C.byref(self._h), C.byref(self.params), device, max_batch, max_n))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PqpError(f"pqp error {rc}: {self.lib.pqp_last_error().decode()}")
+
+    def close(self):
+        if self._h:
+            self.lib.pqp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, params):
+        self.params = params
+        self._check(self.lib.pqp_set_params(self._h, C.byref(params)))
+
+    def sync(self):
+        self._check(self.lib.pqp_sync(self._h))
+
+    def stream(self):
+        s = C.c_void_p()
+        self._check(self.lib.pqp_get_stream(self._h, C.byref(s)))
+        return s.value
+
+    def sizes(self, n, s=None):
+        out = PqpSizes()
+        self._check(self.lib.pqp_path_sizes(C.byref(self.params), n, _ptr(s), C.byref(out)))
+        return {k: getattr(out, k) for k, _ in PqpSizes._fields_}
+
+    def pattern(self, n, precise=None):
+        precise = n if precise is None else precise
+        nv = 3 * n + n - 1 + precise + n
+        nnz_a = 3 * n + 7 * (n - 1) + n + 6 * precise + 2 * (n - precise) + 2
+        rows = np.zeros(nnz_a, dtype=np.int32)
+        colptr = np.zeros(nv + 1, dtype=np.int32)
+        pcols = np.zeros(n + n - 1 + precise + n, dtype=np.int32)
+        self._check(self.lib.pqp_path_pattern(self._h, n, precise, _ptr(rows), _ptr(colptr), _ptr(pcols)))
+        return rows, colptr, pcols
+
+    def assemble(self, ref, lin, bounds, scal, precise=None):
+        batch, n = ref.shape[0], ref.shape[1]
+        precise = n if precise is None else precise
+        nnz_a = 3 * n + 7 * (n - 1) + n + 6 * precise + 2 * (n - precise) + 2
+        nnz_p = n + n - 1 + precise + n
+        cons = 4 * n + precise + n + 2
+        a_val = np.zeros((batch, nnz_a)); p_val = np.zeros((batch, nnz_p))
+        lo = np.zeros((batch, cons)); up = np.zeros((batch, cons))
+        self._check(self.lib.pqp_path_assemble(self._h, batch, n, precise, _ptr(ref), _ptr(lin), _ptr(bounds),
+                                               _ptr(scal), _ptr(a_val), _ptr(p_val), _ptr(lo), _ptr(up)))
+        return a_val, p_val, lo, up
+
+    def solve(self, ref, bounds, scal, lin=None, passes=1, warm=False):
+        """Host-array convenience: returns dict(out, status, iters, info)."""
+        batch, n = ref.shape[0], ref.shape[1]
+        out = np.zeros((batch, n, 7)); status = np.zeros(batch, dtype=np.int32)
+        iters = np.zeros(batch, dtype=np.int32); info = np.zeros((batch, 4))
+        self._check(self.lib.pqp_path_solve(self._h, batch, n, _ptr(ref), _ptr(lin), _ptr(bounds), _ptr(scal),
+                                            passes, 1 if warm else 0, _ptr(out), _ptr(status), _ptr(iters), _ptr(info)))
+        return dict(out=out, status=status, iters=iters, info=info)
+
+    def solve_device(self, batch, n, ref, bounds, scal, out, lin=None, passes=1, warm=False, status=None,
+                     iters=None, info=None):
+        """Device pointers (ints or objects with data_ptr()); asynchronous on the handle's stream."""
+        def dp(x):
+            if x is None:
+                return None
+            return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        self._check(self.lib.pqp_path_solve_device(self._h, batch, n, dp(ref), dp(lin), dp(bounds), dp(scal), passes,
+                                                   1 if warm else 0, dp(out), dp(status), dp(iters), dp(info)))
+
+    def get_solution(self, batch, n, precise=None):
+        precise = n if precise is None else precise
+        nv = 3 * n + n - 1 + precise + n
+        nc = 4 * n + precise + n + 2
+        x = np.zeros((batch, nv)); y = np.zeros((batch, nc))
+        self._check(self.lib.pqp_path_get_solution(self._h, batch, n, precise, _ptr(x), _ptr(y)))
+        return x, y
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._check(self.lib.pqp_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value

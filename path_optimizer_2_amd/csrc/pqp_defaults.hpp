@@ -1,0 +1,36 @@
+// Default pqp_params: the reference's gflags defaults (src/config/planning_flags.cpp), the constants
+// hard-coded in src/solver/base_solver.cpp, and OSQP's documented defaults.
+#pragma once
+#include "../../include/pqp.h"
+
+namespace pqp {
+inline void default_params(pqp_params* p) {
+    p->front_length = 3.9;                          // planning_flags.cpp:20
+    p->rear_length = -1.0;                          // planning_flags.cpp:18
+    p->wheel_base = 2.5;                            // planning_flags.cpp:16
+    p->expected_safety_margin = 0.6;                // planning_flags.cpp:95
+    p->precise_planning_length = 30.0;              // planning_flags.cpp:114
+    p->constraint_end_heading = 1;                  // planning_flags.cpp:98
+    p->rough_constraints_far_away = 0;              // planning_flags.cpp:112
+    p->weight_l = 0.0;                              // base_solver.cpp:123
+    p->weight_kappa = 20.0;                         // base_solver.cpp:124
+    p->weight_dkappa = 100.0;                       // base_solver.cpp:125
+    p->weight_slack = 10.0;                         // base_solver.cpp:126
+    p->end_l_bound = 1.0;                           // base_solver.cpp:250-251
+    p->end_psi_tol = 0.087;                         // base_solver.cpp:257-258
+    p->end_psi_max = 70.0 * 3.14159265358979323846 / 180.0;   // base_solver.cpp:256
+    p->min_clearance = 0.1;                         // base_solver.cpp:292
+    p->eps_abs = 2e-3;                              // base_solver.cpp:61
+    p->eps_rel = 2e-3;                              // base_solver.cpp:62
+    p->rho = 0.1;
+    p->sigma = 1e-6;
+    p->alpha = 1.6;
+    p->max_iter = 4000;
+    p->scaling = 10;
+    p->adaptive_rho = 1;
+    p->adaptive_rho_interval = 100;
+    p->adaptive_rho_tolerance = 5.0;
+    p->check_termination = 25;
+    p->reserved = 0;
+}
+}  // namespace pqp

@@ -1,0 +1,598 @@
+// pqp_kernels.hip — gfx950 (MI355X / CDNA4) kernels and the C ABI of include/pqp.h.
+//
+//   path_solve_kernel     one workgroup (64*NW lanes, 2 waypoints per lane) per QP: assemble -> Ruiz metrics
+//                         -> block-cyclic-reduction factor -> ADMM loop -> unpack -> re-linearise -> warm
+//                         re-solve, everything in VGPRs + ~24 KB of LDS; HBM is read once (scenario) and
+//                         written once (path).  Algorithm: pqp_path_lane.hpp.
+//   path_assemble_kernel  BaseSolver::setCost/setConstraints in the REFERENCE numbering: CSC values of A,
+//                         diagonal of P, l, u; staged through LDS and written with contiguous, coalesced
+//                         stores (base_solver.cpp:119-261).
+//   path_pattern_kernel   the value-independent CSC pattern (integer index maps, base_solver.cpp:154-209).
+//   path_gather_solution  lane layout -> reference numbering of the primal / dual solution.
+//
+// No CPU fallback: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "pqp_defaults.hpp"
+#include "pqp_path_lane.hpp"
+
+namespace pqp {
+
+// -------------------------------------------------------------------------------------------------------
+// device execution context for PathQp: a phase is the code between two workgroup barriers
+// -------------------------------------------------------------------------------------------------------
+template <int NW>
+struct DevCtx {
+    Lane lane;
+    double* shp;
+    __device__ __forceinline__ int T() const { return 64 * NW; }
+    __device__ __forceinline__ double* sh() { return shp; }
+    template <class F>
+    __device__ __forceinline__ void phase(F f) {
+        f((int)threadIdx.x, lane);
+        __syncthreads();
+    }
+    template <int K, bool MAX>
+    __device__ __forceinline__ void reduce(double (&v)[K]) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double x = v[k];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double o = __shfl_xor(x, off, 64);
+                x = MAX ? fmax(x, o) : x + o;
+            }
+            v[k] = x;
+        }
+        if (NW > 1) {
+            double* red = shp + ShLayout{64 * NW}.red();
+            const int w = threadIdx.x >> 6;
+            if ((threadIdx.x & 63) == 0)
+                for (int k = 0; k < K; ++k) red[k * 16 + w] = v[k];
+            __syncthreads();
+            for (int k = 0; k < K; ++k) {
+                double x = red[k * 16];
+                for (int j = 1; j < NW; ++j) x = MAX ? fmax(x, red[k * 16 + j]) : x + red[k * 16 + j];
+                v[k] = x;
+            }
+        }
+        __syncthreads();
+    }
+    template <int K, class F>
+    __device__ __forceinline__ void reduce_max(double (&out)[K], F f) {
+        f((int)threadIdx.x, lane, out);
+        reduce<K, true>(out);
+    }
+    template <int K, class F>
+    __device__ __forceinline__ void reduce_sum(double (&out)[K], F f) {
+        f((int)threadIdx.x, lane, out);
+        reduce<K, false>(out);
+    }
+};
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) path_solve_kernel(const PathSolveArgs args) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    for (int qp = blockIdx.x; qp < args.batch; qp += gridDim.x) {
+        DevCtx<NW> ctx;
+        ctx.shp = smem;
+        PathQp<DevCtx<NW>> solver(ctx, args, qp);
+        solver.run();
+        __syncthreads();
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------
+// reference numbering helpers (base_solver.cpp:22-37,154-158)
+// -------------------------------------------------------------------------------------------------------
+struct RefIndex {
+    int n, precise;
+    __host__ __device__ int state() const { return 3 * n; }
+    __host__ __device__ int control() const { return n - 1; }
+    __host__ __device__ int vars() const { return 3 * n + n - 1 + precise + n; }
+    __host__ __device__ int cons() const { return 4 * n + precise + n + 2; }
+    __host__ __device__ int kappa_idx() const { return 3 * n; }
+    __host__ __device__ int precise_idx() const { return 4 * n; }
+    __host__ __device__ int rough_idx() const { return 4 * n + 2 * precise; }
+    __host__ __device__ int end_idx() const { return 4 * n + 2 * precise + n - precise; }
+    __host__ __device__ int slack_col(int i, int which) const {
+        return i < precise ? 4 * n - 1 + 2 * i + which : 4 * n - 1 + 2 * precise + (i - precise);
+    }
+    __host__ __device__ int nnz_a() const { return 3 * n + 7 * (n - 1) + n + 6 * precise + 2 * (n - precise) + 2; }
+    __host__ __device__ int nnz_p() const { return n + n - 1 + precise + n; }
+    // CSC offset of the first entry of column 3i (state column block of waypoint i)
+    __host__ __device__ int state_col_offset(int i) const {
+        // per waypoint j < n-1: precise -> 5+5+4 = 14 entries, rough -> 4+3+4 = 11
+        const int np = i < precise ? i : precise;
+        return 14 * np + 11 * (i - np);
+    }
+    __host__ __device__ int control_col_offset() const {
+        // all state columns: waypoints 0..n-2 full, last waypoint has no outgoing transition (-2 per column)
+        // but two end rows (+1 on l and psi): l: 1 + (2|1) + 1, psi: 1 + (2|0) + 1, k: 1 + 1
+        const bool last_precise = (n - 1) < precise;
+        return state_col_offset(n - 1) + (last_precise ? 4 + 4 + 2 : 3 + 2 + 2);
+    }
+    __host__ __device__ int slack_col_offset() const { return control_col_offset() + (n - 1); }
+};
+
+// pattern: rows[nnz_a], colptr[vars+1], pcols[nnz_p]; one thread per waypoint
+__global__ void path_pattern_kernel(RefIndex R, int32_t* rows, int32_t* colptr, int32_t* pcols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = R.n;
+    if (i >= n) return;
+    const bool precise = i < R.precise, has_next = i < n - 1, last = i == n - 1;
+    int o = R.state_col_offset(i);
+    // column l_i
+    colptr[3 * i] = o;
+    rows[o++] = 3 * i;
+    if (has_next) { rows[o++] = 3 * (i + 1); rows[o++] = 3 * (i + 1) + 1; }
+    if (precise) { rows[o++] = R.precise_idx() + 2 * i; rows[o++] = R.precise_idx() + 2 * i + 1; }
+    else rows[o++] = R.rough_idx() + (i - R.precise);
+    if (last) rows[o++] = R.end_idx();
+    // column psi_i
+    colptr[3 * i + 1] = o;
+    rows[o++] = 3 * i + 1;
+    if (has_next) { rows[o++] = 3 * (i + 1); rows[o++] = 3 * (i + 1) + 1; }
+    if (precise) { rows[o++] = R.precise_idx() + 2 * i; rows[o++] = R.precise_idx() + 2 * i + 1; }
+    if (last) rows[o++] = R.end_idx() + 1;
+    // column k_i
+    colptr[3 * i + 2] = o;
+    rows[o++] = 3 * i + 2;
+    if (has_next) { rows[o++] = 3 * (i + 1) + 1; rows[o++] = 3 * (i + 1) + 2; }
+    rows[o++] = R.kappa_idx() + i;
+    // control column u_i
+    if (has_next) {
+        const int oc = R.control_col_offset() + i;
+        colptr[R.state() + i] = oc;
+        rows[oc] = 3 * (i + 1) + 2;
+    }
+    // slack columns
+    const int os = R.slack_col_offset();
+    if (precise) {
+        colptr[R.slack_col(i, 0)] = os + 2 * i;
+        colptr[R.slack_col(i, 1)] = os + 2 * i + 1;
+        rows[os + 2 * i] = R.precise_idx() + 2 * i;
+        rows[os + 2 * i + 1] = R.precise_idx() + 2 * i + 1;
+    } else {
+        const int li = i - R.precise;
+        colptr[R.slack_col(i, 0)] = os + 2 * R.precise + li;
+        rows[os + 2 * R.precise + li] = R.rough_idx() + li;
+    }
+    if (last) colptr[R.vars()] = R.nnz_a();
+    // P diagonal columns (base_solver.cpp:127-143), ascending: k_i, then u_i, then slacks
+    pcols[i] = 3 * i + 2;
+    if (has_next) pcols[n + i] = R.state() + i;
+    if (precise) { pcols[2 * n - 1 + 2 * i] = R.slack_col(i, 0); pcols[2 * n - 1 + 2 * i + 1] = R.slack_col(i, 1); }
+    else pcols[2 * n - 1 + 2 * R.precise + (i - R.precise)] = R.slack_col(i, 0);
+}
+
+// assemble in the reference numbering.  One workgroup per QP; values are staged in LDS in their final
+// order and then streamed out with unit-stride stores.
+__global__ void __launch_bounds__(256) path_assemble_kernel(RefIndex R, int batch, const double* __restrict__ ref,
+                                                            const double* __restrict__ lin, const double* __restrict__ bounds,
+                                                            const double* __restrict__ scal, pqp_params prm,
+                                                            double* __restrict__ a_val, double* __restrict__ p_val,
+                                                            double* __restrict__ lower, double* __restrict__ upper,
+                                                            int stage_in_lds) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int n = R.n, nnz_a = R.nnz_a(), nnz_p = R.nnz_p(), cons = R.cons();
+    for (int qp = blockIdx.x; qp < batch; qp += gridDim.x) {
+        double* va = stage_in_lds ? smem : a_val + (size_t)qp * nnz_a;
+        double* vp = stage_in_lds ? smem + nnz_a : p_val + (size_t)qp * nnz_p;
+        double* vl = stage_in_lds ? smem + nnz_a + nnz_p : lower + (size_t)qp * cons;
+        double* vu = stage_in_lds ? smem + nnz_a + nnz_p + cons : upper + (size_t)qp * cons;
+        const double* rq = ref + (size_t)qp * n * PQP_REF_STRIDE;
+        const double* lq = lin ? lin + (size_t)qp * n * PQP_LIN_STRIDE : nullptr;
+        const double* bq = bounds + (size_t)qp * n * PQP_BOUNDS_STRIDE;
+        const double* sc = scal + (size_t)qp * PQP_SCAL_STRIDE;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const bool precise = i < R.precise, has_next = i < n - 1, last = i == n - 1;
+            double a[6] = {0, 0, 0, 0, 0, 0}, c3[3] = {0, 0, 0};
+            if (has_next) {   // outgoing transition i -> i+1 fills the columns of waypoint i
+                double lp[3];
+                double knext;
+                if (lq) { lp[0] = lq[3 * i]; lp[1] = lq[3 * i + 1]; lp[2] = lq[3 * i + 2]; knext = lq[3 * (i + 1) + 2]; }
+                else { lp[0] = 0.0; lp[1] = 0.0; lp[2] = rq[5 * i + 1]; knext = rq[5 * (i + 1) + 1]; }
+                transition_block(lp, knext, rq[5 * i], rq[5 * (i + 1)], rq[5 * i + 1], a, c3);
+            }
+            int o = R.state_col_offset(i);
+            // column l_i
+            va[o++] = -1.0;
+            if (has_next) { va[o++] = a[0]; va[o++] = a[2]; }
+            if (precise) { va[o++] = 1.0; va[o++] = 1.0; } else va[o++] = 1.0;
+            if (last) va[o++] = 1.0;
+            // column psi_i
+            va[o++] = -1.0;
+            if (has_next) { va[o++] = a[1]; va[o++] = a[3]; }
+            if (precise) { va[o++] = prm.front_length; va[o++] = prm.rear_length; }
+            if (last) va[o++] = 1.0;
+            // column k_i
+            va[o++] = -1.0;
+            if (has_next) { va[o++] = a[4]; va[o++] = 1.0; }
+            va[o++] = 1.0;
+            if (has_next) va[R.control_col_offset() + i] = a[5];
+            const int os = R.slack_col_offset();
+            if (precise) { va[os + 2 * i] = 1.0; va[os + 2 * i + 1] = 1.0; }
+            else va[os + 2 * R.precise + (i - R.precise)] = 1.0;
+            // P diagonal (base_solver.cpp:123-143)
+            vp[i] = prm.weight_kappa;
+            if (has_next) vp[n + i] = prm.weight_dkappa;
+            if (precise) { vp[2 * n - 1 + 2 * i] = prm.weight_slack; vp[2 * n - 1 + 2 * i + 1] = prm.weight_slack; }
+            else vp[2 * n - 1 + 2 * R.precise + (i - R.precise)] = prm.weight_slack;
+            // bounds (base_solver.cpp:212-260)
+            if (i == 0) {
+                for (int k = 0; k < 3; ++k) { vl[k] = -sc[k]; vu[k] = -sc[k]; }
+            }
+            if (has_next) {
+                for (int k = 0; k < 3; ++k) { vl[3 * (i + 1) + k] = -c3[k]; vu[3 * (i + 1) + k] = -c3[k]; }
+            }
+            const double kappa_limit = tan(sc[5]) / prm.wheel_base;
+            vl[R.kappa_idx() + i] = -kappa_limit;
+            vu[R.kappa_idx() + i] = kappa_limit;
+            double lo, up;
+            if (precise) {
+                soft_bounds(bq[6 * i], bq[6 * i + 1], prm.expected_safety_margin, prm.min_clearance, lo, up);
+                vl[R.precise_idx() + 2 * i] = lo; vu[R.precise_idx() + 2 * i] = up;
+                soft_bounds(bq[6 * i + 2], bq[6 * i + 3], prm.expected_safety_margin, prm.min_clearance, lo, up);
+                vl[R.precise_idx() + 2 * i + 1] = lo; vu[R.precise_idx() + 2 * i + 1] = up;
+            } else {
+                soft_bounds(bq[6 * i + 4], bq[6 * i + 5], prm.expected_safety_margin, prm.min_clearance, lo, up);
+                vl[R.rough_idx() + (i - R.precise)] = lo; vu[R.rough_idx() + (i - R.precise)] = up;
+            }
+            if (last) {
+                vl[R.end_idx()] = -prm.end_l_bound; vu[R.end_idx()] = prm.end_l_bound;
+                double el = -kInfty, eu = kInfty;
+                if (prm.constraint_end_heading && sc[4] == 0.0) {
+                    const double end_psi = constrain_angle(sc[3] - rq[5 * i + 2]);
+                    if (end_psi < prm.end_psi_max) { el = end_psi - prm.end_psi_tol; eu = end_psi + prm.end_psi_tol; }
+                }
+                vl[R.end_idx() + 1] = el; vu[R.end_idx() + 1] = eu;
+            }
+        }
+        if (stage_in_lds) {
+            __syncthreads();
+            double* ga = a_val + (size_t)qp * nnz_a;
+            double* gp = p_val + (size_t)qp * nnz_p;
+            double* gl = lower + (size_t)qp * cons;
+            double* gu = upper + (size_t)qp * cons;
+            for (int k = threadIdx.x; k < nnz_a; k += blockDim.x) ga[k] = smem[k];
+            for (int k = threadIdx.x; k < nnz_p; k += blockDim.x) gp[k] = smem[nnz_a + k];
+            for (int k = threadIdx.x; k < cons; k += blockDim.x) gl[k] = smem[nnz_a + nnz_p + k];
+            for (int k = threadIdx.x; k < cons; k += blockDim.x) gu[k] = smem[nnz_a + nnz_p + cons + k];
+            __syncthreads();
+        }
+    }
+}
+
+// lane layout (handle's warm state) -> reference numbering (OsqpEigen getSolution order)
+__global__ void path_gather_solution(RefIndex R, int batch, const double* __restrict__ wx, const double* __restrict__ wy,
+                                     const double* __restrict__ wye, double* __restrict__ x, double* __restrict__ y) {
+    const int n = R.n;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * n) return;
+    const int qp = idx / n, i = idx - qp * n;
+    const double* sx = wx + (size_t)idx * 6;
+    const double* sy = wy + (size_t)idx * 6;
+    if (x) {
+        double* xo = x + (size_t)qp * R.vars();
+        xo[3 * i] = sx[0]; xo[3 * i + 1] = sx[1]; xo[3 * i + 2] = sx[2];
+        if (i > 0) xo[R.state() + i - 1] = sx[3];
+        xo[R.slack_col(i, 0)] = sx[4];
+        if (i < R.precise) xo[R.slack_col(i, 1)] = sx[5];
+    }
+    if (y) {
+        double* yo = y + (size_t)qp * R.cons();
+        yo[3 * i] = sy[0]; yo[3 * i + 1] = sy[1]; yo[3 * i + 2] = sy[2];
+        yo[R.kappa_idx() + i] = sy[3];
+        if (i < R.precise) { yo[R.precise_idx() + 2 * i] = sy[4]; yo[R.precise_idx() + 2 * i + 1] = sy[5]; }
+        else yo[R.rough_idx() + (i - R.precise)] = sy[4];
+        if (i == n - 1) { yo[R.end_idx()] = wye[2 * qp]; yo[R.end_idx() + 1] = wye[2 * qp + 1]; }
+    }
+}
+
+}  // namespace pqp
+
+// =========================================================================================================
+// C ABI
+// =========================================================================================================
+namespace {
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+#define PQP_HIP(call)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) return fail(PQP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return PQP_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        PQP_HIP(hipMalloc(&p, need));
+        bytes = need;
+        return PQP_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+}  // namespace
+
+struct pqp_handle {
+    int device = 0;
+    pqp_params prm;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int warm_batch = 0, warm_n = 0;
+    DevBuf wx, wy, wye, wrho;                   // warm state (lane layout)
+    DevBuf s_ref, s_lin, s_bounds, s_scal;      // staging for the host-pointer entry points
+    DevBuf s_out, s_status, s_iters, s_info, s_a, s_p, s_l, s_u, s_idx;
+};
+
+extern "C" {
+
+void pqp_default_params(pqp_params* p) { if (p) pqp::default_params(p); }
+const char* pqp_last_error(void) { return g_last_error.c_str(); }
+const char* pqp_version(void) { return "pqp-hip 0.1 (gfx950)"; }
+
+int pqp_create(pqp_handle** out, const pqp_params* params, int device, int max_batch, int max_n) {
+    if (!out) return fail(PQP_ERR_INVALID, "pqp_create: null handle pointer");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(PQP_ERR_NO_DEVICE, "pqp_create: no HIP device (this library has no CPU fallback)");
+    if (device < 0 || device >= count) return fail(PQP_ERR_INVALID, "pqp_create: bad device ordinal");
+    PQP_HIP(hipSetDevice(device));
+    pqp_handle* h = new (std::nothrow) pqp_handle();
+    if (!h) return fail(PQP_ERR_INVALID, "pqp_create: out of host memory");
+    h->device = device;
+    if (params) h->prm = *params; else pqp::default_params(&h->prm);
+    PQP_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    PQP_HIP(hipEventCreate(&h->ev0));
+    PQP_HIP(hipEventCreate(&h->ev1));
+    if (max_batch > 0 && max_n > 0) {
+        const size_t bn = (size_t)max_batch * max_n;
+        int rc;
+        if ((rc = h->wx.ensure(bn * 6 * 8))) return rc;
+        if ((rc = h->wy.ensure(bn * 6 * 8))) return rc;
+        if ((rc = h->wye.ensure((size_t)max_batch * 2 * 8))) return rc;
+        if ((rc = h->wrho.ensure((size_t)max_batch * 8))) return rc;
+    }
+    *out = h;
+    return PQP_OK;
+}
+
+int pqp_destroy(pqp_handle* h) {
+    if (!h) return PQP_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (DevBuf* b : {&h->wx, &h->wy, &h->wye, &h->wrho, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
+                      &h->s_status, &h->s_iters, &h->s_info, &h->s_a, &h->s_p, &h->s_l, &h->s_u, &h->s_idx})
+        b->release();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PQP_OK;
+}
+
+int pqp_set_params(pqp_handle* h, const pqp_params* params) {
+    if (!h || !params) return fail(PQP_ERR_INVALID, "pqp_set_params: null argument");
+    h->prm = *params;
+    return PQP_OK;
+}
+
+int pqp_get_stream(pqp_handle* h, void** s) {
+    if (!h || !s) return fail(PQP_ERR_INVALID, "pqp_get_stream: null argument");
+    *s = (void*)h->stream;
+    return PQP_OK;
+}
+
+int pqp_sync(pqp_handle* h) {
+    if (!h) return fail(PQP_ERR_INVALID, "pqp_sync: null handle");
+    PQP_HIP(hipSetDevice(h->device));
+    PQP_HIP(hipStreamSynchronize(h->stream));
+    return PQP_OK;
+}
+
+int pqp_path_sizes(const pqp_params* params, int n, const double* s, pqp_sizes* out) {
+    if (!out || n < 2) return fail(PQP_ERR_INVALID, "pqp_path_sizes: need n >= 2 and an output struct");
+    pqp_params def;
+    if (!params) { pqp::default_params(&def); params = &def; }
+    int precise = n;   // base_solver.cpp:24-34
+    if (params->rough_constraints_far_away) {
+        if (!s) return fail(PQP_ERR_INVALID, "pqp_path_sizes: rough_constraints_far_away needs the arclengths");
+        int lo = 0, hi = n;   // std::lower_bound(s, precise_planning_length)
+        while (lo < hi) { const int mid = (lo + hi) / 2; if (s[mid] < params->precise_planning_length) lo = mid + 1; else hi = mid; }
+        precise = lo;
+    }
+    pqp::RefIndex R{n, precise};
+    out->n = n; out->state = 3 * n; out->control = n - 1; out->precise = precise; out->slack = precise + n;
+    out->vars = R.vars(); out->cons = R.cons(); out->nnz_a = R.nnz_a(); out->nnz_p = R.nnz_p();
+    return PQP_OK;
+}
+
+int pqp_path_pattern(pqp_handle* h, int n, int precise, int32_t* rows, int32_t* colptr, int32_t* pcols) {
+    if (!h || !rows || !colptr || !pcols || n < 2 || precise < 0 || precise > n)
+        return fail(PQP_ERR_INVALID, "pqp_path_pattern: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    pqp::RefIndex R{n, precise};
+    const size_t total = (size_t)R.nnz_a() + R.vars() + 1 + R.nnz_p();
+    int rc;
+    if ((rc = h->s_idx.ensure(total * 4))) return rc;
+    int32_t* d_rows = h->s_idx.as<int32_t>();
+    int32_t* d_colptr = d_rows + R.nnz_a();
+    int32_t* d_pcols = d_colptr + R.vars() + 1;
+    PQP_HIP(hipMemsetAsync(d_rows, 0xff, total * 4, h->stream));
+    hipLaunchKernelGGL(pqp::path_pattern_kernel, dim3((n + 127) / 128), dim3(128), 0, h->stream, R, d_rows, d_colptr, d_pcols);
+    PQP_HIP(hipGetLastError());
+    PQP_HIP(hipMemcpyAsync(rows, d_rows, (size_t)R.nnz_a() * 4, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(colptr, d_colptr, (size_t)(R.vars() + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(pcols, d_pcols, (size_t)R.nnz_p() * 4, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipStreamSynchronize(h->stream));
+    return PQP_OK;
+}
+
+int pqp_path_assemble_device(pqp_handle* h, int batch, int n, int precise, const double* ref, const double* lin,
+                             const double* bounds, const double* scal, double* a_val, double* p_val, double* lower,
+                             double* upper) {
+    if (!h || !ref || !bounds || !scal || !a_val || !p_val || !lower || !upper || batch < 1 || n < 2 || precise < 0 || precise > n)
+        return fail(PQP_ERR_INVALID, "pqp_path_assemble: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    pqp::RefIndex R{n, precise};
+    const size_t lds = ((size_t)R.nnz_a() + R.nnz_p() + 2 * (size_t)R.cons()) * 8;
+    const int stage = lds <= 150 * 1024 ? 1 : 0;
+    if (stage && lds > 64 * 1024)
+        PQP_HIP(hipFuncSetAttribute((const void*)pqp::path_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = batch < 4096 ? batch : 4096;
+    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(pqp::path_assemble_kernel, dim3(grid), dim3(256), stage ? lds : 0, h->stream, R, batch, ref, lin, bounds,
+                       scal, h->prm, a_val, p_val, lower, upper, stage);
+    PQP_HIP(hipGetLastError());
+    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return PQP_OK;
+}
+
+int pqp_path_assemble(pqp_handle* h, int batch, int n, int precise, const double* ref, const double* lin,
+                      const double* bounds, const double* scal, double* a_val, double* p_val, double* lower, double* upper) {
+    if (!h || !ref || !bounds || !scal || !a_val || !p_val || !lower || !upper || batch < 1 || n < 2 || precise < 0 || precise > n)
+        return fail(PQP_ERR_INVALID, "pqp_path_assemble: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    pqp::RefIndex R{n, precise};
+    const size_t bn = (size_t)batch * n;
+    int rc;
+    if ((rc = h->s_ref.ensure(bn * 5 * 8)) || (rc = h->s_bounds.ensure(bn * 6 * 8)) || (rc = h->s_scal.ensure((size_t)batch * 6 * 8)) ||
+        (rc = h->s_a.ensure((size_t)batch * R.nnz_a() * 8)) || (rc = h->s_p.ensure((size_t)batch * R.nnz_p() * 8)) ||
+        (rc = h->s_l.ensure((size_t)batch * R.cons() * 8)) || (rc = h->s_u.ensure((size_t)batch * R.cons() * 8)))
+        return rc;
+    if (lin && (rc = h->s_lin.ensure(bn * 3 * 8))) return rc;
+    PQP_HIP(hipMemcpyAsync(h->s_ref.p, ref, bn * 5 * 8, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->s_bounds.p, bounds, bn * 6 * 8, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->s_scal.p, scal, (size_t)batch * 6 * 8, hipMemcpyHostToDevice, h->stream));
+    if (lin) PQP_HIP(hipMemcpyAsync(h->s_lin.p, lin, bn * 3 * 8, hipMemcpyHostToDevice, h->stream));
+    rc = pqp_path_assemble_device(h, batch, n, precise, h->s_ref.as<double>(), lin ? h->s_lin.as<double>() : nullptr,
+                                  h->s_bounds.as<double>(), h->s_scal.as<double>(), h->s_a.as<double>(), h->s_p.as<double>(),
+                                  h->s_l.as<double>(), h->s_u.as<double>());
+    if (rc) return rc;
+    PQP_HIP(hipMemcpyAsync(a_val, h->s_a.p, (size_t)batch * R.nnz_a() * 8, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(p_val, h->s_p.p, (size_t)batch * R.nnz_p() * 8, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(lower, h->s_l.p, (size_t)batch * R.cons() * 8, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(upper, h->s_u.p, (size_t)batch * R.cons() * 8, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipStreamSynchronize(h->stream));
+    return PQP_OK;
+}
+
+int pqp_path_solve_device(pqp_handle* h, int batch, int n, const double* ref, const double* lin, const double* bounds,
+                          const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters,
+                          double* info) {
+    if (!h || !ref || !bounds || !scal || !out || batch < 1 || n < 2 || passes < 0)
+        return fail(PQP_ERR_INVALID, "pqp_path_solve: bad argument");
+    if (n > 2048) return fail(PQP_ERR_CAPACITY, "pqp_path_solve: n > 2048 waypoints is not supported");
+    PQP_HIP(hipSetDevice(h->device));
+    if (warm && (h->warm_batch != batch || h->warm_n != n))
+        return fail(PQP_ERR_INVALID, "pqp_path_solve: warm == 1 needs a previous solve with the same batch and n");
+    const size_t bn = (size_t)batch * n;
+    int rc;
+    if (!warm) {
+        if ((rc = h->wx.ensure(bn * 6 * 8)) || (rc = h->wy.ensure(bn * 6 * 8)) || (rc = h->wye.ensure((size_t)batch * 2 * 8)) ||
+            (rc = h->wrho.ensure((size_t)batch * 8)))
+            return rc;
+    }
+    pqp::PathSolveArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.batch = batch; a.n = n; a.passes = passes; a.warm = warm ? 1 : 0;
+    a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
+    a.status = status; a.iters = iters; a.info = info;
+    a.wx = h->wx.as<double>(); a.wy = h->wy.as<double>(); a.wye = h->wye.as<double>(); a.wrho = h->wrho.as<double>();
+    a.prm = h->prm;
+    int nw = 1;
+    while (128 * nw < n) nw *= 2;
+    const size_t lds = (size_t)pqp::ShLayout{64 * nw}.total() * 8;
+    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    switch (nw) {
+        case 1: hipLaunchKernelGGL(pqp::path_solve_kernel<1>, dim3(batch), dim3(64), lds, h->stream, a); break;
+        case 2: hipLaunchKernelGGL(pqp::path_solve_kernel<2>, dim3(batch), dim3(128), lds, h->stream, a); break;
+        case 4: hipLaunchKernelGGL(pqp::path_solve_kernel<4>, dim3(batch), dim3(256), lds, h->stream, a); break;
+        case 8: hipLaunchKernelGGL(pqp::path_solve_kernel<8>, dim3(batch), dim3(512), lds, h->stream, a); break;
+        default: {
+            PQP_HIP(hipFuncSetAttribute((const void*)pqp::path_solve_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(pqp::path_solve_kernel<16>, dim3(batch), dim3(1024), lds, h->stream, a);
+        }
+    }
+    PQP_HIP(hipGetLastError());
+    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    h->warm_batch = batch; h->warm_n = n;
+    return PQP_OK;
+}
+
+int pqp_path_solve(pqp_handle* h, int batch, int n, const double* ref, const double* lin, const double* bounds,
+                   const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters, double* info) {
+    if (!h || !ref || !bounds || !scal || !out || batch < 1 || n < 2 || passes < 0)
+        return fail(PQP_ERR_INVALID, "pqp_path_solve: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    const size_t bn = (size_t)batch * n;
+    int rc;
+    if ((rc = h->s_ref.ensure(bn * 5 * 8)) || (rc = h->s_bounds.ensure(bn * 6 * 8)) || (rc = h->s_scal.ensure((size_t)batch * 6 * 8)) ||
+        (rc = h->s_out.ensure(bn * 7 * 8)) || (rc = h->s_status.ensure((size_t)batch * 4)) || (rc = h->s_iters.ensure((size_t)batch * 4)) ||
+        (rc = h->s_info.ensure((size_t)batch * 4 * 8)))
+        return rc;
+    if (lin && (rc = h->s_lin.ensure(bn * 3 * 8))) return rc;
+    PQP_HIP(hipMemcpyAsync(h->s_ref.p, ref, bn * 5 * 8, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->s_bounds.p, bounds, bn * 6 * 8, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->s_scal.p, scal, (size_t)batch * 6 * 8, hipMemcpyHostToDevice, h->stream));
+    if (lin) PQP_HIP(hipMemcpyAsync(h->s_lin.p, lin, bn * 3 * 8, hipMemcpyHostToDevice, h->stream));
+    rc = pqp_path_solve_device(h, batch, n, h->s_ref.as<double>(), lin ? h->s_lin.as<double>() : nullptr, h->s_bounds.as<double>(),
+                               h->s_scal.as<double>(), passes, warm, h->s_out.as<double>(), h->s_status.as<int32_t>(),
+                               h->s_iters.as<int32_t>(), h->s_info.as<double>());
+    if (rc) return rc;
+    PQP_HIP(hipMemcpyAsync(out, h->s_out.p, bn * 7 * 8, hipMemcpyDeviceToHost, h->stream));
+    if (status) PQP_HIP(hipMemcpyAsync(status, h->s_status.p, (size_t)batch * 4, hipMemcpyDeviceToHost, h->stream));
+    if (iters) PQP_HIP(hipMemcpyAsync(iters, h->s_iters.p, (size_t)batch * 4, hipMemcpyDeviceToHost, h->stream));
+    if (info) PQP_HIP(hipMemcpyAsync(info, h->s_info.p, (size_t)batch * 4 * 8, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipStreamSynchronize(h->stream));
+    return PQP_OK;
+}
+
+int pqp_path_get_solution(pqp_handle* h, int batch, int n, int precise, double* x, double* y) {
+    if (!h || batch < 1 || n < 2 || precise < 0 || precise > n) return fail(PQP_ERR_INVALID, "pqp_path_get_solution: bad argument");
+    if (h->warm_batch != batch || h->warm_n != n) return fail(PQP_ERR_INVALID, "pqp_path_get_solution: no solve of that shape on this handle");
+    PQP_HIP(hipSetDevice(h->device));
+    pqp::RefIndex R{n, precise};
+    int rc;
+    if ((rc = h->s_a.ensure((size_t)batch * R.vars() * 8)) || (rc = h->s_l.ensure((size_t)batch * R.cons() * 8))) return rc;
+    PQP_HIP(hipMemsetAsync(h->s_a.p, 0, (size_t)batch * R.vars() * 8, h->stream));
+    PQP_HIP(hipMemsetAsync(h->s_l.p, 0, (size_t)batch * R.cons() * 8, h->stream));
+    const int total = batch * n;
+    hipLaunchKernelGGL(pqp::path_gather_solution, dim3((total + 255) / 256), dim3(256), 0, h->stream, R, batch, h->wx.as<double>(),
+                       h->wy.as<double>(), h->wye.as<double>(), x ? h->s_a.as<double>() : nullptr, y ? h->s_l.as<double>() : nullptr);
+    PQP_HIP(hipGetLastError());
+    if (x) PQP_HIP(hipMemcpyAsync(x, h->s_a.p, (size_t)batch * R.vars() * 8, hipMemcpyDeviceToHost, h->stream));
+    if (y) PQP_HIP(hipMemcpyAsync(y, h->s_l.p, (size_t)batch * R.cons() * 8, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipStreamSynchronize(h->stream));
+    return PQP_OK;
+}
+
+int pqp_last_kernel_ms(pqp_handle* h, float* ms) {
+    if (!h || !ms) return fail(PQP_ERR_INVALID, "pqp_last_kernel_ms: null argument");
+    if (!h->timed) return fail(PQP_ERR_INVALID, "pqp_last_kernel_ms: nothing was launched yet");
+    PQP_HIP(hipSetDevice(h->device));
+    PQP_HIP(hipEventSynchronize(h->ev1));
+    PQP_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return PQP_OK;
+}
+
+}  // extern "C"

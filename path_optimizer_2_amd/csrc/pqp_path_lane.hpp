@@ -1,0 +1,1096 @@
+// pqp_path_lane.hpp — the per-waypoint ("lane") formulation of the batched path-QP ADMM solve.
+//
+// One workgroup owns one QP.  Thread t owns waypoints 2t and 2t+1 ("slots" 0 and 1); all iterates,
+// the problem data, the penalty metrics and the factorisation of a QP live in registers, neighbouring
+// waypoints talk through a few hundred bytes of LDS, and HBM is touched only to read the scenario
+// and to write the result.
+//
+// What is computed (reference file:line relative to LiJiangnanBit/path_optimizer_2):
+//   * assemble   — BaseSolver::setCost / setConstraints / getSoftBounds
+//                  (src/solver/base_solver.cpp:119-148,150-261,290-295), per waypoint:
+//                  the 5 non-trivial entries of I + ds*df_x, ds, the 3 transition right-hand sides,
+//                  the soft collision boxes, the curvature box, the 2 end rows.
+//   * ADMM       — the OSQP-paper iteration (Stellato et al. 2020; OsqpEigen::Solver::solve() called at
+//                  base_solver.cpp:88,110) in UNSCALED coordinates with diagonal penalty metrics
+//                  R = rho_i E_i^2 / c and Sigma = sigma / (c D_j^2) taken from the paper's modified Ruiz
+//                  equilibration — algebraically the same iterates as the scaled iteration.
+//   * KKT solve  — reduced SPD system (P + Sigma + A^T R A) x = rhs.  Slack and control variables are
+//                  eliminated in closed form (they touch one row each); what remains is block
+//                  tridiagonal in the 3-vector (l, psi, k) per waypoint and is solved by block cyclic
+//                  reduction: log2 levels instead of a 6N-long dependency chain.
+//   * unpack     — BaseSolver::getOptimizedPath (base_solver.cpp:263-288).
+//   * re-linearise + warm re-solve — BaseSolver::updateProblemFormulationAndSolve (:97-117).
+//
+// Variable grouping per waypoint i:  x = (l_i, psi_i, k_i, v_i = u_{i-1}, sf_i, sr_i)
+//   (the control that LEADS INTO waypoint i is stored with i, so transition row block T_i only needs
+//    the previous waypoint's state; v_0 is a decoupled dummy).
+// Row grouping per waypoint i: T_i (3 equality rows: A_{i-1} X_{i-1} + ds v_i e3 - X_i), K_i, F_i, R_i;
+// the two end rows belong to the last waypoint and live in LDS.
+//
+// The same source compiles for the device (kernels in pqp_kernels.hip) and, for tests only, for the
+// host, where tests/emu runs the phases lane by lane to check the algorithm against the oracle without
+// a GPU.  The host build is test infrastructure: nothing in the product links it.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/pqp.h"
+
+#if defined(__HIPCC__)
+#define PQP_HD __host__ __device__ __forceinline__
+#else
+#define PQP_HD inline
+#endif
+
+namespace pqp {
+
+constexpr double kInfty = 1e30;        // OSQP_INFTY
+constexpr double kMinScaling = 1e-4;
+constexpr double kMaxScaling = 1e4;
+constexpr double kRhoMin = 1e-6;
+constexpr double kRhoMax = 1e6;
+constexpr double kRhoTol = 1e-4;
+constexpr double kRhoEqFactor = 1e3;
+constexpr double kPi = 3.14159265358979323846;   // M_PI
+constexpr double kPi2 = 1.57079632679489661923;  // M_PI_2
+
+// ---- device-side argument block of one solve launch ---------------------------------------------
+struct PathSolveArgs {
+    int batch, n, passes, warm;
+    const double* ref;      // [batch][n][5]
+    const double* lin;      // [batch][n][3] or nullptr
+    const double* bounds;   // [batch][n][6]
+    const double* scal;     // [batch][6]
+    double* out;            // [batch][n][7]
+    int32_t* status;        // [batch] or nullptr
+    int32_t* iters;         // [batch] or nullptr
+    double* info;           // [batch][4] or nullptr
+    // warm state kept by the handle, lane layout
+    double* wx;             // [batch][n][6]
+    double* wy;             // [batch][n][6]  (yT[3], yK, yF, yR)
+    double* wye;            // [batch][2]
+    double* wrho;           // [batch]
+    pqp_params prm;
+};
+
+// ---- small dense helpers: sym3 = [00,01,02,11,12,22], mat3 row-major ---------------------------------
+PQP_HD double fmax3(double a, double b, double c) { return fmax(a, fmax(b, c)); }
+PQP_HD double limit_scaling(double v) { v = v < kMinScaling ? 1.0 : v; return v > kMaxScaling ? kMaxScaling : v; }
+
+// inverse of an SPD sym3 through its LDL^T factorisation
+PQP_HD void sym3_inv(const double* S, double* R) {
+    const double d0 = S[0];
+    const double i0 = 1.0 / d0;
+    const double l10 = S[1] * i0, l20 = S[2] * i0;
+    const double d1 = S[3] - l10 * S[1];
+    const double i1 = 1.0 / d1;
+    const double t21 = S[4] - l20 * S[1];
+    const double l21 = t21 * i1;
+    const double d2 = S[5] - l20 * S[2] - l21 * t21;
+    const double i2 = 1.0 / d2;
+    // inv(L): [[1,0,0],[-l10,1,0],[l10*l21-l20,-l21,1]]
+    const double m10 = -l10, m21 = -l21, m20 = l10 * l21 - l20;
+    R[0] = i0 + m10 * m10 * i1 + m20 * m20 * i2;
+    R[1] = m10 * i1 + m20 * m21 * i2;
+    R[2] = m20 * i2;
+    R[3] = i1 + m21 * m21 * i2;
+    R[4] = m21 * i2;
+    R[5] = i2;
+}
+// C = M * S   (M mat3, S sym3)
+PQP_HD void mat3_mul_sym3(const double* M, const double* S, double* C) {
+    for (int r = 0; r < 3; ++r) {
+        const double a = M[3 * r], b = M[3 * r + 1], c = M[3 * r + 2];
+        C[3 * r + 0] = a * S[0] + b * S[1] + c * S[2];
+        C[3 * r + 1] = a * S[1] + b * S[3] + c * S[4];
+        C[3 * r + 2] = a * S[2] + b * S[4] + c * S[5];
+    }
+}
+// C = M^T * S
+PQP_HD void mat3t_mul_sym3(const double* M, const double* S, double* C) {
+    for (int r = 0; r < 3; ++r) {
+        const double a = M[r], b = M[3 + r], c = M[6 + r];
+        C[3 * r + 0] = a * S[0] + b * S[1] + c * S[2];
+        C[3 * r + 1] = a * S[1] + b * S[3] + c * S[4];
+        C[3 * r + 2] = a * S[2] + b * S[4] + c * S[5];
+    }
+}
+// sym(G * M^T) for G, M mat3 with symmetric product
+PQP_HD void mat3_mul_mat3t_sym(const double* G, const double* M, double* S) {
+    S[0] = G[0] * M[0] + G[1] * M[1] + G[2] * M[2];
+    S[1] = G[0] * M[3] + G[1] * M[4] + G[2] * M[5];
+    S[2] = G[0] * M[6] + G[1] * M[7] + G[2] * M[8];
+    S[3] = G[3] * M[3] + G[4] * M[4] + G[5] * M[5];
+    S[4] = G[3] * M[6] + G[4] * M[7] + G[5] * M[8];
+    S[5] = G[6] * M[6] + G[7] * M[7] + G[8] * M[8];
+}
+// sym(G * M) for G, M mat3 with symmetric product
+PQP_HD void mat3_mul_mat3_sym(const double* G, const double* M, double* S) {
+    S[0] = G[0] * M[0] + G[1] * M[3] + G[2] * M[6];
+    S[1] = G[0] * M[1] + G[1] * M[4] + G[2] * M[7];
+    S[2] = G[0] * M[2] + G[1] * M[5] + G[2] * M[8];
+    S[3] = G[3] * M[1] + G[4] * M[4] + G[5] * M[7];
+    S[4] = G[3] * M[2] + G[4] * M[5] + G[5] * M[8];
+    S[5] = G[6] * M[2] + G[7] * M[5] + G[8] * M[8];
+}
+// C = -(G * M)
+PQP_HD void mat3_mul_mat3_neg(const double* G, const double* M, double* C) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            C[3 * r + c] = -(G[3 * r] * M[c] + G[3 * r + 1] * M[3 + c] + G[3 * r + 2] * M[6 + c]);
+}
+PQP_HD void mat3_vec(const double* M, const double* v, double* o) {
+    for (int r = 0; r < 3; ++r) o[r] = M[3 * r] * v[0] + M[3 * r + 1] * v[1] + M[3 * r + 2] * v[2];
+}
+PQP_HD void mat3t_vec(const double* M, const double* v, double* o) {
+    for (int r = 0; r < 3; ++r) o[r] = M[r] * v[0] + M[3 + r] * v[1] + M[6 + r] * v[2];
+}
+PQP_HD void sym3_vec(const double* S, const double* v, double* o) {
+    o[0] = S[0] * v[0] + S[1] * v[1] + S[2] * v[2];
+    o[1] = S[1] * v[0] + S[3] * v[1] + S[4] * v[2];
+    o[2] = S[2] * v[0] + S[4] * v[1] + S[5] * v[2];
+}
+
+// include/tools/tools.hpp:24-35 — recursive wrap to [-pi, pi], boundaries inclusive.
+PQP_HD double constrain_angle(double a) {
+    for (int it = 0; it < 64; ++it) {
+        if (a > kPi) a -= 2 * kPi;
+        else if (a < -kPi) a += 2 * kPi;
+        else break;
+    }
+    return a;
+}
+
+// base_solver.cpp:290-295
+PQP_HD void soft_bounds(double lb, double ub, double margin, double min_clearance, double& lo, double& up) {
+    const double clearance = ub - lb;
+    const double remain = fmax(min_clearance, clearance - 2 * margin);
+    const double shrink = fmax(0.0, (clearance - remain) / 2.0);
+    lo = lb + shrink;
+    up = ub - shrink;
+}
+
+// The linearised transition (i-1 -> i), base_solver.cpp:165-186, same expression order.
+//   lin_p = (l, psi, k) of waypoint i-1, k_next = lin_i.k, s_p/s_i arclengths, kref_p = ref[i-1].k
+//   a[6]  = a00 a01 a10 a11 a12 ds   (A = I + ds*df_x; a02 = a20 = a21 = 0, a22 = 1, B = ds*e3)
+//   c[3]  = ds * (f - df_x * x - df_u * u)     (the bounds of rows 3(i)..3(i)+2 are -c)
+PQP_HD void transition_block(const double* lin_p, double k_next, double s_p, double s_i, double kref_p,
+                             double* a, double* c) {
+    const double l = lin_p[0], psi = lin_p[1], k = lin_p[2];
+    const double t = tan(psi), cs = cos(psi);
+    const double one_kl = 1 - k * l;
+    const double df00 = -k * t;
+    const double df01 = one_kl / (cs * cs);
+    const double df10 = -k * k / cs;
+    const double df11 = one_kl * k * t / cs;
+    const double df12 = one_kl / cs;
+    const double ds = s_i - s_p;
+    a[0] = ds * df00 + 1.0;
+    a[1] = ds * df01;
+    a[2] = ds * df10;
+    a[3] = ds * df11 + 1.0;
+    a[4] = ds * df12;
+    a[5] = ds;
+    const double u_in = (k_next - k) / ds;
+    const double f0 = one_kl * t;
+    const double f1 = one_kl * k / cs - kref_p;
+    const double f2 = u_in;
+    c[0] = ds * (f0 - (df00 * l + df01 * psi + 0.0 * k) - 0.0 * u_in);
+    c[1] = ds * (f1 - (df10 * l + df11 * psi + df12 * k) - 0.0 * u_in);
+    c[2] = ds * (f2 - (0.0 * l + 0.0 * psi + 0.0 * k) - 1.0 * u_in);
+}
+
+// ---- per-thread state ---------------------------------------------------------------------------------
+enum : int { F_REAL = 1, F_PREV = 2, F_NEXT = 4, F_PRECISE = 8, F_LAST = 16, F_FREE0 = 32 /* <<k: inequality row k is free */ };
+
+// Everything a waypoint needs inside the ADMM loop (86 doubles); kept in registers.
+struct Slot {
+    int flags;
+    // iterates: x = (l, psi, k, v, sf, sr); duals of T rows and of the inequality rows K, F, R
+    double x[6], yT[3], yI[3], zI[3];
+    // problem data: incoming transition, its right-hand side, the F and R boxes (the K box is uniform per QP)
+    double a[6], bT[3], lo[2], up[2];
+    // penalty metrics: Sigma = sigma/(c D^2); R = rho * class * E^2 / c
+    double sig[6], rhoT[3], rhoI[3], rinvI[3];
+    // elimination of v, sf, sr
+    double cF, cR, idsf, idsr, tu, tudc, idu;
+    // cyclic-reduction factor of this slot's node
+    double Dinv[6], GL[9], GR[9];
+    // per-iteration scratch that crosses a phase boundary
+    double r[3], rv, rsf, rsr, xt[6];
+};
+// setup-time state (dead inside the ADMM loop)
+struct SlotSetup {
+    double D[6], E[6];               // Ruiz
+    double Dg[6], Lc[9], Rc[9];      // factor: current diagonal block, couplings (left: rows prev, cols own; right: rows own, cols next)
+};
+
+struct Lane {
+    Slot s[2];
+    SlotSetup w[2];
+};
+
+// end rows (owned by the thread holding waypoint n-1), kept in shared memory
+struct EndRows {
+    double lo[2], up[2], z[2], y[2], E[2], rb[2], rho[2], rinv[2];
+};
+
+// shared-memory layout in doubles, T = threads per QP.  The per-iteration exchange buffers and the
+// factor-time exchange buffers are never live at the same time and share one region.
+struct ShLayout {
+    int T;
+    // per-iteration exchange
+    PQP_HD int bufG() const { return 0; }                   // [T][3]  message to the previous waypoint
+    PQP_HD int bufP() const { return 3 * T; }               // [T][3]  CR forward, to the right neighbour
+    PQP_HD int bufQ() const { return 6 * T; }               // [T][3]  CR forward, to the left neighbour
+    PQP_HD int xbuf() const { return 9 * T; }               // [T][3]  X~ of slot 0
+    PQP_HD int xodd() const { return 12 * T; }              // [T][3]  X~ of slot 1
+    // factor-time exchange (aliases the above)
+    PQP_HD int fbuf() const { return 0; }                   // [T][21] SL(6) SR(6) Cnew(9)
+    PQP_HD int fbufA() const { return 0; }                  // [T][15] M(6) Lc(9)   (dead before fbuf is written)
+    PQP_HD int fbufB() const { return 21 * T; }             // [T][15] SR(6) Cnew(9)
+    // persistent
+    PQP_HD int lin() const { return 36 * T; }               // [2T][3] linearisation point
+    PQP_HD int sk() const { return 42 * T; }                // [2T][2] s, k_ref
+    PQP_HD int end() const { return 46 * T; }               // EndRows (16 doubles)
+    PQP_HD int red() const { return 46 * T + 16; }          // reduction scratch [8][16]
+    PQP_HD int total() const { return 46 * T + 16 + 128; }
+};
+
+// diagonal of P by variable slot (base_solver.cpp:123-143); dummy variables (padding waypoints, v of waypoint 0,
+// sr of a rough waypoint) get 1 so their block stays invertible
+PQP_HD double cost_diag(const pqp_params& prm, int flags, int k) {
+    const bool real = flags & F_REAL, prev = flags & F_PREV, precise = flags & F_PRECISE;
+    switch (k) {
+        case 0: return real ? prm.weight_l : 1.0;
+        case 1: return real ? 0.0 : 1.0;
+        case 2: return real ? prm.weight_kappa : 1.0;
+        case 3: return prev ? prm.weight_dkappa : 1.0;
+        case 4: return real ? prm.weight_slack : 1.0;
+        default: return (real && precise) ? prm.weight_slack : 1.0;
+    }
+}
+PQP_HD double coef_front(const pqp_params& prm, int flags) { return ((flags & F_REAL) && (flags & F_PRECISE)) ? prm.front_length : 0.0; }
+PQP_HD double coef_rear(const pqp_params& prm, int flags) { return ((flags & F_REAL) && (flags & F_PRECISE)) ? prm.rear_length : 0.0; }
+
+// =======================================================================================================
+// The solver.  Ctx provides:
+//   int  T()                              threads per QP (power of two, >= 1)
+//   double* sh()                          shared scratch of ShLayout(T).total() doubles
+//   template<F> void phase(F f)           run f(t, Lane&) for every thread, then synchronise
+//   template<int K,F> void reduce_max/sum(double (&out)[K], F f)   f(t, Lane&, double (&v)[K])
+// =======================================================================================================
+template <class Ctx>
+struct PathQp {
+    Ctx& ctx;
+    const PathSolveArgs& A;
+    const int qp;
+    const int n;
+    const int T;
+    const ShLayout L;
+    double* const sh;
+    // uniform per-QP scalars
+    double rho, cscale, kap;
+
+    PQP_HD PathQp(Ctx& c, const PathSolveArgs& a, int q)
+        : ctx(c), A(a), qp(q), n(a.n), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0) {}
+
+    PQP_HD EndRows* end_rows() const { return reinterpret_cast<EndRows*>(sh + L.end()); }
+
+    // NOTE on style: per-lane state must stay in registers, which needs every Lane field to be written through
+    // one unconditional store (values chosen with selects); only LDS / global stores sit under branches.
+    // (if/else branches that store to different places get merged by LLVM into a store through a pointer phi,
+    // which pins the whole Lane struct in scratch memory.)
+
+    // ---------------------------------------------------------------------------------------------
+    // load the scenario
+    // ---------------------------------------------------------------------------------------------
+    PQP_HD void load() {
+        const pqp_params& prm = A.prm;
+        ctx.phase([&](int t, Lane& ln) {
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                Slot& S = ln.s[q];
+                const int i = 2 * t + q;
+                const bool real = i < n;
+                const int ic = real ? i : n - 1;
+                const double* r = A.ref + ((size_t)qp * n + ic) * PQP_REF_STRIDE;
+                const double r0 = r[0], r1 = r[1];
+                // base_solver.cpp:25-34: precise planning size = lower_bound(s, precise_planning_length)
+                const bool precise = !prm.rough_constraints_far_away || r0 < prm.precise_planning_length;
+                S.flags = real ? (F_REAL | (i > 0 ? F_PREV : 0) | (i < n - 1 ? F_NEXT : 0) | (i == n - 1 ? F_LAST : 0) |
+                                  (precise ? F_PRECISE : 0))
+                               : 0;
+                double l0 = 0.0, l1 = 0.0, l2 = r1;      // path_optimizer.cpp:128-137: (0, 0, k_ref)
+                if (A.lin) {
+                    const double* li = A.lin + ((size_t)qp * n + ic) * PQP_LIN_STRIDE;
+                    l0 = li[0]; l1 = li[1]; l2 = li[2];
+                }
+                if (real) {
+                    sh[L.lin() + 3 * i + 0] = l0; sh[L.lin() + 3 * i + 1] = l1; sh[L.lin() + 3 * i + 2] = l2;
+                    sh[L.sk() + 2 * i + 0] = r0; sh[L.sk() + 2 * i + 1] = r1;
+                }
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = 0.0;
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) { S.yT[k] = 0.0; S.yI[k] = 0.0; S.zI[k] = 0.0; }
+            }
+        });
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // assemble the per-waypoint blocks around the linearisation point in sh[lin]
+    // (setCost: base_solver.cpp:119-148 -> cost_diag(); setConstraints: :150-261)
+    // ---------------------------------------------------------------------------------------------
+    PQP_HD void assemble() {
+        const pqp_params& prm = A.prm;
+        const double* sc = A.scal + (size_t)qp * PQP_SCAL_STRIDE;
+        kap = tan(sc[5]) / prm.wheel_base;                  // curvature box (:226-231), the same for every waypoint
+        ctx.phase([&](int t, Lane& ln) {
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                Slot& S = ln.s[q];
+                const int i = 2 * t + q;
+                const bool real = S.flags & F_REAL, prev = S.flags & F_PREV, precise = S.flags & F_PRECISE;
+                double a6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, c3[3] = {0.0, 0.0, 0.0};
+                if (prev)
+                    transition_block(sh + L.lin() + 3 * (i - 1), sh[L.lin() + 3 * i + 2], sh[L.sk() + 2 * (i - 1)],
+                                     sh[L.sk() + 2 * i], sh[L.sk() + 2 * (i - 1) + 1], a6, c3);
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.a[k] = a6[k];
+                // transition right-hand sides: -c (:221-224), or -x0 at the first waypoint (:216-220)
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.bT[k] = !real ? 0.0 : (prev ? -c3[k] : -sc[k]);
+                // collision boxes (:232-248); rough: one row l + s_c on the centre box, the R row and sr are dummies
+                const int ic = real ? i : n - 1;
+                const double* b = A.bounds + ((size_t)qp * n + ic) * PQP_BOUNDS_STRIDE;
+                const double f_lb = precise ? b[0] : b[4], f_ub = precise ? b[1] : b[5];
+                double flo, fup, rlo, rup;
+                soft_bounds(f_lb, f_ub, prm.expected_safety_margin, prm.min_clearance, flo, fup);
+                soft_bounds(b[2], b[3], prm.expected_safety_margin, prm.min_clearance, rlo, rup);
+                S.lo[0] = real ? flo : 0.0; S.up[0] = real ? fup : 0.0;
+                S.lo[1] = (real && precise) ? rlo : 0.0; S.up[1] = (real && precise) ? rup : 0.0;
+                if (S.flags & F_LAST) {                                         // :250-259
+                    EndRows* er = end_rows();
+                    double elo = -kInfty, eup = kInfty;
+                    if (prm.constraint_end_heading && sc[4] == 0.0) {
+                        const double heading = A.ref[((size_t)qp * n + i) * PQP_REF_STRIDE + 2];
+                        const double end_psi = constrain_angle(sc[3] - heading);
+                        if (end_psi < prm.end_psi_max) {     // signed compare, no fabs (:256)
+                            elo = end_psi - prm.end_psi_tol;
+                            eup = end_psi + prm.end_psi_tol;
+                        }
+                    }
+                    er->lo[0] = -prm.end_l_bound; er->up[0] = prm.end_l_bound;
+                    er->lo[1] = elo; er->up[1] = eup;
+                }
+            }
+        });
+    }
+
+    PQP_HD double box_lo(const Slot& S, int k) const { return k == 0 ? ((S.flags & F_REAL) ? -kap : 0.0) : S.lo[k - 1]; }
+    PQP_HD double box_up(const Slot& S, int k) const { return k == 0 ? ((S.flags & F_REAL) ? kap : 0.0) : S.up[k - 1]; }
+
+    // ---------------------------------------------------------------------------------------------
+    // modified Ruiz equilibration (OSQP paper Alg. 2) on the structured KKT -> D, E, c, then the
+    // penalty metrics Sigma = sigma/(c D^2) and R = rho * class * E^2 / c for the current rho
+    // ---------------------------------------------------------------------------------------------
+    PQP_HD void ruiz() {
+        const pqp_params& prm = A.prm;
+        cscale = 1.0;
+        ctx.phase([&](int, Lane& ln) {
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) { ln.w[q].D[k] = 1.0; ln.w[q].E[k] = 1.0; }
+                if (ln.s[q].flags & F_LAST) { end_rows()->E[0] = 1.0; end_rows()->E[1] = 1.0; }
+            }
+        });
+        int nreal_cols = 0;   // 3n + (n-1) + precise + n
+        if (prm.scaling > 0) {
+            double cnt[1];
+            ctx.template reduce_sum<1>(cnt, [&](int, Lane& ln, double (&v)[1]) {
+                v[0] = 0.0;
+                _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                    const int f = ln.s[q].flags;
+                    if (f & F_REAL) v[0] += 4.0 + ((f & F_PREV) ? 1.0 : 0.0) + ((f & F_PRECISE) ? 1.0 : 0.0);
+                }
+            });
+            nreal_cols = (int)(cnt[0] + 0.5);
+        }
+        for (int pass = 0; pass < prm.scaling; ++pass) {
+            // exchange: column contributions of T rows go to the previous waypoint, D of X goes to the next
+            ctx.phase([&](int t, Lane& ln) {
+                _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                    const Slot& S = ln.s[q];
+                    const SlotSetup& W = ln.w[q];
+                    double m[3];
+                    m[0] = fmax(W.E[0] * fabs(S.a[0]), W.E[1] * fabs(S.a[2]));
+                    m[1] = fmax(W.E[0] * fabs(S.a[1]), W.E[1] * fabs(S.a[3]));
+                    m[2] = fmax(W.E[1] * fabs(S.a[4]), (S.flags & F_PREV) ? W.E[2] : 0.0);
+                    if (q == 0) { _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufG() + 3 * t + k] = m[k]; }
+                    else { _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xodd() + 3 * t + k] = W.D[k]; }
+                }
+            });
+            double csum[1];
+            const double c_now = cscale;
+            ctx.template reduce_sum<1>(csum, [&](int t, Lane& ln, double (&v)[1]) {
+                double Dprev0[3], mnext1[3], m1[3], Dold0[3];
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) Dprev0[k] = (t > 0) ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) mnext1[k] = (t + 1 < T) ? sh[L.bufG() + 3 * (t + 1) + k] : 0.0;
+                {   // slot 1's column message to slot 0 (same thread)
+                    const Slot& S = ln.s[1];
+                    const SlotSetup& W = ln.w[1];
+                    m1[0] = fmax(W.E[0] * fabs(S.a[0]), W.E[1] * fabs(S.a[2]));
+                    m1[1] = fmax(W.E[0] * fabs(S.a[1]), W.E[1] * fabs(S.a[3]));
+                    m1[2] = fmax(W.E[1] * fabs(S.a[4]), (S.flags & F_PREV) ? W.E[2] : 0.0);
+                }
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) Dold0[k] = ln.w[0].D[k];
+                v[0] = 0.0;
+                _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                    const Slot& S = ln.s[q];
+                    SlotSetup& W = ln.w[q];
+                    const double* mn = (q == 0) ? m1 : mnext1;
+                    const double* Dp = (q == 0) ? Dprev0 : Dold0;
+                    const bool real = S.flags & F_REAL, last = S.flags & F_LAST, precise = S.flags & F_PRECISE, prev = S.flags & F_PREV;
+                    EndRows* er = end_rows();
+                    const double ee0 = last ? er->E[0] : 0.0, ee1 = last ? er->E[1] : 0.0;
+                    const double acf = fabs(coef_front(prm, S.flags)), acr = fabs(coef_rear(prm, S.flags));
+                    // column norms of [P; A] (scaled)
+                    double cn[6], rn[6];
+                    cn[0] = fmax(fmax3(W.E[0], mn[0], W.E[4]), fmax(precise ? W.E[5] : 0.0, ee0));
+                    cn[1] = fmax(fmax3(W.E[1], mn[1], W.E[4] * acf), fmax(precise ? W.E[5] * acr : 0.0, ee1));
+                    cn[2] = fmax3(W.E[2], mn[2], W.E[3]);
+                    cn[3] = W.E[2] * fabs(S.a[5]);
+                    cn[4] = W.E[4];
+                    cn[5] = W.E[5];
+                    // row norms of A (scaled)
+                    rn[0] = fmax3(W.D[0], Dp[0] * fabs(S.a[0]), Dp[1] * fabs(S.a[1]));
+                    rn[1] = fmax(fmax3(W.D[1], Dp[0] * fabs(S.a[2]), Dp[1] * fabs(S.a[3])), Dp[2] * fabs(S.a[4]));
+                    rn[2] = fmax3(W.D[2], prev ? Dp[2] : 0.0, W.D[3] * fabs(S.a[5]));
+                    rn[3] = W.D[2];
+                    rn[4] = fmax3(W.D[0], W.D[1] * acf, W.D[4]);
+                    rn[5] = fmax3(W.D[0], W.D[1] * acr, W.D[5]);
+                    const double ren0 = W.D[0] * ee0, ren1 = W.D[1] * ee1;
+                    const bool colreal[6] = {real, real, real, prev, real, real && precise};
+                    const bool rowreal[6] = {real, real, real, real, real, real && precise};
+                    _Pragma("unroll") for (int k = 0; k < 6; ++k) {
+                        const double cnk = fmax(cn[k] * W.D[k], c_now * W.D[k] * W.D[k] * cost_diag(prm, S.flags, k));
+                        const double rnk = rn[k] * W.E[k];
+                        const double dnew = W.D[k] / sqrt(limit_scaling(cnk));
+                        const double enew = W.E[k] / sqrt(limit_scaling(rnk));
+                        W.D[k] = colreal[k] ? dnew : 1.0;
+                        W.E[k] = rowreal[k] ? enew : 1.0;
+                        if (colreal[k]) v[0] += fabs(c_now * W.D[k] * W.D[k] * cost_diag(prm, S.flags, k));
+                    }
+                    if (last) {
+                        er->E[0] = ee0 / sqrt(limit_scaling(ren0));
+                        er->E[1] = ee1 / sqrt(limit_scaling(ren1));
+                    }
+                }
+            });
+            // cost scaling: c <- c / max(mean column norm of P, ||q||_inf -> 1 when q == 0)
+            double ct = csum[0] / (double)nreal_cols;
+            ct = fmax(ct, 1.0);
+            ct = limit_scaling(ct);
+            cscale = cscale / ct;
+        }
+        // metrics
+        const double c = cscale, rho_now = rho;
+        ctx.phase([&](int, Lane& ln) {
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                Slot& S = ln.s[q];
+                const SlotSetup& W = ln.w[q];
+                const bool real = S.flags & F_REAL, precise = S.flags & F_PRECISE;
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] = prm.sigma / (c * W.D[k] * W.D[k]);
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] = real ? rho_now * kRhoEqFactor * W.E[k] * W.E[k] / c : 0.0;
+                int fl = S.flags & ~(F_FREE0 | (F_FREE0 << 1) | (F_FREE0 << 2));
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                    const bool rowreal = real && (k < 2 || precise);
+                    const double e = W.E[3 + k], e2 = e * e / c;
+                    const double sl = e * box_lo(S, k), su = e * box_up(S, k);
+                    const bool free_row = sl < -kInfty * kMinScaling && su > kInfty * kMinScaling;
+                    const bool eq_row = !free_row && (su - sl < kRhoTol);
+                    const double r = !rowreal ? 0.0 : (free_row ? kRhoMin * e2 : (eq_row ? rho_now * kRhoEqFactor * e2 : rho_now * e2));
+                    S.rhoI[k] = r;
+                    S.rinvI[k] = r > 0.0 ? 1.0 / r : 0.0;
+                    if (rowreal && free_row) fl |= (F_FREE0 << k);
+                }
+                S.flags = fl;
+                if (S.flags & F_LAST) {
+                    EndRows* er = end_rows();
+                    for (int k = 0; k < 2; ++k) {
+                        const double e = er->E[k], e2 = e * e / c;
+                        const double sl = e * fmax(er->lo[k], -kInfty), su = e * fmin(er->up[k], kInfty);
+                        double rb;
+                        if (sl < -kInfty * kMinScaling && su > kInfty * kMinScaling) rb = -kRhoMin * e2;
+                        else if (su - sl < kRhoTol) rb = kRhoEqFactor * e2;
+                        else rb = e2;
+                        er->rb[k] = rb;
+                        const double r = rb < 0.0 ? -rb : rho_now * rb;
+                        er->rho[k] = r; er->rinv[k] = 1.0 / r;
+                    }
+                }
+            }
+        });
+    }
+
+    // rho changed by `ratio`: rescale every penalty that is proportional to rho
+    PQP_HD void rescale_rho(double ratio) {
+        const double rho_now = rho;
+        ctx.phase([&](int, Lane& ln) {
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                Slot& S = ln.s[q];
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] *= ratio;
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                    const bool fr = S.flags & (F_FREE0 << k);
+                    const double r = fr ? S.rhoI[k] : S.rhoI[k] * ratio;
+                    S.rhoI[k] = r;
+                    S.rinvI[k] = r > 0.0 ? 1.0 / r : 0.0;
+                }
+                if (S.flags & F_LAST) {
+                    EndRows* er = end_rows();
+                    for (int k = 0; k < 2; ++k) {
+                        const double rb = er->rb[k];
+                        const double r = rb < 0.0 ? -rb : rho_now * rb;
+                        er->rho[k] = r; er->rinv[k] = 1.0 / r;
+                    }
+                }
+            }
+        });
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // factorisation for the current penalties: closed-form eliminations, block cyclic reduction
+    // ---------------------------------------------------------------------------------------------
+    PQP_HD void factor() {
+        const pqp_params& prm = A.prm;
+        // F1: own diagonal block + message to the previous waypoint
+        ctx.phase([&](int t, Lane& ln) {
+            double M1[6];
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                Slot& S = ln.s[q];
+                SlotSetup& W = ln.w[q];
+                double re0 = 0.0, re1 = 0.0;
+                if (S.flags & F_LAST) { re0 = end_rows()->rho[0]; re1 = end_rows()->rho[1]; }
+                const double rK = S.rhoI[0], rF = S.rhoI[1], rR = S.rhoI[2];
+                const double dsf = cost_diag(prm, S.flags, 4) + S.sig[4] + rF, dsr = cost_diag(prm, S.flags, 5) + S.sig[5] + rR;
+                S.idsf = 1.0 / dsf; S.idsr = 1.0 / dsr;
+                S.cF = rF * S.idsf; S.cR = rR * S.idsr;
+                const double gf = rF - rF * S.cF, gr = rR - rR * S.cR;
+                const double ds = S.a[5];
+                S.tu = S.rhoT[2] * ds;
+                const double du = cost_diag(prm, S.flags, 3) + S.sig[3] + S.tu * ds;
+                S.idu = 1.0 / du;
+                S.tudc = S.tu * S.idu;
+                const double gu = S.rhoT[2] - S.tu * S.tudc;
+                const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
+                W.Dg[0] = cost_diag(prm, S.flags, 0) + S.sig[0] + S.rhoT[0] + gf + gr + re0;
+                W.Dg[1] = gf * cf + gr * cr;
+                W.Dg[2] = 0.0;
+                W.Dg[3] = cost_diag(prm, S.flags, 1) + S.sig[1] + S.rhoT[1] + gf * cf * cf + gr * cr * cr + re1;
+                W.Dg[4] = 0.0;
+                W.Dg[5] = cost_diag(prm, S.flags, 2) + S.sig[2] + gu + rK;
+                const double r0 = S.rhoT[0], r1 = S.rhoT[1];
+                const double a00 = S.a[0], a01 = S.a[1], a10 = S.a[2], a11 = S.a[3], a12 = S.a[4];
+                const double gup = (S.flags & F_PREV) ? gu : 0.0;
+                // coupling block: rows = previous waypoint's (l,psi,k), cols = own
+                W.Lc[0] = -r0 * a00; W.Lc[1] = -r1 * a10; W.Lc[2] = 0.0;
+                W.Lc[3] = -r0 * a01; W.Lc[4] = -r1 * a11; W.Lc[5] = 0.0;
+                W.Lc[6] = 0.0;       W.Lc[7] = -r1 * a12; W.Lc[8] = -gup;
+                // contribution of this waypoint's T rows to the previous waypoint's diagonal block
+                double M[6];
+                M[0] = r0 * a00 * a00 + r1 * a10 * a10;
+                M[1] = r0 * a00 * a01 + r1 * a10 * a11;
+                M[2] = r1 * a10 * a12;
+                M[3] = r0 * a01 * a01 + r1 * a11 * a11;
+                M[4] = r1 * a11 * a12;
+                M[5] = r1 * a12 * a12 + gup;
+                if (q == 0) {
+                    double* f = sh + L.fbufA() + 15 * t;
+                    _Pragma("unroll") for (int k = 0; k < 6; ++k) f[k] = M[k];
+                    _Pragma("unroll") for (int k = 0; k < 9; ++k) f[6 + k] = W.Lc[k];
+                } else {
+                    _Pragma("unroll") for (int k = 0; k < 6; ++k) M1[k] = M[k];
+                }
+            }
+            // slot 0 receives from own slot 1
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) ln.w[0].Dg[k] += M1[k];
+            _Pragma("unroll") for (int k = 0; k < 9; ++k) ln.w[0].Rc[k] = ln.w[1].Lc[k];
+        });
+        // F2: slot 1 receives from thread t+1, then level 0 eliminates slot 1
+        ctx.phase([&](int t, Lane& ln) {
+            Slot& S1 = ln.s[1];
+            SlotSetup& W1 = ln.w[1];
+            SlotSetup& W0 = ln.w[0];
+            const bool has = t + 1 < T;
+            const double* f = sh + L.fbufA() + 15 * (has ? t + 1 : t);
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) W1.Dg[k] += has ? f[k] : 0.0;
+            _Pragma("unroll") for (int k = 0; k < 9; ++k) W1.Rc[k] = has ? f[6 + k] : 0.0;
+            sym3_inv(W1.Dg, S1.Dinv);
+            mat3_mul_sym3(W1.Lc, S1.Dinv, S1.GL);
+            mat3t_mul_sym3(W1.Rc, S1.Dinv, S1.GR);
+            double SL[6], SR[6], Cn[9];
+            mat3_mul_mat3t_sym(S1.GL, W1.Lc, SL);
+            mat3_mul_mat3_sym(S1.GR, W1.Rc, SR);
+            mat3_mul_mat3_neg(S1.GL, W1.Rc, Cn);
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) W0.Dg[k] -= SL[k];
+            _Pragma("unroll") for (int k = 0; k < 9; ++k) W0.Rc[k] = Cn[k];
+            double* g = sh + L.fbufB() + 15 * t;
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) g[k] = SR[k];
+            _Pragma("unroll") for (int k = 0; k < 9; ++k) g[6 + k] = Cn[k];
+        });
+        // level 0 receive + levels 1..log2(T): receive from the previous level, then eliminate
+        for (int h = 1; h <= T; h <<= 1) {   // h = stride of the level being eliminated (thread units); h == T: root only
+            ctx.phase([&](int t, Lane& ln) {
+                Slot& S0 = ln.s[0];
+                SlotSetup& W0 = ln.w[0];
+                if (h == 1) {
+                    const bool has = t >= 1;
+                    const double* f = sh + L.fbufB() + 15 * (has ? t - 1 : 0);
+                    _Pragma("unroll") for (int k = 0; k < 6; ++k) W0.Dg[k] -= has ? f[k] : 0.0;
+                    _Pragma("unroll") for (int k = 0; k < 9; ++k) W0.Lc[k] = has ? f[6 + k] : 0.0;
+                } else {
+                    const int hp = h >> 1;   // stride of the level just eliminated
+                    const bool surv = (t & (h - 1)) == 0;
+                    const bool hr = surv && (t + hp < T), hl = surv && (t - hp >= 0);
+                    const double* fr = sh + L.fbuf() + 21 * (hr ? t + hp : t);
+                    const double* fl = sh + L.fbuf() + 21 * (hl ? t - hp : t);
+                    _Pragma("unroll") for (int k = 0; k < 6; ++k) W0.Dg[k] -= (hr ? fr[k] : 0.0) + (hl ? fl[6 + k] : 0.0);
+                    _Pragma("unroll") for (int k = 0; k < 9; ++k) {
+                        W0.Rc[k] = surv ? (hr ? fr[12 + k] : 0.0) : W0.Rc[k];
+                        W0.Lc[k] = hl ? fl[12 + k] : W0.Lc[k];
+                    }
+                }
+                const bool elim = (h < T) ? ((t & (2 * h - 1)) == h) : (t == 0);
+                double Di[6], GLn[9], GRn[9];
+                sym3_inv(W0.Dg, Di);
+                mat3_mul_sym3(W0.Lc, Di, GLn);
+                mat3t_mul_sym3(W0.Rc, Di, GRn);
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) S0.Dinv[k] = elim ? Di[k] : S0.Dinv[k];
+                _Pragma("unroll") for (int k = 0; k < 9; ++k) {
+                    S0.GL[k] = elim ? GLn[k] : S0.GL[k];
+                    S0.GR[k] = elim ? GRn[k] : S0.GR[k];
+                }
+                if (elim && h < T) {
+                    double* f = sh + L.fbuf() + 21 * t;
+                    mat3_mul_mat3t_sym(GLn, W0.Lc, f);
+                    mat3_mul_mat3_sym(GRn, W0.Rc, f + 6);
+                    mat3_mul_mat3_neg(GLn, W0.Rc, f + 12);
+                }
+            });
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // A x for the rows of a slot (T rows need the previous waypoint's X)
+    // ---------------------------------------------------------------------------------------------
+    PQP_HD void rows_of(const Slot& S, const double* Xp, const double* x, double* aT, double* aI) const {
+        const double cf = coef_front(A.prm, S.flags), cr = coef_rear(A.prm, S.flags);
+        aT[0] = S.a[0] * Xp[0] + S.a[1] * Xp[1] - x[0];
+        aT[1] = S.a[2] * Xp[0] + S.a[3] * Xp[1] + S.a[4] * Xp[2] - x[1];
+        aT[2] = ((S.flags & F_PREV) ? Xp[2] : 0.0) + S.a[5] * x[3] - x[2];
+        aI[0] = x[2];
+        aI[1] = x[0] + cf * x[1] + x[4];
+        aI[2] = (S.flags & F_PRECISE) ? x[0] + cr * x[1] + x[5] : 0.0;
+    }
+
+    // message a slot sends to the previous waypoint: A_in^T w restricted to (l,psi,k)_{i-1}
+    PQP_HD static void back_msg(const Slot& S, const double* wT, double* g) {
+        g[0] = S.a[0] * wT[0] + S.a[2] * wT[1];
+        g[1] = S.a[1] * wT[0] + S.a[3] * wT[1];
+        g[2] = S.a[4] * wT[1] + ((S.flags & F_PREV) ? wT[2] : 0.0);
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // one ADMM iteration
+    // ---------------------------------------------------------------------------------------------
+    PQP_HD void iterate() {
+        const pqp_params& prm = A.prm;
+        const double alpha = prm.alpha;
+        // I1: w = R z - y, reduced right-hand side pieces, message to the previous waypoint
+        ctx.phase([&](int t, Lane& ln) {
+            double g1[3];
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                Slot& S = ln.s[q];
+                const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
+                double wT[3], wI[3];
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) wT[k] = S.rhoT[k] * S.bT[k] - S.yT[k];
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) wI[k] = S.rhoI[k] * S.zI[k] - S.yI[k];
+                double we0 = 0.0, we1 = 0.0;
+                if (S.flags & F_LAST) {
+                    const EndRows* er = end_rows();
+                    we0 = er->rho[0] * er->z[0] - er->y[0];
+                    we1 = er->rho[1] * er->z[1] - er->y[1];
+                }
+                S.rv = S.sig[3] * S.x[3] + S.a[5] * wT[2];
+                S.rsf = S.sig[4] * S.x[4] + wI[1];
+                S.rsr = S.sig[5] * S.x[5] + wI[2];
+                const double tud = S.tudc * S.rv;
+                double g[3];
+                back_msg(S, wT, g);
+                g[2] -= tud;
+                const double eF = S.cF * S.rsf, eR = S.cR * S.rsr;
+                S.r[0] = S.sig[0] * S.x[0] - wT[0] + wI[1] + wI[2] + we0 - eF - eR;
+                S.r[1] = S.sig[1] * S.x[1] - wT[1] + cf * wI[1] + cr * wI[2] + we1 - cf * eF - cr * eR;
+                S.r[2] = S.sig[2] * S.x[2] - wT[2] + wI[0] + tud;
+                if (q == 0) { _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufG() + 3 * t + k] = g[k]; }
+                else { _Pragma("unroll") for (int k = 0; k < 3; ++k) g1[k] = g[k]; }
+            }
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) ln.s[0].r[k] += g1[k];   // slot 1 -> own slot 0
+        });
+        // I2: slot 1 gets the message of thread t+1; CR level 0 forward
+        ctx.phase([&](int t, Lane& ln) {
+            Slot& S1 = ln.s[1];
+            Slot& S0 = ln.s[0];
+            const bool has = t + 1 < T;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) S1.r[k] += has ? sh[L.bufG() + 3 * (t + 1) + k] : 0.0;
+            double p[3];
+            mat3_vec(S1.GL, S1.r, p);
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) S0.r[k] -= p[k];
+            mat3_vec(S1.GR, S1.r, p);
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xodd() + 3 * t + k] = p[k];   // level-0 message (xodd is free until the backward pass ends)
+        });
+        // forward levels: receive from the previous level, then send if eliminated at this level
+        for (int h = 1; h <= T; h <<= 1) {
+            ctx.phase([&](int t, Lane& ln) {
+                Slot& S0 = ln.s[0];
+                if (h == 1) {
+                    const bool has = t >= 1;
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S0.r[k] -= has ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;
+                } else {
+                    const int hp = h >> 1;
+                    const bool surv = (t & (h - 1)) == 0;
+                    const bool hr = surv && (t + hp < T), hl = surv && (t - hp >= 0);
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k)
+                        S0.r[k] -= (hr ? sh[L.bufQ() + 3 * (t + hp) + k] : 0.0) + (hl ? sh[L.bufP() + 3 * (t - hp) + k] : 0.0);
+                }
+                if (h < T) {
+                    if ((t & (2 * h - 1)) == h) {
+                        double p[3];
+                        mat3_vec(S0.GL, S0.r, p);
+                        _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufQ() + 3 * t + k] = p[k];
+                        mat3_vec(S0.GR, S0.r, p);
+                        _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufP() + 3 * t + k] = p[k];
+                    }
+                } else {
+                    double x3[3];
+                    sym3_vec(S0.Dinv, S0.r, x3);
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S0.xt[k] = x3[k];      // only thread 0's value survives
+                    if (t == 0) { _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xbuf() + k] = x3[k]; }
+                }
+            });
+        }
+        // backward levels
+        for (int h = T >> 1; h >= 1; h >>= 1) {
+            ctx.phase([&](int t, Lane& ln) {
+                Slot& S0 = ln.s[0];
+                const bool act = (t & (2 * h - 1)) == h;
+                const bool hr = act && (t + h < T);
+                const double* xl = sh + L.xbuf() + 3 * (act ? t - h : t);
+                const double* xr = sh + L.xbuf() + 3 * (hr ? t + h : t);
+                double x3[3], p[3], pr[3];
+                sym3_vec(S0.Dinv, S0.r, x3);
+                mat3t_vec(S0.GL, xl, p);
+                mat3t_vec(S0.GR, xr, pr);
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                    const double v = x3[k] - p[k] - (hr ? pr[k] : 0.0);
+                    S0.xt[k] = act ? v : S0.xt[k];
+                    if (act) sh[L.xbuf() + 3 * t + k] = v;
+                }
+            });
+        }
+        // level 0 backward (slot 1) and publication of slot 1's X
+        ctx.phase([&](int t, Lane& ln) {
+            Slot& S1 = ln.s[1];
+            Slot& S0 = ln.s[0];
+            const bool has = t + 1 < T;
+            double x3[3], p[3], pr[3];
+            sym3_vec(S1.Dinv, S1.r, x3);
+            mat3t_vec(S1.GL, S0.xt, p);
+            mat3t_vec(S1.GR, sh + L.xbuf() + 3 * (has ? t + 1 : t), pr);
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                const double v = x3[k] - p[k] - (has ? pr[k] : 0.0);
+                S1.xt[k] = v;
+                sh[L.xodd() + 3 * t + k] = v;
+            }
+        });
+        // I3: back-substitute v, sf, sr; z~ = A x~; relaxed updates, projection, dual update
+        ctx.phase([&](int t, Lane& ln) {
+            double Xprev0[3];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xprev0[k] = (t > 0) ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                Slot& S = ln.s[q];
+                const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
+                const double* Xp = (q == 0) ? Xprev0 : ln.s[0].xt;
+                double xt[6];
+                xt[0] = S.xt[0]; xt[1] = S.xt[1]; xt[2] = S.xt[2];
+                xt[3] = (S.rv - S.tu * (((S.flags & F_PREV) ? Xp[2] : 0.0) - xt[2])) * S.idu;
+                xt[4] = (S.rsf - S.rhoI[1] * (xt[0] + cf * xt[1])) * S.idsf;
+                xt[5] = (S.rsr - S.rhoI[2] * (xt[0] + cr * xt[1])) * S.idsr;
+                double zT[3], zI[3];
+                rows_of(S, Xp, xt, zT, zI);
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = alpha * xt[k] + (1.0 - alpha) * S.x[k];
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.yT[k] += S.rhoT[k] * alpha * (zT[k] - S.bT[k]);
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                    const double zh = alpha * zI[k] + (1.0 - alpha) * S.zI[k];
+                    const double v = zh + S.yI[k] * S.rinvI[k];
+                    const double zn = fmin(fmax(v, box_lo(S, k)), box_up(S, k));
+                    S.yI[k] += S.rhoI[k] * (zh - zn);
+                    S.zI[k] = zn;
+                }
+                if (S.flags & F_LAST) {
+                    EndRows* er = end_rows();
+                    for (int k = 0; k < 2; ++k) {
+                        const double zh = alpha * xt[k] + (1.0 - alpha) * er->z[k];
+                        const double v = zh + er->y[k] * er->rinv[k];
+                        const double zn = fmin(fmax(v, er->lo[k]), er->up[k]);
+                        er->y[k] += er->rho[k] * (zh - zn);
+                        er->z[k] = zn;
+                    }
+                }
+            }
+        });
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // residuals (unscaled inf-norms, OSQP termination quantities):
+    //   res[0] = ||Ax - z||, res[1] = ||Px + A^T y|| (q == 0), res[2] = max(||Ax||, ||z||), res[3] = max(||Px||, ||A^T y||)
+    //   res[4] = 1 if an iterate is not finite
+    // ---------------------------------------------------------------------------------------------
+    PQP_HD void residuals(double (&res)[5]) {
+        const pqp_params& prm = A.prm;
+        ctx.phase([&](int t, Lane& ln) {
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xodd() + 3 * t + k] = ln.s[1].x[k];
+            double g[3];
+            back_msg(ln.s[0], ln.s[0].yT, g);
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufG() + 3 * t + k] = g[k];
+        });
+        ctx.template reduce_max<5>(res, [&](int t, Lane& ln, double (&v)[5]) {
+            _Pragma("unroll") for (int k = 0; k < 5; ++k) v[k] = 0.0;
+            double Xprev0[3], gnext1[3], g1[3];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xprev0[k] = (t > 0) ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) gnext1[k] = (t + 1 < T) ? sh[L.bufG() + 3 * (t + 1) + k] : 0.0;
+            back_msg(ln.s[1], ln.s[1].yT, g1);
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                const Slot& S = ln.s[q];
+                const bool real = S.flags & F_REAL;
+                const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
+                const double* Xp = (q == 0) ? Xprev0 : ln.s[0].x;
+                const double* gn = (q == 0) ? g1 : gnext1;
+                double aT[3], aI[3];
+                rows_of(S, Xp, S.x, aT, aI);
+                double pr = 0.0, nz = 0.0;
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                    pr = fmax(pr, fmax(fabs(aT[k] - S.bT[k]), fabs(aI[k] - S.zI[k])));
+                    nz = fmax(nz, fmax(fmax(fabs(aT[k]), fabs(S.bT[k])), fmax(fabs(aI[k]), fabs(S.zI[k]))));
+                }
+                double ye0 = 0.0, ye1 = 0.0;
+                if (S.flags & F_LAST) {
+                    const EndRows* er = end_rows();
+                    pr = fmax(pr, fmax(fabs(S.x[0] - er->z[0]), fabs(S.x[1] - er->z[1])));
+                    nz = fmax(nz, fmax(fmax(fabs(S.x[0]), fabs(er->z[0])), fmax(fabs(S.x[1]), fabs(er->z[1]))));
+                    ye0 = er->y[0]; ye1 = er->y[1];
+                }
+                double aty[6];
+                aty[0] = -S.yT[0] + gn[0] + S.yI[1] + S.yI[2] + ye0;
+                aty[1] = -S.yT[1] + gn[1] + cf * S.yI[1] + cr * S.yI[2] + ye1;
+                aty[2] = -S.yT[2] + gn[2] + S.yI[0];
+                aty[3] = S.a[5] * S.yT[2];
+                aty[4] = S.yI[1];
+                aty[5] = S.yI[2];
+                const bool colreal[6] = {real, real, real, (S.flags & F_PREV) != 0, real, real && (S.flags & F_PRECISE)};
+                double du = 0.0, nd = 0.0, bad = 0.0;
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) {
+                    const double px = cost_diag(prm, S.flags, k) * S.x[k];
+                    du = fmax(du, colreal[k] ? fabs(px + aty[k]) : 0.0);
+                    nd = fmax(nd, colreal[k] ? fmax(fabs(px), fabs(aty[k])) : 0.0);
+                    bad = (fabs(S.x[k]) <= 1e300) ? bad : 1.0;   // NaN / Inf guard
+                }
+                v[0] = fmax(v[0], real ? pr : 0.0);
+                v[1] = fmax(v[1], du);
+                v[2] = fmax(v[2], real ? nz : 0.0);
+                v[3] = fmax(v[3], nd);
+                v[4] = fmax(v[4], bad);
+            }
+        });
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // start of a solve (osqp_warm_start semantics: x, y given, z = A x; cold: all zero)
+    // ---------------------------------------------------------------------------------------------
+    // OSQP starts an equality row from z_0 (0 cold, (A x)_i warm), not from its bound b; afterwards z == b
+    // forever.  The solve keeps z_T implicit (== bT), so the first iteration is made exact by shifting the
+    // dual: y' = y - rho (z_0 - b) before it, y += rho (2 - alpha) (z_0 - b) after it.  dz lives in sh[lin]
+    // (free between assemble and unpack).
+    PQP_HD void start_transition_rows(bool have_warm) {
+        if (have_warm) {
+            ctx.phase([&](int t, Lane& ln) {
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xodd() + 3 * t + k] = ln.s[1].x[k];
+            });
+        }
+        ctx.phase([&](int t, Lane& ln) {
+            double Xprev0[3];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xprev0[k] = (have_warm && t > 0) ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                Slot& S = ln.s[q];
+                const int i = 2 * t + q;
+                const double* Xp = (q == 0) ? Xprev0 : ln.s[0].x;
+                double aT[3], aI[3];
+                rows_of(S, Xp, S.x, aT, aI);
+                const bool real = S.flags & F_REAL;
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                    const double dz = real ? (have_warm ? aT[k] : 0.0) - S.bT[k] : 0.0;
+                    sh[L.lin() + 3 * i + k] = dz;
+                    S.yT[k] -= S.rhoT[k] * dz;
+                    S.zI[k] = (real && have_warm) ? aI[k] : 0.0;
+                }
+                if (S.flags & F_LAST) {
+                    end_rows()->z[0] = have_warm ? S.x[0] : 0.0;
+                    end_rows()->z[1] = have_warm ? S.x[1] : 0.0;
+                }
+            }
+        });
+    }
+    PQP_HD void finish_first_iteration() {
+        const double f = 2.0 - A.prm.alpha;
+        ctx.phase([&](int t, Lane& ln) {
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                Slot& S = ln.s[q];
+                const int i = 2 * t + q;
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.yT[k] += S.rhoT[k] * f * sh[L.lin() + 3 * i + k];
+            }
+        });
+    }
+
+    PQP_HD void load_warm() {
+        ctx.phase([&](int t, Lane& ln) {
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                Slot& S = ln.s[q];
+                const int i = 2 * t + q;
+                const bool real = S.flags & F_REAL;
+                const size_t o = ((size_t)qp * n + (real ? i : n - 1)) * 6;
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = real ? A.wx[o + k] : 0.0;
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) { S.yT[k] = real ? A.wy[o + k] : 0.0; S.yI[k] = real ? A.wy[o + 3 + k] : 0.0; }
+                if (S.flags & F_LAST) { end_rows()->y[0] = A.wye[2 * (size_t)qp]; end_rows()->y[1] = A.wye[2 * (size_t)qp + 1]; }
+            }
+        });
+    }
+
+    PQP_HD void store_warm() {
+        ctx.phase([&](int t, Lane& ln) {
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                const Slot& S = ln.s[q];
+                const int i = 2 * t + q;
+                if (!(S.flags & F_REAL)) continue;
+                double* wx = A.wx + ((size_t)qp * n + i) * 6;
+                double* wy = A.wy + ((size_t)qp * n + i) * 6;
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) wx[k] = S.x[k];
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) { wy[k] = S.yT[k]; wy[3 + k] = S.yI[k]; }
+                if (S.flags & F_LAST) { A.wye[2 * (size_t)qp] = end_rows()->y[0]; A.wye[2 * (size_t)qp + 1] = end_rows()->y[1]; }
+            }
+        });
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // unpack (base_solver.cpp:263-288) and publish the next linearisation point
+    // ---------------------------------------------------------------------------------------------
+    PQP_HD void unpack() {
+        ctx.phase([&](int t, Lane& ln) {
+            sh[L.xbuf() + t] = ln.s[0].x[3];    // v of slot 0 = u of waypoint 2t-1
+        });
+        ctx.phase([&](int t, Lane& ln) {
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                const Slot& S = ln.s[q];
+                const int i = 2 * t + q;
+                if (!(S.flags & F_REAL)) continue;
+                const double* r = A.ref + ((size_t)qp * n + i) * PQP_REF_STRIDE;
+                double* o = A.out + ((size_t)qp * n + i) * PQP_OUT_STRIDE;
+                const double angle = r[2];
+                const double l = S.x[0], dpsi = S.x[1];
+                const double new_angle = constrain_angle(angle + kPi2);
+                o[0] = r[3] + l * cos(new_angle);
+                o[1] = r[4] + l * sin(new_angle);
+                o[2] = constrain_angle(angle + dpsi);
+                o[3] = l;
+                o[4] = dpsi;
+                o[5] = S.x[2];
+                double dk = 0.0;
+                if (S.flags & F_NEXT) dk = (q == 0) ? ln.s[1].x[3] : sh[L.xbuf() + t + 1];
+                o[6] = dk;
+                // input_path_ = first solution (base_solver.cpp:100): l, d_heading, k
+                sh[L.lin() + 3 * i + 0] = l; sh[L.lin() + 3 * i + 1] = dpsi; sh[L.lin() + 3 * i + 2] = S.x[2];
+            }
+        });
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // the whole path: (warm) solve + `passes` re-linearised warm re-solves
+    // ---------------------------------------------------------------------------------------------
+    PQP_HD void run() {
+        const pqp_params& prm = A.prm;
+        load();
+        int total_iters = 0, last_iters = 0, status = PQP_STATUS_UNSOLVED;
+        double res[5] = {0, 0, 0, 0, 0};
+        rho = prm.rho;
+        bool have_warm = false;
+        if (A.warm) {
+            load_warm();
+            rho = A.wrho[qp];
+            have_warm = true;
+        } else {
+            ctx.phase([&](int, Lane& ln) {
+                _Pragma("unroll") for (int q = 0; q < 2; ++q)
+                    if (ln.s[q].flags & F_LAST) { end_rows()->y[0] = 0.0; end_rows()->y[1] = 0.0; }
+            });
+        }
+        for (int pass = 0; pass <= A.passes; ++pass) {
+            assemble();
+            ruiz();
+            factor();
+            start_transition_rows(have_warm);
+            status = PQP_STATUS_MAX_ITER;
+            int it = 0;
+            for (it = 1; it <= prm.max_iter; ++it) {
+                iterate();
+                if (it == 1) finish_first_iteration();
+                const bool check = prm.check_termination > 0 && (it % prm.check_termination) == 0;
+                const bool adapt = prm.adaptive_rho && prm.adaptive_rho_interval > 0 && (it % prm.adaptive_rho_interval) == 0;
+                if (check || adapt) {
+                    residuals(res);
+                    if (res[4] != 0.0) { status = PQP_STATUS_NUMERICAL; break; }
+                    if (check) {
+                        const double eps_p = prm.eps_abs + prm.eps_rel * res[2];
+                        const double eps_d = prm.eps_abs + prm.eps_rel * res[3];
+                        if (res[0] <= eps_p && res[1] <= eps_d) { status = PQP_STATUS_SOLVED; break; }
+                    }
+                    if (adapt) {
+                        const double pn = res[0] / (res[2] + 1e-10);
+                        const double dn = res[1] / (res[3] + 1e-10);
+                        double rn = rho * sqrt(pn / (dn + 1e-10));
+                        rn = fmin(fmax(rn, kRhoMin), kRhoMax);
+                        if (rn > rho * prm.adaptive_rho_tolerance || rn < rho / prm.adaptive_rho_tolerance) {
+                            const double ratio = rn / rho;
+                            rho = rn;
+                            rescale_rho(ratio);
+                            factor();
+                        }
+                    }
+                }
+            }
+            if (it > prm.max_iter) it = prm.max_iter;
+            last_iters = it;
+            total_iters += it;
+            unpack();
+            have_warm = true;
+            if (status != PQP_STATUS_SOLVED) break;   // reference: solve() false -> optimizePath returns false
+        }
+        store_warm();
+        const double rho_final = rho;
+        ctx.phase([&](int t, Lane&) {
+            if (t == 0) {
+                A.wrho[qp] = rho_final;
+                if (A.status) A.status[qp] = status;
+                if (A.iters) A.iters[qp] = total_iters;
+                if (A.info) {
+                    double* f = A.info + 4 * (size_t)qp;
+                    f[0] = res[0]; f[1] = res[1]; f[2] = rho_final; f[3] = (double)last_iters;
+                }
+            }
+        });
+    }
+};
+
+}  // namespace pqp

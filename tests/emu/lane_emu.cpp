@@ -1,0 +1,90 @@
+// lane_emu.cpp — TEST INFRASTRUCTURE: runs the device algorithm source (pqp_path_lane.hpp) on the host,
+// phase by phase, lane by lane, so the algorithm can be checked against the oracle without a GPU.
+// Built only by tests/ (tests/test_lane_emulation.py); never linked into libpqp_hip.so, never timed.
+#include <cstring>
+#include <vector>
+
+#include "../../path_optimizer_2_amd/csrc/pqp_path_lane.hpp"
+#include "../../path_optimizer_2_amd/csrc/pqp_defaults.hpp"
+
+namespace {
+struct HostCtx {
+    int T_;
+    std::vector<pqp::Lane> lanes;
+    std::vector<double> shm;
+    explicit HostCtx(int T) : T_(T), lanes(T), shm(pqp::ShLayout{T}.total(), 0.0) {}
+    int T() const { return T_; }
+    double* sh() { return shm.data(); }
+    template <class F> void phase(F f) { for (int t = 0; t < T_; ++t) f(t, lanes[t]); }
+    template <int K, class F> void reduce_max(double (&out)[K], F f) {
+        for (int k = 0; k < K; ++k) out[k] = 0.0;
+        for (int t = 0; t < T_; ++t) { double v[K]; f(t, lanes[t], v); for (int k = 0; k < K; ++k) out[k] = out[k] > v[k] ? out[k] : v[k]; }
+    }
+    template <int K, class F> void reduce_sum(double (&out)[K], F f) {
+        for (int k = 0; k < K; ++k) out[k] = 0.0;
+        for (int t = 0; t < T_; ++t) { double v[K]; f(t, lanes[t], v); for (int k = 0; k < K; ++k) out[k] += v[k]; }
+    }
+};
+}  // namespace
+
+extern "C" void pqp_emu_default_params(pqp_params* p) { pqp::default_params(p); }
+
+extern "C" int pqp_emu_path_solve(const pqp_params* prm, int batch, int n, const double* ref, const double* lin,
+                                  const double* bounds, const double* scal, int passes, int warm, double* out,
+                                  int32_t* status, int32_t* iters, double* info, double* wx, double* wy,
+                                  double* wye, double* wrho) {
+    int T = 64;
+    while (2 * T < n) T *= 2;
+    pqp::PathSolveArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.batch = batch; a.n = n; a.passes = passes; a.warm = warm;
+    a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
+    a.status = status; a.iters = iters; a.info = info;
+    a.wx = wx; a.wy = wy; a.wye = wye; a.wrho = wrho;
+    a.prm = *prm;
+    for (int q = 0; q < batch; ++q) {
+        HostCtx ctx(T);
+        pqp::PathQp<HostCtx> s(ctx, a, q);
+        s.run();
+    }
+    return 0;
+}
+
+// Debug probe: run load/assemble/ruiz/factor (+ iterations) and dump per-waypoint state.
+//   dump [n][64]: a(6) bT(3) lo(3) up(3) D(6) E(6) sig(6) rhoT(3) rhoI(3)  = 39 used
+extern "C" int pqp_emu_probe(const pqp_params* prm, int n, const double* ref, const double* bounds, const double* scal,
+                             double* dump, double* endrows, double* cscale, int do_iters, double* xout) {
+    int T = 64;
+    while (2 * T < n) T *= 2;
+    pqp::PathSolveArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.batch = 1; a.n = n; a.ref = ref; a.bounds = bounds; a.scal = scal; a.prm = *prm;
+    HostCtx ctx(T);
+    pqp::PathQp<HostCtx> s(ctx, a, 0);
+    s.load();
+    s.end_rows()->y[0] = s.end_rows()->y[1] = 0.0;
+    s.assemble();
+    s.ruiz();
+    s.factor();
+    s.start_transition_rows(false);
+    for (int it = 0; it < do_iters; ++it) { s.iterate(); if (it == 0) s.finish_first_iteration(); }
+    for (int i = 0; i < n; ++i) {
+        const pqp::Slot& S = ctx.lanes[i / 2].s[i & 1];
+        const pqp::SlotSetup& W = ctx.lanes[i / 2].w[i & 1];
+        double* d = dump + 64 * i;
+        int o = 0;
+        for (int k = 0; k < 6; ++k) d[o++] = S.a[k];
+        for (int k = 0; k < 3; ++k) d[o++] = S.bT[k];
+        for (int k = 0; k < 3; ++k) d[o++] = s.box_lo(S, k);
+        for (int k = 0; k < 3; ++k) d[o++] = s.box_up(S, k);
+        for (int k = 0; k < 6; ++k) d[o++] = W.D[k];
+        for (int k = 0; k < 6; ++k) d[o++] = W.E[k];
+        for (int k = 0; k < 6; ++k) d[o++] = S.sig[k];
+        for (int k = 0; k < 3; ++k) d[o++] = S.rhoT[k];
+        for (int k = 0; k < 3; ++k) d[o++] = S.rhoI[k];
+        for (int k = 0; k < 6; ++k) xout[6 * i + k] = S.x[k];
+    }
+    std::memcpy(endrows, s.end_rows(), sizeof(pqp::EndRows));
+    *cscale = s.cscale;
+    return 0;
+}

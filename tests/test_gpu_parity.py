@@ -1,0 +1,178 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle.  Run with -m gpu on an MI355X.
+
+Parity rule: integer index maps bit-exact; assembled values to a few ulp; the solution
+against the CONVERGED, KKT-certified oracle optimum: max |l|, |d_heading| error <= 1e-4 (we assert 1e-6
+where both sides run to eps 1e-9/1e-7)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import pqp_oracle as O
+from path_optimizer_2_amd import capi
+from path_optimizer_2_amd.synth import make_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def handle(hip_lib):
+    h = capi.Handle(capi.default_params(hip_lib), device=0, max_batch=64, max_n=128)
+    yield h
+    h.close()
+
+
+def _tight(**kw):
+    return capi.default_params(eps_abs=1e-8, eps_rel=1e-8, max_iter=20000, **kw)
+
+
+ORACLE_TIGHT = O.OsqpSettings(eps_abs=1e-9, eps_rel=1e-9, max_iter=40000)
+
+
+@pytest.mark.parametrize("n,precise", [(3, 3), (8, 8), (80, 80), (120, 120), (200, 200), (80, 50), (9, 0)])
+def test_pattern_bit_exact(handle, n, precise):
+    rows, colptr, pcols = handle.pattern(n, precise)
+    orow, ocol, ocolptr, opcols = O.structural_pattern(n, precise)
+    assert rows.dtype == np.int32
+    np.testing.assert_array_equal(rows, orow)
+    np.testing.assert_array_equal(colptr, ocolptr)
+    np.testing.assert_array_equal(pcols, opcols)
+
+
+@pytest.mark.parametrize("n,profile", [(8, "uniform"), (80, "uniform"), (120, "varied"), (200, "varied")])
+def test_assemble_matches_oracle(handle, n, profile):
+    b = make_batch(6, n, profile)
+    rng = np.random.default_rng(n)
+    lin = np.stack([O.first_linearization(b["ref"][q]) for q in range(6)])
+    lin[3:] += rng.normal(scale=[0.3, 0.05, 0.01], size=(3, n, 3))      # a non-trivial linearisation point
+    for lin_arg in (None, lin):
+        a_val, p_val, lo, up = handle.assemble(b["ref"], lin_arg, b["bounds"], b["scal"])
+        rows, colptr, pcols = handle.pattern(n)
+        for q in range(6):
+            l_q = O.first_linearization(b["ref"][q]) if lin_arg is None else lin[q]
+            Pd, A, olo, oup, sz = O.assemble_path_qp(b["ref"][q], l_q, b["bounds"][q], b["scal"][q])
+            Ag = sp.csc_matrix((a_val[q], rows, colptr), shape=(sz["cons"], sz["vars"])).toarray()
+            np.testing.assert_allclose(Ag, A, rtol=1e-13, atol=1e-15)
+            Pg = np.zeros(sz["vars"]); Pg[pcols] = p_val[q]
+            np.testing.assert_array_equal(Pg, Pd)
+            np.testing.assert_allclose(lo[q], olo, rtol=1e-12, atol=1e-15)
+            np.testing.assert_allclose(up[q], oup, rtol=1e-12, atol=1e-15)
+            # reference sparseView() drops exact zeros only: every non-zero of the dense build is a pattern slot
+            assert np.count_nonzero(A) <= len(rows)
+
+
+def test_assemble_rough_constraints(hip_lib):
+    n = 60
+    prm = capi.default_params(hip_lib, rough_constraints_far_away=1, precise_planning_length=10.0)
+    h = capi.Handle(prm, max_batch=4, max_n=n)
+    b = make_batch(2, n)
+    sz = h.sizes(n, b["ref"][0, :, 0].copy())
+    oprm = O.PathQpParams(rough_constraints_far_away=True, precise_planning_length=10.0)
+    osz = O.path_qp_sizes(n, b["ref"][0, :, 0], oprm)
+    assert sz["precise"] == osz["precise"] and sz["vars"] == osz["vars"] and sz["cons"] == osz["cons"]
+    a_val, p_val, lo, up = h.assemble(b["ref"], None, b["bounds"], b["scal"], precise=sz["precise"])
+    rows, colptr, pcols = h.pattern(n, sz["precise"])
+    for q in range(2):
+        Pd, A, olo, oup, _ = O.assemble_path_qp(b["ref"][q], O.first_linearization(b["ref"][q]), b["bounds"][q], b["scal"][q], oprm)
+        Ag = sp.csc_matrix((a_val[q], rows, colptr), shape=A.shape).toarray()
+        np.testing.assert_allclose(Ag, A, rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(lo[q], olo, rtol=1e-12)
+        np.testing.assert_allclose(up[q], oup, rtol=1e-12)
+    h.close()
+
+
+@pytest.mark.parametrize("n,profile,batch", [(80, "uniform", 6), (120, "varied", 4), (200, "varied", 2), (33, "varied", 3), (8, "uniform", 3)])
+def test_solve_matches_converged_oracle(hip_lib, n, profile, batch):
+    b = make_batch(batch, n, profile)
+    h = capi.Handle(_tight(), max_batch=batch, max_n=n)
+    r0 = h.solve(b["ref"], b["bounds"], b["scal"], passes=0)
+    x0, y0 = h.get_solution(batch, n)
+    assert (r0["status"] == capi_status_solved()).all()
+    for q in range(batch):
+        lin = O.first_linearization(b["ref"][q])
+        Pd, A, lo, up, sz = O.assemble_path_qp(b["ref"][q], lin, b["bounds"][q], b["scal"][q])
+        ro = O.osqp_admm(sp.diags(Pd), np.zeros(sz["vars"]), A, lo, up, ORACLE_TIGHT)
+        assert ro["status"] == "solved"
+        # (1) same optimum as the oracle
+        assert np.abs(x0[q] - ro["x"]).max() < 1e-6
+        assert np.abs(r0["out"][q] - O.unpack_path(ro["x"], b["ref"][q])).max() < 1e-6
+        # (2) solver-independent certificate of the GPU point
+        cert = O.kkt_certificate(sp.diags(Pd), np.zeros(sz["vars"]), A, lo, up, x0[q], y0[q])
+        assert cert["pri"] < 1e-6 and cert["stat"] < 1e-6 and cert["comp"] < 1e-6, cert
+    # (3) re-linearised warm re-solve (BaseSolver::updateProblemFormulationAndSolve) through the warm API
+    r1 = h.solve(b["ref"], b["bounds"], b["scal"], lin=np.ascontiguousarray(r0["out"][:, :, 3:6]), passes=0, warm=True)
+    # (4) fused two-pass launch == the two separate calls
+    h2 = capi.Handle(_tight(), max_batch=batch, max_n=n)
+    r2 = h2.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    np.testing.assert_allclose(r2["out"], r1["out"], rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(r2["iters"], r0["iters"] + r1["iters"])
+    for q in range(batch):
+        ref = O.solve_path(b["ref"][q], b["bounds"][q], b["scal"][q], st=ORACLE_TIGHT)
+        assert np.abs(r2["out"][q][:, 3:5] - ref[-1]["out"][:, 3:5]).max() < 1e-6     # l, d_heading
+        assert np.abs(r2["out"][q] - ref[-1]["out"]).max() < 1e-5
+    h.close(); h2.close()
+
+
+def capi_status_solved():
+    return 1
+
+
+def test_iteration_counts_follow_the_osqp_restatement(hip_lib):
+    """The GPU runs the same ADMM iteration (in unscaled coordinates); with the reference's eps = 2e-3 and at
+    1e-4 it must stop at the same check as the CPU restatement (allow one 25-iteration check of slack)."""
+    b = make_batch(8, 80)
+    for eps in (2e-3, 1e-4):
+        h = capi.Handle(capi.default_params(hip_lib, eps_abs=eps, eps_rel=eps), max_batch=8, max_n=80)
+        r = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+        for q in range(8):
+            ref = O.solve_path(b["ref"][q], b["bounds"][q], b["scal"][q], st=O.OsqpSettings(eps_abs=eps, eps_rel=eps))
+            assert abs(int(r["iters"][q]) - sum(x["iters"] for x in ref)) <= 50
+        h.close()
+
+
+def test_analytic_straight_reference(hip_lib):
+    """Straight reference, wide corridor, zero initial error: the optimum is x == 0 (SURVEY.md §8c KAT 5)."""
+    n = 40
+    ref = np.zeros((1, n, 5)); ref[0, :, 0] = 0.3 * np.arange(n); ref[0, :, 3] = ref[0, :, 0]
+    bounds = np.tile(np.array([-3.0, 3.0, -3.0, 3.0, -3.0, 3.0]), (1, n, 1))
+    scal = np.array([[0.0, 0.0, 0.0, 0.0, 0.0, 35 * np.pi / 180]])
+    h = capi.Handle(_tight(), max_batch=1, max_n=n)
+    r = h.solve(ref, bounds, scal, passes=1)
+    assert r["status"][0] == 1
+    assert np.abs(r["out"][0][:, 3:7]).max() < 1e-9
+    np.testing.assert_allclose(r["out"][0][:, 0], ref[0, :, 3], atol=1e-9)
+    h.close()
+
+
+def test_full_size_properties(hip_lib):
+    """BASELINE config 2 (batch 1024, N = 80) at full size: size-independent properties instead of the oracle:
+    every QP solved, outputs finite, the dynamics rows hold, boxes respected within the residual tolerance,
+    and the run is bit-reproducible."""
+    b = make_batch(1024, 80)
+    eps = 1e-6
+    h = capi.Handle(capi.default_params(hip_lib, eps_abs=eps, eps_rel=eps), max_batch=1024, max_n=80)
+    r = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    assert (r["status"] == 1).all()
+    assert np.isfinite(r["out"]).all()
+    out = r["out"]
+    kap = np.tan(b["scal"][:, 5]) / 2.5
+    assert (np.abs(out[:, :, 5]) <= kap[:, None] + 1e-4).all()            # curvature box
+    assert (np.abs(out[:, -1, 3]) <= 1.0 + 1e-4).all()                     # end-l box
+    # k_{i+1} = k_i + ds * dk_i  (third transition row, exact for any linearisation point)
+    ds = np.diff(b["ref"][:, :, 0], axis=1)
+    assert np.abs(out[:, 1:, 5] - out[:, :-1, 5] - ds * out[:, :-1, 6]).max() < 1e-4
+    assert np.abs(out[:, 0, 3] - b["scal"][:, 0]).max() < 1e-4            # initial state pinned
+    assert np.abs(out[:, 0, 4] - b["scal"][:, 1]).max() < 1e-4
+    r2 = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    np.testing.assert_array_equal(r2["out"], r["out"])                    # deterministic
+    np.testing.assert_array_equal(r2["iters"], r["iters"])
+    h.close()
+
+
+def test_error_paths(hip_lib):
+    h = capi.Handle(capi.default_params(hip_lib), max_batch=2, max_n=16)
+    b = make_batch(2, 16)
+    with pytest.raises(capi.PqpError):
+        h.solve(b["ref"], b["bounds"], b["scal"], passes=0, warm=True)       # warm without a previous solve
+    with pytest.raises(capi.PqpError):
+        h.pattern(1)
+    h.close()
