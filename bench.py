@@ -58,7 +58,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="QPs per GPU")
     ap.add_argument("--n", type=int, default=80, help="waypoints per path")
-    ap.add_argument("--eps", type=float, default=1e-6, help="eps_abs = eps_rel of the ADMM termination test")
+    ap.add_argument("--eps", type=float, default=1e-4, help="eps_abs = eps_rel of the ADMM termination test")
+    ap.add_argument("--no-polish", action="store_true", help="plain OSQP termination (the reference setting), no polish")
+    ap.add_argument("--rho-interval", type=int, default=50, help="adaptive_rho_interval (iterations)")
     ap.add_argument("--profile", default="uniform", choices=["uniform", "varied"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="all_gather the result slabs over RCCL inside the timed region")
@@ -90,7 +92,8 @@ def main():
     iters = torch.zeros(batch, dtype=torch.int32, device=dev)
     gathered = [torch.empty_like(out) for _ in range(world)] if (args.gather and world > 1) else None
 
-    prm = capi.default_params(eps_abs=args.eps, eps_rel=args.eps)
+    prm = capi.default_params(eps_abs=args.eps, eps_rel=args.eps, polish=0 if args.no_polish else 1,
+                              adaptive_rho_interval=args.rho_interval)
     h = capi.Handle(prm, device=local_rank, max_batch=batch, max_n=n)
 
     def step():
@@ -141,7 +144,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: batch={batch} QPs/GPU, N={n}, shared sparsity, synthetic obstacle bounds ({args.profile})",
-                       "batch_per_gpu": batch, "n_waypoints": n, "eps_abs": args.eps, "eps_rel": args.eps,
+                       "batch_per_gpu": batch, "n_waypoints": n, "eps_abs": args.eps, "eps_rel": args.eps, "polish": not args.no_polish, "adaptive_rho_interval": args.rho_interval,
                        "passes": "cold solve + 1 re-linearised warm re-solve (optimizePath)",
                        "parallelism": f"{world} x independent shards" + (", RCCL all_gather of results" if gathered is not None else "")},
             "admm_iters": {"min": int(it_np.min()), "median": float(np.median(it_np)), "p99": float(np.percentile(it_np, 99)),

@@ -66,7 +66,8 @@ typedef enum pqp_error {
 /* Per-QP termination status written to status[batch] (osqp-eigen collapses this to bool). */
 typedef enum pqp_status {
     PQP_STATUS_UNSOLVED = 0,
-    PQP_STATUS_SOLVED = 1,         /* both residual tests passed                       -> solve() == true  */
+    PQP_STATUS_SOLVED = 1,         /* both residual tests passed (and, with polish on, the KKT-verified polish
+                                      was accepted or ADMM reached 1e-10)             -> solve() == true  */
     PQP_STATUS_MAX_ITER = 2,       /* max_iter reached                                  -> solve() == false */
     PQP_STATUS_NUMERICAL = 3       /* NaN/Inf in the iterates                           -> solve() == false */
 } pqp_status;
@@ -103,7 +104,16 @@ typedef struct pqp_params {
     int32_t adaptive_rho_interval;    /* 100 (OSQP's "auto" value without wall-clock profiling) */
     double adaptive_rho_tolerance;    /* 5     */
     int32_t check_termination;        /* 25    */
+    /* solution polishing (OSQP paper section 4.2; OSQP default and the reference: off).  When on, the active
+     * set the ADMM iterate predicts is solved as an equality-constrained QP (regularised KKT + iterative
+     * refinement) and ACCEPTED ONLY IF the polished point passes a KKT check (primal feasibility of inactive
+     * rows, dual signs of active rows, stationarity) - i.e. it is then the exact optimum of the QP.  A
+     * rejected polish resumes ADMM with a 10x tighter internal tolerance and tries again later. */
+    int32_t polish;                   /* 0 (reference) ; bench and parity tests use 1 */
+    int32_t polish_refine_iter;       /* 4     */
     int32_t reserved;
+    double polish_delta;              /* 1e-6  regularisation; active rows get penalty 1/delta */
+    double polish_tol;                /* 1e-7  KKT acceptance tolerance of the polished point  */
 } pqp_params;
 
 typedef struct pqp_sizes {

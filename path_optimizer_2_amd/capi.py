@@ -23,7 +23,8 @@ class PqpParams(C.Structure):
         ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("rho", C.c_double), ("sigma", C.c_double),
         ("alpha", C.c_double), ("max_iter", C.c_int32), ("scaling", C.c_int32),
         ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32),
-        ("adaptive_rho_tolerance", C.c_double), ("check_termination", C.c_int32), ("reserved", C.c_int32),
+        ("adaptive_rho_tolerance", C.c_double), ("check_termination", C.c_int32), ("polish", C.c_int32),
+        ("polish_refine_iter", C.c_int32), ("reserved", C.c_int32), ("polish_delta", C.c_double), ("polish_tol", C.c_double),
     ]
 
 

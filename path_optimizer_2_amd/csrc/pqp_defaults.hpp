@@ -31,6 +31,10 @@ inline void default_params(pqp_params* p) {
     p->adaptive_rho_interval = 100;
     p->adaptive_rho_tolerance = 5.0;
     p->check_termination = 25;
+    p->polish = 0;
+    p->polish_refine_iter = 4;
     p->reserved = 0;
+    p->polish_delta = 1e-6;
+    p->polish_tol = 1e-7;
 }
 }  // namespace pqp

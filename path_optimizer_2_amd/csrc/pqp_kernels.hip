@@ -336,7 +336,7 @@ struct pqp_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int warm_batch = 0, warm_n = 0;
-    DevBuf wx, wy, wye, wrho;                   // warm state (lane layout)
+    DevBuf wx, wy, wye, wrho, wsave;            // warm state (lane layout) + polish save area
     DevBuf s_ref, s_lin, s_bounds, s_scal;      // staging for the host-pointer entry points
     DevBuf s_out, s_status, s_iters, s_info, s_a, s_p, s_l, s_u, s_idx;
 };
@@ -378,7 +378,7 @@ int pqp_destroy(pqp_handle* h) {
     if (!h) return PQP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (DevBuf* b : {&h->wx, &h->wy, &h->wye, &h->wrho, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
+    for (DevBuf* b : {&h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
                       &h->s_status, &h->s_iters, &h->s_info, &h->s_a, &h->s_p, &h->s_l, &h->s_u, &h->s_idx})
         b->release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -511,12 +511,13 @@ int pqp_path_solve_device(pqp_handle* h, int batch, int n, const double* ref, co
             (rc = h->wrho.ensure((size_t)batch * 8)))
             return rc;
     }
+    if ((rc = h->wsave.ensure(bn * 20 * 8))) return rc;
     pqp::PathSolveArgs a;
     std::memset(&a, 0, sizeof(a));
     a.batch = batch; a.n = n; a.passes = passes; a.warm = warm ? 1 : 0;
     a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
     a.status = status; a.iters = iters; a.info = info;
-    a.wx = h->wx.as<double>(); a.wy = h->wy.as<double>(); a.wye = h->wye.as<double>(); a.wrho = h->wrho.as<double>();
+    a.wx = h->wx.as<double>(); a.wy = h->wy.as<double>(); a.wye = h->wye.as<double>(); a.wrho = h->wrho.as<double>(); a.wsave = h->wsave.as<double>();
     a.prm = h->prm;
     int nw = 1;
     while (128 * nw < n) nw *= 2;

@@ -70,6 +70,7 @@ struct PathSolveArgs {
     double* wy;             // [batch][n][6]  (yT[3], yK, yF, yR)
     double* wye;            // [batch][2]
     double* wrho;           // [batch]
+    double* wsave;          // [batch][n][16] ADMM state parked while a polish is tried
     pqp_params prm;
 };
 
@@ -201,7 +202,14 @@ PQP_HD void transition_block(const double* lin_p, double k_next, double s_p, dou
 }
 
 // ---- per-thread state ---------------------------------------------------------------------------------
-enum : int { F_REAL = 1, F_PREV = 2, F_NEXT = 4, F_PRECISE = 8, F_LAST = 16, F_FREE0 = 32 /* <<k: inequality row k is free */ };
+enum : int {
+    F_REAL = 1, F_PREV = 2, F_NEXT = 4, F_PRECISE = 8, F_LAST = 16,
+    F_FREE0 = 1 << 5,     // << k: inequality row k (K, F, R) has no finite bound            (rho class "free")
+    F_EQ0 = 1 << 8,       // << k: inequality row k has l == u within RHO_TOL               (rho class "equality")
+    F_ACTLO0 = 1 << 11,   // << k: polish: row k is taken as active at its lower bound
+    F_ACTUP0 = 1 << 14,   // << k: polish: row k is taken as active at its upper bound
+    F_ROWBITS = (7 << 5) | (7 << 8) | (7 << 11) | (7 << 14)
+};
 
 // Everything a waypoint needs inside the ADMM loop (86 doubles); kept in registers.
 struct Slot {
@@ -233,6 +241,9 @@ struct Lane {
 // end rows (owned by the thread holding waypoint n-1), kept in shared memory
 struct EndRows {
     double lo[2], up[2], z[2], y[2], E[2], rb[2], rho[2], rinv[2];
+    double act[2];          // polish: -1 lower-active, +1 upper-active, 0 inactive
+    double sz[2], sy[2];    // ADMM state parked while a polish is tried
+    double pad[2];
 };
 
 // shared-memory layout in doubles, T = threads per QP.  The per-iteration exchange buffers and the
@@ -252,9 +263,9 @@ struct ShLayout {
     // persistent
     PQP_HD int lin() const { return 36 * T; }               // [2T][3] linearisation point
     PQP_HD int sk() const { return 42 * T; }                // [2T][2] s, k_ref
-    PQP_HD int end() const { return 46 * T; }               // EndRows (16 doubles)
-    PQP_HD int red() const { return 46 * T + 16; }          // reduction scratch [8][16]
-    PQP_HD int total() const { return 46 * T + 16 + 128; }
+    PQP_HD int end() const { return 46 * T; }               // EndRows (24 doubles)
+    PQP_HD int red() const { return 46 * T + 24; }          // reduction scratch [8][16]
+    PQP_HD int total() const { return 46 * T + 24 + 128; }
 };
 
 // diagonal of P by variable slot (base_solver.cpp:123-143); dummy variables (padding waypoints, v of waypoint 0,
@@ -290,10 +301,11 @@ struct PathQp {
     const ShLayout L;
     double* const sh;
     // uniform per-QP scalars
-    double rho, cscale, kap;
+    double rho, cscale, kap, alpha_;
+    bool polishing_;
 
     PQP_HD PathQp(Ctx& c, const PathSolveArgs& a, int q)
-        : ctx(c), A(a), qp(q), n(a.n), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0) {}
+        : ctx(c), A(a), qp(q), n(a.n), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false) {}
 
     PQP_HD EndRows* end_rows() const { return reinterpret_cast<EndRows*>(sh + L.end()); }
 
@@ -382,8 +394,20 @@ struct PathQp {
         });
     }
 
-    PQP_HD double box_lo(const Slot& S, int k) const { return k == 0 ? ((S.flags & F_REAL) ? -kap : 0.0) : S.lo[k - 1]; }
-    PQP_HD double box_up(const Slot& S, int k) const { return k == 0 ? ((S.flags & F_REAL) ? kap : 0.0) : S.up[k - 1]; }
+    // the box of inequality row k (0: curvature, 1: front, 2: rear) as assembled ...
+    PQP_HD double raw_lo(const Slot& S, int k) const { return k == 0 ? ((S.flags & F_REAL) ? -kap : 0.0) : S.lo[k - 1]; }
+    PQP_HD double raw_up(const Slot& S, int k) const { return k == 0 ? ((S.flags & F_REAL) ? kap : 0.0) : S.up[k - 1]; }
+    // ... and as the iteration sees it: while polishing, an active row is pinned to its bound, an inactive row is free
+    PQP_HD double box_lo(const Slot& S, int k) const {
+        const double lo = raw_lo(S, k), up = raw_up(S, k);
+        if (!polishing_) return lo;
+        return (S.flags & (F_ACTLO0 << k)) ? lo : ((S.flags & (F_ACTUP0 << k)) ? up : -kInfty);
+    }
+    PQP_HD double box_up(const Slot& S, int k) const {
+        const double lo = raw_lo(S, k), up = raw_up(S, k);
+        if (!polishing_) return up;
+        return (S.flags & (F_ACTLO0 << k)) ? lo : ((S.flags & (F_ACTUP0 << k)) ? up : kInfty);
+    }
 
     // ---------------------------------------------------------------------------------------------
     // modified Ruiz equilibration (OSQP paper Alg. 2) on the structured KKT -> D, E, c, then the
@@ -496,17 +520,18 @@ struct PathQp {
                 const bool real = S.flags & F_REAL, precise = S.flags & F_PRECISE;
                 _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] = prm.sigma / (c * W.D[k] * W.D[k]);
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] = real ? rho_now * kRhoEqFactor * W.E[k] * W.E[k] / c : 0.0;
-                int fl = S.flags & ~(F_FREE0 | (F_FREE0 << 1) | (F_FREE0 << 2));
+                int fl = S.flags & ~F_ROWBITS;
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                     const bool rowreal = real && (k < 2 || precise);
                     const double e = W.E[3 + k], e2 = e * e / c;
-                    const double sl = e * box_lo(S, k), su = e * box_up(S, k);
+                    const double sl = e * raw_lo(S, k), su = e * raw_up(S, k);
                     const bool free_row = sl < -kInfty * kMinScaling && su > kInfty * kMinScaling;
                     const bool eq_row = !free_row && (su - sl < kRhoTol);
                     const double r = !rowreal ? 0.0 : (free_row ? kRhoMin * e2 : (eq_row ? rho_now * kRhoEqFactor * e2 : rho_now * e2));
                     S.rhoI[k] = r;
                     S.rinvI[k] = r > 0.0 ? 1.0 / r : 0.0;
                     if (rowreal && free_row) fl |= (F_FREE0 << k);
+                    if (rowreal && eq_row) fl |= (F_EQ0 << k);
                 }
                 S.flags = fl;
                 if (S.flags & F_LAST) {
@@ -550,6 +575,146 @@ struct PathQp {
                 }
             }
         });
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // Solution polishing (OSQP paper section 4.2) with a KKT acceptance test.
+    //   1. park the ADMM state, guess the active set from (z, y) with OSQP's rule
+    //   2. equality-constrained QP on that set = the same reduced system with penalty 1/delta on active rows,
+    //      0 on inactive rows, Sigma scaled to delta; `polish_refine_iter` proximal-multiplier iterations
+    //      (alpha = 1) are the iterative refinement
+    //   3. accept iff the polished point is primal feasible on the inactive rows, has the right dual signs on
+    //      the active rows and is stationary -> it then IS the optimum of the QP; otherwise restore and resume.
+    // ---------------------------------------------------------------------------------------------
+    static constexpr int kSaveStride = 20;   // x6 yT3 yI3 zI3 rhoI3 (+2 pad)
+
+    PQP_HD bool try_polish() {
+        const pqp_params& prm = A.prm;
+        const double rho_now = rho;
+        const double gain = 1.0 / prm.polish_delta;          // penalty of an active row (times E^2/c)
+        const double sgain = prm.polish_delta / prm.sigma;    // Sigma -> delta / (c D^2)
+        const double tgain = gain / (rho_now * kRhoEqFactor);
+        ctx.phase([&](int t, Lane& ln) {
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                Slot& S = ln.s[q];
+                const int i = 2 * t + q;
+                const bool real = S.flags & F_REAL;
+                if (real) {
+                    double* w = A.wsave + ((size_t)qp * n + i) * kSaveStride;
+                    _Pragma("unroll") for (int k = 0; k < 6; ++k) w[k] = S.x[k];
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) { w[6 + k] = S.yT[k]; w[9 + k] = S.yI[k]; w[12 + k] = S.zI[k]; w[15 + k] = S.rhoI[k]; }
+                }
+                int fl = S.flags & ~((7 * F_ACTLO0) | (7 * F_ACTUP0));
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] *= tgain;
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                    const bool fr = S.flags & (F_FREE0 << k), eq = S.flags & (F_EQ0 << k);
+                    const double e2 = S.rhoI[k] / (rho_now * (eq ? kRhoEqFactor : 1.0));     // E^2 / c of the row
+                    const double lo = raw_lo(S, k), up = raw_up(S, k);
+                    const bool can = !fr && S.rhoI[k] > 0.0;
+                    const bool act_lo = can && ((S.zI[k] - lo) * e2 < -S.yI[k]);
+                    const bool act_up = can && !act_lo && ((up - S.zI[k]) * e2 < S.yI[k]);
+                    if (act_lo) fl |= (F_ACTLO0 << k);
+                    if (act_up) fl |= (F_ACTUP0 << k);
+                    const bool act = act_lo || act_up;
+                    const double r = act ? gain * e2 : 0.0;
+                    S.rhoI[k] = r;
+                    S.rinvI[k] = act ? 1.0 / r : 0.0;
+                    S.yI[k] = act ? S.yI[k] : 0.0;
+                    S.zI[k] = act_lo ? lo : (act_up ? up : S.zI[k]);
+                }
+                S.flags = fl;
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] *= sgain;
+                if (S.flags & F_LAST) {
+                    EndRows* er = end_rows();
+                    for (int k = 0; k < 2; ++k) {
+                        er->sz[k] = er->z[k]; er->sy[k] = er->y[k];
+                        const bool fr = er->rb[k] < 0.0;
+                        const double e2 = er->E[k] * er->E[k] / cscale;
+                        const bool act_lo = !fr && ((er->z[k] - er->lo[k]) * e2 < -er->y[k]);
+                        const bool act_up = !fr && !act_lo && ((er->up[k] - er->z[k]) * e2 < er->y[k]);
+                        er->act[k] = act_lo ? -1.0 : (act_up ? 1.0 : 0.0);
+                        const bool act = act_lo || act_up;
+                        const double r = act ? gain * e2 : 0.0;
+                        er->rho[k] = r; er->rinv[k] = act ? 1.0 / r : 0.0;
+                        er->y[k] = act ? er->y[k] : 0.0;
+                        er->z[k] = act_lo ? er->lo[k] : (act_up ? er->up[k] : er->z[k]);
+                    }
+                }
+            }
+        });
+        polishing_ = true;
+        alpha_ = 1.0;
+        factor();
+        for (int r = 0; r < prm.polish_refine_iter; ++r) iterate();
+        // acceptance test
+        double res[5];
+        residuals(res);
+        double viol[1];
+        const double tol = prm.polish_tol;
+        ctx.template reduce_max<1>(viol, [&](int t, Lane& ln, double (&v)[1]) {
+            v[0] = 0.0;
+            double Xprev0[3];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xprev0[k] = (t > 0) ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;   // published by residuals()
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                const Slot& S = ln.s[q];
+                const double* Xp = (q == 0) ? Xprev0 : ln.s[0].x;
+                double aT[3], aI[3];
+                rows_of(S, Xp, S.x, aT, aI);
+                double w = 0.0;
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                    const bool rowreal = (S.flags & F_REAL) && (k < 2 || (S.flags & F_PRECISE));
+                    const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
+                    const double lo = raw_lo(S, k), up = raw_up(S, k);
+                    const double pv = fmax(lo - aI[k], aI[k] - up);             // violation of the true box
+                    const double dv = alo ? S.yI[k] : (aup ? -S.yI[k] : 0.0);   // wrong-signed multiplier
+                    w = fmax(w, rowreal ? fmax(pv, dv) : 0.0);
+                }
+                if (S.flags & F_LAST) {
+                    const EndRows* er = end_rows();
+                    for (int k = 0; k < 2; ++k) {
+                        const double pv = fmax(er->lo[k] - S.x[k], S.x[k] - er->up[k]);
+                        const double dv = er->act[k] < 0.0 ? er->y[k] : (er->act[k] > 0.0 ? -er->y[k] : 0.0);
+                        w = fmax(w, fmax(pv, dv));
+                    }
+                }
+                v[0] = fmax(v[0], w);
+            }
+        });
+        const bool ok = res[4] == 0.0 && res[0] <= tol * (1.0 + res[2]) && res[1] <= tol * (1.0 + res[3]) && viol[0] <= tol;
+        polishing_ = false;
+        alpha_ = prm.alpha;
+        // accept: keep (x, y).  reject: restore the ADMM iterate.  Either way put the ADMM penalties back.
+        ctx.phase([&](int t, Lane& ln) {
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                Slot& S = ln.s[q];
+                const int i = 2 * t + q;
+                const bool real = S.flags & F_REAL;
+                const double* w = A.wsave + ((size_t)qp * n + (real ? i : n - 1)) * kSaveStride;
+                const bool rest = real && !ok;
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = rest ? w[k] : S.x[k];
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                    S.yT[k] = rest ? w[6 + k] : S.yT[k];
+                    S.yI[k] = rest ? w[9 + k] : S.yI[k];
+                    S.zI[k] = rest ? w[12 + k] : S.zI[k];
+                    const double r = real ? w[15 + k] : 0.0;
+                    S.rhoI[k] = r;
+                    S.rinvI[k] = r > 0.0 ? 1.0 / r : 0.0;
+                    S.rhoT[k] *= 1.0 / tgain;
+                }
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] *= 1.0 / sgain;
+                if (S.flags & F_LAST) {
+                    EndRows* er = end_rows();
+                    for (int k = 0; k < 2; ++k) {
+                        if (!ok) { er->z[k] = er->sz[k]; er->y[k] = er->sy[k]; }
+                        const double rb = er->rb[k];
+                        const double r = rb < 0.0 ? -rb : rho_now * rb;
+                        er->rho[k] = r; er->rinv[k] = 1.0 / r;
+                    }
+                }
+            }
+        });
+        if (!ok) factor();
+        return ok;
     }
 
     // ---------------------------------------------------------------------------------------------
@@ -699,7 +864,7 @@ struct PathQp {
     // ---------------------------------------------------------------------------------------------
     PQP_HD void iterate() {
         const pqp_params& prm = A.prm;
-        const double alpha = prm.alpha;
+        const double alpha = alpha_;
         // I1: w = R z - y, reduced right-hand side pieces, message to the previous waypoint
         ctx.phase([&](int t, Lane& ln) {
             double g1[3];
@@ -836,7 +1001,13 @@ struct PathQp {
                     for (int k = 0; k < 2; ++k) {
                         const double zh = alpha * xt[k] + (1.0 - alpha) * er->z[k];
                         const double v = zh + er->y[k] * er->rinv[k];
-                        const double zn = fmin(fmax(v, er->lo[k]), er->up[k]);
+                        double elo = er->lo[k], eup = er->up[k];
+                        if (polishing_) {
+                            const double bnd = er->act[k] < 0.0 ? elo : eup;
+                            elo = er->act[k] != 0.0 ? bnd : -kInfty;
+                            eup = er->act[k] != 0.0 ? bnd : kInfty;
+                        }
+                        const double zn = fmin(fmax(v, elo), eup);
                         er->y[k] += er->rho[k] * (zh - zn);
                         er->z[k] = zn;
                     }
@@ -1022,7 +1193,7 @@ struct PathQp {
     PQP_HD void run() {
         const pqp_params& prm = A.prm;
         load();
-        int total_iters = 0, last_iters = 0, status = PQP_STATUS_UNSOLVED;
+        int total_iters = 0, last_iters = 0, status = PQP_STATUS_UNSOLVED, polished = 0;
         double res[5] = {0, 0, 0, 0, 0};
         rho = prm.rho;
         bool have_warm = false;
@@ -1042,6 +1213,7 @@ struct PathQp {
             factor();
             start_transition_rows(have_warm);
             status = PQP_STATUS_MAX_ITER;
+            double eps_scale = 1.0;
             int it = 0;
             for (it = 1; it <= prm.max_iter; ++it) {
                 iterate();
@@ -1052,9 +1224,14 @@ struct PathQp {
                     residuals(res);
                     if (res[4] != 0.0) { status = PQP_STATUS_NUMERICAL; break; }
                     if (check) {
-                        const double eps_p = prm.eps_abs + prm.eps_rel * res[2];
-                        const double eps_d = prm.eps_abs + prm.eps_rel * res[3];
-                        if (res[0] <= eps_p && res[1] <= eps_d) { status = PQP_STATUS_SOLVED; break; }
+                        const double eps_p = eps_scale * (prm.eps_abs + prm.eps_rel * res[2]);
+                        const double eps_d = eps_scale * (prm.eps_abs + prm.eps_rel * res[3]);
+                        if (res[0] <= eps_p && res[1] <= eps_d) {
+                            if (!prm.polish) { status = PQP_STATUS_SOLVED; break; }
+                            if (try_polish()) { status = PQP_STATUS_SOLVED; polished += 1; break; }
+                            eps_scale *= 0.1;      // rejected: resume ADMM, try again one decade tighter
+                            if (eps_scale * fmax(prm.eps_abs, prm.eps_rel) < 1e-10) { status = PQP_STATUS_SOLVED; break; }
+                        }
                     }
                     if (adapt) {
                         const double pn = res[0] / (res[2] + 1e-10);
@@ -1086,7 +1263,7 @@ struct PathQp {
                 if (A.iters) A.iters[qp] = total_iters;
                 if (A.info) {
                     double* f = A.info + 4 * (size_t)qp;
-                    f[0] = res[0]; f[1] = res[1]; f[2] = rho_final; f[3] = (double)last_iters;
+                    f[0] = res[0]; f[1] = res[1]; f[2] = rho_final; f[3] = (double)last_iters + 1e-3 * polished;
                 }
             }
         });

@@ -41,6 +41,8 @@ extern "C" int pqp_emu_path_solve(const pqp_params* prm, int batch, int n, const
     a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
     a.status = status; a.iters = iters; a.info = info;
     a.wx = wx; a.wy = wy; a.wye = wye; a.wrho = wrho;
+    std::vector<double> wsave((size_t)batch * n * 20, 0.0);
+    a.wsave = wsave.data();
     a.prm = *prm;
     for (int q = 0; q < batch; ++q) {
         HostCtx ctx(T);
