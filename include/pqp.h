@@ -54,6 +54,7 @@ extern "C" {
 #define PQP_BOUNDS_STRIDE 6
 #define PQP_SCAL_STRIDE 6
 #define PQP_OUT_STRIDE 7
+#define PQP_INFO_STRIDE 6
 
 typedef enum pqp_error {
     PQP_OK = 0,
@@ -111,7 +112,7 @@ typedef struct pqp_params {
      * rejected polish resumes ADMM with a 10x tighter internal tolerance and tries again later. */
     int32_t polish;                   /* 0 (reference) ; bench and parity tests use 1 */
     int32_t polish_refine_iter;       /* 4     */
-    int32_t reserved;
+    int32_t polish_every;             /* 0: only when the residual test passes; k: also try every k iterations */
     double polish_delta;              /* 1e-6  regularisation; active rows get penalty 1/delta */
     double polish_tol;                /* 1e-7  KKT acceptance tolerance of the polished point  */
 } pqp_params;
@@ -158,7 +159,8 @@ int pqp_path_assemble_device(pqp_handle* h, int batch, int n, int precise, const
  *   kept from its previous pqp_path_solve* call with the same batch and n
  *   (BaseSolver::updateProblemFormulationAndSolve: pass the previous output as `lin`).
  *   status[batch], iters[batch] (total ADMM iterations over all passes) may be NULL.
- *   info (may be NULL) [batch][4]: primal residual, dual residual, final rho, iterations of last pass. */
+ *   info (may be NULL) [batch][PQP_INFO_STRIDE]: primal residual, dual residual, final rho, ADMM iterations of the
+ *   last pass, number of accepted polishes, total reduced-KKT solves (ADMM iterations + polish refinement). */
 int pqp_path_solve(pqp_handle* h, int batch, int n, const double* ref, const double* lin,
                    const double* bounds, const double* scal, int passes, int warm,
                    double* out, int32_t* status, int32_t* iters, double* info);

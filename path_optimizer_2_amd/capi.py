@@ -24,7 +24,7 @@ class PqpParams(C.Structure):
         ("alpha", C.c_double), ("max_iter", C.c_int32), ("scaling", C.c_int32),
         ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32),
         ("adaptive_rho_tolerance", C.c_double), ("check_termination", C.c_int32), ("polish", C.c_int32),
-        ("polish_refine_iter", C.c_int32), ("reserved", C.c_int32), ("polish_delta", C.c_double), ("polish_tol", C.c_double),
+        ("polish_refine_iter", C.c_int32), ("polish_every", C.c_int32), ("polish_delta", C.c_double), ("polish_tol", C.c_double),
     ]
 
 
@@ -164,7 +164,7 @@ class Handle:
         """Host-array convenience: returns dict(out, status, iters, info)."""
         batch, n = ref.shape[0], ref.shape[1]
         out = np.zeros((batch, n, 7)); status = np.zeros(batch, dtype=np.int32)
-        iters = np.zeros(batch, dtype=np.int32); info = np.zeros((batch, 4))
+        iters = np.zeros(batch, dtype=np.int32); info = np.zeros((batch, 6))
         self._check(self.lib.pqp_path_solve(self._h, batch, n, _ptr(ref), _ptr(lin), _ptr(bounds), _ptr(scal),
                                             passes, 1 if warm else 0, _ptr(out), _ptr(status), _ptr(iters), _ptr(info)))
         return dict(out=out, status=status, iters=iters, info=info)

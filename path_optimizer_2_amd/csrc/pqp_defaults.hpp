@@ -33,7 +33,7 @@ inline void default_params(pqp_params* p) {
     p->check_termination = 25;
     p->polish = 0;
     p->polish_refine_iter = 4;
-    p->reserved = 0;
+    p->polish_every = 0;
     p->polish_delta = 1e-6;
     p->polish_tol = 1e-7;
 }

@@ -549,7 +549,7 @@ int pqp_path_solve(pqp_handle* h, int batch, int n, const double* ref, const dou
     int rc;
     if ((rc = h->s_ref.ensure(bn * 5 * 8)) || (rc = h->s_bounds.ensure(bn * 6 * 8)) || (rc = h->s_scal.ensure((size_t)batch * 6 * 8)) ||
         (rc = h->s_out.ensure(bn * 7 * 8)) || (rc = h->s_status.ensure((size_t)batch * 4)) || (rc = h->s_iters.ensure((size_t)batch * 4)) ||
-        (rc = h->s_info.ensure((size_t)batch * 4 * 8)))
+        (rc = h->s_info.ensure((size_t)batch * PQP_INFO_STRIDE * 8)))
         return rc;
     if (lin && (rc = h->s_lin.ensure(bn * 3 * 8))) return rc;
     PQP_HIP(hipMemcpyAsync(h->s_ref.p, ref, bn * 5 * 8, hipMemcpyHostToDevice, h->stream));
@@ -563,7 +563,7 @@ int pqp_path_solve(pqp_handle* h, int batch, int n, const double* ref, const dou
     PQP_HIP(hipMemcpyAsync(out, h->s_out.p, bn * 7 * 8, hipMemcpyDeviceToHost, h->stream));
     if (status) PQP_HIP(hipMemcpyAsync(status, h->s_status.p, (size_t)batch * 4, hipMemcpyDeviceToHost, h->stream));
     if (iters) PQP_HIP(hipMemcpyAsync(iters, h->s_iters.p, (size_t)batch * 4, hipMemcpyDeviceToHost, h->stream));
-    if (info) PQP_HIP(hipMemcpyAsync(info, h->s_info.p, (size_t)batch * 4 * 8, hipMemcpyDeviceToHost, h->stream));
+    if (info) PQP_HIP(hipMemcpyAsync(info, h->s_info.p, (size_t)batch * PQP_INFO_STRIDE * 8, hipMemcpyDeviceToHost, h->stream));
     PQP_HIP(hipStreamSynchronize(h->stream));
     return PQP_OK;
 }

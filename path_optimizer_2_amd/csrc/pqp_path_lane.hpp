@@ -64,7 +64,7 @@ struct PathSolveArgs {
     double* out;            // [batch][n][7]
     int32_t* status;        // [batch] or nullptr
     int32_t* iters;         // [batch] or nullptr
-    double* info;           // [batch][4] or nullptr
+    double* info;           // [batch][PQP_INFO_STRIDE] or nullptr
     // warm state kept by the handle, lane layout
     double* wx;             // [batch][n][6]
     double* wy;             // [batch][n][6]  (yT[3], yK, yF, yR)
@@ -303,9 +303,10 @@ struct PathQp {
     // uniform per-QP scalars
     double rho, cscale, kap, alpha_;
     bool polishing_;
+    int kkt_solves_;          // iterate() executions: ADMM iterations + polish refinement solves
 
     PQP_HD PathQp(Ctx& c, const PathSolveArgs& a, int q)
-        : ctx(c), A(a), qp(q), n(a.n), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false) {}
+        : ctx(c), A(a), qp(q), n(a.n), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false), kkt_solves_(0) {}
 
     PQP_HD EndRows* end_rows() const { return reinterpret_cast<EndRows*>(sh + L.end()); }
 
@@ -587,6 +588,7 @@ struct PathQp {
     //      the active rows and is stationary -> it then IS the optimum of the QP; otherwise restore and resume.
     // ---------------------------------------------------------------------------------------------
     static constexpr int kSaveStride = 20;   // x6 yT3 yI3 zI3 rhoI3 (+2 pad)
+    static constexpr int kPolishRounds = 40; // active-set correction rounds per polish attempt
 
     PQP_HD bool try_polish() {
         const pqp_params& prm = A.prm;
@@ -594,6 +596,8 @@ struct PathQp {
         const double gain = 1.0 / prm.polish_delta;          // penalty of an active row (times E^2/c)
         const double sgain = prm.polish_delta / prm.sigma;    // Sigma -> delta / (c D^2)
         const double tgain = gain / (rho_now * kRhoEqFactor);
+        const double tol = prm.polish_tol;
+        // P1: park the ADMM state; first guess of the active set by OSQP's rule (z - l < -y  /  u - z < y, scaled)
         ctx.phase([&](int t, Lane& ln) {
             _Pragma("unroll") for (int q = 0; q < 2; ++q) {
                 Slot& S = ln.s[q];
@@ -609,18 +613,11 @@ struct PathQp {
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                     const bool fr = S.flags & (F_FREE0 << k), eq = S.flags & (F_EQ0 << k);
                     const double e2 = S.rhoI[k] / (rho_now * (eq ? kRhoEqFactor : 1.0));     // E^2 / c of the row
-                    const double lo = raw_lo(S, k), up = raw_up(S, k);
                     const bool can = !fr && S.rhoI[k] > 0.0;
-                    const bool act_lo = can && ((S.zI[k] - lo) * e2 < -S.yI[k]);
-                    const bool act_up = can && !act_lo && ((up - S.zI[k]) * e2 < S.yI[k]);
+                    const bool act_lo = can && ((S.zI[k] - raw_lo(S, k)) * e2 < -S.yI[k]);
+                    const bool act_up = can && !act_lo && ((raw_up(S, k) - S.zI[k]) * e2 < S.yI[k]);
                     if (act_lo) fl |= (F_ACTLO0 << k);
                     if (act_up) fl |= (F_ACTUP0 << k);
-                    const bool act = act_lo || act_up;
-                    const double r = act ? gain * e2 : 0.0;
-                    S.rhoI[k] = r;
-                    S.rinvI[k] = act ? 1.0 / r : 0.0;
-                    S.yI[k] = act ? S.yI[k] : 0.0;
-                    S.zI[k] = act_lo ? lo : (act_up ? up : S.zI[k]);
                 }
                 S.flags = fl;
                 _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] *= sgain;
@@ -633,54 +630,101 @@ struct PathQp {
                         const bool act_lo = !fr && ((er->z[k] - er->lo[k]) * e2 < -er->y[k]);
                         const bool act_up = !fr && !act_lo && ((er->up[k] - er->z[k]) * e2 < er->y[k]);
                         er->act[k] = act_lo ? -1.0 : (act_up ? 1.0 : 0.0);
-                        const bool act = act_lo || act_up;
-                        const double r = act ? gain * e2 : 0.0;
-                        er->rho[k] = r; er->rinv[k] = act ? 1.0 / r : 0.0;
-                        er->y[k] = act ? er->y[k] : 0.0;
-                        er->z[k] = act_lo ? er->lo[k] : (act_up ? er->up[k] : er->z[k]);
                     }
                 }
             }
         });
         polishing_ = true;
         alpha_ = 1.0;
-        factor();
-        for (int r = 0; r < prm.polish_refine_iter; ++r) iterate();
-        // acceptance test
-        double res[5];
-        residuals(res);
-        double viol[1];
-        const double tol = prm.polish_tol;
-        ctx.template reduce_max<1>(viol, [&](int t, Lane& ln, double (&v)[1]) {
-            v[0] = 0.0;
-            double Xprev0[3];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xprev0[k] = (t > 0) ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;   // published by residuals()
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                const Slot& S = ln.s[q];
-                const double* Xp = (q == 0) ? Xprev0 : ln.s[0].x;
-                double aT[3], aI[3];
-                rows_of(S, Xp, S.x, aT, aI);
-                double w = 0.0;
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                    const bool rowreal = (S.flags & F_REAL) && (k < 2 || (S.flags & F_PRECISE));
-                    const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
-                    const double lo = raw_lo(S, k), up = raw_up(S, k);
-                    const double pv = fmax(lo - aI[k], aI[k] - up);             // violation of the true box
-                    const double dv = alo ? S.yI[k] : (aup ? -S.yI[k] : 0.0);   // wrong-signed multiplier
-                    w = fmax(w, rowreal ? fmax(pv, dv) : 0.0);
-                }
-                if (S.flags & F_LAST) {
-                    const EndRows* er = end_rows();
-                    for (int k = 0; k < 2; ++k) {
-                        const double pv = fmax(er->lo[k] - S.x[k], S.x[k] - er->up[k]);
-                        const double dv = er->act[k] < 0.0 ? er->y[k] : (er->act[k] > 0.0 ? -er->y[k] : 0.0);
-                        w = fmax(w, fmax(pv, dv));
+        bool ok = false;
+        for (int round = 0; round < kPolishRounds; ++round) {
+            // P2: penalties, multipliers and z of the current active set
+            ctx.phase([&](int t, Lane& ln) {
+                _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                    Slot& S = ln.s[q];
+                    const int i = 2 * t + q;
+                    const bool real = S.flags & F_REAL;
+                    const double* w = A.wsave + ((size_t)qp * n + (real ? i : n - 1)) * kSaveStride;
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                        const bool eq = S.flags & (F_EQ0 << k);
+                        const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
+                        const bool act = real && (alo || aup);
+                        const double e2 = w[15 + k] / (rho_now * (eq ? kRhoEqFactor : 1.0));
+                        const double r = act ? gain * e2 : 0.0;
+                        S.rhoI[k] = r;
+                        S.rinvI[k] = act ? 1.0 / r : 0.0;
+                        S.yI[k] = act ? S.yI[k] : 0.0;
+                        S.zI[k] = alo ? raw_lo(S, k) : (aup ? raw_up(S, k) : S.zI[k]);
+                    }
+                    if (S.flags & F_LAST) {
+                        EndRows* er = end_rows();
+                        for (int k = 0; k < 2; ++k) {
+                            const bool act = er->act[k] != 0.0;
+                            const double r = act ? gain * er->E[k] * er->E[k] / cscale : 0.0;
+                            er->rho[k] = r; er->rinv[k] = act ? 1.0 / r : 0.0;
+                            er->y[k] = act ? er->y[k] : 0.0;
+                            er->z[k] = er->act[k] < 0.0 ? er->lo[k] : (er->act[k] > 0.0 ? er->up[k] : er->z[k]);
+                        }
                     }
                 }
-                v[0] = fmax(v[0], w);
-            }
-        });
-        const bool ok = res[4] == 0.0 && res[0] <= tol * (1.0 + res[2]) && res[1] <= tol * (1.0 + res[3]) && viol[0] <= tol;
+            });
+            factor();
+            for (int r = 0; r < prm.polish_refine_iter; ++r) iterate();
+            // P3: KKT test of the polished point; rows that fail it change sides (primal-dual active-set step)
+            double res[5];
+            residuals(res);
+            double viol[2];
+            ctx.template reduce_max<2>(viol, [&](int t, Lane& ln, double (&v)[2]) {
+                v[0] = 0.0; v[1] = 0.0;
+                double Xprev0[3];
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) Xprev0[k] = (t > 0) ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;   // published by residuals()
+                _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                    Slot& S = ln.s[q];
+                    const double* Xp = (q == 0) ? Xprev0 : ln.s[0].x;
+                    double aT[3], aI[3];
+                    rows_of(S, Xp, S.x, aT, aI);
+                    int fl = S.flags;
+                    double w = 0.0, chg = 0.0;
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                        const bool rowreal = (S.flags & F_REAL) && (k < 2 || (S.flags & F_PRECISE)) && !(S.flags & (F_FREE0 << k));
+                        const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
+                        const double lo = raw_lo(S, k), up = raw_up(S, k);
+                        const double pvl = lo - aI[k], pvu = aI[k] - up;               // violation of the true box
+                        const double dv = alo ? S.yI[k] : (aup ? -S.yI[k] : 0.0);      // wrong-signed multiplier
+                        const double worst = fmax(fmax(pvl, pvu), dv);
+                        w = fmax(w, rowreal ? worst : 0.0);
+                        const bool drop = rowreal && (alo || aup) && dv > tol;
+                        const bool add_lo = rowreal && !alo && !aup && pvl > tol;
+                        const bool add_up = rowreal && !alo && !aup && pvu > tol;
+                        if (drop) fl &= ~((F_ACTLO0 << k) | (F_ACTUP0 << k));
+                        if (add_lo) fl |= (F_ACTLO0 << k);
+                        if (add_up) fl |= (F_ACTUP0 << k);
+                        chg = (drop || add_lo || add_up) ? 1.0 : chg;
+                    }
+                    S.flags = fl;
+                    if (S.flags & F_LAST) {
+                        EndRows* er = end_rows();
+                        for (int k = 0; k < 2; ++k) {
+                            if (er->rb[k] < 0.0) continue;      // free row
+                            const double pvl = er->lo[k] - S.x[k], pvu = S.x[k] - er->up[k];
+                            const double dv = er->act[k] < 0.0 ? er->y[k] : (er->act[k] > 0.0 ? -er->y[k] : 0.0);
+                            w = fmax(w, fmax(fmax(pvl, pvu), dv));
+                            if (er->act[k] != 0.0 && dv > tol) { er->act[k] = 0.0; chg = 1.0; }
+                            else if (er->act[k] == 0.0 && pvl > tol) { er->act[k] = -1.0; chg = 1.0; }
+                            else if (er->act[k] == 0.0 && pvu > tol) { er->act[k] = 1.0; chg = 1.0; }
+                        }
+                    }
+                    v[0] = fmax(v[0], w);
+                    v[1] = fmax(v[1], chg);
+                }
+            });
+            const bool solve_ok = res[4] == 0.0 && res[0] <= tol * (1.0 + res[2]) && res[1] <= tol * (1.0 + res[3]);
+            ok = solve_ok && viol[0] <= tol;
+#ifdef PQP_EMU_DEBUG
+            printf("  polish qp %d round %d: pri %.3e dua %.3e viol %.3e changed %g -> %s\n", qp, round, res[0], res[1], viol[0], viol[1], ok ? "ACCEPT" : "reject");
+#endif
+            if (ok || !solve_ok || viol[1] == 0.0) break;
+        }
         polishing_ = false;
         alpha_ = prm.alpha;
         // accept: keep (x, y).  reject: restore the ADMM iterate.  Either way put the ADMM penalties back.
@@ -864,6 +908,7 @@ struct PathQp {
     // ---------------------------------------------------------------------------------------------
     PQP_HD void iterate() {
         const pqp_params& prm = A.prm;
+        kkt_solves_ += 1;
         const double alpha = alpha_;
         // I1: w = R z - y, reduced right-hand side pieces, message to the previous waypoint
         ctx.phase([&](int t, Lane& ln) {
@@ -1231,6 +1276,9 @@ struct PathQp {
                             if (try_polish()) { status = PQP_STATUS_SOLVED; polished += 1; break; }
                             eps_scale *= 0.1;      // rejected: resume ADMM, try again one decade tighter
                             if (eps_scale * fmax(prm.eps_abs, prm.eps_rel) < 1e-10) { status = PQP_STATUS_SOLVED; break; }
+                        } else if (prm.polish && prm.polish_every > 0 && (it % prm.polish_every) == 0) {
+                            // a slow ADMM tail: the active set is often already right long before the residuals say so
+                            if (try_polish()) { status = PQP_STATUS_SOLVED; polished += 1; break; }
                         }
                     }
                     if (adapt) {
@@ -1256,14 +1304,16 @@ struct PathQp {
         }
         store_warm();
         const double rho_final = rho;
+        const int kkt_total = kkt_solves_;
         ctx.phase([&](int t, Lane&) {
             if (t == 0) {
                 A.wrho[qp] = rho_final;
                 if (A.status) A.status[qp] = status;
                 if (A.iters) A.iters[qp] = total_iters;
                 if (A.info) {
-                    double* f = A.info + 4 * (size_t)qp;
-                    f[0] = res[0]; f[1] = res[1]; f[2] = rho_final; f[3] = (double)last_iters + 1e-3 * polished;
+                    double* f = A.info + PQP_INFO_STRIDE * (size_t)qp;
+                    f[0] = res[0]; f[1] = res[1]; f[2] = rho_final; f[3] = (double)last_iters;
+                    f[4] = (double)polished; f[5] = (double)kkt_total;
                 }
             }
         });

@@ -1,0 +1,47 @@
+"""Generates the golden fixtures of tests/golden/*.npz from the oracle (oracle/pqp_oracle.py) and the synthetic
+generator.  The reference holds no vectors for this path, so these are produced here, by the
+build's own restatement, and pinned by the KKT certificate stored next to them.
+Run from the repo root:  python tests/golden/make_golden.py"""
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import pqp_oracle as O  # noqa: E402
+from path_optimizer_2_amd.synth import make_batch  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def make(name, n, batch, profile):
+    b = make_batch(batch, n, profile)
+    rng = np.random.default_rng(n)
+    rows, cols, colptr, pcols = O.structural_pattern(n, n)
+    st = O.OsqpSettings(eps_abs=1e-10, eps_rel=1e-10, max_iter=100000)
+    lin = np.zeros((batch, n, 3)); a_val = []; lower = []; upper = []; xs = []; ys = []; outs = []; cert = []
+    for q in range(batch):
+        lin[q] = O.first_linearization(b["ref"][q])
+        if q % 2 == 1:
+            lin[q] += rng.normal(scale=[0.2, 0.04, 0.01], size=(n, 3))
+        Pd, A, lo, up, sz = O.assemble_path_qp(b["ref"][q], lin[q], b["bounds"][q], b["scal"][q])
+        r = O.osqp_admm(sp.diags(Pd), np.zeros(sz["vars"]), A, lo, up, st)
+        assert r["status"] == "solved"
+        c = O.kkt_certificate(sp.diags(Pd), np.zeros(sz["vars"]), A, lo, up, r["x"], r["y"])
+        a_val.append(A[rows, cols]); lower.append(lo); upper.append(up); xs.append(r["x"]); ys.append(r["y"])
+        outs.append(O.unpack_path(r["x"], b["ref"][q])); cert.append([c["pri"], c["stat"], c["comp"]])
+    # the two-pass pipeline output (optimizePath) for the un-perturbed start
+    path_out = np.stack([O.solve_path(b["ref"][q], b["bounds"][q], b["scal"][q], st=st)[-1]["out"] for q in range(batch)])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), ref=b["ref"], bounds=b["bounds"], scal=b["scal"], lin=lin,
+                        rows=rows, cols=cols, colptr=colptr, pcols=pcols, a_val=np.array(a_val), lower=np.array(lower),
+                        upper=np.array(upper), x_star=np.array(xs), y_star=np.array(ys), out_star=np.array(outs),
+                        cert=np.array(cert), path_out=path_out)
+    print(name, "cert max", np.max(cert))
+
+
+if __name__ == "__main__":
+    make("path_n8", 8, 4, "varied")
+    make("path_n80", 80, 4, "uniform")

@@ -1,0 +1,67 @@
+"""The device algorithm source (pqp_path_lane.hpp), compiled for the host and executed phase by phase, lane by
+lane (tests/emu), against the oracle.  This is how the HIP kernel's algorithm is validated on a box without a
+GPU; the -m gpu tests then check the real kernel through the C ABI."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import emu_util as E
+import pqp_oracle as O
+from path_optimizer_2_amd.synth import make_batch
+
+TIGHT = O.OsqpSettings(eps_abs=1e-9, eps_rel=1e-9, max_iter=40000)
+
+
+@pytest.mark.parametrize("n,profile", [(80, "uniform"), (120, "varied"), (31, "varied")])
+def test_plain_admm_follows_the_oracle_iteration_for_iteration(n, profile):
+    b = make_batch(3, n, profile)
+    for eps in (2e-3, 1e-5):
+        r = E.solve(E.params(eps_abs=eps, eps_rel=eps), b["ref"], b["bounds"], b["scal"], passes=1)
+        for q in range(3):
+            ref = O.solve_path(b["ref"][q], b["bounds"][q], b["scal"][q], st=O.OsqpSettings(eps_abs=eps, eps_rel=eps))
+            assert r["status"][q] == 1
+            assert r["iters"][q] == sum(x["iters"] for x in ref)          # same ADMM, same stopping check
+            assert np.abs(r["out"][q] - ref[-1]["out"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("n,profile,batch", [(80, "uniform", 16), (200, "varied", 4), (9, "uniform", 4)])
+def test_polished_solution_is_the_converged_optimum(n, profile, batch):
+    b = make_batch(batch, n, profile)
+    prm = E.params(eps_abs=1e-4, eps_rel=1e-4, polish=1, polish_every=25, adaptive_rho_interval=25)
+    r = E.solve(prm, b["ref"], b["bounds"], b["scal"], passes=1)
+    assert (r["status"] == 1).all() and (r["info"][:, 4] == 2).all()      # both passes ended in an accepted polish
+    for q in range(min(batch, 4)):
+        ref = O.solve_path(b["ref"][q], b["bounds"][q], b["scal"][q], st=TIGHT)
+        # the ADMM oracle at eps 1e-9 is itself only good to ~1e-6 on the weakly determined l of long paths
+        assert np.abs(r["out"][q][:, 3:5] - ref[-1]["out"][:, 3:5]).max() < (1e-6 if n <= 80 else 5e-6)
+        # ... so the sharper statement is the solver-independent certificate of the polished point itself
+        Pd, A, lo, up = ref[-1]["qp"]
+        lin = ref[0]["out"][:, 3:6]
+        x, y = E.to_reference_order(r["wx"][q], r["wy"][q], r["wye"][q], n)
+        Pd2, A2, lo2, up2, sz = O.assemble_path_qp(b["ref"][q], E.solve(prm, b["ref"][q:q + 1], b["bounds"][q:q + 1], b["scal"][q:q + 1], passes=0)["out"][0][:, 3:6], b["bounds"][q], b["scal"][q])
+        cert = O.kkt_certificate(sp.diags(Pd2), np.zeros(sz["vars"]), A2, lo2, up2, x, y)
+        assert cert["pri"] < 1e-8 and cert["stat"] < 1e-7 and cert["comp"] < 1e-8, cert
+    assert r["iters"].max() <= 400
+
+
+def test_rough_constraints_mode():
+    n = 70
+    b = make_batch(2, n)
+    oprm = O.PathQpParams(rough_constraints_far_away=True, precise_planning_length=9.0)
+    prm = E.params(eps_abs=1e-8, eps_rel=1e-8, max_iter=40000, rough_constraints_far_away=1, precise_planning_length=9.0)
+    r = E.solve(prm, b["ref"], b["bounds"], b["scal"], passes=0)
+    for q in range(2):
+        ref = O.solve_path(b["ref"][q], b["bounds"][q], b["scal"][q], prm=oprm, st=TIGHT, passes=0)
+        assert r["status"][q] == 1
+        assert np.abs(r["out"][q][:, 3:6] - ref[-1]["out"][:, 3:6]).max() < 1e-6
+
+
+def test_given_linearisation_point():
+    n = 40
+    b = make_batch(2, n, "varied")
+    rng = np.random.default_rng(1)
+    lin = np.stack([O.first_linearization(b["ref"][q]) for q in range(2)]) + rng.normal(scale=[0.1, 0.02, 0.005], size=(2, n, 3))
+    r = E.solve(E.params(eps_abs=1e-8, eps_rel=1e-8, max_iter=40000), b["ref"], b["bounds"], b["scal"], lin=lin, passes=0)
+    for q in range(2):
+        ref = O.solve_path(b["ref"][q], b["bounds"][q], b["scal"][q], st=TIGHT, passes=0, lin0=lin[q])
+        assert np.abs(r["out"][q][:, 3:6] - ref[-1]["out"][:, 3:6]).max() < 1e-6
