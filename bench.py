@@ -95,7 +95,8 @@ def main():
     gathered = [torch.empty_like(out) for _ in range(world)] if (args.gather and world > 1) else None
 
     prm = capi.default_params(eps_abs=args.eps, eps_rel=args.eps, polish=0 if args.no_polish else 1,
-                              polish_every=args.polish_every, adaptive_rho_interval=args.rho_interval)
+                              polish_every=args.polish_every, adaptive_rho_interval=args.rho_interval,
+                              polish_warm_set=0 if args.no_polish else 1, polish_refine_iter=3)
     h = capi.Handle(prm, device=local_rank, max_batch=batch, max_n=n)
 
     def step():
@@ -148,7 +149,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: batch={batch} QPs/GPU, N={n}, shared sparsity, synthetic obstacle bounds ({args.profile})",
-                       "batch_per_gpu": batch, "n_waypoints": n, "eps_abs": args.eps, "eps_rel": args.eps, "polish": not args.no_polish, "polish_every": args.polish_every, "adaptive_rho_interval": args.rho_interval,
+                       "batch_per_gpu": batch, "n_waypoints": n, "eps_abs": args.eps, "eps_rel": args.eps, "polish": not args.no_polish, "polish_every": args.polish_every, "polish_warm_set": not args.no_polish, "polish_refine_iter": 3, "adaptive_rho_interval": args.rho_interval,
                        "passes": "cold solve + 1 re-linearised warm re-solve (optimizePath)",
                        "parallelism": f"{world} x independent shards" + (", RCCL all_gather of results" if gathered is not None else "")},
             "admm_iters": {"min": int(it_np.min()), "median": float(np.median(it_np)), "p99": float(np.percentile(it_np, 99)),

@@ -113,6 +113,8 @@ typedef struct pqp_params {
     int32_t polish;                   /* 0 (reference) ; bench and parity tests use 1 */
     int32_t polish_refine_iter;       /* 4     */
     int32_t polish_every;             /* 0: only when the residual test passes; k: also try every k iterations */
+    int32_t polish_warm_set;          /* 1: a warm re-linearised re-solve starts with a polish on the previous pass's active set */
+    int32_t reserved2;
     double polish_delta;              /* 1e-6  regularisation; active rows get penalty 1/delta */
     double polish_tol;                /* 1e-7  KKT acceptance tolerance of the polished point  */
 } pqp_params;

@@ -24,7 +24,7 @@ class PqpParams(C.Structure):
         ("alpha", C.c_double), ("max_iter", C.c_int32), ("scaling", C.c_int32),
         ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32),
         ("adaptive_rho_tolerance", C.c_double), ("check_termination", C.c_int32), ("polish", C.c_int32),
-        ("polish_refine_iter", C.c_int32), ("polish_every", C.c_int32), ("polish_delta", C.c_double), ("polish_tol", C.c_double),
+        ("polish_refine_iter", C.c_int32), ("polish_every", C.c_int32), ("polish_warm_set", C.c_int32), ("reserved2", C.c_int32), ("polish_delta", C.c_double), ("polish_tol", C.c_double),
     ]
 
 

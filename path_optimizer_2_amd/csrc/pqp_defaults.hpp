@@ -34,6 +34,8 @@ inline void default_params(pqp_params* p) {
     p->polish = 0;
     p->polish_refine_iter = 4;
     p->polish_every = 0;
+    p->polish_warm_set = 0;
+    p->reserved2 = 0;
     p->polish_delta = 1e-6;
     p->polish_tol = 1e-7;
 }

@@ -26,8 +26,38 @@ namespace pqp {
 // -------------------------------------------------------------------------------------------------------
 // device execution context for PathQp: a phase is the code between two workgroup barriers
 // -------------------------------------------------------------------------------------------------------
+// wave / workgroup reductions shared by the hot and the cold context
+template <int NW, int K, bool MAX>
+__device__ __forceinline__ void wg_reduce(double (&v)[K], double* shp) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double x = v[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o = __shfl_xor(x, off, 64);
+            x = MAX ? fmax(x, o) : x + o;
+        }
+        v[k] = x;
+    }
+    if (NW > 1) {
+        double* red = shp + ShLayout{64 * NW}.red();
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0)
+            for (int k = 0; k < K; ++k) red[k * 16 + w] = v[k];
+        __syncthreads();
+        for (int k = 0; k < K; ++k) {
+            double x = red[k * 16];
+            for (int j = 1; j < NW; ++j) x = MAX ? fmax(x, red[k * 16 + j]) : x + red[k * 16 + j];
+            v[k] = x;
+        }
+    }
+    __syncthreads();
+}
+
+// Context whose lane state is a local struct (SROA -> registers).  A phase is the code between two workgroup
+// barriers (for a one-wave workgroup the barrier is only a wait on outstanding LDS traffic).
 template <int NW>
-struct DevCtx {
+struct RegCtx {
     Lane lane;
     double* shp;
     __device__ __forceinline__ int T() const { return 64 * NW; }
@@ -37,50 +67,96 @@ struct DevCtx {
         f((int)threadIdx.x, lane);
         __syncthreads();
     }
-    template <int K, bool MAX>
-    __device__ __forceinline__ void reduce(double (&v)[K]) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            double x = v[k];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const double o = __shfl_xor(x, off, 64);
-                x = MAX ? fmax(x, o) : x + o;
-            }
-            v[k] = x;
-        }
-        if (NW > 1) {
-            double* red = shp + ShLayout{64 * NW}.red();
-            const int w = threadIdx.x >> 6;
-            if ((threadIdx.x & 63) == 0)
-                for (int k = 0; k < K; ++k) red[k * 16 + w] = v[k];
-            __syncthreads();
-            for (int k = 0; k < K; ++k) {
-                double x = red[k * 16];
-                for (int j = 1; j < NW; ++j) x = MAX ? fmax(x, red[k * 16 + j]) : x + red[k * 16 + j];
-                v[k] = x;
-            }
-        }
+    template <int K, class F>
+    __device__ __forceinline__ void reduce_max(double (&out)[K], F f) {
+        f((int)threadIdx.x, lane, out);
+        wg_reduce<NW, K, true>(out, shp);
+    }
+    template <int K, class F>
+    __device__ __forceinline__ void reduce_sum(double (&out)[K], F f) {
+        f((int)threadIdx.x, lane, out);
+        wg_reduce<NW, K, false>(out, shp);
+    }
+    template <class PQ>
+    __device__ __forceinline__ void cold(PQ& pq, int op, int i0, int i1, double d0) { pq.do_cold(op, i0, i1, d0); }
+};
+
+// The rare, register-hungry part of the solver (assemble, Ruiz, factorisation, polish bookkeeping, unpack) runs
+// here, out of line, one function per operation: the lane state comes in through memory, lives in registers
+// inside, goes back through memory.  Whatever these functions spill never touches the ADMM loop.
+template <int NW, int OP>
+__device__ __noinline__ Uni cold_entry(const PathSolveArgs* args, int qp, double* shp, Lane* mem, Uni u, int i0, int i1, double d0) {
+    RegCtx<NW> cctx;
+    cctx.shp = shp;
+    cctx.lane.s[0] = mem->s[0];
+    cctx.lane.s[1] = mem->s[1];
+    PathQp<RegCtx<NW>> c(cctx, *args, qp);
+    c.set_uni(u);
+    c.do_cold(OP, i0, i1, d0);
+    mem->s[0] = cctx.lane.s[0];
+    mem->s[1] = cctx.lane.s[1];
+    return c.get_uni();
+}
+
+// Hot context: the lane state is a local struct that SROA turns into registers; a phase is the code between two
+// workgroup barriers (for a one-wave workgroup the barrier is only a wait on outstanding LDS traffic).
+template <int NW>
+struct DevCtx {
+    Lane lane;
+    Lane* mem;
+    double* shp;
+    const PathSolveArgs* args;
+    __device__ __forceinline__ int T() const { return 64 * NW; }
+    __device__ __forceinline__ double* sh() { return shp; }
+    template <class F>
+    __device__ __forceinline__ void phase(F f) {
+        f((int)threadIdx.x, lane);
         __syncthreads();
     }
     template <int K, class F>
     __device__ __forceinline__ void reduce_max(double (&out)[K], F f) {
         f((int)threadIdx.x, lane, out);
-        reduce<K, true>(out);
+        wg_reduce<NW, K, true>(out, shp);
     }
     template <int K, class F>
     __device__ __forceinline__ void reduce_sum(double (&out)[K], F f) {
         f((int)threadIdx.x, lane, out);
-        reduce<K, false>(out);
+        wg_reduce<NW, K, false>(out, shp);
+    }
+    // hot -> cold -> hot: spill the whole lane state once, explicitly, around the out-of-line call
+    template <class PQ>
+    __device__ __forceinline__ void cold(PQ& pq, int op, int i0, int i1, double d0) {
+#ifdef PQP_MONOLITH
+        pq.do_cold(op, i0, i1, d0);
+        return;
+#endif
+        copy_hot(*mem, lane);
+        Uni u;
+        switch (op) {      // `op` is a literal at every call site: one case survives inlining
+            case COLD_BEGIN_PASS: u = cold_entry<NW, COLD_BEGIN_PASS>(args, pq.qp, shp, mem, pq.get_uni(), i0, i1, d0); break;
+            case COLD_REFACTOR: u = cold_entry<NW, COLD_REFACTOR>(args, pq.qp, shp, mem, pq.get_uni(), i0, i1, d0); break;
+            case COLD_END_PASS: u = cold_entry<NW, COLD_END_PASS>(args, pq.qp, shp, mem, pq.get_uni(), i0, i1, d0); break;
+            default: u = cold_entry<NW, COLD_FINISH>(args, pq.qp, shp, mem, pq.get_uni(), i0, i1, d0); break;
+        }
+        copy_hot(lane, *mem);
+        pq.set_uni(u);
+    }
+    // only what the ADMM loop reads: Slot (the SlotSetup part of a Lane is cold-only)
+    __device__ __forceinline__ static void copy_hot(Lane& dst, const Lane& src) {
+        dst.s[0] = src.s[0];
+        dst.s[1] = src.s[1];
     }
 };
 
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) path_solve_kernel(const PathSolveArgs args) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    Lane memlane;
     for (int qp = blockIdx.x; qp < args.batch; qp += gridDim.x) {
         DevCtx<NW> ctx;
+        ctx.mem = &memlane;
         ctx.shp = smem;
+        ctx.args = &args;
         PathQp<DevCtx<NW>> solver(ctx, args, qp);
         solver.run();
         __syncthreads();
@@ -511,16 +587,17 @@ int pqp_path_solve_device(pqp_handle* h, int batch, int n, const double* ref, co
             (rc = h->wrho.ensure((size_t)batch * 8)))
             return rc;
     }
-    if ((rc = h->wsave.ensure(bn * 20 * 8))) return rc;
     pqp::PathSolveArgs a;
     std::memset(&a, 0, sizeof(a));
     a.batch = batch; a.n = n; a.passes = passes; a.warm = warm ? 1 : 0;
     a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
     a.status = status; a.iters = iters; a.info = info;
-    a.wx = h->wx.as<double>(); a.wy = h->wy.as<double>(); a.wye = h->wye.as<double>(); a.wrho = h->wrho.as<double>(); a.wsave = h->wsave.as<double>();
+    a.wx = h->wx.as<double>(); a.wy = h->wy.as<double>(); a.wye = h->wye.as<double>(); a.wrho = h->wrho.as<double>();
     a.prm = h->prm;
     int nw = 1;
     while (128 * nw < n) nw *= 2;
+    if ((rc = h->wsave.ensure((size_t)batch * 128 * nw * 44 * 8))) return rc;
+    a.wsave = h->wsave.as<double>();
     const size_t lds = (size_t)pqp::ShLayout{64 * nw}.total() * 8;
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
     switch (nw) {

@@ -70,9 +70,33 @@ struct PathSolveArgs {
     double* wy;             // [batch][n][6]  (yT[3], yK, yF, yR)
     double* wye;            // [batch][2]
     double* wrho;           // [batch]
-    double* wsave;          // [batch][n][16] ADMM state parked while a polish is tried
+    double* wsave;          // [batch][2T][44] save area: ADMM state during a polish + iterates parked around factor()
     pqp_params prm;
 };
+
+// ---- scalar helpers ----------------------------------------------------------------------------------------
+// reciprocal and reciprocal square root: on the device the hardware seed + two Newton steps (~1 ulp) instead of the
+// 30-40 instruction IEEE division / sqrt sequences -- the cold code is instruction-fetch bound, so code size is time
+#if defined(__HIP_DEVICE_COMPILE__)
+PQP_HD double rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+PQP_HD double rsq(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r;
+}
+// one out-of-line copy of sin/cos (their argument-reduction code is large)
+__device__ __noinline__ void sincos_shared(double a, double* s, double* c) { sincos(a, s, c); }
+#else
+PQP_HD double rcp(double x) { return 1.0 / x; }
+PQP_HD double rsq(double x) { return 1.0 / sqrt(x); }
+inline void sincos_shared(double a, double* s, double* c) { *s = sin(a); *c = cos(a); }
+#endif
 
 // ---- small dense helpers: sym3 = [00,01,02,11,12,22], mat3 row-major ---------------------------------
 PQP_HD double fmax3(double a, double b, double c) { return fmax(a, fmax(b, c)); }
@@ -81,14 +105,14 @@ PQP_HD double limit_scaling(double v) { v = v < kMinScaling ? 1.0 : v; return v 
 // inverse of an SPD sym3 through its LDL^T factorisation
 PQP_HD void sym3_inv(const double* S, double* R) {
     const double d0 = S[0];
-    const double i0 = 1.0 / d0;
+    const double i0 = rcp(d0);
     const double l10 = S[1] * i0, l20 = S[2] * i0;
     const double d1 = S[3] - l10 * S[1];
-    const double i1 = 1.0 / d1;
+    const double i1 = rcp(d1);
     const double t21 = S[4] - l20 * S[1];
     const double l21 = t21 * i1;
     const double d2 = S[5] - l20 * S[2] - l21 * t21;
-    const double i2 = 1.0 / d2;
+    const double i2 = rcp(d2);
     // inv(L): [[1,0,0],[-l10,1,0],[l10*l21-l20,-l21,1]]
     const double m10 = -l10, m21 = -l21, m20 = l10 * l21 - l20;
     R[0] = i0 + m10 * m10 * i1 + m20 * m20 * i2;
@@ -178,7 +202,9 @@ PQP_HD void soft_bounds(double lb, double ub, double margin, double min_clearanc
 PQP_HD void transition_block(const double* lin_p, double k_next, double s_p, double s_i, double kref_p,
                              double* a, double* c) {
     const double l = lin_p[0], psi = lin_p[1], k = lin_p[2];
-    const double t = tan(psi), cs = cos(psi);
+    double sn, cs;
+    sincos_shared(psi, &sn, &cs);
+    const double t = sn / cs;
     const double one_kl = 1 - k * l;
     const double df00 = -k * t;
     const double df01 = one_kl / (cs * cs);
@@ -284,6 +310,21 @@ PQP_HD double cost_diag(const pqp_params& prm, int flags, int k) {
 PQP_HD double coef_front(const pqp_params& prm, int flags) { return ((flags & F_REAL) && (flags & F_PRECISE)) ? prm.front_length : 0.0; }
 PQP_HD double coef_rear(const pqp_params& prm, int flags) { return ((flags & F_REAL) && (flags & F_PRECISE)) ? prm.rear_length : 0.0; }
 
+// uniform (per-QP) solver scalars; handed by value across the hot / cold boundary
+struct Uni {
+    double rho, cscale, kap, alpha;
+    int kkt_solves;
+    int polishing;
+};
+// cold operations (rare, register-hungry): executed out of line on a memory-resident copy of the lane state
+enum ColdOp : int {
+    COLD_BEGIN_PASS = 0,     // i0 = pass index, i1 = have_warm: [load, warm-load], assemble, Ruiz, start rows, factor
+    COLD_REFACTOR = 1,       // i0 = RefactorKind, d0 = parameter: penalty change + factor
+    COLD_END_PASS = 2,       // i0 = polish accepted: [polish_end(true)], unpack
+    COLD_FINISH = 3          // store the warm state
+};
+enum RefactorKind : int { RF_RESCALE = 0 /* d0 = ratio */, RF_POLISH_BEGIN = 1, RF_POLISH_UPDATE = 2 /* d0 = threshold */, RF_POLISH_REJECT = 3 };
+
 // =======================================================================================================
 // The solver.  Ctx provides:
 //   int  T()                              threads per QP (power of two, >= 1)
@@ -355,7 +396,11 @@ struct PathQp {
     PQP_HD void assemble() {
         const pqp_params& prm = A.prm;
         const double* sc = A.scal + (size_t)qp * PQP_SCAL_STRIDE;
-        kap = tan(sc[5]) / prm.wheel_base;                  // curvature box (:226-231), the same for every waypoint
+        {   // curvature box (:226-231), the same for every waypoint
+            double sn, cn;
+            sincos_shared(sc[5], &sn, &cn);
+            kap = (sn / cn) / prm.wheel_base;
+        }
         ctx.phase([&](int t, Lane& ln) {
             _Pragma("unroll") for (int q = 0; q < 2; ++q) {
                 Slot& S = ln.s[q];
@@ -494,15 +539,15 @@ struct PathQp {
                     _Pragma("unroll") for (int k = 0; k < 6; ++k) {
                         const double cnk = fmax(cn[k] * W.D[k], c_now * W.D[k] * W.D[k] * cost_diag(prm, S.flags, k));
                         const double rnk = rn[k] * W.E[k];
-                        const double dnew = W.D[k] / sqrt(limit_scaling(cnk));
-                        const double enew = W.E[k] / sqrt(limit_scaling(rnk));
+                        const double dnew = W.D[k] * rsq(limit_scaling(cnk));
+                        const double enew = W.E[k] * rsq(limit_scaling(rnk));
                         W.D[k] = colreal[k] ? dnew : 1.0;
                         W.E[k] = rowreal[k] ? enew : 1.0;
                         if (colreal[k]) v[0] += fabs(c_now * W.D[k] * W.D[k] * cost_diag(prm, S.flags, k));
                     }
                     if (last) {
-                        er->E[0] = ee0 / sqrt(limit_scaling(ren0));
-                        er->E[1] = ee1 / sqrt(limit_scaling(ren1));
+                        er->E[0] = ee0 * rsq(limit_scaling(ren0));
+                        er->E[1] = ee1 * rsq(limit_scaling(ren1));
                     }
                 }
             });
@@ -519,9 +564,9 @@ struct PathQp {
                 Slot& S = ln.s[q];
                 const SlotSetup& W = ln.w[q];
                 const bool real = S.flags & F_REAL, precise = S.flags & F_PRECISE;
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] = prm.sigma / (c * W.D[k] * W.D[k]);
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] = prm.sigma * rcp(c * W.D[k] * W.D[k]);
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] = real ? rho_now * kRhoEqFactor * W.E[k] * W.E[k] / c : 0.0;
-                int fl = S.flags & ~F_ROWBITS;
+                int fl = S.flags & ~((7 * F_FREE0) | (7 * F_EQ0));      // the active-set bits of a previous polish survive
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                     const bool rowreal = real && (k < 2 || precise);
                     const double e = W.E[3 + k], e2 = e * e / c;
@@ -530,7 +575,7 @@ struct PathQp {
                     const bool eq_row = !free_row && (su - sl < kRhoTol);
                     const double r = !rowreal ? 0.0 : (free_row ? kRhoMin * e2 : (eq_row ? rho_now * kRhoEqFactor * e2 : rho_now * e2));
                     S.rhoI[k] = r;
-                    S.rinvI[k] = r > 0.0 ? 1.0 / r : 0.0;
+                    S.rinvI[k] = r > 0.0 ? rcp(r) : 0.0;
                     if (rowreal && free_row) fl |= (F_FREE0 << k);
                     if (rowreal && eq_row) fl |= (F_EQ0 << k);
                 }
@@ -546,7 +591,7 @@ struct PathQp {
                         else rb = e2;
                         er->rb[k] = rb;
                         const double r = rb < 0.0 ? -rb : rho_now * rb;
-                        er->rho[k] = r; er->rinv[k] = 1.0 / r;
+                        er->rho[k] = r; er->rinv[k] = rcp(r);
                     }
                 }
             }
@@ -564,14 +609,14 @@ struct PathQp {
                     const bool fr = S.flags & (F_FREE0 << k);
                     const double r = fr ? S.rhoI[k] : S.rhoI[k] * ratio;
                     S.rhoI[k] = r;
-                    S.rinvI[k] = r > 0.0 ? 1.0 / r : 0.0;
+                    S.rinvI[k] = r > 0.0 ? rcp(r) : 0.0;
                 }
                 if (S.flags & F_LAST) {
                     EndRows* er = end_rows();
                     for (int k = 0; k < 2; ++k) {
                         const double rb = er->rb[k];
                         const double r = rb < 0.0 ? -rb : rho_now * rb;
-                        er->rho[k] = r; er->rinv[k] = 1.0 / r;
+                        er->rho[k] = r; er->rinv[k] = rcp(r);
                     }
                 }
             }
@@ -587,24 +632,42 @@ struct PathQp {
     //   3. accept iff the polished point is primal feasible on the inactive rows, has the right dual signs on
     //      the active rows and is stationary -> it then IS the optimum of the QP; otherwise restore and resume.
     // ---------------------------------------------------------------------------------------------
-    static constexpr int kSaveStride = 20;   // x6 yT3 yI3 zI3 rhoI3 (+2 pad)
+    static constexpr int kSaveStride = 44;   // polish: x6 yT3 yI3 zI3 rhoI3 (+2 pad) | park: x6 yT3 yI3 zI3 bT3 lo2 up2 (+2 pad)
+    static constexpr int kParkOffset = 20;
     static constexpr int kPolishRounds = 40; // active-set correction rounds per polish attempt
 
-    PQP_HD bool try_polish() {
+    // how badly inequality row k fails the KKT test at the polished point: violation of its true box when it is
+    // treated as inactive, wrong-signed multiplier when it is treated as active (0 for rows that do not exist)
+    PQP_HD double row_violation(const Slot& S, int k, double ax) const {
+        const bool rowreal = (S.flags & F_REAL) && (k < 2 || (S.flags & F_PRECISE)) && !(S.flags & (F_FREE0 << k));
+        const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
+        const double pv = fmax(raw_lo(S, k) - ax, ax - raw_up(S, k));
+        const double dv = alo ? S.yI[k] : (aup ? -S.yI[k] : 0.0);
+        return rowreal ? fmax(fmax(pv, dv), 0.0) : 0.0;
+    }
+    PQP_HD double end_violation(const EndRows* er, int k, double ax) const {
+        if (er->rb[k] < 0.0) return 0.0;      // free row
+        const double pv = fmax(er->lo[k] - ax, ax - er->up[k]);
+        const double dv = er->act[k] < 0.0 ? er->y[k] : (er->act[k] > 0.0 ? -er->y[k] : 0.0);
+        return fmax(fmax(pv, dv), 0.0);
+    }
+
+    // --- polish piece 1: park the ADMM state; first guess of the active set by OSQP's rule
+    //     (z - l < -y  /  u - z < y, in scaled units); switch the penalties of T rows and Sigma to polish values
+    PQP_HD void polish_begin(bool keep_set) {
         const pqp_params& prm = A.prm;
         const double rho_now = rho;
         const double gain = 1.0 / prm.polish_delta;          // penalty of an active row (times E^2/c)
         const double sgain = prm.polish_delta / prm.sigma;    // Sigma -> delta / (c D^2)
         const double tgain = gain / (rho_now * kRhoEqFactor);
-        const double tol = prm.polish_tol;
-        // P1: park the ADMM state; first guess of the active set by OSQP's rule (z - l < -y  /  u - z < y, scaled)
+        const double irho = 1.0 / rho_now, irho_eq = 1.0 / (rho_now * kRhoEqFactor);
         ctx.phase([&](int t, Lane& ln) {
             _Pragma("unroll") for (int q = 0; q < 2; ++q) {
                 Slot& S = ln.s[q];
                 const int i = 2 * t + q;
                 const bool real = S.flags & F_REAL;
                 if (real) {
-                    double* w = A.wsave + ((size_t)qp * n + i) * kSaveStride;
+                    double* w = A.wsave + ((size_t)qp * (2 * T) + i) * kSaveStride;
                     _Pragma("unroll") for (int k = 0; k < 6; ++k) w[k] = S.x[k];
                     _Pragma("unroll") for (int k = 0; k < 3; ++k) { w[6 + k] = S.yT[k]; w[9 + k] = S.yI[k]; w[12 + k] = S.zI[k]; w[15 + k] = S.rhoI[k]; }
                 }
@@ -612,7 +675,7 @@ struct PathQp {
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] *= tgain;
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                     const bool fr = S.flags & (F_FREE0 << k), eq = S.flags & (F_EQ0 << k);
-                    const double e2 = S.rhoI[k] / (rho_now * (eq ? kRhoEqFactor : 1.0));     // E^2 / c of the row
+                    const double e2 = S.rhoI[k] * (eq ? irho_eq : irho);     // E^2 / c of the row
                     const bool can = !fr && S.rhoI[k] > 0.0;
                     const bool act_lo = can && ((S.zI[k] - raw_lo(S, k)) * e2 < -S.yI[k]);
                     const bool act_up = can && !act_lo && ((raw_up(S, k) - S.zI[k]) * e2 < S.yI[k]);
@@ -629,111 +692,123 @@ struct PathQp {
                         const double e2 = er->E[k] * er->E[k] / cscale;
                         const bool act_lo = !fr && ((er->z[k] - er->lo[k]) * e2 < -er->y[k]);
                         const bool act_up = !fr && !act_lo && ((er->up[k] - er->z[k]) * e2 < er->y[k]);
-                        er->act[k] = act_lo ? -1.0 : (act_up ? 1.0 : 0.0);
+                        er->act[k] = keep_set ? (fr ? 0.0 : er->act[k]) : (act_lo ? -1.0 : (act_up ? 1.0 : 0.0));
                     }
                 }
             }
         });
-        polishing_ = true;
-        alpha_ = 1.0;
-        bool ok = false;
-        for (int round = 0; round < kPolishRounds; ++round) {
-            // P2: penalties, multipliers and z of the current active set
-            ctx.phase([&](int t, Lane& ln) {
-                _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                    Slot& S = ln.s[q];
-                    const int i = 2 * t + q;
-                    const bool real = S.flags & F_REAL;
-                    const double* w = A.wsave + ((size_t)qp * n + (real ? i : n - 1)) * kSaveStride;
-                    _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                        const bool eq = S.flags & (F_EQ0 << k);
-                        const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
-                        const bool act = real && (alo || aup);
-                        const double e2 = w[15 + k] / (rho_now * (eq ? kRhoEqFactor : 1.0));
-                        const double r = act ? gain * e2 : 0.0;
-                        S.rhoI[k] = r;
-                        S.rinvI[k] = act ? 1.0 / r : 0.0;
-                        S.yI[k] = act ? S.yI[k] : 0.0;
-                        S.zI[k] = alo ? raw_lo(S, k) : (aup ? raw_up(S, k) : S.zI[k]);
-                    }
-                    if (S.flags & F_LAST) {
-                        EndRows* er = end_rows();
-                        for (int k = 0; k < 2; ++k) {
-                            const bool act = er->act[k] != 0.0;
-                            const double r = act ? gain * er->E[k] * er->E[k] / cscale : 0.0;
-                            er->rho[k] = r; er->rinv[k] = act ? 1.0 / r : 0.0;
-                            er->y[k] = act ? er->y[k] : 0.0;
-                            er->z[k] = er->act[k] < 0.0 ? er->lo[k] : (er->act[k] > 0.0 ? er->up[k] : er->z[k]);
-                        }
-                    }
-                }
-            });
-            factor();
-            for (int r = 0; r < prm.polish_refine_iter; ++r) iterate();
-            // P3: KKT test of the polished point; rows that fail it change sides (primal-dual active-set step)
-            double res[5];
-            residuals(res);
-            double viol[2];
-            ctx.template reduce_max<2>(viol, [&](int t, Lane& ln, double (&v)[2]) {
-                v[0] = 0.0; v[1] = 0.0;
-                double Xprev0[3];
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) Xprev0[k] = (t > 0) ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;   // published by residuals()
-                _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                    Slot& S = ln.s[q];
-                    const double* Xp = (q == 0) ? Xprev0 : ln.s[0].x;
-                    double aT[3], aI[3];
-                    rows_of(S, Xp, S.x, aT, aI);
-                    int fl = S.flags;
-                    double w = 0.0, chg = 0.0;
-                    _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                        const bool rowreal = (S.flags & F_REAL) && (k < 2 || (S.flags & F_PRECISE)) && !(S.flags & (F_FREE0 << k));
-                        const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
-                        const double lo = raw_lo(S, k), up = raw_up(S, k);
-                        const double pvl = lo - aI[k], pvu = aI[k] - up;               // violation of the true box
-                        const double dv = alo ? S.yI[k] : (aup ? -S.yI[k] : 0.0);      // wrong-signed multiplier
-                        const double worst = fmax(fmax(pvl, pvu), dv);
-                        w = fmax(w, rowreal ? worst : 0.0);
-                        const bool drop = rowreal && (alo || aup) && dv > tol;
-                        const bool add_lo = rowreal && !alo && !aup && pvl > tol;
-                        const bool add_up = rowreal && !alo && !aup && pvu > tol;
-                        if (drop) fl &= ~((F_ACTLO0 << k) | (F_ACTUP0 << k));
-                        if (add_lo) fl |= (F_ACTLO0 << k);
-                        if (add_up) fl |= (F_ACTUP0 << k);
-                        chg = (drop || add_lo || add_up) ? 1.0 : chg;
-                    }
-                    S.flags = fl;
-                    if (S.flags & F_LAST) {
-                        EndRows* er = end_rows();
-                        for (int k = 0; k < 2; ++k) {
-                            if (er->rb[k] < 0.0) continue;      // free row
-                            const double pvl = er->lo[k] - S.x[k], pvu = S.x[k] - er->up[k];
-                            const double dv = er->act[k] < 0.0 ? er->y[k] : (er->act[k] > 0.0 ? -er->y[k] : 0.0);
-                            w = fmax(w, fmax(fmax(pvl, pvu), dv));
-                            if (er->act[k] != 0.0 && dv > tol) { er->act[k] = 0.0; chg = 1.0; }
-                            else if (er->act[k] == 0.0 && pvl > tol) { er->act[k] = -1.0; chg = 1.0; }
-                            else if (er->act[k] == 0.0 && pvu > tol) { er->act[k] = 1.0; chg = 1.0; }
-                        }
-                    }
-                    v[0] = fmax(v[0], w);
-                    v[1] = fmax(v[1], chg);
-                }
-            });
-            const bool solve_ok = res[4] == 0.0 && res[0] <= tol * (1.0 + res[2]) && res[1] <= tol * (1.0 + res[3]);
-            ok = solve_ok && viol[0] <= tol;
-#ifdef PQP_EMU_DEBUG
-            printf("  polish qp %d round %d: pri %.3e dua %.3e viol %.3e changed %g -> %s\n", qp, round, res[0], res[1], viol[0], viol[1], ok ? "ACCEPT" : "reject");
-#endif
-            if (ok || !solve_ok || viol[1] == 0.0) break;
-        }
-        polishing_ = false;
-        alpha_ = prm.alpha;
-        // accept: keep (x, y).  reject: restore the ADMM iterate.  Either way put the ADMM penalties back.
+    }
+
+    // --- polish piece 2: penalties, multipliers and z of the current active set
+    PQP_HD void polish_apply_set() {
+        const pqp_params& prm = A.prm;
+        const double rho_now = rho;
+        const double gain = 1.0 / prm.polish_delta;
+        const double irho = 1.0 / rho_now, irho_eq = 1.0 / (rho_now * kRhoEqFactor);
         ctx.phase([&](int t, Lane& ln) {
             _Pragma("unroll") for (int q = 0; q < 2; ++q) {
                 Slot& S = ln.s[q];
                 const int i = 2 * t + q;
                 const bool real = S.flags & F_REAL;
-                const double* w = A.wsave + ((size_t)qp * n + (real ? i : n - 1)) * kSaveStride;
+                const double* w = A.wsave + ((size_t)qp * (2 * T) + (real ? i : n - 1)) * kSaveStride;
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                    const bool eq = S.flags & (F_EQ0 << k);
+                    const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
+                    const bool act = real && (alo || aup);
+                    const double e2 = w[15 + k] * (eq ? irho_eq : irho);
+                    const double r = act ? gain * e2 : 0.0;
+                    S.rhoI[k] = r;
+                    S.rinvI[k] = act ? rcp(r) : 0.0;
+                    S.yI[k] = act ? S.yI[k] : 0.0;
+                    S.zI[k] = alo ? raw_lo(S, k) : (aup ? raw_up(S, k) : S.zI[k]);
+                }
+                if (S.flags & F_LAST) {
+                    EndRows* er = end_rows();
+                    for (int k = 0; k < 2; ++k) {
+                        const bool act = er->act[k] != 0.0;
+                        const double r = act ? gain * er->E[k] * er->E[k] / cscale : 0.0;
+                        er->rho[k] = r; er->rinv[k] = act ? rcp(r) : 0.0;
+                        er->y[k] = act ? er->y[k] : 0.0;
+                        er->z[k] = er->act[k] < 0.0 ? er->lo[k] : (er->act[k] > 0.0 ? er->up[k] : er->z[k]);
+                    }
+                }
+            }
+        });
+    }
+
+    // --- polish piece 3: worst KKT failure of the polished point over all inequality rows
+    //     (needs sh[xodd] = X of slot 1, published by residuals())
+    PQP_HD double polish_violation() {
+        double viol[1];
+        ctx.template reduce_max<1>(viol, [&](int t, Lane& ln, double (&v)[1]) {
+            v[0] = 0.0;
+            double Xprev0[3];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xprev0[k] = (t > 0) ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                const Slot& S = ln.s[q];
+                const double* Xp = (q == 0) ? Xprev0 : ln.s[0].x;
+                double aT[3], aI[3];
+                rows_of(S, Xp, S.x, aT, aI);
+                double w = 0.0;
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) w = fmax(w, row_violation(S, k, aI[k]));
+                if (S.flags & F_LAST) {
+                    const EndRows* er = end_rows();
+                    for (int k = 0; k < 2; ++k) w = fmax(w, end_violation(er, k, S.x[k]));
+                }
+                v[0] = fmax(v[0], w);
+            }
+        });
+        return viol[0];
+    }
+
+    // --- polish piece 4: primal-dual active-set step: rows failing the test by more than thr change sides
+    PQP_HD void polish_update_set(double thr) {
+        ctx.phase([&](int t, Lane& ln) {
+            double Xprev0[3];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xprev0[k] = (t > 0) ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                Slot& S = ln.s[q];
+                const double* Xp = (q == 0) ? Xprev0 : ln.s[0].x;
+                double aT[3], aI[3];
+                rows_of(S, Xp, S.x, aT, aI);
+                int fl = S.flags;
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                    const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
+                    const bool move = row_violation(S, k, aI[k]) > thr;
+                    const bool add_lo = move && !alo && !aup && (raw_lo(S, k) - aI[k] > aI[k] - raw_up(S, k));
+                    const bool add_up = move && !alo && !aup && !add_lo;
+                    if (move && (alo || aup)) fl &= ~((F_ACTLO0 << k) | (F_ACTUP0 << k));
+                    if (add_lo) fl |= (F_ACTLO0 << k);
+                    if (add_up) fl |= (F_ACTUP0 << k);
+                }
+                S.flags = fl;
+                if (S.flags & F_LAST) {
+                    EndRows* er = end_rows();
+                    for (int k = 0; k < 2; ++k) {
+                        if (!(end_violation(er, k, S.x[k]) > thr)) continue;
+                        if (er->act[k] != 0.0) er->act[k] = 0.0;
+                        else er->act[k] = (er->lo[k] - S.x[k] > S.x[k] - er->up[k]) ? -1.0 : 1.0;
+                    }
+                }
+            }
+        });
+    }
+
+    // --- polish piece 5: leave polish mode.  accept: keep (x, y).  reject: restore the ADMM iterate.
+    //     Either way put the ADMM penalties back.
+    PQP_HD void polish_end(bool ok) {
+        const pqp_params& prm = A.prm;
+        const double rho_now = rho;
+        const double gain = 1.0 / prm.polish_delta;
+        const double sgain = prm.polish_delta / prm.sigma;
+        const double tgain = gain / (rho_now * kRhoEqFactor);
+        const double itgain = 1.0 / tgain, isgain = 1.0 / sgain;
+        ctx.phase([&](int t, Lane& ln) {
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                Slot& S = ln.s[q];
+                const int i = 2 * t + q;
+                const bool real = S.flags & F_REAL;
+                const double* w = A.wsave + ((size_t)qp * (2 * T) + (real ? i : n - 1)) * kSaveStride;
                 const bool rest = real && !ok;
                 _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = rest ? w[k] : S.x[k];
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) {
@@ -742,23 +817,50 @@ struct PathQp {
                     S.zI[k] = rest ? w[12 + k] : S.zI[k];
                     const double r = real ? w[15 + k] : 0.0;
                     S.rhoI[k] = r;
-                    S.rinvI[k] = r > 0.0 ? 1.0 / r : 0.0;
-                    S.rhoT[k] *= 1.0 / tgain;
+                    S.rinvI[k] = r > 0.0 ? rcp(r) : 0.0;
+                    S.rhoT[k] *= itgain;
                 }
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] *= 1.0 / sgain;
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] *= isgain;
                 if (S.flags & F_LAST) {
                     EndRows* er = end_rows();
                     for (int k = 0; k < 2; ++k) {
                         if (!ok) { er->z[k] = er->sz[k]; er->y[k] = er->sy[k]; }
                         const double rb = er->rb[k];
                         const double r = rb < 0.0 ? -rb : rho_now * rb;
-                        er->rho[k] = r; er->rinv[k] = 1.0 / r;
+                        er->rho[k] = r; er->rinv[k] = rcp(r);
                     }
                 }
             }
         });
-        if (!ok) factor();
-        return ok;
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // Register-pressure relief around the factorisation: the iterates and the row data are not touched by
+    // factor(), so they are parked in (L2-resident) global memory and re-loaded afterwards.  The re-loaded values
+    // are new live ranges: during factor() the allocator has ~90 more VGPRs and does not have to spill values the
+    // ADMM loop needs every iteration.
+    // ---------------------------------------------------------------------------------------------
+    PQP_HD void park_iterates() {
+        ctx.phase([&](int t, Lane& ln) {
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                const Slot& S = ln.s[q];
+                double* w = A.wsave + ((size_t)qp * (2 * T) + 2 * t + q) * kSaveStride + kParkOffset;
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) w[k] = S.x[k];
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) { w[6 + k] = S.yT[k]; w[9 + k] = S.yI[k]; w[12 + k] = S.zI[k]; w[15 + k] = S.bT[k]; }
+                w[18] = S.lo[0]; w[19] = S.lo[1]; w[20] = S.up[0]; w[21] = S.up[1];
+            }
+        });
+    }
+    PQP_HD void unpark_iterates() {
+        ctx.phase([&](int t, Lane& ln) {
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
+                Slot& S = ln.s[q];
+                const double* w = A.wsave + ((size_t)qp * (2 * T) + 2 * t + q) * kSaveStride + kParkOffset;
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = w[k];
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) { S.yT[k] = w[6 + k]; S.yI[k] = w[9 + k]; S.zI[k] = w[12 + k]; S.bT[k] = w[15 + k]; }
+                S.lo[0] = w[18]; S.lo[1] = w[19]; S.up[0] = w[20]; S.up[1] = w[21];
+            }
+        });
     }
 
     // ---------------------------------------------------------------------------------------------
@@ -776,13 +878,13 @@ struct PathQp {
                 if (S.flags & F_LAST) { re0 = end_rows()->rho[0]; re1 = end_rows()->rho[1]; }
                 const double rK = S.rhoI[0], rF = S.rhoI[1], rR = S.rhoI[2];
                 const double dsf = cost_diag(prm, S.flags, 4) + S.sig[4] + rF, dsr = cost_diag(prm, S.flags, 5) + S.sig[5] + rR;
-                S.idsf = 1.0 / dsf; S.idsr = 1.0 / dsr;
+                S.idsf = rcp(dsf); S.idsr = rcp(dsr);
                 S.cF = rF * S.idsf; S.cR = rR * S.idsr;
                 const double gf = rF - rF * S.cF, gr = rR - rR * S.cR;
                 const double ds = S.a[5];
                 S.tu = S.rhoT[2] * ds;
                 const double du = cost_diag(prm, S.flags, 3) + S.sig[3] + S.tu * ds;
-                S.idu = 1.0 / du;
+                S.idu = rcp(du);
                 S.tudc = S.tu * S.idu;
                 const double gu = S.rhoT[2] - S.tu * S.tudc;
                 const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
@@ -842,7 +944,7 @@ struct PathQp {
             _Pragma("unroll") for (int k = 0; k < 9; ++k) g[6 + k] = Cn[k];
         });
         // level 0 receive + levels 1..log2(T): receive from the previous level, then eliminate
-        for (int h = 1; h <= T; h <<= 1) {   // h = stride of the level being eliminated (thread units); h == T: root only
+        _Pragma("nounroll") for (int h = 1; h <= T; h <<= 1) {   // h = stride of the level being eliminated (thread units); h == T: root only
             ctx.phase([&](int t, Lane& ln) {
                 Slot& S0 = ln.s[0];
                 SlotSetup& W0 = ln.w[0];
@@ -1217,8 +1319,10 @@ struct PathQp {
                 const double angle = r[2];
                 const double l = S.x[0], dpsi = S.x[1];
                 const double new_angle = constrain_angle(angle + kPi2);
-                o[0] = r[3] + l * cos(new_angle);
-                o[1] = r[4] + l * sin(new_angle);
+                double sn, cn;
+                sincos_shared(new_angle, &sn, &cn);
+                o[0] = r[3] + l * cn;
+                o[1] = r[4] + l * sn;
                 o[2] = constrain_angle(angle + dpsi);
                 o[3] = l;
                 o[4] = dpsi;
@@ -1235,74 +1339,193 @@ struct PathQp {
     // ---------------------------------------------------------------------------------------------
     // the whole path: (warm) solve + `passes` re-linearised warm re-solves
     // ---------------------------------------------------------------------------------------------
-    PQP_HD void run() {
+    PQP_HD Uni get_uni() const { return Uni{rho, cscale, kap, alpha_, kkt_solves_, polishing_ ? 1 : 0}; }
+    PQP_HD void set_uni(const Uni& u) { rho = u.rho; cscale = u.cscale; kap = u.kap; alpha_ = u.alpha; kkt_solves_ = u.kkt_solves; polishing_ = u.polishing != 0; }
+
+    // The cold side of the solver.  On the device this runs inside a __noinline__ function on a copy of the lane
+    // state that lives in memory (DevCtx::cold), so its register needs never leak into the ADMM loop.
+    PQP_HD void do_cold(int op, int i0, int i1, double d0) {
         const pqp_params& prm = A.prm;
-        load();
-        int total_iters = 0, last_iters = 0, status = PQP_STATUS_UNSOLVED, polished = 0;
-        double res[5] = {0, 0, 0, 0, 0};
-        rho = prm.rho;
-        bool have_warm = false;
-        if (A.warm) {
-            load_warm();
-            rho = A.wrho[qp];
-            have_warm = true;
-        } else {
-            ctx.phase([&](int, Lane& ln) {
-                _Pragma("unroll") for (int q = 0; q < 2; ++q)
-                    if (ln.s[q].flags & F_LAST) { end_rows()->y[0] = 0.0; end_rows()->y[1] = 0.0; }
-            });
-        }
-        for (int pass = 0; pass <= A.passes; ++pass) {
+        if (op == COLD_BEGIN_PASS) {
+            const bool have_warm = (i1 & 1) != 0;
+            if (i0 == 0) {
+                load();
+                rho = prm.rho;
+                if (A.warm) {
+                    load_warm();
+                    rho = A.wrho[qp];
+                } else {
+                    ctx.phase([&](int, Lane& ln) {
+                        _Pragma("unroll") for (int q = 0; q < 2; ++q)
+                            if (ln.s[q].flags & F_LAST) { end_rows()->y[0] = 0.0; end_rows()->y[1] = 0.0; }
+                    });
+                }
+            }
             assemble();
             ruiz();
-            factor();
             start_transition_rows(have_warm);
-            status = PQP_STATUS_MAX_ITER;
-            double eps_scale = 1.0;
-            int it = 0;
-            for (it = 1; it <= prm.max_iter; ++it) {
+            if (i1 & 2) {      // warm re-solve: go straight to a polish on the active set the previous pass ended with
+                polish_begin(true);
+                polishing_ = true; alpha_ = 1.0;
+                polish_apply_set();
+            }
+            factor();
+        } else if (op == COLD_REFACTOR) {
+            if (i0 == RF_RESCALE) {
+                rescale_rho(d0);
+            } else if (i0 == RF_POLISH_BEGIN) {
+                polish_begin(false);
+                polishing_ = true; alpha_ = 1.0;
+                polish_apply_set();
+            } else if (i0 == RF_POLISH_UPDATE) {
+                polish_update_set(d0);
+                polish_apply_set();
+            } else {   // RF_POLISH_REJECT
+                polish_end(false);
+                polishing_ = false; alpha_ = prm.alpha;
+            }
+            factor();
+        } else if (op == COLD_END_PASS) {
+            if (i0) {
+                polish_end(true);
+                polishing_ = false; alpha_ = prm.alpha;
+            }
+            unpack();
+        } else {
+            store_warm();
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // the whole path: (warm) solve + `passes` re-linearised warm re-solves.
+    // Hot side: one loop around iterate() / residuals() / the KKT test.  Everything else is a cold operation, issued
+    // from ONE call site (the lane state crosses the hot/cold boundary through memory there, once per operation).
+    //   mode ADMM  : OSQP iterations; every check_termination iterations residuals -> stop / adapt rho / start a polish
+    //   mode POLISH: polish_refine_iter solves, then the KKT test -> accept / next active-set round / give up
+    // ---------------------------------------------------------------------------------------------
+    PQP_HD void run() {
+        const pqp_params& prm = A.prm;
+        int total_iters = 0, last_iters = 0, status = PQP_STATUS_UNSOLVED, polished = 0;
+        double res[5] = {0, 0, 0, 0, 0};
+        int pass = 0;
+        // per-pass state of the hot loop
+        bool polish_mode = false, conservative = false, end_after_reject = false;
+        double eps_scale = 1.0, best = 1e300;
+        int it = 0, refine_left = 0, round = 0, stall = 0, polish_gap = 0, next_polish = 0;
+        bool direct_polish = false, last_accepted = false;
+        // the pending cold operation
+        int op = COLD_BEGIN_PASS, i0 = 0, i1 = A.warm ? 1 : 0;
+        double d0 = 0.0;
+        for (;;) {
+            ctx.cold(*this, op, i0, i1, d0);
+            if (op == COLD_FINISH) break;
+            if (op == COLD_END_PASS) {
+                last_iters = it;
+                total_iters += it;
+                if (status != PQP_STATUS_SOLVED || pass == A.passes) { op = COLD_FINISH; continue; }   // reference: solve() false -> stop
+                pass += 1;
+                direct_polish = prm.polish && prm.polish_warm_set && last_accepted;
+                op = COLD_BEGIN_PASS; i0 = pass; i1 = 1 | (direct_polish ? 2 : 0);
+                continue;
+            }
+            if (op == COLD_BEGIN_PASS) {
+                status = PQP_STATUS_MAX_ITER;
+                polish_mode = false; conservative = false; end_after_reject = false;
+                eps_scale = 1.0; best = 1e300;
+                it = 0; refine_left = 0; round = 0; stall = 0;
+                polish_gap = prm.polish_every; next_polish = prm.polish_every;
+                last_accepted = false;
+                if (direct_polish) { polish_mode = true; refine_left = prm.polish_refine_iter; }
+            } else if (end_after_reject) {       // a rejected polish at max_iter
+                op = COLD_END_PASS; i0 = 0;
+                continue;
+            }
+            // ---- hot loop: runs until the next cold operation is due
+            for (;;) {
                 iterate();
-                if (it == 1) finish_first_iteration();
-                const bool check = prm.check_termination > 0 && (it % prm.check_termination) == 0;
-                const bool adapt = prm.adaptive_rho && prm.adaptive_rho_interval > 0 && (it % prm.adaptive_rho_interval) == 0;
-                if (check || adapt) {
-                    residuals(res);
-                    if (res[4] != 0.0) { status = PQP_STATUS_NUMERICAL; break; }
+                bool want_res, check = false, adapt = false;
+                if (!polish_mode) {
+                    it += 1;
+                    if (it == 1) finish_first_iteration();
+                    check = prm.check_termination > 0 && (it % prm.check_termination) == 0;
+                    adapt = prm.adaptive_rho && prm.adaptive_rho_interval > 0 && (it % prm.adaptive_rho_interval) == 0;
+                    want_res = check || adapt;
+                } else {
+                    refine_left -= 1;
+                    want_res = refine_left <= 0;
+                }
+                if (!want_res) {
+                    if (!polish_mode && it >= prm.max_iter) { op = COLD_END_PASS; i0 = 0; break; }
+                    continue;
+                }
+                residuals(res);
+                if (!polish_mode) {
+                    bool start_polish = false;
+                    if (res[4] != 0.0) { status = PQP_STATUS_NUMERICAL; op = COLD_END_PASS; i0 = 0; break; }
                     if (check) {
                         const double eps_p = eps_scale * (prm.eps_abs + prm.eps_rel * res[2]);
                         const double eps_d = eps_scale * (prm.eps_abs + prm.eps_rel * res[3]);
                         if (res[0] <= eps_p && res[1] <= eps_d) {
-                            if (!prm.polish) { status = PQP_STATUS_SOLVED; break; }
-                            if (try_polish()) { status = PQP_STATUS_SOLVED; polished += 1; break; }
-                            eps_scale *= 0.1;      // rejected: resume ADMM, try again one decade tighter
-                            if (eps_scale * fmax(prm.eps_abs, prm.eps_rel) < 1e-10) { status = PQP_STATUS_SOLVED; break; }
-                        } else if (prm.polish && prm.polish_every > 0 && (it % prm.polish_every) == 0) {
+                            if (!prm.polish || eps_scale * fmax(prm.eps_abs, prm.eps_rel) < 1e-10) {
+                                status = PQP_STATUS_SOLVED; op = COLD_END_PASS; i0 = 0; break;
+                            }
+                            start_polish = true;
+                            eps_scale *= 0.1;      // if this polish is rejected ADMM resumes one decade tighter
+                        } else if (prm.polish && prm.polish_every > 0 && it >= next_polish) {
                             // a slow ADMM tail: the active set is often already right long before the residuals say so
-                            if (try_polish()) { status = PQP_STATUS_SOLVED; polished += 1; break; }
+                            start_polish = true;
+                            polish_gap *= 2;       // back off if it is rejected
+                            next_polish = it + polish_gap;
                         }
                     }
+                    if (start_polish) {
+                        polish_mode = true;
+                        refine_left = prm.polish_refine_iter; round = 0; stall = 0; best = 1e300; conservative = false;
+                        op = COLD_REFACTOR; i0 = RF_POLISH_BEGIN; break;
+                    }
+                    bool refactor = false;
                     if (adapt) {
                         const double pn = res[0] / (res[2] + 1e-10);
                         const double dn = res[1] / (res[3] + 1e-10);
                         double rn = rho * sqrt(pn / (dn + 1e-10));
                         rn = fmin(fmax(rn, kRhoMin), kRhoMax);
                         if (rn > rho * prm.adaptive_rho_tolerance || rn < rho / prm.adaptive_rho_tolerance) {
-                            const double ratio = rn / rho;
+                            d0 = rn / rho;
                             rho = rn;
-                            rescale_rho(ratio);
-                            factor();
+                            refactor = true;
                         }
                     }
+                    if (it >= prm.max_iter) { op = COLD_END_PASS; i0 = 0; break; }
+                    if (refactor) { op = COLD_REFACTOR; i0 = RF_RESCALE; break; }
+                } else {
+                    // KKT acceptance test of the polished point (OSQP paper 4.2 + verification)
+                    const double tol = prm.polish_tol;
+                    const double viol = polish_violation();
+                    const bool solve_ok = res[4] == 0.0 && res[0] <= tol * (1.0 + res[2]) && res[1] <= tol * (1.0 + res[3]);
+                    const bool ok = solve_ok && viol <= tol;
+#ifdef PQP_EMU_DEBUG
+                    printf("  polish qp %d it %d round %d: pri %.3e dua %.3e viol %.3e %s -> %s\n", qp, it, round, res[0], res[1], viol, conservative ? "(cons)" : "", ok ? "ACCEPT" : "reject");
+#endif
+                    if (ok) { status = PQP_STATUS_SOLVED; polished += 1; polish_mode = false; last_accepted = true; op = COLD_END_PASS; i0 = 1; break; }
+                    bool give_up = !solve_ok;
+                    if (!give_up) {
+                        // primal-dual active-set step.  A full update can cycle: when the violation stops improving only
+                        // the worst offenders (>= 90 % of the maximum) move.
+                        if (viol < 0.7 * best) { best = viol; stall = 0; } else { stall += 1; }
+                        if (stall >= 3) conservative = true;
+                        round += 1;
+                        give_up = (conservative && stall >= 16) || round >= kPolishRounds;
+                    }
+                    if (give_up) {
+                        polish_mode = false;
+                        end_after_reject = it >= prm.max_iter;
+                        op = COLD_REFACTOR; i0 = RF_POLISH_REJECT; break;
+                    }
+                    refine_left = prm.polish_refine_iter;
+                    op = COLD_REFACTOR; i0 = RF_POLISH_UPDATE; d0 = conservative ? fmax(tol, 0.9 * viol) : tol; break;
                 }
             }
-            if (it > prm.max_iter) it = prm.max_iter;
-            last_iters = it;
-            total_iters += it;
-            unpack();
-            have_warm = true;
-            if (status != PQP_STATUS_SOLVED) break;   // reference: solve() false -> optimizePath returns false
         }
-        store_warm();
         const double rho_final = rho;
         const int kkt_total = kkt_solves_;
         ctx.phase([&](int t, Lane&) {

@@ -16,6 +16,7 @@ struct HostCtx {
     int T() const { return T_; }
     double* sh() { return shm.data(); }
     template <class F> void phase(F f) { for (int t = 0; t < T_; ++t) f(t, lanes[t]); }
+    template <class PQ> void cold(PQ& pq, int op, int i0, int i1, double d0) { pq.do_cold(op, i0, i1, d0); }
     template <int K, class F> void reduce_max(double (&out)[K], F f) {
         for (int k = 0; k < K; ++k) out[k] = 0.0;
         for (int t = 0; t < T_; ++t) { double v[K]; f(t, lanes[t], v); for (int k = 0; k < K; ++k) out[k] = out[k] > v[k] ? out[k] : v[k]; }
@@ -41,7 +42,7 @@ extern "C" int pqp_emu_path_solve(const pqp_params* prm, int batch, int n, const
     a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
     a.status = status; a.iters = iters; a.info = info;
     a.wx = wx; a.wy = wy; a.wye = wye; a.wrho = wrho;
-    std::vector<double> wsave((size_t)batch * n * 20, 0.0);
+    std::vector<double> wsave((size_t)batch * 2 * T * 44, 0.0);
     a.wsave = wsave.data();
     a.prm = *prm;
     for (int q = 0; q < batch; ++q) {
