@@ -1,0 +1,483 @@
+/*
+ * pqp_oracle.c — plain-C restatement of the reference path-QP hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * PARITY UNPINNED: the reference (LiJiangnanBit/path_optimizer_2) has no tests, golden vectors or fixtures for
+ * this path, and its ADMM arithmetic lives in the un-vendored, un-pinned third-party solver OSQP
+ * (oxfordcontrol/osqp cloned at HEAD by script/install_deps.sh:102, v0.6.x era; reached through
+ * robotology/osqp-eigen, install_deps.sh:116) which is not in this image.  This file restates the OSQP PAPER
+ * algorithm (Stellato et al., Math. Prog. Comp. 2020) with the documented v0.6 defaults.
+ * It is the SECOND, independent formulation next to oracle/pqp_oracle.py: reduced SPD system
+ * (P + sigma I + A^T R A) in band storage under the per-waypoint interleave, banded Cholesky — the Python oracle
+ * solves the full quasi-definite KKT with a sparse LU.  tests/test_oracle_c.py checks they agree.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.  Nothing in the
+ * product path (path_optimizer_2_amd/, include/) may.
+ *
+ * What follows what (file:line relative to the reference tree):
+ *   pqo_assemble      src/solver/base_solver.cpp:119-148 (setCost), :150-261 (setConstraints), :290-295
+ *   pqo_unpack        src/solver/base_solver.cpp:263-288 (getOptimizedPath)
+ *   pqo_solve_path    src/path_optimizer.cpp:124-161 (optimizePath) + base_solver.cpp:56-117
+ *   constrain_angle   include/tools/tools.hpp:24-35
+ *   osqp_*            the OSQP paper; written from the paper, not from OSQP source
+ *
+ * Build: gcc -O3 -march=native -fopenmp -fPIC -shared -o libpqp_oracle.so pqp_oracle.c -lm
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define OSQP_INFTY 1e30
+#define MIN_SCALING 1e-4
+#define MAX_SCALING 1e4
+#define RHO_MIN 1e-6
+#define RHO_MAX 1e6
+#define RHO_TOL 1e-4
+#define RHO_EQ_OVER_RHO_INEQ 1e3
+
+typedef struct {
+    double front_length, rear_length, wheel_base, expected_safety_margin;
+    double weight_l, weight_kappa, weight_dkappa, weight_slack;
+    double end_l_bound, end_psi_tol, end_psi_max, min_clearance;
+    int constraint_end_heading;
+    /* OSQP settings */
+    double eps_abs, eps_rel, rho, sigma, alpha;
+    int max_iter, scaling, adaptive_rho, adaptive_rho_interval, check_termination;
+    double adaptive_rho_tolerance;
+} pqo_params;
+
+void pqo_default_params(pqo_params* p) {
+    p->front_length = 3.9; p->rear_length = -1.0; p->wheel_base = 2.5; p->expected_safety_margin = 0.6;
+    p->weight_l = 0.0; p->weight_kappa = 20.0; p->weight_dkappa = 100.0; p->weight_slack = 10.0;
+    p->end_l_bound = 1.0; p->end_psi_tol = 0.087; p->end_psi_max = 70.0 * M_PI / 180.0; p->min_clearance = 0.1;
+    p->constraint_end_heading = 1;
+    p->eps_abs = 2e-3; p->eps_rel = 2e-3; p->rho = 0.1; p->sigma = 1e-6; p->alpha = 1.6;
+    p->max_iter = 4000; p->scaling = 10; p->adaptive_rho = 1; p->adaptive_rho_interval = 100; p->check_termination = 25;
+    p->adaptive_rho_tolerance = 5.0;
+}
+
+static double constrain_angle(double a) {          /* tools.hpp:24-35 */
+    for (;;) {
+        if (a > M_PI) a -= 2 * M_PI;
+        else if (a < -M_PI) a += 2 * M_PI;
+        else return a;
+    }
+}
+
+static void soft_bounds(double lb, double ub, double margin, double min_clearance, double* lo, double* up) {   /* :290-295 */
+    double clearance = ub - lb;
+    double remain = fmax(min_clearance, clearance - 2 * margin);
+    double shrink = fmax(0.0, (clearance - remain) / 2.0);
+    *lo = lb + shrink;
+    *up = ub - shrink;
+}
+
+/* ---- the QP in triplet form, reference numbering, precise == n (default flags) ------------------------ */
+typedef struct {
+    int n, nv, nc, nnz;
+    int *ri, *ci;        /* [nnz] */
+    double* av;          /* [nnz] */
+    double *pd, *lo, *up; /* [nv], [nc], [nc] */
+} pqo_qp;
+
+static pqo_qp* qp_alloc(int n) {
+    pqo_qp* q = (pqo_qp*)calloc(1, sizeof(pqo_qp));
+    q->n = n; q->nv = 6 * n - 1; q->nc = 6 * n + 2; q->nnz = 17 * n - 5;
+    q->ri = (int*)malloc(sizeof(int) * q->nnz); q->ci = (int*)malloc(sizeof(int) * q->nnz);
+    q->av = (double*)malloc(sizeof(double) * q->nnz);
+    q->pd = (double*)calloc(q->nv, sizeof(double));
+    q->lo = (double*)calloc(q->nc, sizeof(double)); q->up = (double*)calloc(q->nc, sizeof(double));
+    return q;
+}
+static void qp_free(pqo_qp* q) { free(q->ri); free(q->ci); free(q->av); free(q->pd); free(q->lo); free(q->up); free(q); }
+
+/* setCost + setConstraints, direct O(N) fill of the structural pattern.
+ * ref [n][5] s,k,heading,x,y; lin [n][3] l,dpsi,k; bounds [n][6]; scal [6]. */
+static void assemble(const pqo_params* prm, int n, const double* ref, const double* lin, const double* bounds,
+                     const double* scal, pqo_qp* q) {
+    const int state = 3 * n, control = n - 1;
+    const int kappa_idx = 3 * n, precise_idx = 4 * n, end_idx = 6 * n;
+    int e = 0;
+#define PUT(r, c, v) do { q->ri[e] = (r); q->ci[e] = (c); q->av[e] = (v); ++e; } while (0)
+    memset(q->pd, 0, sizeof(double) * q->nv);
+    for (int i = 0; i < n; ++i) {                                   /* :127-143 */
+        q->pd[3 * i] += prm->weight_l;
+        q->pd[3 * i + 2] += prm->weight_kappa;
+        q->pd[state + control + 2 * i] += prm->weight_slack;
+        q->pd[state + control + 2 * i + 1] += prm->weight_slack;
+        if (i != n - 1) q->pd[state + i] += prm->weight_dkappa;
+    }
+    for (int i = 0; i < state; ++i) PUT(i, i, -1.0);                /* :161-163 */
+    q->lo[0] = q->up[0] = -scal[0]; q->lo[1] = q->up[1] = -scal[1]; q->lo[2] = q->up[2] = -scal[2];   /* :216-220 */
+    for (int i = 0; i < n - 1; ++i) {                               /* :165-187 */
+        const double l = lin[3 * i], psi = lin[3 * i + 1], k = lin[3 * i + 2], knext = lin[3 * (i + 1) + 2];
+        const double t = tan(psi), cs = cos(psi);
+        const double df00 = -k * t, df01 = (1 - k * l) / pow(cs, 2);
+        const double df10 = -k * k / cs, df11 = (1 - k * l) * k * t / cs, df12 = (1 - k * l) / cs;
+        const double ds = ref[5 * (i + 1)] - ref[5 * i];
+        const int r0 = 3 * (i + 1);
+        PUT(r0, 3 * i, ds * df00 + 1.0); PUT(r0, 3 * i + 1, ds * df01);
+        PUT(r0 + 1, 3 * i, ds * df10); PUT(r0 + 1, 3 * i + 1, ds * df11 + 1.0); PUT(r0 + 1, 3 * i + 2, ds * df12);
+        PUT(r0 + 2, 3 * i + 2, 1.0); PUT(r0 + 2, state + i, ds);
+        const double u_in = (knext - k) / ds;
+        const double f0 = (1 - k * l) * t, f1 = (1 - k * l) * k / cs - ref[5 * i + 1], f2 = u_in;
+        const double c0 = ds * (f0 - (df00 * l + df01 * psi + 0.0 * k) - 0.0 * u_in);
+        const double c1 = ds * (f1 - (df10 * l + df11 * psi + df12 * k) - 0.0 * u_in);
+        const double c2 = ds * (f2 - (0.0 * l + 0.0 * psi + 0.0 * k) - 1.0 * u_in);
+        q->lo[r0] = q->up[r0] = -c0; q->lo[r0 + 1] = q->up[r0 + 1] = -c1; q->lo[r0 + 2] = q->up[r0 + 2] = -c2;
+    }
+    const double kappa_limit = tan(scal[5]) / prm->wheel_base;      /* :226-231 */
+    for (int i = 0; i < n; ++i) {
+        PUT(kappa_idx + i, 3 * i + 2, 1.0);
+        q->lo[kappa_idx + i] = -kappa_limit; q->up[kappa_idx + i] = kappa_limit;
+    }
+    for (int i = 0; i < n; ++i) {                                   /* :193-205, :232-248 */
+        const int r = precise_idx + 2 * i;
+        PUT(r, 3 * i, 1.0); PUT(r, 3 * i + 1, prm->front_length); PUT(r, state + control + 2 * i, 1.0);
+        PUT(r + 1, 3 * i, 1.0); PUT(r + 1, 3 * i + 1, prm->rear_length); PUT(r + 1, state + control + 2 * i + 1, 1.0);
+        soft_bounds(bounds[6 * i], bounds[6 * i + 1], prm->expected_safety_margin, prm->min_clearance, &q->lo[r], &q->up[r]);
+        soft_bounds(bounds[6 * i + 2], bounds[6 * i + 3], prm->expected_safety_margin, prm->min_clearance, &q->lo[r + 1], &q->up[r + 1]);
+    }
+    PUT(end_idx, state - 3, 1.0); PUT(end_idx + 1, state - 2, 1.0); /* :208-209 */
+    q->lo[end_idx] = -prm->end_l_bound; q->up[end_idx] = prm->end_l_bound;     /* :250-259 */
+    q->lo[end_idx + 1] = -OSQP_INFTY; q->up[end_idx + 1] = OSQP_INFTY;
+    if (prm->constraint_end_heading && scal[4] == 0.0) {
+        const double end_psi = constrain_angle(scal[3] - ref[5 * (n - 1) + 2]);
+        if (end_psi < prm->end_psi_max) { q->lo[end_idx + 1] = end_psi - prm->end_psi_tol; q->up[end_idx + 1] = end_psi + prm->end_psi_tol; }
+    }
+#undef PUT
+}
+
+/* interleave permutation: reference variable -> position in the banded ordering
+ * per waypoint i: [l, psi, k, u_i, sf, sr] (last waypoint has no u) */
+static void interleave_perm(int n, int* pos) {
+    int p = 0;
+    for (int i = 0; i < n; ++i) {
+        pos[3 * i] = p++; pos[3 * i + 1] = p++; pos[3 * i + 2] = p++;
+        if (i < n - 1) pos[3 * n + i] = p++;
+        pos[4 * n - 1 + 2 * i] = p++; pos[4 * n - 1 + 2 * i + 1] = p++;
+    }
+}
+
+/* ---- OSQP-paper ADMM on (Pdiag, q = 0, A triplets, l, u) ---------------------------------------------- */
+typedef struct {
+    int iters, status, refactors;   /* status 1 solved, 2 max_iter */
+    double rho, pri_res, dua_res;
+} osqp_info;
+
+#define BW 12   /* half bandwidth bound of the interleaved reduced KKT (actual: 7 for the path QP) */
+
+static double limit_scaling(double v) { v = v < MIN_SCALING ? 1.0 : v; return v > MAX_SCALING ? MAX_SCALING : v; }
+
+typedef struct {
+    int nv, nc, nnz, bw;
+    const int *ri, *ci; const int* pos;
+    double *a, *pd, *l, *u;          /* scaled data */
+    double *D, *E, c;
+    double *rv;                      /* rho vector */
+    double *band;                    /* [(bw+1)][nv] lower band of the Cholesky factor, column-major by diagonal */
+    int *rowptr, *rowent;            /* CSR view of A: entries of row r are rowent[rowptr[r]..rowptr[r+1]) */
+    double *x, *z, *y, *xt, *zt, *rhs, *tmp_n, *tmp_m, *ax, *px, *aty;
+} osqp_work;
+
+static void build_csr(osqp_work* w) {
+    w->rowptr = (int*)calloc(w->nc + 1, sizeof(int));
+    w->rowent = (int*)malloc(sizeof(int) * w->nnz);
+    for (int e = 0; e < w->nnz; ++e) w->rowptr[w->ri[e] + 1]++;
+    for (int r = 0; r < w->nc; ++r) w->rowptr[r + 1] += w->rowptr[r];
+    int* fill = (int*)calloc(w->nc, sizeof(int));
+    for (int e = 0; e < w->nnz; ++e) { int r = w->ri[e]; w->rowent[w->rowptr[r] + fill[r]++] = e; }
+    free(fill);
+}
+
+/* modified Ruiz equilibration, paper Alg. 2 (P diagonal, q = 0) */
+static void ruiz(osqp_work* w, int passes) {
+    const int n = w->nv, m = w->nc;
+    for (int j = 0; j < n; ++j) w->D[j] = 1.0;
+    for (int i = 0; i < m; ++i) w->E[i] = 1.0;
+    w->c = 1.0;
+    double* dt = w->tmp_n; double* et = w->tmp_m;
+    for (int pass = 0; pass < passes; ++pass) {
+        for (int j = 0; j < n; ++j) dt[j] = fabs(w->pd[j]);
+        for (int i = 0; i < m; ++i) et[i] = 0.0;
+        for (int e = 0; e < w->nnz; ++e) {
+            const double v = fabs(w->a[e]);
+            if (v > dt[w->ci[e]]) dt[w->ci[e]] = v;
+            if (v > et[w->ri[e]]) et[w->ri[e]] = v;
+        }
+        for (int j = 0; j < n; ++j) dt[j] = 1.0 / sqrt(limit_scaling(dt[j]));
+        for (int i = 0; i < m; ++i) et[i] = 1.0 / sqrt(limit_scaling(et[i]));
+        for (int j = 0; j < n; ++j) { w->pd[j] *= dt[j] * dt[j]; w->D[j] *= dt[j]; }
+        for (int e = 0; e < w->nnz; ++e) w->a[e] *= et[w->ri[e]] * dt[w->ci[e]];
+        for (int i = 0; i < m; ++i) w->E[i] *= et[i];
+        double mean = 0.0;
+        for (int j = 0; j < n; ++j) mean += fabs(w->pd[j]);
+        mean /= n;
+        double ct = fmax(mean, 1.0);            /* ||q||_inf == 0 is limited to 1 */
+        ct = limit_scaling(ct);
+        ct = 1.0 / ct;
+        for (int j = 0; j < n; ++j) w->pd[j] *= ct;
+        w->c *= ct;
+    }
+    for (int i = 0; i < m; ++i) { w->l[i] *= w->E[i]; w->u[i] *= w->E[i]; }
+}
+
+static void set_rho_vec(osqp_work* w, double rho) {
+    for (int i = 0; i < w->nc; ++i) {
+        if (w->l[i] < -OSQP_INFTY * MIN_SCALING && w->u[i] > OSQP_INFTY * MIN_SCALING) w->rv[i] = RHO_MIN;
+        else if (w->u[i] - w->l[i] < RHO_TOL) w->rv[i] = RHO_EQ_OVER_RHO_INEQ * rho;
+        else w->rv[i] = rho;
+    }
+}
+
+/* band[d][j] = S[perm j + d][perm j] */
+static void factor(osqp_work* w, double sigma) {
+    const int n = w->nv, bw = w->bw;
+    double* B = w->band;
+    memset(B, 0, sizeof(double) * (size_t)(bw + 1) * n);
+    for (int j = 0; j < n; ++j) B[w->pos[j]] += w->pd[j] + sigma;
+    for (int r = 0; r < w->nc; ++r) {
+        for (int a = w->rowptr[r]; a < w->rowptr[r + 1]; ++a) {
+            const int ea = w->rowent[a];
+            const int pa = w->pos[w->ci[ea]];
+            const double va = w->rv[r] * w->a[ea];
+            for (int b = w->rowptr[r]; b < w->rowptr[r + 1]; ++b) {
+                const int eb = w->rowent[b];
+                const int pb = w->pos[w->ci[eb]];
+                if (pb >= pa) B[(size_t)(pb - pa) * n + pa] += va * w->a[eb];
+            }
+        }
+    }
+    /* banded Cholesky, in place: L[j+d][j] */
+    for (int j = 0; j < n; ++j) {
+        double d = B[j];
+        const int kmin = j - bw > 0 ? j - bw : 0;
+        for (int k = kmin; k < j; ++k) { const double v = B[(size_t)(j - k) * n + k]; d -= v * v; }
+        d = sqrt(d);
+        B[j] = d;
+        const int imax = j + bw < n - 1 ? j + bw : n - 1;
+        for (int i = j + 1; i <= imax; ++i) {
+            double s = B[(size_t)(i - j) * n + j];
+            const int k0 = i - bw > kmin ? i - bw : kmin;
+            for (int k = k0; k < j; ++k) s -= B[(size_t)(i - k) * n + k] * B[(size_t)(j - k) * n + k];
+            B[(size_t)(i - j) * n + j] = s / d;
+        }
+    }
+}
+
+static void band_solve(const osqp_work* w, double* b /* in permuted order, in place */) {
+    const int n = w->nv, bw = w->bw;
+    const double* B = w->band;
+    for (int j = 0; j < n; ++j) {
+        double s = b[j];
+        const int kmin = j - bw > 0 ? j - bw : 0;
+        for (int k = kmin; k < j; ++k) s -= B[(size_t)(j - k) * n + k] * b[k];
+        b[j] = s / B[j];
+    }
+    for (int j = n - 1; j >= 0; --j) {
+        double s = b[j];
+        const int imax = j + bw < n - 1 ? j + bw : n - 1;
+        for (int i = j + 1; i <= imax; ++i) s -= B[(size_t)(i - j) * n + j] * b[i];
+        b[j] = s / B[j];
+    }
+}
+
+static void mat_vec(const osqp_work* w, const double* x, double* out) {       /* out = A x */
+    for (int r = 0; r < w->nc; ++r) out[r] = 0.0;
+    for (int e = 0; e < w->nnz; ++e) out[w->ri[e]] += w->a[e] * x[w->ci[e]];
+}
+static void mat_tvec(const osqp_work* w, const double* y, double* out) {      /* out = A^T y */
+    for (int j = 0; j < w->nv; ++j) out[j] = 0.0;
+    for (int e = 0; e < w->nnz; ++e) out[w->ci[e]] += w->a[e] * y[w->ri[e]];
+}
+
+static osqp_work* work_alloc(const pqo_qp* q, const int* pos) {
+    osqp_work* w = (osqp_work*)calloc(1, sizeof(osqp_work));
+    w->nv = q->nv; w->nc = q->nc; w->nnz = q->nnz; w->ri = q->ri; w->ci = q->ci; w->pos = pos;
+    int bw = 0;
+    for (int r = 0, e0 = 0; r < 1; ++r) (void)e0;
+    w->a = (double*)malloc(sizeof(double) * q->nnz); w->pd = (double*)malloc(sizeof(double) * q->nv);
+    w->l = (double*)malloc(sizeof(double) * q->nc); w->u = (double*)malloc(sizeof(double) * q->nc);
+    w->D = (double*)malloc(sizeof(double) * q->nv); w->E = (double*)malloc(sizeof(double) * q->nc);
+    w->rv = (double*)malloc(sizeof(double) * q->nc);
+    build_csr(w);
+    for (int r = 0; r < w->nc; ++r)
+        for (int a = w->rowptr[r]; a < w->rowptr[r + 1]; ++a)
+            for (int b = w->rowptr[r]; b < w->rowptr[r + 1]; ++b) {
+                int d = pos[q->ci[w->rowent[a]]] - pos[q->ci[w->rowent[b]]];
+                if (d > bw) bw = d;
+            }
+    w->bw = bw;
+    w->band = (double*)malloc(sizeof(double) * (size_t)(bw + 1) * q->nv);
+    w->x = (double*)calloc(q->nv, sizeof(double)); w->z = (double*)calloc(q->nc, sizeof(double)); w->y = (double*)calloc(q->nc, sizeof(double));
+    w->xt = (double*)malloc(sizeof(double) * q->nv); w->zt = (double*)malloc(sizeof(double) * q->nc);
+    w->rhs = (double*)malloc(sizeof(double) * q->nv);
+    w->tmp_n = (double*)malloc(sizeof(double) * q->nv); w->tmp_m = (double*)malloc(sizeof(double) * q->nc);
+    w->ax = (double*)malloc(sizeof(double) * q->nc); w->px = (double*)malloc(sizeof(double) * q->nv); w->aty = (double*)malloc(sizeof(double) * q->nv);
+    return w;
+}
+static void work_free(osqp_work* w) {
+    free(w->a); free(w->pd); free(w->l); free(w->u); free(w->D); free(w->E); free(w->rv); free(w->band); free(w->rowptr); free(w->rowent);
+    free(w->x); free(w->z); free(w->y); free(w->xt); free(w->zt); free(w->rhs); free(w->tmp_n); free(w->tmp_m); free(w->ax); free(w->px); free(w->aty);
+    free(w);
+}
+
+/* solve the QP held in q.  x_out[nv], y_out[nc] unscaled.  warm_x / warm_y may be NULL. */
+static void osqp_solve(const pqo_params* prm, const pqo_qp* q, osqp_work* w, const double* warm_x, const double* warm_y,
+                       double rho_init, double* x_out, double* y_out, osqp_info* info) {
+    const int n = q->nv, m = q->nc;
+    memcpy(w->a, q->av, sizeof(double) * q->nnz); memcpy(w->pd, q->pd, sizeof(double) * n);
+    for (int i = 0; i < m; ++i) { w->l[i] = fmax(q->lo[i], -OSQP_INFTY); w->u[i] = fmin(q->up[i], OSQP_INFTY); }
+    if (prm->scaling > 0) ruiz(w, prm->scaling);
+    else { for (int j = 0; j < n; ++j) w->D[j] = 1.0; for (int i = 0; i < m; ++i) w->E[i] = 1.0; w->c = 1.0; }
+    double rho = rho_init > 0 ? rho_init : prm->rho;
+    set_rho_vec(w, rho);
+    factor(w, prm->sigma);
+    const double cinv = 1.0 / w->c;
+    for (int j = 0; j < n; ++j) w->x[j] = warm_x ? warm_x[j] / w->D[j] : 0.0;
+    if (warm_x) mat_vec(w, w->x, w->z); else memset(w->z, 0, sizeof(double) * m);
+    for (int i = 0; i < m; ++i) w->y[i] = warm_y ? w->c * warm_y[i] / w->E[i] : 0.0;
+    info->status = 2; info->refactors = 0; info->pri_res = info->dua_res = NAN;
+    int it;
+    for (it = 1; it <= prm->max_iter; ++it) {
+        /* reduced KKT: (P + sigma I + A^T R A) xt = sigma x - q + A^T (R z - y) */
+        for (int i = 0; i < m; ++i) w->tmp_m[i] = w->rv[i] * w->z[i] - w->y[i];
+        mat_tvec(w, w->tmp_m, w->tmp_n);
+        for (int j = 0; j < n; ++j) w->rhs[w->pos[j]] = prm->sigma * w->x[j] + w->tmp_n[j];
+        band_solve(w, w->rhs);
+        for (int j = 0; j < n; ++j) w->xt[j] = w->rhs[w->pos[j]];
+        mat_vec(w, w->xt, w->zt);
+        for (int j = 0; j < n; ++j) w->x[j] = prm->alpha * w->xt[j] + (1 - prm->alpha) * w->x[j];
+        for (int i = 0; i < m; ++i) {
+            const double zh = prm->alpha * w->zt[i] + (1 - prm->alpha) * w->z[i];
+            double zn = zh + w->y[i] / w->rv[i];
+            zn = zn < w->l[i] ? w->l[i] : (zn > w->u[i] ? w->u[i] : zn);
+            w->y[i] += w->rv[i] * (zh - zn);
+            w->z[i] = zn;
+        }
+        const int check = prm->check_termination > 0 && it % prm->check_termination == 0;
+        const int adapt = prm->adaptive_rho && prm->adaptive_rho_interval > 0 && it % prm->adaptive_rho_interval == 0;
+        if (!check && !adapt) continue;
+        mat_vec(w, w->x, w->ax); mat_tvec(w, w->y, w->aty);
+        double pri = 0, n_ax = 0, n_z = 0, dua = 0, n_px = 0, n_aty = 0;
+        for (int i = 0; i < m; ++i) {
+            const double ei = 1.0 / w->E[i];
+            pri = fmax(pri, fabs(ei * (w->ax[i] - w->z[i]))); n_ax = fmax(n_ax, fabs(ei * w->ax[i])); n_z = fmax(n_z, fabs(ei * w->z[i]));
+        }
+        for (int j = 0; j < n; ++j) {
+            const double dj = 1.0 / w->D[j], px = w->pd[j] * w->x[j];
+            dua = fmax(dua, fabs(dj * (px + w->aty[j]))); n_px = fmax(n_px, fabs(dj * px)); n_aty = fmax(n_aty, fabs(dj * w->aty[j]));
+        }
+        dua *= cinv; n_px *= cinv; n_aty *= cinv;
+        info->pri_res = pri; info->dua_res = dua;
+        if (check) {
+            const double eps_p = prm->eps_abs + prm->eps_rel * fmax(n_ax, n_z);
+            const double eps_d = prm->eps_abs + prm->eps_rel * fmax(n_px, n_aty);
+            if (pri <= eps_p && dua <= eps_d) { info->status = 1; break; }
+        }
+        if (adapt) {
+            const double pn = pri / (fmax(n_ax, n_z) + 1e-10), dn = dua / (fmax(n_px, n_aty) + 1e-10);
+            double rn = rho * sqrt(pn / (dn + 1e-10));
+            rn = fmin(fmax(rn, RHO_MIN), RHO_MAX);
+            if (rn > rho * prm->adaptive_rho_tolerance || rn < rho / prm->adaptive_rho_tolerance) {
+                rho = rn; set_rho_vec(w, rho); factor(w, prm->sigma); info->refactors++;
+            }
+        }
+    }
+    if (it > prm->max_iter) it = prm->max_iter;
+    info->iters = it; info->rho = rho;
+    for (int j = 0; j < n; ++j) x_out[j] = w->D[j] * w->x[j];
+    for (int i = 0; i < m; ++i) y_out[i] = cinv * w->E[i] * w->y[i];
+}
+
+static void unpack(int n, const double* x, const double* ref, double* out) {   /* base_solver.cpp:263-288 */
+    for (int i = 0; i < n; ++i) {
+        const double angle = ref[5 * i + 2];
+        double* o = out + 7 * i;
+        o[2] = constrain_angle(angle + x[3 * i + 1]);
+        o[4] = x[3 * i + 1];
+        o[3] = x[3 * i];
+        const double new_angle = constrain_angle(angle + M_PI_2);
+        o[0] = ref[5 * i + 3] + x[3 * i] * cos(new_angle);
+        o[1] = ref[5 * i + 4] + x[3 * i] * sin(new_angle);
+        o[5] = x[3 * i + 2];
+        o[6] = i < n - 1 ? x[3 * n + i] : 0.0;
+    }
+}
+
+/* PathOptimizer::optimizePath for ONE path: cold solve around lin0 (NULL: (0,0,k_ref)), then `passes` re-linearised
+ * warm re-solves.  out [n][7]; x_out [6n-1], y_out [6n+2] of the LAST solve (may be NULL); iters_out[passes+1]. */
+int pqo_solve_path(const pqo_params* prm, int n, const double* ref, const double* lin0, const double* bounds, const double* scal,
+                   int passes, double* out, double* x_out, double* y_out, int* iters_out, int* status_out, double* rho_out) {
+    pqo_qp* q = qp_alloc(n);
+    int* pos = (int*)malloc(sizeof(int) * q->nv);
+    interleave_perm(n, pos);
+    double* lin = (double*)malloc(sizeof(double) * 3 * n);
+    double* x = (double*)calloc(q->nv, sizeof(double)); double* y = (double*)calloc(q->nc, sizeof(double));
+    for (int i = 0; i < n; ++i) {
+        if (lin0) { lin[3 * i] = lin0[3 * i]; lin[3 * i + 1] = lin0[3 * i + 1]; lin[3 * i + 2] = lin0[3 * i + 2]; }
+        else { lin[3 * i] = 0.0; lin[3 * i + 1] = 0.0; lin[3 * i + 2] = ref[5 * i + 1]; }   /* path_optimizer.cpp:128-137 */
+    }
+    osqp_work* w = NULL;
+    osqp_info info; info.rho = -1; info.status = 0;
+    int ok = 1;
+    for (int p = 0; p <= passes; ++p) {
+        assemble(prm, n, ref, lin, bounds, scal, q);
+        if (!w) w = work_alloc(q, pos);
+        osqp_solve(prm, q, w, p ? x : NULL, p ? y : NULL, p ? info.rho : -1.0, x, y, &info);
+        unpack(n, x, ref, out);
+        if (iters_out) iters_out[p] = info.iters;
+        if (status_out) status_out[p] = info.status;
+        for (int i = 0; i < n; ++i) { lin[3 * i] = out[7 * i + 3]; lin[3 * i + 1] = out[7 * i + 4]; lin[3 * i + 2] = out[7 * i + 5]; }   /* :100 */
+        if (info.status != 1) { ok = 0; break; }
+    }
+    if (rho_out) *rho_out = info.rho;
+    if (x_out) memcpy(x_out, x, sizeof(double) * q->nv);
+    if (y_out) memcpy(y_out, y, sizeof(double) * q->nc);
+    if (w) work_free(w);
+    free(lin); free(x); free(y); free(pos); qp_free(q);
+    return ok;
+}
+
+/* assembled values in triplet order (for cross-checks against the Python oracle) */
+int pqo_assemble(const pqo_params* prm, int n, const double* ref, const double* lin, const double* bounds, const double* scal,
+                 int* ri, int* ci, double* av, double* pd, double* lo, double* up) {
+    pqo_qp* q = qp_alloc(n);
+    assemble(prm, n, ref, lin, bounds, scal, q);
+    memcpy(ri, q->ri, sizeof(int) * q->nnz); memcpy(ci, q->ci, sizeof(int) * q->nnz); memcpy(av, q->av, sizeof(double) * q->nnz);
+    memcpy(pd, q->pd, sizeof(double) * q->nv); memcpy(lo, q->lo, sizeof(double) * q->nc); memcpy(up, q->up, sizeof(double) * q->nc);
+    int nnz = q->nnz;
+    qp_free(q);
+    return nnz;
+}
+
+/* batch driver: one path per task over `threads` OpenMP threads (0: all).  Returns the number of solved paths. */
+int pqo_solve_batch(const pqo_params* prm, int batch, int n, const double* ref, const double* bounds, const double* scal, int passes,
+                    int threads, double* out, int* iters_total) {
+    int solved = 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : solved)
+    for (int b = 0; b < batch; ++b) {
+        int its[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int ok = pqo_solve_path(prm, n, ref + (size_t)b * n * 5, NULL, bounds + (size_t)b * n * 6, scal + (size_t)b * 6, passes,
+                                      out + (size_t)b * n * 7, NULL, NULL, its, NULL, NULL);
+        int t = 0;
+        for (int p = 0; p <= passes && p < 8; ++p) t += its[p];
+        if (iters_total) iters_total[b] = t;
+        solved += ok;
+    }
+    return solved;
+}
+
+int pqo_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
