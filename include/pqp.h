@@ -54,7 +54,7 @@ extern "C" {
 #define PQP_BOUNDS_STRIDE 6
 #define PQP_SCAL_STRIDE 6
 #define PQP_OUT_STRIDE 7
-#define PQP_INFO_STRIDE 6
+#define PQP_INFO_STRIDE 8
 
 typedef enum pqp_error {
     PQP_OK = 0,
@@ -162,7 +162,8 @@ int pqp_path_assemble_device(pqp_handle* h, int batch, int n, int precise, const
  *   (BaseSolver::updateProblemFormulationAndSolve: pass the previous output as `lin`).
  *   status[batch], iters[batch] (total ADMM iterations over all passes) may be NULL.
  *   info (may be NULL) [batch][PQP_INFO_STRIDE]: primal residual, dual residual, final rho, ADMM iterations of the
- *   last pass, number of accepted polishes, total reduced-KKT solves (ADMM iterations + polish refinement). */
+ *   last pass, number of accepted polishes, total reduced-KKT solves (ADMM iterations + polish refinement),
+ *   number of factorisations, reserved. */
 int pqp_path_solve(pqp_handle* h, int batch, int n, const double* ref, const double* lin,
                    const double* bounds, const double* scal, int passes, int warm,
                    double* out, int32_t* status, int32_t* iters, double* info);

@@ -164,7 +164,7 @@ class Handle:
         """Host-array convenience: returns dict(out, status, iters, info)."""
         batch, n = ref.shape[0], ref.shape[1]
         out = np.zeros((batch, n, 7)); status = np.zeros(batch, dtype=np.int32)
-        iters = np.zeros(batch, dtype=np.int32); info = np.zeros((batch, 6))
+        iters = np.zeros(batch, dtype=np.int32); info = np.zeros((batch, 8))
         self._check(self.lib.pqp_path_solve(self._h, batch, n, _ptr(ref), _ptr(lin), _ptr(bounds), _ptr(scal),
                                             passes, 1 if warm else 0, _ptr(out), _ptr(status), _ptr(iters), _ptr(info)))
         return dict(out=out, status=status, iters=iters, info=info)

@@ -314,6 +314,7 @@ PQP_HD double coef_rear(const pqp_params& prm, int flags) { return ((flags & F_R
 struct Uni {
     double rho, cscale, kap, alpha;
     int kkt_solves;
+    int factors;
     int polishing;
 };
 // cold operations (rare, register-hungry): executed out of line on a memory-resident copy of the lane state
@@ -345,9 +346,10 @@ struct PathQp {
     double rho, cscale, kap, alpha_;
     bool polishing_;
     int kkt_solves_;          // iterate() executions: ADMM iterations + polish refinement solves
+    int factors_;             // factor() executions
 
     PQP_HD PathQp(Ctx& c, const PathSolveArgs& a, int q)
-        : ctx(c), A(a), qp(q), n(a.n), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false), kkt_solves_(0) {}
+        : ctx(c), A(a), qp(q), n(a.n), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false), kkt_solves_(0), factors_(0) {}
 
     PQP_HD EndRows* end_rows() const { return reinterpret_cast<EndRows*>(sh + L.end()); }
 
@@ -868,6 +870,7 @@ struct PathQp {
     // ---------------------------------------------------------------------------------------------
     PQP_HD void factor() {
         const pqp_params& prm = A.prm;
+        factors_ += 1;
         // F1: own diagonal block + message to the previous waypoint
         ctx.phase([&](int t, Lane& ln) {
             double M1[6];
@@ -1339,8 +1342,8 @@ struct PathQp {
     // ---------------------------------------------------------------------------------------------
     // the whole path: (warm) solve + `passes` re-linearised warm re-solves
     // ---------------------------------------------------------------------------------------------
-    PQP_HD Uni get_uni() const { return Uni{rho, cscale, kap, alpha_, kkt_solves_, polishing_ ? 1 : 0}; }
-    PQP_HD void set_uni(const Uni& u) { rho = u.rho; cscale = u.cscale; kap = u.kap; alpha_ = u.alpha; kkt_solves_ = u.kkt_solves; polishing_ = u.polishing != 0; }
+    PQP_HD Uni get_uni() const { return Uni{rho, cscale, kap, alpha_, kkt_solves_, factors_, polishing_ ? 1 : 0}; }
+    PQP_HD void set_uni(const Uni& u) { rho = u.rho; cscale = u.cscale; kap = u.kap; alpha_ = u.alpha; kkt_solves_ = u.kkt_solves; factors_ = u.factors; polishing_ = u.polishing != 0; }
 
     // The cold side of the solver.  On the device this runs inside a __noinline__ function on a copy of the lane
     // state that lives in memory (DevCtx::cold), so its register needs never leak into the ADMM loop.
@@ -1527,7 +1530,7 @@ struct PathQp {
             }
         }
         const double rho_final = rho;
-        const int kkt_total = kkt_solves_;
+        const int kkt_total = kkt_solves_, fac_total = factors_;
         ctx.phase([&](int t, Lane&) {
             if (t == 0) {
                 A.wrho[qp] = rho_final;
@@ -1536,7 +1539,7 @@ struct PathQp {
                 if (A.info) {
                     double* f = A.info + PQP_INFO_STRIDE * (size_t)qp;
                     f[0] = res[0]; f[1] = res[1]; f[2] = rho_final; f[3] = (double)last_iters;
-                    f[4] = (double)polished; f[5] = (double)kkt_total;
+                    f[4] = (double)polished; f[5] = (double)kkt_total; f[6] = (double)fac_total; f[7] = 0.0;
                 }
             }
         });

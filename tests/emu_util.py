@@ -38,7 +38,7 @@ def solve(prm, ref, bounds, scal, lin=None, passes=1):
     lib = load()
     B, n = ref.shape[0], ref.shape[1]
     vp = lambda a: None if a is None else np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
-    out = np.zeros((B, n, 7)); st = np.zeros(B, dtype=np.int32); it = np.zeros(B, dtype=np.int32); info = np.zeros((B, 6))
+    out = np.zeros((B, n, 7)); st = np.zeros(B, dtype=np.int32); it = np.zeros(B, dtype=np.int32); info = np.zeros((B, 8))
     wx = np.zeros((B, n, 6)); wy = np.zeros((B, n, 6)); wye = np.zeros((B, 2)); wrho = np.zeros(B)
     ref = np.ascontiguousarray(ref); bounds = np.ascontiguousarray(bounds); scal = np.ascontiguousarray(scal)
     lin_c = None if lin is None else np.ascontiguousarray(lin)
