@@ -43,12 +43,12 @@ def algorithmic_bytes(n, kkt_solves, factors, setups):
     return base, ext
 
 
-def cpu_baseline(batch_np, n, eps, budget_s):
+def cpu_baseline(make_sample, n, eps, budget_s):
     """The oracle (C restatement of the OSQP-paper algorithm, oracle/pqp_oracle.c) timed on this box's host cores over
     a bounded sample of the same workload.  kind = "port": OSQP itself is not in this image."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pqp_oracle_c as OC
-    return OC.timed_baseline(batch_np, n, eps, budget_s)
+    return OC.timed_baseline(make_sample, n, eps, budget_s)
 
 
 def main():
@@ -164,7 +164,7 @@ def main():
                                  "traffic is far below this (profiles/, DESIGN.md 5)"},
         }
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(host, n, args.eps, args.cpu_budget)
+            line["cpu_baseline"] = cpu_baseline(lambda k: make_batch(k, n, args.profile), n, args.eps, args.cpu_budget)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

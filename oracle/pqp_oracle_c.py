@@ -68,22 +68,24 @@ def solve_batch(prm, ref, bounds, scal, passes=1, threads=0):
     return dict(out=out, iters=its, solved=solved)
 
 
-def timed_baseline(batch_np, n, eps, budget_s=20.0, rho_interval=100):
+def timed_baseline(make_sample, n, eps, budget_s=15.0, rho_interval=100):
     """bench.py's cpu_baseline: the C restatement of the OSQP-paper algorithm (no polish: that is what the reference
-    runs), one path per task over all host cores, on as many paths of the SAME workload as fit the time budget."""
+    runs) with one path per task over all host cores, on a bounded sample of the SAME workload:
+    make_sample(k) returns k scenarios of the bench's distribution; k is sized to ~budget_s seconds of wall time."""
     lib = load()
     cores = lib.pqo_num_threads()
     prm = params(eps_abs=eps, eps_rel=eps, adaptive_rho_interval=rho_interval)
-    total = batch_np["ref"].shape[0]
-    k = min(total, 4 * cores)
+    probe = make_sample(4 * cores)
     t0 = time.perf_counter()
-    solve_batch(prm, batch_np["ref"][:k], batch_np["bounds"][:k], batch_np["scal"][:k])
-    per = (time.perf_counter() - t0) / k
-    k = int(max(4 * cores, min(total, budget_s / max(per, 1e-6))))
+    solve_batch(prm, probe["ref"], probe["bounds"], probe["scal"])
+    per = (time.perf_counter() - t0) / (4 * cores)
+    k = int(min(262144, max(4 * cores, budget_s / max(per, 1e-7))))
+    b = make_sample(k)
     t0 = time.perf_counter()
-    r = solve_batch(prm, batch_np["ref"][:k], batch_np["bounds"][:k], batch_np["scal"][:k])
+    r = solve_batch(prm, b["ref"], b["bounds"], b["scal"])
     dt = time.perf_counter() - t0
     return {"value": k / dt, "unit": "paths/s", "cores": cores, "kind": "port",
-            "sample": f"{k} paths of the same batch (N={n}), OSQP-paper restatement in C (oracle/pqp_oracle.c), eps {eps:g}, no polish, "
-                      f"OpenMP over {cores} threads; mean ADMM iterations {float(r['iters'].mean()):.0f}; solved {r['solved']}/{k}",
+            "sample": f"{k} paths of the bench distribution (N={n}) in {dt:.1f} s, OSQP-paper restatement in C (oracle/pqp_oracle.c), "
+                      f"eps {eps:g}, no polish, one path per OpenMP task over {cores} threads; mean ADMM iterations "
+                      f"{float(r['iters'].mean()):.0f}; solved {r['solved']}/{k}",
             "per_core": k / dt / cores}

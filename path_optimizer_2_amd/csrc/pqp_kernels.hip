@@ -151,10 +151,16 @@ struct DevCtx {
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) path_solve_kernel(const PathSolveArgs args) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+#ifndef PQP_MONOLITH
     Lane memlane;
+#endif
     for (int qp = blockIdx.x; qp < args.batch; qp += gridDim.x) {
         DevCtx<NW> ctx;
+#ifndef PQP_MONOLITH
         ctx.mem = &memlane;
+#else
+        ctx.mem = nullptr;
+#endif
         ctx.shp = smem;
         ctx.args = &args;
         PathQp<DevCtx<NW>> solver(ctx, args, qp);
