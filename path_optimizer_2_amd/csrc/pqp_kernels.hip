@@ -88,13 +88,11 @@ template <int NW, int OP>
 __device__ __noinline__ Uni cold_entry(const PathSolveArgs* args, int qp, double* shp, Lane* mem, Uni u, int i0, int i1, double d0) {
     RegCtx<NW> cctx;
     cctx.shp = shp;
-    cctx.lane.s[0] = mem->s[0];
-    cctx.lane.s[1] = mem->s[1];
+    cctx.lane.s = mem->s;
     PathQp<RegCtx<NW>> c(cctx, *args, qp);
     c.set_uni(u);
     c.do_cold(OP, i0, i1, d0);
-    mem->s[0] = cctx.lane.s[0];
-    mem->s[1] = cctx.lane.s[1];
+    mem->s = cctx.lane.s;
     return c.get_uni();
 }
 
@@ -143,8 +141,7 @@ struct DevCtx {
     }
     // only what the ADMM loop reads: Slot (the SlotSetup part of a Lane is cold-only)
     __device__ __forceinline__ static void copy_hot(Lane& dst, const Lane& src) {
-        dst.s[0] = src.s[0];
-        dst.s[1] = src.s[1];
+        dst.s = src.s;
     }
 };
 
@@ -582,7 +579,7 @@ int pqp_path_solve_device(pqp_handle* h, int batch, int n, const double* ref, co
                           double* info) {
     if (!h || !ref || !bounds || !scal || !out || batch < 1 || n < 2 || passes < 0)
         return fail(PQP_ERR_INVALID, "pqp_path_solve: bad argument");
-    if (n > 2048) return fail(PQP_ERR_CAPACITY, "pqp_path_solve: n > 2048 waypoints is not supported");
+    if (n > 1024) return fail(PQP_ERR_CAPACITY, "pqp_path_solve: n > 1024 waypoints is not supported");
     PQP_HIP(hipSetDevice(h->device));
     if (warm && (h->warm_batch != batch || h->warm_n != n))
         return fail(PQP_ERR_INVALID, "pqp_path_solve: warm == 1 needs a previous solve with the same batch and n");
@@ -601,8 +598,8 @@ int pqp_path_solve_device(pqp_handle* h, int batch, int n, const double* ref, co
     a.wx = h->wx.as<double>(); a.wy = h->wy.as<double>(); a.wye = h->wye.as<double>(); a.wrho = h->wrho.as<double>();
     a.prm = h->prm;
     int nw = 1;
-    while (128 * nw < n) nw *= 2;
-    if ((rc = h->wsave.ensure((size_t)batch * 128 * nw * 44 * 8))) return rc;
+    while (64 * nw < n) nw *= 2;           // one waypoint per lane: T = 64 * nw >= n threads per QP
+    if ((rc = h->wsave.ensure((size_t)batch * 64 * nw * 20 * 8))) return rc;
     a.wsave = h->wsave.as<double>();
     const size_t lds = (size_t)pqp::ShLayout{64 * nw}.total() * 8;
     PQP_HIP(hipEventRecord(h->ev0, h->stream));

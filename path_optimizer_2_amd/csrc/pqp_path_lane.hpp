@@ -1,9 +1,11 @@
 // pqp_path_lane.hpp — the per-waypoint ("lane") formulation of the batched path-QP ADMM solve.
 //
-// One workgroup owns one QP.  Thread t owns waypoints 2t and 2t+1 ("slots" 0 and 1); all iterates,
-// the problem data, the penalty metrics and the factorisation of a QP live in registers, neighbouring
-// waypoints talk through a few hundred bytes of LDS, and HBM is touched only to read the scenario
-// and to write the result.
+// One workgroup owns one QP and one thread owns one waypoint (T = 64 * NW >= N threads, NW = 2 waves for the
+// N = 80 / 120 configurations).  All iterates, the problem data, the penalty metrics and the factorisation of a
+// QP live in registers (86 fp64 per waypoint -> the whole solver fits in 256 VGPRs, two waves per SIMD, no
+// scratch), neighbouring waypoints talk through ~27 KB of LDS, and HBM is touched only to read the scenario
+// and to write the result.  (Round-1 history: a 2-waypoints-per-lane layout needed > 512 VGPRs at the
+// factorisation and spilled 2 GB per launch; see DESIGN.md.)
 //
 // What is computed (reference file:line relative to LiJiangnanBit/path_optimizer_2):
 //   * assemble   — BaseSolver::setCost / setConstraints / getSoftBounds
@@ -70,7 +72,7 @@ struct PathSolveArgs {
     double* wy;             // [batch][n][6]  (yT[3], yK, yF, yR)
     double* wye;            // [batch][2]
     double* wrho;           // [batch]
-    double* wsave;          // [batch][2T][44] save area: ADMM state during a polish + iterates parked around factor()
+    double* wsave;          // [batch][T][20] save area: the ADMM state while a polish is tried
     pqp_params prm;
 };
 
@@ -248,7 +250,7 @@ struct Slot {
     double sig[6], rhoT[3], rhoI[3], rinvI[3];
     // elimination of v, sf, sr
     double cF, cR, idsf, idsr, tu, tudc, idu;
-    // cyclic-reduction factor of this slot's node
+    // cyclic-reduction factor of this waypoint's node
     double Dinv[6], GL[9], GR[9];
     // per-iteration scratch that crosses a phase boundary
     double r[3], rv, rsf, rsr, xt[6];
@@ -260,8 +262,8 @@ struct SlotSetup {
 };
 
 struct Lane {
-    Slot s[2];
-    SlotSetup w[2];
+    Slot s;
+    SlotSetup w;
 };
 
 // end rows (owned by the thread holding waypoint n-1), kept in shared memory
@@ -272,26 +274,23 @@ struct EndRows {
     double pad[2];
 };
 
-// shared-memory layout in doubles, T = threads per QP.  The per-iteration exchange buffers and the
-// factor-time exchange buffers are never live at the same time and share one region.
+// shared-memory layout in doubles, T = threads per QP = padded number of waypoints.  The per-iteration exchange
+// buffers and the factor-time exchange buffer are never live at the same time and share one region.
 struct ShLayout {
     int T;
     // per-iteration exchange
     PQP_HD int bufG() const { return 0; }                   // [T][3]  message to the previous waypoint
     PQP_HD int bufP() const { return 3 * T; }               // [T][3]  CR forward, to the right neighbour
     PQP_HD int bufQ() const { return 6 * T; }               // [T][3]  CR forward, to the left neighbour
-    PQP_HD int xbuf() const { return 9 * T; }               // [T][3]  X~ of slot 0
-    PQP_HD int xodd() const { return 12 * T; }              // [T][3]  X~ of slot 1
-    // factor-time exchange (aliases the above)
-    PQP_HD int fbuf() const { return 0; }                   // [T][21] SL(6) SR(6) Cnew(9)
-    PQP_HD int fbufA() const { return 0; }                  // [T][15] M(6) Lc(9)   (dead before fbuf is written)
-    PQP_HD int fbufB() const { return 21 * T; }             // [T][15] SR(6) Cnew(9)
+    PQP_HD int xbuf() const { return 9 * T; }               // [T][3]  X~ (and X for the residuals)
+    // factor-time exchange (aliases the above): first [T][15] M(6) Lc(9), then [T][21] SL(6) SR(6) Cnew(9)
+    PQP_HD int fbuf() const { return 0; }
     // persistent
-    PQP_HD int lin() const { return 36 * T; }               // [2T][3] linearisation point
-    PQP_HD int sk() const { return 42 * T; }                // [2T][2] s, k_ref
-    PQP_HD int end() const { return 46 * T; }               // EndRows (24 doubles)
-    PQP_HD int red() const { return 46 * T + 24; }          // reduction scratch [8][16]
-    PQP_HD int total() const { return 46 * T + 24 + 128; }
+    PQP_HD int lin() const { return 21 * T; }               // [T][3] linearisation point / first-iteration dz
+    PQP_HD int sk() const { return 24 * T; }                // [T][2] s, k_ref
+    PQP_HD int end() const { return 26 * T; }               // EndRows (24 doubles)
+    PQP_HD int red() const { return 26 * T + 24; }          // reduction scratch [8][16]
+    PQP_HD int total() const { return 26 * T + 24 + 128; }
 };
 
 // diagonal of P by variable slot (base_solver.cpp:123-143); dummy variables (padding waypoints, v of waypoint 0,
@@ -328,10 +327,11 @@ enum RefactorKind : int { RF_RESCALE = 0 /* d0 = ratio */, RF_POLISH_BEGIN = 1, 
 
 // =======================================================================================================
 // The solver.  Ctx provides:
-//   int  T()                              threads per QP (power of two, >= 1)
+//   int  T()                              threads per QP (power of two, >= 64)
 //   double* sh()                          shared scratch of ShLayout(T).total() doubles
 //   template<F> void phase(F f)           run f(t, Lane&) for every thread, then synchronise
 //   template<int K,F> void reduce_max/sum(double (&out)[K], F f)   f(t, Lane&, double (&v)[K])
+//   void cold(PathQp&, op, i0, i1, d0)    run do_cold() (possibly out of line)
 // =======================================================================================================
 template <class Ctx>
 struct PathQp {
@@ -354,9 +354,9 @@ struct PathQp {
     PQP_HD EndRows* end_rows() const { return reinterpret_cast<EndRows*>(sh + L.end()); }
 
     // NOTE on style: per-lane state must stay in registers, which needs every Lane field to be written through
-    // one unconditional store (values chosen with selects); only LDS / global stores sit under branches.
-    // (if/else branches that store to different places get merged by LLVM into a store through a pointer phi,
-    // which pins the whole Lane struct in scratch memory.)
+    // one unconditional store (values chosen with selects) or under a single branch without an else-store; only
+    // LDS / global stores sit freely under branches.  (if/else branches that store to different places get merged by
+    // LLVM into a store through a pointer phi, which pins the whole Lane struct in scratch memory.)
 
     // ---------------------------------------------------------------------------------------------
     // load the scenario
@@ -364,30 +364,26 @@ struct PathQp {
     PQP_HD void load() {
         const pqp_params& prm = A.prm;
         ctx.phase([&](int t, Lane& ln) {
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                Slot& S = ln.s[q];
-                const int i = 2 * t + q;
-                const bool real = i < n;
-                const int ic = real ? i : n - 1;
-                const double* r = A.ref + ((size_t)qp * n + ic) * PQP_REF_STRIDE;
-                const double r0 = r[0], r1 = r[1];
-                // base_solver.cpp:25-34: precise planning size = lower_bound(s, precise_planning_length)
-                const bool precise = !prm.rough_constraints_far_away || r0 < prm.precise_planning_length;
-                S.flags = real ? (F_REAL | (i > 0 ? F_PREV : 0) | (i < n - 1 ? F_NEXT : 0) | (i == n - 1 ? F_LAST : 0) |
-                                  (precise ? F_PRECISE : 0))
-                               : 0;
-                double l0 = 0.0, l1 = 0.0, l2 = r1;      // path_optimizer.cpp:128-137: (0, 0, k_ref)
-                if (A.lin) {
-                    const double* li = A.lin + ((size_t)qp * n + ic) * PQP_LIN_STRIDE;
-                    l0 = li[0]; l1 = li[1]; l2 = li[2];
-                }
-                if (real) {
-                    sh[L.lin() + 3 * i + 0] = l0; sh[L.lin() + 3 * i + 1] = l1; sh[L.lin() + 3 * i + 2] = l2;
-                    sh[L.sk() + 2 * i + 0] = r0; sh[L.sk() + 2 * i + 1] = r1;
-                }
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = 0.0;
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) { S.yT[k] = 0.0; S.yI[k] = 0.0; S.zI[k] = 0.0; }
+            Slot& S = ln.s;
+            const int i = t;
+            const bool real = i < n;
+            const int ic = real ? i : n - 1;
+            const double* r = A.ref + ((size_t)qp * n + ic) * PQP_REF_STRIDE;
+            const double r0 = r[0], r1 = r[1];
+            // base_solver.cpp:25-34: precise planning size = lower_bound(s, precise_planning_length)
+            const bool precise = !prm.rough_constraints_far_away || r0 < prm.precise_planning_length;
+            S.flags = real ? (F_REAL | (i > 0 ? F_PREV : 0) | (i < n - 1 ? F_NEXT : 0) | (i == n - 1 ? F_LAST : 0) | (precise ? F_PRECISE : 0)) : 0;
+            double l0 = 0.0, l1 = 0.0, l2 = r1;      // path_optimizer.cpp:128-137: (0, 0, k_ref)
+            if (A.lin) {
+                const double* li = A.lin + ((size_t)qp * n + ic) * PQP_LIN_STRIDE;
+                l0 = li[0]; l1 = li[1]; l2 = li[2];
             }
+            if (real) {
+                sh[L.lin() + 3 * i + 0] = l0; sh[L.lin() + 3 * i + 1] = l1; sh[L.lin() + 3 * i + 2] = l2;
+                sh[L.sk() + 2 * i + 0] = r0; sh[L.sk() + 2 * i + 1] = r1;
+            }
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = 0.0;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { S.yT[k] = 0.0; S.yI[k] = 0.0; S.zI[k] = 0.0; }
         });
     }
 
@@ -404,40 +400,38 @@ struct PathQp {
             kap = (sn / cn) / prm.wheel_base;
         }
         ctx.phase([&](int t, Lane& ln) {
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                Slot& S = ln.s[q];
-                const int i = 2 * t + q;
-                const bool real = S.flags & F_REAL, prev = S.flags & F_PREV, precise = S.flags & F_PRECISE;
-                double a6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, c3[3] = {0.0, 0.0, 0.0};
-                if (prev)
-                    transition_block(sh + L.lin() + 3 * (i - 1), sh[L.lin() + 3 * i + 2], sh[L.sk() + 2 * (i - 1)],
-                                     sh[L.sk() + 2 * i], sh[L.sk() + 2 * (i - 1) + 1], a6, c3);
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.a[k] = a6[k];
-                // transition right-hand sides: -c (:221-224), or -x0 at the first waypoint (:216-220)
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.bT[k] = !real ? 0.0 : (prev ? -c3[k] : -sc[k]);
-                // collision boxes (:232-248); rough: one row l + s_c on the centre box, the R row and sr are dummies
-                const int ic = real ? i : n - 1;
-                const double* b = A.bounds + ((size_t)qp * n + ic) * PQP_BOUNDS_STRIDE;
-                const double f_lb = precise ? b[0] : b[4], f_ub = precise ? b[1] : b[5];
-                double flo, fup, rlo, rup;
-                soft_bounds(f_lb, f_ub, prm.expected_safety_margin, prm.min_clearance, flo, fup);
-                soft_bounds(b[2], b[3], prm.expected_safety_margin, prm.min_clearance, rlo, rup);
-                S.lo[0] = real ? flo : 0.0; S.up[0] = real ? fup : 0.0;
-                S.lo[1] = (real && precise) ? rlo : 0.0; S.up[1] = (real && precise) ? rup : 0.0;
-                if (S.flags & F_LAST) {                                         // :250-259
-                    EndRows* er = end_rows();
-                    double elo = -kInfty, eup = kInfty;
-                    if (prm.constraint_end_heading && sc[4] == 0.0) {
-                        const double heading = A.ref[((size_t)qp * n + i) * PQP_REF_STRIDE + 2];
-                        const double end_psi = constrain_angle(sc[3] - heading);
-                        if (end_psi < prm.end_psi_max) {     // signed compare, no fabs (:256)
-                            elo = end_psi - prm.end_psi_tol;
-                            eup = end_psi + prm.end_psi_tol;
-                        }
+            Slot& S = ln.s;
+            const int i = t;
+            const bool real = S.flags & F_REAL, prev = S.flags & F_PREV, precise = S.flags & F_PRECISE;
+            double a6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, c3[3] = {0.0, 0.0, 0.0};
+            if (prev)
+                transition_block(sh + L.lin() + 3 * (i - 1), sh[L.lin() + 3 * i + 2], sh[L.sk() + 2 * (i - 1)],
+                                 sh[L.sk() + 2 * i], sh[L.sk() + 2 * (i - 1) + 1], a6, c3);
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) S.a[k] = a6[k];
+            // transition right-hand sides: -c (:221-224), or -x0 at the first waypoint (:216-220)
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) S.bT[k] = !real ? 0.0 : (prev ? -c3[k] : -sc[k]);
+            // collision boxes (:232-248); rough: one row l + s_c on the centre box, the R row and sr are dummies
+            const int ic = real ? i : n - 1;
+            const double* b = A.bounds + ((size_t)qp * n + ic) * PQP_BOUNDS_STRIDE;
+            const double f_lb = precise ? b[0] : b[4], f_ub = precise ? b[1] : b[5];
+            double flo, fup, rlo, rup;
+            soft_bounds(f_lb, f_ub, prm.expected_safety_margin, prm.min_clearance, flo, fup);
+            soft_bounds(b[2], b[3], prm.expected_safety_margin, prm.min_clearance, rlo, rup);
+            S.lo[0] = real ? flo : 0.0; S.up[0] = real ? fup : 0.0;
+            S.lo[1] = (real && precise) ? rlo : 0.0; S.up[1] = (real && precise) ? rup : 0.0;
+            if (S.flags & F_LAST) {                                         // :250-259
+                EndRows* er = end_rows();
+                double elo = -kInfty, eup = kInfty;
+                if (prm.constraint_end_heading && sc[4] == 0.0) {
+                    const double heading = A.ref[((size_t)qp * n + i) * PQP_REF_STRIDE + 2];
+                    const double end_psi = constrain_angle(sc[3] - heading);
+                    if (end_psi < prm.end_psi_max) {     // signed compare, no fabs (:256)
+                        elo = end_psi - prm.end_psi_tol;
+                        eup = end_psi + prm.end_psi_tol;
                     }
-                    er->lo[0] = -prm.end_l_bound; er->up[0] = prm.end_l_bound;
-                    er->lo[1] = elo; er->up[1] = eup;
                 }
+                er->lo[0] = -prm.end_l_bound; er->up[0] = prm.end_l_bound;
+                er->lo[1] = elo; er->up[1] = eup;
             }
         });
     }
@@ -457,6 +451,13 @@ struct PathQp {
         return (S.flags & (F_ACTLO0 << k)) ? lo : ((S.flags & (F_ACTUP0 << k)) ? up : kInfty);
     }
 
+    // column message of a waypoint's T rows to the previous waypoint (Ruiz)
+    PQP_HD static void col_msg(const Slot& S, const SlotSetup& W, double* m) {
+        m[0] = fmax(W.E[0] * fabs(S.a[0]), W.E[1] * fabs(S.a[2]));
+        m[1] = fmax(W.E[0] * fabs(S.a[1]), W.E[1] * fabs(S.a[3]));
+        m[2] = fmax(W.E[1] * fabs(S.a[4]), (S.flags & F_PREV) ? W.E[2] : 0.0);
+    }
+
     // ---------------------------------------------------------------------------------------------
     // modified Ruiz equilibration (OSQP paper Alg. 2) on the structured KKT -> D, E, c, then the
     // penalty metrics Sigma = sigma/(c D^2) and R = rho * class * E^2 / c for the current rho
@@ -465,93 +466,71 @@ struct PathQp {
         const pqp_params& prm = A.prm;
         cscale = 1.0;
         ctx.phase([&](int, Lane& ln) {
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) { ln.w[q].D[k] = 1.0; ln.w[q].E[k] = 1.0; }
-                if (ln.s[q].flags & F_LAST) { end_rows()->E[0] = 1.0; end_rows()->E[1] = 1.0; }
-            }
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) { ln.w.D[k] = 1.0; ln.w.E[k] = 1.0; }
+            if (ln.s.flags & F_LAST) { end_rows()->E[0] = 1.0; end_rows()->E[1] = 1.0; }
         });
         int nreal_cols = 0;   // 3n + (n-1) + precise + n
         if (prm.scaling > 0) {
             double cnt[1];
             ctx.template reduce_sum<1>(cnt, [&](int, Lane& ln, double (&v)[1]) {
-                v[0] = 0.0;
-                _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                    const int f = ln.s[q].flags;
-                    if (f & F_REAL) v[0] += 4.0 + ((f & F_PREV) ? 1.0 : 0.0) + ((f & F_PRECISE) ? 1.0 : 0.0);
-                }
+                const int f = ln.s.flags;
+                v[0] = (f & F_REAL) ? 4.0 + ((f & F_PREV) ? 1.0 : 0.0) + ((f & F_PRECISE) ? 1.0 : 0.0) : 0.0;
             });
             nreal_cols = (int)(cnt[0] + 0.5);
         }
         for (int pass = 0; pass < prm.scaling; ++pass) {
             // exchange: column contributions of T rows go to the previous waypoint, D of X goes to the next
             ctx.phase([&](int t, Lane& ln) {
-                _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                    const Slot& S = ln.s[q];
-                    const SlotSetup& W = ln.w[q];
-                    double m[3];
-                    m[0] = fmax(W.E[0] * fabs(S.a[0]), W.E[1] * fabs(S.a[2]));
-                    m[1] = fmax(W.E[0] * fabs(S.a[1]), W.E[1] * fabs(S.a[3]));
-                    m[2] = fmax(W.E[1] * fabs(S.a[4]), (S.flags & F_PREV) ? W.E[2] : 0.0);
-                    if (q == 0) { _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufG() + 3 * t + k] = m[k]; }
-                    else { _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xodd() + 3 * t + k] = W.D[k]; }
-                }
+                double m[3];
+                col_msg(ln.s, ln.w, m);
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) { sh[L.bufG() + 3 * t + k] = m[k]; sh[L.xbuf() + 3 * t + k] = ln.w.D[k]; }
             });
             double csum[1];
             const double c_now = cscale;
             ctx.template reduce_sum<1>(csum, [&](int t, Lane& ln, double (&v)[1]) {
-                double Dprev0[3], mnext1[3], m1[3], Dold0[3];
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) Dprev0[k] = (t > 0) ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) mnext1[k] = (t + 1 < T) ? sh[L.bufG() + 3 * (t + 1) + k] : 0.0;
-                {   // slot 1's column message to slot 0 (same thread)
-                    const Slot& S = ln.s[1];
-                    const SlotSetup& W = ln.w[1];
-                    m1[0] = fmax(W.E[0] * fabs(S.a[0]), W.E[1] * fabs(S.a[2]));
-                    m1[1] = fmax(W.E[0] * fabs(S.a[1]), W.E[1] * fabs(S.a[3]));
-                    m1[2] = fmax(W.E[1] * fabs(S.a[4]), (S.flags & F_PREV) ? W.E[2] : 0.0);
+                const Slot& S = ln.s;
+                SlotSetup& W = ln.w;
+                double Dp[3], mn[3];
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) Dp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) mn[k] = (t + 1 < T) ? sh[L.bufG() + 3 * (t + 1) + k] : 0.0;
+                const bool real = S.flags & F_REAL, last = S.flags & F_LAST, precise = S.flags & F_PRECISE, prev = S.flags & F_PREV;
+                EndRows* er = end_rows();
+                const double ee0 = last ? er->E[0] : 0.0, ee1 = last ? er->E[1] : 0.0;
+                const double acf = fabs(coef_front(prm, S.flags)), acr = fabs(coef_rear(prm, S.flags));
+                double cn[6], rn[6];
+                // column norms of [P; A] (scaled)
+                cn[0] = fmax(fmax3(W.E[0], mn[0], W.E[4]), fmax(precise ? W.E[5] : 0.0, ee0));
+                cn[1] = fmax(fmax3(W.E[1], mn[1], W.E[4] * acf), fmax(precise ? W.E[5] * acr : 0.0, ee1));
+                cn[2] = fmax3(W.E[2], mn[2], W.E[3]);
+                cn[3] = W.E[2] * fabs(S.a[5]);
+                cn[4] = W.E[4];
+                cn[5] = W.E[5];
+                // row norms of A (scaled)
+                rn[0] = fmax3(W.D[0], Dp[0] * fabs(S.a[0]), Dp[1] * fabs(S.a[1]));
+                rn[1] = fmax(fmax3(W.D[1], Dp[0] * fabs(S.a[2]), Dp[1] * fabs(S.a[3])), Dp[2] * fabs(S.a[4]));
+                rn[2] = fmax3(W.D[2], prev ? Dp[2] : 0.0, W.D[3] * fabs(S.a[5]));
+                rn[3] = W.D[2];
+                rn[4] = fmax3(W.D[0], W.D[1] * acf, W.D[4]);
+                rn[5] = fmax3(W.D[0], W.D[1] * acr, W.D[5]);
+                const double ren0 = W.D[0] * ee0, ren1 = W.D[1] * ee1;
+                const bool colreal[6] = {real, real, real, prev, real, real && precise};
+                const bool rowreal[6] = {real, real, real, real, real, real && precise};
+                double acc = 0.0;
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) {
+                    const double pk = cost_diag(prm, S.flags, k);
+                    const double cnk = fmax(cn[k] * W.D[k], c_now * W.D[k] * W.D[k] * pk);
+                    const double rnk = rn[k] * W.E[k];
+                    const double dnew = W.D[k] * rsq(limit_scaling(cnk));
+                    const double enew = W.E[k] * rsq(limit_scaling(rnk));
+                    W.D[k] = colreal[k] ? dnew : 1.0;
+                    W.E[k] = rowreal[k] ? enew : 1.0;
+                    acc += colreal[k] ? fabs(c_now * W.D[k] * W.D[k] * pk) : 0.0;
                 }
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) Dold0[k] = ln.w[0].D[k];
-                v[0] = 0.0;
-                _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                    const Slot& S = ln.s[q];
-                    SlotSetup& W = ln.w[q];
-                    const double* mn = (q == 0) ? m1 : mnext1;
-                    const double* Dp = (q == 0) ? Dprev0 : Dold0;
-                    const bool real = S.flags & F_REAL, last = S.flags & F_LAST, precise = S.flags & F_PRECISE, prev = S.flags & F_PREV;
-                    EndRows* er = end_rows();
-                    const double ee0 = last ? er->E[0] : 0.0, ee1 = last ? er->E[1] : 0.0;
-                    const double acf = fabs(coef_front(prm, S.flags)), acr = fabs(coef_rear(prm, S.flags));
-                    // column norms of [P; A] (scaled)
-                    double cn[6], rn[6];
-                    cn[0] = fmax(fmax3(W.E[0], mn[0], W.E[4]), fmax(precise ? W.E[5] : 0.0, ee0));
-                    cn[1] = fmax(fmax3(W.E[1], mn[1], W.E[4] * acf), fmax(precise ? W.E[5] * acr : 0.0, ee1));
-                    cn[2] = fmax3(W.E[2], mn[2], W.E[3]);
-                    cn[3] = W.E[2] * fabs(S.a[5]);
-                    cn[4] = W.E[4];
-                    cn[5] = W.E[5];
-                    // row norms of A (scaled)
-                    rn[0] = fmax3(W.D[0], Dp[0] * fabs(S.a[0]), Dp[1] * fabs(S.a[1]));
-                    rn[1] = fmax(fmax3(W.D[1], Dp[0] * fabs(S.a[2]), Dp[1] * fabs(S.a[3])), Dp[2] * fabs(S.a[4]));
-                    rn[2] = fmax3(W.D[2], prev ? Dp[2] : 0.0, W.D[3] * fabs(S.a[5]));
-                    rn[3] = W.D[2];
-                    rn[4] = fmax3(W.D[0], W.D[1] * acf, W.D[4]);
-                    rn[5] = fmax3(W.D[0], W.D[1] * acr, W.D[5]);
-                    const double ren0 = W.D[0] * ee0, ren1 = W.D[1] * ee1;
-                    const bool colreal[6] = {real, real, real, prev, real, real && precise};
-                    const bool rowreal[6] = {real, real, real, real, real, real && precise};
-                    _Pragma("unroll") for (int k = 0; k < 6; ++k) {
-                        const double cnk = fmax(cn[k] * W.D[k], c_now * W.D[k] * W.D[k] * cost_diag(prm, S.flags, k));
-                        const double rnk = rn[k] * W.E[k];
-                        const double dnew = W.D[k] * rsq(limit_scaling(cnk));
-                        const double enew = W.E[k] * rsq(limit_scaling(rnk));
-                        W.D[k] = colreal[k] ? dnew : 1.0;
-                        W.E[k] = rowreal[k] ? enew : 1.0;
-                        if (colreal[k]) v[0] += fabs(c_now * W.D[k] * W.D[k] * cost_diag(prm, S.flags, k));
-                    }
-                    if (last) {
-                        er->E[0] = ee0 * rsq(limit_scaling(ren0));
-                        er->E[1] = ee1 * rsq(limit_scaling(ren1));
-                    }
+                if (last) {
+                    er->E[0] = ee0 * rsq(limit_scaling(ren0));
+                    er->E[1] = ee1 * rsq(limit_scaling(ren1));
                 }
+                v[0] = acc;
             });
             // cost scaling: c <- c / max(mean column norm of P, ||q||_inf -> 1 when q == 0)
             double ct = csum[0] / (double)nreal_cols;
@@ -561,40 +540,39 @@ struct PathQp {
         }
         // metrics
         const double c = cscale, rho_now = rho;
+        const double ic = 1.0 / c;
         ctx.phase([&](int, Lane& ln) {
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                Slot& S = ln.s[q];
-                const SlotSetup& W = ln.w[q];
-                const bool real = S.flags & F_REAL, precise = S.flags & F_PRECISE;
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] = prm.sigma * rcp(c * W.D[k] * W.D[k]);
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] = real ? rho_now * kRhoEqFactor * W.E[k] * W.E[k] / c : 0.0;
-                int fl = S.flags & ~((7 * F_FREE0) | (7 * F_EQ0));      // the active-set bits of a previous polish survive
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                    const bool rowreal = real && (k < 2 || precise);
-                    const double e = W.E[3 + k], e2 = e * e / c;
-                    const double sl = e * raw_lo(S, k), su = e * raw_up(S, k);
-                    const bool free_row = sl < -kInfty * kMinScaling && su > kInfty * kMinScaling;
-                    const bool eq_row = !free_row && (su - sl < kRhoTol);
-                    const double r = !rowreal ? 0.0 : (free_row ? kRhoMin * e2 : (eq_row ? rho_now * kRhoEqFactor * e2 : rho_now * e2));
-                    S.rhoI[k] = r;
-                    S.rinvI[k] = r > 0.0 ? rcp(r) : 0.0;
-                    if (rowreal && free_row) fl |= (F_FREE0 << k);
-                    if (rowreal && eq_row) fl |= (F_EQ0 << k);
-                }
-                S.flags = fl;
-                if (S.flags & F_LAST) {
-                    EndRows* er = end_rows();
-                    for (int k = 0; k < 2; ++k) {
-                        const double e = er->E[k], e2 = e * e / c;
-                        const double sl = e * fmax(er->lo[k], -kInfty), su = e * fmin(er->up[k], kInfty);
-                        double rb;
-                        if (sl < -kInfty * kMinScaling && su > kInfty * kMinScaling) rb = -kRhoMin * e2;
-                        else if (su - sl < kRhoTol) rb = kRhoEqFactor * e2;
-                        else rb = e2;
-                        er->rb[k] = rb;
-                        const double r = rb < 0.0 ? -rb : rho_now * rb;
-                        er->rho[k] = r; er->rinv[k] = rcp(r);
-                    }
+            Slot& S = ln.s;
+            const SlotSetup& W = ln.w;
+            const bool real = S.flags & F_REAL, precise = S.flags & F_PRECISE;
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] = prm.sigma * rcp(c * W.D[k] * W.D[k]);
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] = real ? rho_now * kRhoEqFactor * W.E[k] * W.E[k] * ic : 0.0;
+            int fl = S.flags & ~((7 * F_FREE0) | (7 * F_EQ0));      // the active-set bits of a previous polish survive
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                const bool rowreal = real && (k < 2 || precise);
+                const double e = W.E[3 + k], e2 = e * e * ic;
+                const double sl = e * raw_lo(S, k), su = e * raw_up(S, k);
+                const bool free_row = sl < -kInfty * kMinScaling && su > kInfty * kMinScaling;
+                const bool eq_row = !free_row && (su - sl < kRhoTol);
+                const double r = !rowreal ? 0.0 : (free_row ? kRhoMin * e2 : (eq_row ? rho_now * kRhoEqFactor * e2 : rho_now * e2));
+                S.rhoI[k] = r;
+                S.rinvI[k] = r > 0.0 ? rcp(r) : 0.0;
+                if (rowreal && free_row) fl |= (F_FREE0 << k);
+                if (rowreal && eq_row) fl |= (F_EQ0 << k);
+            }
+            S.flags = fl;
+            if (S.flags & F_LAST) {
+                EndRows* er = end_rows();
+                for (int k = 0; k < 2; ++k) {
+                    const double e = er->E[k], e2 = e * e * ic;
+                    const double sl = e * fmax(er->lo[k], -kInfty), su = e * fmin(er->up[k], kInfty);
+                    double rb;
+                    if (sl < -kInfty * kMinScaling && su > kInfty * kMinScaling) rb = -kRhoMin * e2;
+                    else if (su - sl < kRhoTol) rb = kRhoEqFactor * e2;
+                    else rb = e2;
+                    er->rb[k] = rb;
+                    const double r = rb < 0.0 ? -rb : rho_now * rb;
+                    er->rho[k] = r; er->rinv[k] = rcp(r);
                 }
             }
         });
@@ -604,22 +582,20 @@ struct PathQp {
     PQP_HD void rescale_rho(double ratio) {
         const double rho_now = rho;
         ctx.phase([&](int, Lane& ln) {
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                Slot& S = ln.s[q];
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] *= ratio;
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                    const bool fr = S.flags & (F_FREE0 << k);
-                    const double r = fr ? S.rhoI[k] : S.rhoI[k] * ratio;
-                    S.rhoI[k] = r;
-                    S.rinvI[k] = r > 0.0 ? rcp(r) : 0.0;
-                }
-                if (S.flags & F_LAST) {
-                    EndRows* er = end_rows();
-                    for (int k = 0; k < 2; ++k) {
-                        const double rb = er->rb[k];
-                        const double r = rb < 0.0 ? -rb : rho_now * rb;
-                        er->rho[k] = r; er->rinv[k] = rcp(r);
-                    }
+            Slot& S = ln.s;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] *= ratio;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                const bool fr = S.flags & (F_FREE0 << k);
+                const double r = fr ? S.rhoI[k] : S.rhoI[k] * ratio;
+                S.rhoI[k] = r;
+                S.rinvI[k] = r > 0.0 ? rcp(r) : 0.0;
+            }
+            if (S.flags & F_LAST) {
+                EndRows* er = end_rows();
+                for (int k = 0; k < 2; ++k) {
+                    const double rb = er->rb[k];
+                    const double r = rb < 0.0 ? -rb : rho_now * rb;
+                    er->rho[k] = r; er->rinv[k] = rcp(r);
                 }
             }
         });
@@ -627,16 +603,18 @@ struct PathQp {
 
     // ---------------------------------------------------------------------------------------------
     // Solution polishing (OSQP paper section 4.2) with a KKT acceptance test.
-    //   1. park the ADMM state, guess the active set from (z, y) with OSQP's rule
+    //   1. park the ADMM state, guess the active set from (z, y) with OSQP's rule (or keep the previous pass's set)
     //   2. equality-constrained QP on that set = the same reduced system with penalty 1/delta on active rows,
     //      0 on inactive rows, Sigma scaled to delta; `polish_refine_iter` proximal-multiplier iterations
     //      (alpha = 1) are the iterative refinement
     //   3. accept iff the polished point is primal feasible on the inactive rows, has the right dual signs on
-    //      the active rows and is stationary -> it then IS the optimum of the QP; otherwise restore and resume.
+    //      the active rows and is stationary -> it then IS the optimum of the QP; otherwise rows that fail the test
+    //      change sides (primal-dual active-set rounds) or, when that stalls, the ADMM state is restored.
     // ---------------------------------------------------------------------------------------------
-    static constexpr int kSaveStride = 44;   // polish: x6 yT3 yI3 zI3 rhoI3 (+2 pad) | park: x6 yT3 yI3 zI3 bT3 lo2 up2 (+2 pad)
-    static constexpr int kParkOffset = 20;
+    static constexpr int kSaveStride = 20;   // x6 yT3 yI3 zI3 rhoI3 (+2 pad)
     static constexpr int kPolishRounds = 40; // active-set correction rounds per polish attempt
+
+    PQP_HD double* save_slot(int t) const { return A.wsave + ((size_t)qp * T + t) * kSaveStride; }
 
     // how badly inequality row k fails the KKT test at the polished point: violation of its true box when it is
     // treated as inactive, wrong-signed multiplier when it is treated as active (0 for rows that do not exist)
@@ -664,38 +642,32 @@ struct PathQp {
         const double tgain = gain / (rho_now * kRhoEqFactor);
         const double irho = 1.0 / rho_now, irho_eq = 1.0 / (rho_now * kRhoEqFactor);
         ctx.phase([&](int t, Lane& ln) {
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                Slot& S = ln.s[q];
-                const int i = 2 * t + q;
-                const bool real = S.flags & F_REAL;
-                if (real) {
-                    double* w = A.wsave + ((size_t)qp * (2 * T) + i) * kSaveStride;
-                    _Pragma("unroll") for (int k = 0; k < 6; ++k) w[k] = S.x[k];
-                    _Pragma("unroll") for (int k = 0; k < 3; ++k) { w[6 + k] = S.yT[k]; w[9 + k] = S.yI[k]; w[12 + k] = S.zI[k]; w[15 + k] = S.rhoI[k]; }
-                }
-                int fl = S.flags & ~((7 * F_ACTLO0) | (7 * F_ACTUP0));
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] *= tgain;
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                    const bool fr = S.flags & (F_FREE0 << k), eq = S.flags & (F_EQ0 << k);
-                    const double e2 = S.rhoI[k] * (eq ? irho_eq : irho);     // E^2 / c of the row
-                    const bool can = !fr && S.rhoI[k] > 0.0;
-                    const bool act_lo = can && ((S.zI[k] - raw_lo(S, k)) * e2 < -S.yI[k]);
-                    const bool act_up = can && !act_lo && ((raw_up(S, k) - S.zI[k]) * e2 < S.yI[k]);
-                    if (act_lo) fl |= (F_ACTLO0 << k);
-                    if (act_up) fl |= (F_ACTUP0 << k);
-                }
-                S.flags = fl;
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] *= sgain;
-                if (S.flags & F_LAST) {
-                    EndRows* er = end_rows();
-                    for (int k = 0; k < 2; ++k) {
-                        er->sz[k] = er->z[k]; er->sy[k] = er->y[k];
-                        const bool fr = er->rb[k] < 0.0;
-                        const double e2 = er->E[k] * er->E[k] / cscale;
-                        const bool act_lo = !fr && ((er->z[k] - er->lo[k]) * e2 < -er->y[k]);
-                        const bool act_up = !fr && !act_lo && ((er->up[k] - er->z[k]) * e2 < er->y[k]);
-                        er->act[k] = keep_set ? (fr ? 0.0 : er->act[k]) : (act_lo ? -1.0 : (act_up ? 1.0 : 0.0));
-                    }
+            Slot& S = ln.s;
+            double* w = save_slot(t);
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) w[k] = S.x[k];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { w[6 + k] = S.yT[k]; w[9 + k] = S.yI[k]; w[12 + k] = S.zI[k]; w[15 + k] = S.rhoI[k]; }
+            int fl = S.flags & ~((7 * F_ACTLO0) | (7 * F_ACTUP0));
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] *= tgain;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                const bool fr = S.flags & (F_FREE0 << k), eq = S.flags & (F_EQ0 << k);
+                const double e2 = S.rhoI[k] * (eq ? irho_eq : irho);     // E^2 / c of the row
+                const bool can = !fr && S.rhoI[k] > 0.0;
+                const bool act_lo = can && ((S.zI[k] - raw_lo(S, k)) * e2 < -S.yI[k]);
+                const bool act_up = can && !act_lo && ((raw_up(S, k) - S.zI[k]) * e2 < S.yI[k]);
+                if (act_lo) fl |= (F_ACTLO0 << k);
+                if (act_up) fl |= (F_ACTUP0 << k);
+            }
+            S.flags = keep_set ? S.flags : fl;      // keep_set: start from the active set of the previous pass
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] *= sgain;
+            if (S.flags & F_LAST) {
+                EndRows* er = end_rows();
+                for (int k = 0; k < 2; ++k) {
+                    er->sz[k] = er->z[k]; er->sy[k] = er->y[k];
+                    const bool fr = er->rb[k] < 0.0;
+                    const double e2 = er->E[k] * er->E[k] / cscale;
+                    const bool act_lo = !fr && ((er->z[k] - er->lo[k]) * e2 < -er->y[k]);
+                    const bool act_up = !fr && !act_lo && ((er->up[k] - er->z[k]) * e2 < er->y[k]);
+                    er->act[k] = keep_set ? (fr ? 0.0 : er->act[k]) : (act_lo ? -1.0 : (act_up ? 1.0 : 0.0));
                 }
             }
         });
@@ -708,57 +680,52 @@ struct PathQp {
         const double gain = 1.0 / prm.polish_delta;
         const double irho = 1.0 / rho_now, irho_eq = 1.0 / (rho_now * kRhoEqFactor);
         ctx.phase([&](int t, Lane& ln) {
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                Slot& S = ln.s[q];
-                const int i = 2 * t + q;
-                const bool real = S.flags & F_REAL;
-                const double* w = A.wsave + ((size_t)qp * (2 * T) + (real ? i : n - 1)) * kSaveStride;
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                    const bool eq = S.flags & (F_EQ0 << k);
-                    const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
-                    const bool act = real && (alo || aup);
-                    const double e2 = w[15 + k] * (eq ? irho_eq : irho);
-                    const double r = act ? gain * e2 : 0.0;
-                    S.rhoI[k] = r;
-                    S.rinvI[k] = act ? rcp(r) : 0.0;
-                    S.yI[k] = act ? S.yI[k] : 0.0;
-                    S.zI[k] = alo ? raw_lo(S, k) : (aup ? raw_up(S, k) : S.zI[k]);
-                }
-                if (S.flags & F_LAST) {
-                    EndRows* er = end_rows();
-                    for (int k = 0; k < 2; ++k) {
-                        const bool act = er->act[k] != 0.0;
-                        const double r = act ? gain * er->E[k] * er->E[k] / cscale : 0.0;
-                        er->rho[k] = r; er->rinv[k] = act ? rcp(r) : 0.0;
-                        er->y[k] = act ? er->y[k] : 0.0;
-                        er->z[k] = er->act[k] < 0.0 ? er->lo[k] : (er->act[k] > 0.0 ? er->up[k] : er->z[k]);
-                    }
+            Slot& S = ln.s;
+            const bool real = S.flags & F_REAL;
+            const double* w = save_slot(t);
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                const bool eq = S.flags & (F_EQ0 << k);
+                const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
+                const bool act = real && (alo || aup);
+                const double e2 = w[15 + k] * (eq ? irho_eq : irho);
+                const double r = act ? gain * e2 : 0.0;
+                // (read every candidate into a value first: a select between two lane FIELDS becomes an address select,
+                //  i.e. dynamic indexing of the lane struct, which would push the whole struct into scratch memory)
+                const double lo_k = raw_lo(S, k), up_k = raw_up(S, k), z_k = S.zI[k], y_k = S.yI[k];
+                S.rhoI[k] = r;
+                S.rinvI[k] = act ? rcp(r) : 0.0;
+                S.yI[k] = act ? y_k : 0.0;
+                S.zI[k] = alo ? lo_k : (aup ? up_k : z_k);
+            }
+            if (S.flags & F_LAST) {
+                EndRows* er = end_rows();
+                for (int k = 0; k < 2; ++k) {
+                    const bool act = er->act[k] != 0.0;
+                    const double r = act ? gain * er->E[k] * er->E[k] / cscale : 0.0;
+                    er->rho[k] = r; er->rinv[k] = act ? rcp(r) : 0.0;
+                    er->y[k] = act ? er->y[k] : 0.0;
+                    er->z[k] = er->act[k] < 0.0 ? er->lo[k] : (er->act[k] > 0.0 ? er->up[k] : er->z[k]);
                 }
             }
         });
     }
 
     // --- polish piece 3: worst KKT failure of the polished point over all inequality rows
-    //     (needs sh[xodd] = X of slot 1, published by residuals())
+    //     (needs sh[xbuf] = X of every waypoint, published by residuals())
     PQP_HD double polish_violation() {
         double viol[1];
         ctx.template reduce_max<1>(viol, [&](int t, Lane& ln, double (&v)[1]) {
-            v[0] = 0.0;
-            double Xprev0[3];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xprev0[k] = (t > 0) ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                const Slot& S = ln.s[q];
-                const double* Xp = (q == 0) ? Xprev0 : ln.s[0].x;
-                double aT[3], aI[3];
-                rows_of(S, Xp, S.x, aT, aI);
-                double w = 0.0;
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) w = fmax(w, row_violation(S, k, aI[k]));
-                if (S.flags & F_LAST) {
-                    const EndRows* er = end_rows();
-                    for (int k = 0; k < 2; ++k) w = fmax(w, end_violation(er, k, S.x[k]));
-                }
-                v[0] = fmax(v[0], w);
+            const Slot& S = ln.s;
+            double Xp[3], aT[3], aI[3];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
+            rows_of(S, Xp, S.x, aT, aI);
+            double w = 0.0;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) w = fmax(w, row_violation(S, k, aI[k]));
+            if (S.flags & F_LAST) {
+                const EndRows* er = end_rows();
+                for (int k = 0; k < 2; ++k) w = fmax(w, end_violation(er, k, S.x[k]));
             }
+            v[0] = w;
         });
         return viol[0];
     }
@@ -766,31 +733,27 @@ struct PathQp {
     // --- polish piece 4: primal-dual active-set step: rows failing the test by more than thr change sides
     PQP_HD void polish_update_set(double thr) {
         ctx.phase([&](int t, Lane& ln) {
-            double Xprev0[3];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xprev0[k] = (t > 0) ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                Slot& S = ln.s[q];
-                const double* Xp = (q == 0) ? Xprev0 : ln.s[0].x;
-                double aT[3], aI[3];
-                rows_of(S, Xp, S.x, aT, aI);
-                int fl = S.flags;
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                    const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
-                    const bool move = row_violation(S, k, aI[k]) > thr;
-                    const bool add_lo = move && !alo && !aup && (raw_lo(S, k) - aI[k] > aI[k] - raw_up(S, k));
-                    const bool add_up = move && !alo && !aup && !add_lo;
-                    if (move && (alo || aup)) fl &= ~((F_ACTLO0 << k) | (F_ACTUP0 << k));
-                    if (add_lo) fl |= (F_ACTLO0 << k);
-                    if (add_up) fl |= (F_ACTUP0 << k);
-                }
-                S.flags = fl;
-                if (S.flags & F_LAST) {
-                    EndRows* er = end_rows();
-                    for (int k = 0; k < 2; ++k) {
-                        if (!(end_violation(er, k, S.x[k]) > thr)) continue;
-                        if (er->act[k] != 0.0) er->act[k] = 0.0;
-                        else er->act[k] = (er->lo[k] - S.x[k] > S.x[k] - er->up[k]) ? -1.0 : 1.0;
-                    }
+            Slot& S = ln.s;
+            double Xp[3], aT[3], aI[3];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
+            rows_of(S, Xp, S.x, aT, aI);
+            int fl = S.flags;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
+                const bool move = row_violation(S, k, aI[k]) > thr;
+                const bool add_lo = move && !alo && !aup && (raw_lo(S, k) - aI[k] > aI[k] - raw_up(S, k));
+                const bool add_up = move && !alo && !aup && !add_lo;
+                if (move && (alo || aup)) fl &= ~((F_ACTLO0 << k) | (F_ACTUP0 << k));
+                if (add_lo) fl |= (F_ACTLO0 << k);
+                if (add_up) fl |= (F_ACTUP0 << k);
+            }
+            S.flags = fl;
+            if (S.flags & F_LAST) {
+                EndRows* er = end_rows();
+                for (int k = 0; k < 2; ++k) {
+                    if (!(end_violation(er, k, S.x[k]) > thr)) continue;
+                    if (er->act[k] != 0.0) er->act[k] = 0.0;
+                    else er->act[k] = (er->lo[k] - S.x[k] > S.x[k] - er->up[k]) ? -1.0 : 1.0;
                 }
             }
         });
@@ -806,190 +769,123 @@ struct PathQp {
         const double tgain = gain / (rho_now * kRhoEqFactor);
         const double itgain = 1.0 / tgain, isgain = 1.0 / sgain;
         ctx.phase([&](int t, Lane& ln) {
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                Slot& S = ln.s[q];
-                const int i = 2 * t + q;
-                const bool real = S.flags & F_REAL;
-                const double* w = A.wsave + ((size_t)qp * (2 * T) + (real ? i : n - 1)) * kSaveStride;
-                const bool rest = real && !ok;
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = rest ? w[k] : S.x[k];
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                    S.yT[k] = rest ? w[6 + k] : S.yT[k];
-                    S.yI[k] = rest ? w[9 + k] : S.yI[k];
-                    S.zI[k] = rest ? w[12 + k] : S.zI[k];
-                    const double r = real ? w[15 + k] : 0.0;
-                    S.rhoI[k] = r;
-                    S.rinvI[k] = r > 0.0 ? rcp(r) : 0.0;
-                    S.rhoT[k] *= itgain;
-                }
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] *= isgain;
-                if (S.flags & F_LAST) {
-                    EndRows* er = end_rows();
-                    for (int k = 0; k < 2; ++k) {
-                        if (!ok) { er->z[k] = er->sz[k]; er->y[k] = er->sy[k]; }
-                        const double rb = er->rb[k];
-                        const double r = rb < 0.0 ? -rb : rho_now * rb;
-                        er->rho[k] = r; er->rinv[k] = rcp(r);
-                    }
+            Slot& S = ln.s;
+            const bool real = S.flags & F_REAL;
+            const double* w = save_slot(t);
+            const bool rest = real && !ok;
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = rest ? w[k] : S.x[k];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                S.yT[k] = rest ? w[6 + k] : S.yT[k];
+                S.yI[k] = rest ? w[9 + k] : S.yI[k];
+                S.zI[k] = rest ? w[12 + k] : S.zI[k];
+                const double r = real ? w[15 + k] : 0.0;
+                S.rhoI[k] = r;
+                S.rinvI[k] = r > 0.0 ? rcp(r) : 0.0;
+                S.rhoT[k] *= itgain;
+            }
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] *= isgain;
+            if (S.flags & F_LAST) {
+                EndRows* er = end_rows();
+                for (int k = 0; k < 2; ++k) {
+                    if (!ok) { er->z[k] = er->sz[k]; er->y[k] = er->sy[k]; }
+                    const double rb = er->rb[k];
+                    const double r = rb < 0.0 ? -rb : rho_now * rb;
+                    er->rho[k] = r; er->rinv[k] = rcp(r);
                 }
             }
         });
     }
 
     // ---------------------------------------------------------------------------------------------
-    // Register-pressure relief around the factorisation: the iterates and the row data are not touched by
-    // factor(), so they are parked in (L2-resident) global memory and re-loaded afterwards.  The re-loaded values
-    // are new live ranges: during factor() the allocator has ~90 more VGPRs and does not have to spill values the
-    // ADMM loop needs every iteration.
-    // ---------------------------------------------------------------------------------------------
-    PQP_HD void park_iterates() {
-        ctx.phase([&](int t, Lane& ln) {
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                const Slot& S = ln.s[q];
-                double* w = A.wsave + ((size_t)qp * (2 * T) + 2 * t + q) * kSaveStride + kParkOffset;
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) w[k] = S.x[k];
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) { w[6 + k] = S.yT[k]; w[9 + k] = S.yI[k]; w[12 + k] = S.zI[k]; w[15 + k] = S.bT[k]; }
-                w[18] = S.lo[0]; w[19] = S.lo[1]; w[20] = S.up[0]; w[21] = S.up[1];
-            }
-        });
-    }
-    PQP_HD void unpark_iterates() {
-        ctx.phase([&](int t, Lane& ln) {
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                Slot& S = ln.s[q];
-                const double* w = A.wsave + ((size_t)qp * (2 * T) + 2 * t + q) * kSaveStride + kParkOffset;
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = w[k];
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) { S.yT[k] = w[6 + k]; S.yI[k] = w[9 + k]; S.zI[k] = w[12 + k]; S.bT[k] = w[15 + k]; }
-                S.lo[0] = w[18]; S.lo[1] = w[19]; S.up[0] = w[20]; S.up[1] = w[21];
-            }
-        });
-    }
-
-    // ---------------------------------------------------------------------------------------------
-    // factorisation for the current penalties: closed-form eliminations, block cyclic reduction
+    // factorisation for the current penalties: closed-form eliminations, block cyclic reduction over the T nodes
     // ---------------------------------------------------------------------------------------------
     PQP_HD void factor() {
         const pqp_params& prm = A.prm;
         factors_ += 1;
-        // F1: own diagonal block + message to the previous waypoint
+        // F1: own diagonal block + message (M, Lc) to the previous waypoint
         ctx.phase([&](int t, Lane& ln) {
-            double M1[6];
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                Slot& S = ln.s[q];
-                SlotSetup& W = ln.w[q];
-                double re0 = 0.0, re1 = 0.0;
-                if (S.flags & F_LAST) { re0 = end_rows()->rho[0]; re1 = end_rows()->rho[1]; }
-                const double rK = S.rhoI[0], rF = S.rhoI[1], rR = S.rhoI[2];
-                const double dsf = cost_diag(prm, S.flags, 4) + S.sig[4] + rF, dsr = cost_diag(prm, S.flags, 5) + S.sig[5] + rR;
-                S.idsf = rcp(dsf); S.idsr = rcp(dsr);
-                S.cF = rF * S.idsf; S.cR = rR * S.idsr;
-                const double gf = rF - rF * S.cF, gr = rR - rR * S.cR;
-                const double ds = S.a[5];
-                S.tu = S.rhoT[2] * ds;
-                const double du = cost_diag(prm, S.flags, 3) + S.sig[3] + S.tu * ds;
-                S.idu = rcp(du);
-                S.tudc = S.tu * S.idu;
-                const double gu = S.rhoT[2] - S.tu * S.tudc;
-                const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
-                W.Dg[0] = cost_diag(prm, S.flags, 0) + S.sig[0] + S.rhoT[0] + gf + gr + re0;
-                W.Dg[1] = gf * cf + gr * cr;
-                W.Dg[2] = 0.0;
-                W.Dg[3] = cost_diag(prm, S.flags, 1) + S.sig[1] + S.rhoT[1] + gf * cf * cf + gr * cr * cr + re1;
-                W.Dg[4] = 0.0;
-                W.Dg[5] = cost_diag(prm, S.flags, 2) + S.sig[2] + gu + rK;
-                const double r0 = S.rhoT[0], r1 = S.rhoT[1];
-                const double a00 = S.a[0], a01 = S.a[1], a10 = S.a[2], a11 = S.a[3], a12 = S.a[4];
-                const double gup = (S.flags & F_PREV) ? gu : 0.0;
-                // coupling block: rows = previous waypoint's (l,psi,k), cols = own
-                W.Lc[0] = -r0 * a00; W.Lc[1] = -r1 * a10; W.Lc[2] = 0.0;
-                W.Lc[3] = -r0 * a01; W.Lc[4] = -r1 * a11; W.Lc[5] = 0.0;
-                W.Lc[6] = 0.0;       W.Lc[7] = -r1 * a12; W.Lc[8] = -gup;
-                // contribution of this waypoint's T rows to the previous waypoint's diagonal block
-                double M[6];
-                M[0] = r0 * a00 * a00 + r1 * a10 * a10;
-                M[1] = r0 * a00 * a01 + r1 * a10 * a11;
-                M[2] = r1 * a10 * a12;
-                M[3] = r0 * a01 * a01 + r1 * a11 * a11;
-                M[4] = r1 * a11 * a12;
-                M[5] = r1 * a12 * a12 + gup;
-                if (q == 0) {
-                    double* f = sh + L.fbufA() + 15 * t;
-                    _Pragma("unroll") for (int k = 0; k < 6; ++k) f[k] = M[k];
-                    _Pragma("unroll") for (int k = 0; k < 9; ++k) f[6 + k] = W.Lc[k];
-                } else {
-                    _Pragma("unroll") for (int k = 0; k < 6; ++k) M1[k] = M[k];
-                }
-            }
-            // slot 0 receives from own slot 1
-            _Pragma("unroll") for (int k = 0; k < 6; ++k) ln.w[0].Dg[k] += M1[k];
-            _Pragma("unroll") for (int k = 0; k < 9; ++k) ln.w[0].Rc[k] = ln.w[1].Lc[k];
+            Slot& S = ln.s;
+            SlotSetup& W = ln.w;
+            double re0 = 0.0, re1 = 0.0;
+            if (S.flags & F_LAST) { re0 = end_rows()->rho[0]; re1 = end_rows()->rho[1]; }
+            const double rK = S.rhoI[0], rF = S.rhoI[1], rR = S.rhoI[2];
+            const double dsf = cost_diag(prm, S.flags, 4) + S.sig[4] + rF, dsr = cost_diag(prm, S.flags, 5) + S.sig[5] + rR;
+            S.idsf = rcp(dsf); S.idsr = rcp(dsr);
+            S.cF = rF * S.idsf; S.cR = rR * S.idsr;
+            const double gf = rF - rF * S.cF, gr = rR - rR * S.cR;
+            const double ds = S.a[5];
+            S.tu = S.rhoT[2] * ds;
+            const double du = cost_diag(prm, S.flags, 3) + S.sig[3] + S.tu * ds;
+            S.idu = rcp(du);
+            S.tudc = S.tu * S.idu;
+            const double gu = S.rhoT[2] - S.tu * S.tudc;
+            const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
+            W.Dg[0] = cost_diag(prm, S.flags, 0) + S.sig[0] + S.rhoT[0] + gf + gr + re0;
+            W.Dg[1] = gf * cf + gr * cr;
+            W.Dg[2] = 0.0;
+            W.Dg[3] = cost_diag(prm, S.flags, 1) + S.sig[1] + S.rhoT[1] + gf * cf * cf + gr * cr * cr + re1;
+            W.Dg[4] = 0.0;
+            W.Dg[5] = cost_diag(prm, S.flags, 2) + S.sig[2] + gu + rK;
+            const double r0 = S.rhoT[0], r1 = S.rhoT[1];
+            const double a00 = S.a[0], a01 = S.a[1], a10 = S.a[2], a11 = S.a[3], a12 = S.a[4];
+            const double gup = (S.flags & F_PREV) ? gu : 0.0;
+            // coupling block: rows = previous waypoint's (l,psi,k), cols = own
+            W.Lc[0] = -r0 * a00; W.Lc[1] = -r1 * a10; W.Lc[2] = 0.0;
+            W.Lc[3] = -r0 * a01; W.Lc[4] = -r1 * a11; W.Lc[5] = 0.0;
+            W.Lc[6] = 0.0;       W.Lc[7] = -r1 * a12; W.Lc[8] = -gup;
+            // contribution of this waypoint's T rows to the previous waypoint's diagonal block
+            double* f = sh + L.fbuf() + 15 * t;
+            f[0] = r0 * a00 * a00 + r1 * a10 * a10;
+            f[1] = r0 * a00 * a01 + r1 * a10 * a11;
+            f[2] = r1 * a10 * a12;
+            f[3] = r0 * a01 * a01 + r1 * a11 * a11;
+            f[4] = r1 * a11 * a12;
+            f[5] = r1 * a12 * a12 + gup;
+            _Pragma("unroll") for (int k = 0; k < 9; ++k) f[6 + k] = W.Lc[k];
         });
-        // F2: slot 1 receives from thread t+1, then level 0 eliminates slot 1
+        // F2: receive from the next waypoint
         ctx.phase([&](int t, Lane& ln) {
-            Slot& S1 = ln.s[1];
-            SlotSetup& W1 = ln.w[1];
-            SlotSetup& W0 = ln.w[0];
+            SlotSetup& W = ln.w;
             const bool has = t + 1 < T;
-            const double* f = sh + L.fbufA() + 15 * (has ? t + 1 : t);
-            _Pragma("unroll") for (int k = 0; k < 6; ++k) W1.Dg[k] += has ? f[k] : 0.0;
-            _Pragma("unroll") for (int k = 0; k < 9; ++k) W1.Rc[k] = has ? f[6 + k] : 0.0;
-            sym3_inv(W1.Dg, S1.Dinv);
-            mat3_mul_sym3(W1.Lc, S1.Dinv, S1.GL);
-            mat3t_mul_sym3(W1.Rc, S1.Dinv, S1.GR);
-            double SL[6], SR[6], Cn[9];
-            mat3_mul_mat3t_sym(S1.GL, W1.Lc, SL);
-            mat3_mul_mat3_sym(S1.GR, W1.Rc, SR);
-            mat3_mul_mat3_neg(S1.GL, W1.Rc, Cn);
-            _Pragma("unroll") for (int k = 0; k < 6; ++k) W0.Dg[k] -= SL[k];
-            _Pragma("unroll") for (int k = 0; k < 9; ++k) W0.Rc[k] = Cn[k];
-            double* g = sh + L.fbufB() + 15 * t;
-            _Pragma("unroll") for (int k = 0; k < 6; ++k) g[k] = SR[k];
-            _Pragma("unroll") for (int k = 0; k < 9; ++k) g[6 + k] = Cn[k];
+            const double* f = sh + L.fbuf() + 15 * (has ? t + 1 : t);
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) W.Dg[k] += has ? f[k] : 0.0;
+            _Pragma("unroll") for (int k = 0; k < 9; ++k) W.Rc[k] = has ? f[6 + k] : 0.0;
         });
-        // level 0 receive + levels 1..log2(T): receive from the previous level, then eliminate
-        _Pragma("nounroll") for (int h = 1; h <= T; h <<= 1) {   // h = stride of the level being eliminated (thread units); h == T: root only
+        // levels: receive from the level just eliminated, then eliminate the nodes t = h (mod 2h); h == T: root
+        _Pragma("nounroll") for (int h = 1; h <= T; h <<= 1) {
             ctx.phase([&](int t, Lane& ln) {
-                Slot& S0 = ln.s[0];
-                SlotSetup& W0 = ln.w[0];
-                if (h == 1) {
-                    const bool has = t >= 1;
-                    const double* f = sh + L.fbufB() + 15 * (has ? t - 1 : 0);
-                    _Pragma("unroll") for (int k = 0; k < 6; ++k) W0.Dg[k] -= has ? f[k] : 0.0;
-                    _Pragma("unroll") for (int k = 0; k < 9; ++k) W0.Lc[k] = has ? f[6 + k] : 0.0;
-                } else {
+                Slot& S = ln.s;
+                SlotSetup& W = ln.w;
+                if (h > 1) {
                     const int hp = h >> 1;   // stride of the level just eliminated
                     const bool surv = (t & (h - 1)) == 0;
                     const bool hr = surv && (t + hp < T), hl = surv && (t - hp >= 0);
                     const double* fr = sh + L.fbuf() + 21 * (hr ? t + hp : t);
                     const double* fl = sh + L.fbuf() + 21 * (hl ? t - hp : t);
-                    _Pragma("unroll") for (int k = 0; k < 6; ++k) W0.Dg[k] -= (hr ? fr[k] : 0.0) + (hl ? fl[6 + k] : 0.0);
+                    _Pragma("unroll") for (int k = 0; k < 6; ++k) W.Dg[k] -= (hr ? fr[k] : 0.0) + (hl ? fl[6 + k] : 0.0);
                     _Pragma("unroll") for (int k = 0; k < 9; ++k) {
-                        W0.Rc[k] = surv ? (hr ? fr[12 + k] : 0.0) : W0.Rc[k];
-                        W0.Lc[k] = hl ? fl[12 + k] : W0.Lc[k];
+                        W.Rc[k] = surv ? (hr ? fr[12 + k] : 0.0) : W.Rc[k];
+                        W.Lc[k] = hl ? fl[12 + k] : W.Lc[k];
                     }
                 }
                 const bool elim = (h < T) ? ((t & (2 * h - 1)) == h) : (t == 0);
-                double Di[6], GLn[9], GRn[9];
-                sym3_inv(W0.Dg, Di);
-                mat3_mul_sym3(W0.Lc, Di, GLn);
-                mat3t_mul_sym3(W0.Rc, Di, GRn);
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) S0.Dinv[k] = elim ? Di[k] : S0.Dinv[k];
-                _Pragma("unroll") for (int k = 0; k < 9; ++k) {
-                    S0.GL[k] = elim ? GLn[k] : S0.GL[k];
-                    S0.GR[k] = elim ? GRn[k] : S0.GR[k];
-                }
-                if (elim && h < T) {
-                    double* f = sh + L.fbuf() + 21 * t;
-                    mat3_mul_mat3t_sym(GLn, W0.Lc, f);
-                    mat3_mul_mat3_sym(GRn, W0.Rc, f + 6);
-                    mat3_mul_mat3_neg(GLn, W0.Rc, f + 12);
+                if (elim) {      // every thread is eliminated at exactly one level (thread 0: the root)
+                    sym3_inv(W.Dg, S.Dinv);
+                    mat3_mul_sym3(W.Lc, S.Dinv, S.GL);
+                    mat3t_mul_sym3(W.Rc, S.Dinv, S.GR);
+                    if (h < T) {
+                        double* f = sh + L.fbuf() + 21 * t;
+                        mat3_mul_mat3t_sym(S.GL, W.Lc, f);
+                        mat3_mul_mat3_sym(S.GR, W.Rc, f + 6);
+                        mat3_mul_mat3_neg(S.GL, W.Rc, f + 12);
+                    }
                 }
             });
         }
     }
 
     // ---------------------------------------------------------------------------------------------
-    // A x for the rows of a slot (T rows need the previous waypoint's X)
+    // A x for the rows of a waypoint (T rows need the previous waypoint's X)
     // ---------------------------------------------------------------------------------------------
     PQP_HD void rows_of(const Slot& S, const double* Xp, const double* x, double* aT, double* aI) const {
         const double cf = coef_front(A.prm, S.flags), cr = coef_rear(A.prm, S.flags);
@@ -1001,7 +897,7 @@ struct PathQp {
         aI[2] = (S.flags & F_PRECISE) ? x[0] + cr * x[1] + x[5] : 0.0;
     }
 
-    // message a slot sends to the previous waypoint: A_in^T w restricted to (l,psi,k)_{i-1}
+    // message a waypoint sends to the previous one: A_in^T w restricted to (l,psi,k)_{i-1}
     PQP_HD static void back_msg(const Slot& S, const double* wT, double* g) {
         g[0] = S.a[0] * wT[0] + S.a[2] * wT[1];
         g[1] = S.a[1] * wT[0] + S.a[3] * wT[1];
@@ -1017,73 +913,57 @@ struct PathQp {
         const double alpha = alpha_;
         // I1: w = R z - y, reduced right-hand side pieces, message to the previous waypoint
         ctx.phase([&](int t, Lane& ln) {
-            double g1[3];
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                Slot& S = ln.s[q];
-                const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
-                double wT[3], wI[3];
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) wT[k] = S.rhoT[k] * S.bT[k] - S.yT[k];
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) wI[k] = S.rhoI[k] * S.zI[k] - S.yI[k];
-                double we0 = 0.0, we1 = 0.0;
-                if (S.flags & F_LAST) {
-                    const EndRows* er = end_rows();
-                    we0 = er->rho[0] * er->z[0] - er->y[0];
-                    we1 = er->rho[1] * er->z[1] - er->y[1];
-                }
-                S.rv = S.sig[3] * S.x[3] + S.a[5] * wT[2];
-                S.rsf = S.sig[4] * S.x[4] + wI[1];
-                S.rsr = S.sig[5] * S.x[5] + wI[2];
-                const double tud = S.tudc * S.rv;
-                double g[3];
-                back_msg(S, wT, g);
-                g[2] -= tud;
-                const double eF = S.cF * S.rsf, eR = S.cR * S.rsr;
-                S.r[0] = S.sig[0] * S.x[0] - wT[0] + wI[1] + wI[2] + we0 - eF - eR;
-                S.r[1] = S.sig[1] * S.x[1] - wT[1] + cf * wI[1] + cr * wI[2] + we1 - cf * eF - cr * eR;
-                S.r[2] = S.sig[2] * S.x[2] - wT[2] + wI[0] + tud;
-                if (q == 0) { _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufG() + 3 * t + k] = g[k]; }
-                else { _Pragma("unroll") for (int k = 0; k < 3; ++k) g1[k] = g[k]; }
+            Slot& S = ln.s;
+            const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
+            double wT[3], wI[3];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) wT[k] = S.rhoT[k] * S.bT[k] - S.yT[k];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) wI[k] = S.rhoI[k] * S.zI[k] - S.yI[k];
+            double we0 = 0.0, we1 = 0.0;
+            if (S.flags & F_LAST) {
+                const EndRows* er = end_rows();
+                we0 = er->rho[0] * er->z[0] - er->y[0];
+                we1 = er->rho[1] * er->z[1] - er->y[1];
             }
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) ln.s[0].r[k] += g1[k];   // slot 1 -> own slot 0
+            S.rv = S.sig[3] * S.x[3] + S.a[5] * wT[2];
+            S.rsf = S.sig[4] * S.x[4] + wI[1];
+            S.rsr = S.sig[5] * S.x[5] + wI[2];
+            const double tud = S.tudc * S.rv;
+            double g[3];
+            back_msg(S, wT, g);
+            g[2] -= tud;
+            const double eF = S.cF * S.rsf, eR = S.cR * S.rsr;
+            S.r[0] = S.sig[0] * S.x[0] - wT[0] + wI[1] + wI[2] + we0 - eF - eR;
+            S.r[1] = S.sig[1] * S.x[1] - wT[1] + cf * wI[1] + cr * wI[2] + we1 - cf * eF - cr * eR;
+            S.r[2] = S.sig[2] * S.x[2] - wT[2] + wI[0] + tud;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufG() + 3 * t + k] = g[k];
         });
-        // I2: slot 1 gets the message of thread t+1; CR level 0 forward
-        ctx.phase([&](int t, Lane& ln) {
-            Slot& S1 = ln.s[1];
-            Slot& S0 = ln.s[0];
-            const bool has = t + 1 < T;
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) S1.r[k] += has ? sh[L.bufG() + 3 * (t + 1) + k] : 0.0;
-            double p[3];
-            mat3_vec(S1.GL, S1.r, p);
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) S0.r[k] -= p[k];
-            mat3_vec(S1.GR, S1.r, p);
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xodd() + 3 * t + k] = p[k];   // level-0 message (xodd is free until the backward pass ends)
-        });
-        // forward levels: receive from the previous level, then send if eliminated at this level
+        // forward levels: (first: add the message of the next waypoint) receive from the level just eliminated, then send
+        // if eliminated at this level; h == T: root
         for (int h = 1; h <= T; h <<= 1) {
             ctx.phase([&](int t, Lane& ln) {
-                Slot& S0 = ln.s[0];
+                Slot& S = ln.s;
                 if (h == 1) {
-                    const bool has = t >= 1;
-                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S0.r[k] -= has ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;
+                    const bool has = t + 1 < T;
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += has ? sh[L.bufG() + 3 * (t + 1) + k] : 0.0;
                 } else {
                     const int hp = h >> 1;
                     const bool surv = (t & (h - 1)) == 0;
                     const bool hr = surv && (t + hp < T), hl = surv && (t - hp >= 0);
                     _Pragma("unroll") for (int k = 0; k < 3; ++k)
-                        S0.r[k] -= (hr ? sh[L.bufQ() + 3 * (t + hp) + k] : 0.0) + (hl ? sh[L.bufP() + 3 * (t - hp) + k] : 0.0);
+                        S.r[k] -= (hr ? sh[L.bufQ() + 3 * (t + hp) + k] : 0.0) + (hl ? sh[L.bufP() + 3 * (t - hp) + k] : 0.0);
                 }
                 if (h < T) {
                     if ((t & (2 * h - 1)) == h) {
                         double p[3];
-                        mat3_vec(S0.GL, S0.r, p);
+                        mat3_vec(S.GL, S.r, p);
                         _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufQ() + 3 * t + k] = p[k];
-                        mat3_vec(S0.GR, S0.r, p);
+                        mat3_vec(S.GR, S.r, p);
                         _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufP() + 3 * t + k] = p[k];
                     }
                 } else {
                     double x3[3];
-                    sym3_vec(S0.Dinv, S0.r, x3);
-                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S0.xt[k] = x3[k];      // only thread 0's value survives
+                    sym3_vec(S.Dinv, S.r, x3);
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.xt[k] = x3[k];      // only thread 0's value survives
                     if (t == 0) { _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xbuf() + k] = x3[k]; }
                 }
             });
@@ -1091,76 +971,58 @@ struct PathQp {
         // backward levels
         for (int h = T >> 1; h >= 1; h >>= 1) {
             ctx.phase([&](int t, Lane& ln) {
-                Slot& S0 = ln.s[0];
+                Slot& S = ln.s;
                 const bool act = (t & (2 * h - 1)) == h;
                 const bool hr = act && (t + h < T);
                 const double* xl = sh + L.xbuf() + 3 * (act ? t - h : t);
                 const double* xr = sh + L.xbuf() + 3 * (hr ? t + h : t);
                 double x3[3], p[3], pr[3];
-                sym3_vec(S0.Dinv, S0.r, x3);
-                mat3t_vec(S0.GL, xl, p);
-                mat3t_vec(S0.GR, xr, pr);
+                sym3_vec(S.Dinv, S.r, x3);
+                mat3t_vec(S.GL, xl, p);
+                mat3t_vec(S.GR, xr, pr);
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                     const double v = x3[k] - p[k] - (hr ? pr[k] : 0.0);
-                    S0.xt[k] = act ? v : S0.xt[k];
+                    S.xt[k] = act ? v : S.xt[k];
                     if (act) sh[L.xbuf() + 3 * t + k] = v;
                 }
             });
         }
-        // level 0 backward (slot 1) and publication of slot 1's X
-        ctx.phase([&](int t, Lane& ln) {
-            Slot& S1 = ln.s[1];
-            Slot& S0 = ln.s[0];
-            const bool has = t + 1 < T;
-            double x3[3], p[3], pr[3];
-            sym3_vec(S1.Dinv, S1.r, x3);
-            mat3t_vec(S1.GL, S0.xt, p);
-            mat3t_vec(S1.GR, sh + L.xbuf() + 3 * (has ? t + 1 : t), pr);
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                const double v = x3[k] - p[k] - (has ? pr[k] : 0.0);
-                S1.xt[k] = v;
-                sh[L.xodd() + 3 * t + k] = v;
-            }
-        });
         // I3: back-substitute v, sf, sr; z~ = A x~; relaxed updates, projection, dual update
         ctx.phase([&](int t, Lane& ln) {
-            double Xprev0[3];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xprev0[k] = (t > 0) ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                Slot& S = ln.s[q];
-                const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
-                const double* Xp = (q == 0) ? Xprev0 : ln.s[0].xt;
-                double xt[6];
-                xt[0] = S.xt[0]; xt[1] = S.xt[1]; xt[2] = S.xt[2];
-                xt[3] = (S.rv - S.tu * (((S.flags & F_PREV) ? Xp[2] : 0.0) - xt[2])) * S.idu;
-                xt[4] = (S.rsf - S.rhoI[1] * (xt[0] + cf * xt[1])) * S.idsf;
-                xt[5] = (S.rsr - S.rhoI[2] * (xt[0] + cr * xt[1])) * S.idsr;
-                double zT[3], zI[3];
-                rows_of(S, Xp, xt, zT, zI);
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = alpha * xt[k] + (1.0 - alpha) * S.x[k];
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.yT[k] += S.rhoT[k] * alpha * (zT[k] - S.bT[k]);
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                    const double zh = alpha * zI[k] + (1.0 - alpha) * S.zI[k];
-                    const double v = zh + S.yI[k] * S.rinvI[k];
-                    const double zn = fmin(fmax(v, box_lo(S, k)), box_up(S, k));
-                    S.yI[k] += S.rhoI[k] * (zh - zn);
-                    S.zI[k] = zn;
-                }
-                if (S.flags & F_LAST) {
-                    EndRows* er = end_rows();
-                    for (int k = 0; k < 2; ++k) {
-                        const double zh = alpha * xt[k] + (1.0 - alpha) * er->z[k];
-                        const double v = zh + er->y[k] * er->rinv[k];
-                        double elo = er->lo[k], eup = er->up[k];
-                        if (polishing_) {
-                            const double bnd = er->act[k] < 0.0 ? elo : eup;
-                            elo = er->act[k] != 0.0 ? bnd : -kInfty;
-                            eup = er->act[k] != 0.0 ? bnd : kInfty;
-                        }
-                        const double zn = fmin(fmax(v, elo), eup);
-                        er->y[k] += er->rho[k] * (zh - zn);
-                        er->z[k] = zn;
+            Slot& S = ln.s;
+            double Xp[3];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
+            const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
+            double xt[6];
+            xt[0] = S.xt[0]; xt[1] = S.xt[1]; xt[2] = S.xt[2];
+            xt[3] = (S.rv - S.tu * (((S.flags & F_PREV) ? Xp[2] : 0.0) - xt[2])) * S.idu;
+            xt[4] = (S.rsf - S.rhoI[1] * (xt[0] + cf * xt[1])) * S.idsf;
+            xt[5] = (S.rsr - S.rhoI[2] * (xt[0] + cr * xt[1])) * S.idsr;
+            double zT[3], zI[3];
+            rows_of(S, Xp, xt, zT, zI);
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = alpha * xt[k] + (1.0 - alpha) * S.x[k];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) S.yT[k] += S.rhoT[k] * alpha * (zT[k] - S.bT[k]);
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                const double zh = alpha * zI[k] + (1.0 - alpha) * S.zI[k];
+                const double v = zh + S.yI[k] * S.rinvI[k];
+                const double zn = fmin(fmax(v, box_lo(S, k)), box_up(S, k));
+                S.yI[k] += S.rhoI[k] * (zh - zn);
+                S.zI[k] = zn;
+            }
+            if (S.flags & F_LAST) {
+                EndRows* er = end_rows();
+                for (int k = 0; k < 2; ++k) {
+                    const double zh = alpha * xt[k] + (1.0 - alpha) * er->z[k];
+                    const double v = zh + er->y[k] * er->rinv[k];
+                    double elo = er->lo[k], eup = er->up[k];
+                    if (polishing_) {
+                        const double bnd = er->act[k] < 0.0 ? elo : eup;
+                        elo = er->act[k] != 0.0 ? bnd : -kInfty;
+                        eup = er->act[k] != 0.0 ? bnd : kInfty;
                     }
+                    const double zn = fmin(fmax(v, elo), eup);
+                    er->y[k] += er->rho[k] * (zh - zn);
+                    er->z[k] = zn;
                 }
             }
         });
@@ -1174,58 +1036,51 @@ struct PathQp {
     PQP_HD void residuals(double (&res)[5]) {
         const pqp_params& prm = A.prm;
         ctx.phase([&](int t, Lane& ln) {
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xodd() + 3 * t + k] = ln.s[1].x[k];
             double g[3];
-            back_msg(ln.s[0], ln.s[0].yT, g);
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufG() + 3 * t + k] = g[k];
+            back_msg(ln.s, ln.s.yT, g);
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { sh[L.xbuf() + 3 * t + k] = ln.s.x[k]; sh[L.bufG() + 3 * t + k] = g[k]; }
         });
         ctx.template reduce_max<5>(res, [&](int t, Lane& ln, double (&v)[5]) {
-            _Pragma("unroll") for (int k = 0; k < 5; ++k) v[k] = 0.0;
-            double Xprev0[3], gnext1[3], g1[3];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xprev0[k] = (t > 0) ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) gnext1[k] = (t + 1 < T) ? sh[L.bufG() + 3 * (t + 1) + k] : 0.0;
-            back_msg(ln.s[1], ln.s[1].yT, g1);
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                const Slot& S = ln.s[q];
-                const bool real = S.flags & F_REAL;
-                const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
-                const double* Xp = (q == 0) ? Xprev0 : ln.s[0].x;
-                const double* gn = (q == 0) ? g1 : gnext1;
-                double aT[3], aI[3];
-                rows_of(S, Xp, S.x, aT, aI);
-                double pr = 0.0, nz = 0.0;
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                    pr = fmax(pr, fmax(fabs(aT[k] - S.bT[k]), fabs(aI[k] - S.zI[k])));
-                    nz = fmax(nz, fmax(fmax(fabs(aT[k]), fabs(S.bT[k])), fmax(fabs(aI[k]), fabs(S.zI[k]))));
-                }
-                double ye0 = 0.0, ye1 = 0.0;
-                if (S.flags & F_LAST) {
-                    const EndRows* er = end_rows();
-                    pr = fmax(pr, fmax(fabs(S.x[0] - er->z[0]), fabs(S.x[1] - er->z[1])));
-                    nz = fmax(nz, fmax(fmax(fabs(S.x[0]), fabs(er->z[0])), fmax(fabs(S.x[1]), fabs(er->z[1]))));
-                    ye0 = er->y[0]; ye1 = er->y[1];
-                }
-                double aty[6];
-                aty[0] = -S.yT[0] + gn[0] + S.yI[1] + S.yI[2] + ye0;
-                aty[1] = -S.yT[1] + gn[1] + cf * S.yI[1] + cr * S.yI[2] + ye1;
-                aty[2] = -S.yT[2] + gn[2] + S.yI[0];
-                aty[3] = S.a[5] * S.yT[2];
-                aty[4] = S.yI[1];
-                aty[5] = S.yI[2];
-                const bool colreal[6] = {real, real, real, (S.flags & F_PREV) != 0, real, real && (S.flags & F_PRECISE)};
-                double du = 0.0, nd = 0.0, bad = 0.0;
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) {
-                    const double px = cost_diag(prm, S.flags, k) * S.x[k];
-                    du = fmax(du, colreal[k] ? fabs(px + aty[k]) : 0.0);
-                    nd = fmax(nd, colreal[k] ? fmax(fabs(px), fabs(aty[k])) : 0.0);
-                    bad = (fabs(S.x[k]) <= 1e300) ? bad : 1.0;   // NaN / Inf guard
-                }
-                v[0] = fmax(v[0], real ? pr : 0.0);
-                v[1] = fmax(v[1], du);
-                v[2] = fmax(v[2], real ? nz : 0.0);
-                v[3] = fmax(v[3], nd);
-                v[4] = fmax(v[4], bad);
+            const Slot& S = ln.s;
+            double Xp[3], gn[3];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) gn[k] = (t + 1 < T) ? sh[L.bufG() + 3 * (t + 1) + k] : 0.0;
+            const bool real = S.flags & F_REAL;
+            const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
+            double aT[3], aI[3];
+            rows_of(S, Xp, S.x, aT, aI);
+            double pr = 0.0, nz = 0.0;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                pr = fmax(pr, fmax(fabs(aT[k] - S.bT[k]), fabs(aI[k] - S.zI[k])));
+                nz = fmax(nz, fmax(fmax(fabs(aT[k]), fabs(S.bT[k])), fmax(fabs(aI[k]), fabs(S.zI[k]))));
             }
+            double ye0 = 0.0, ye1 = 0.0;
+            if (S.flags & F_LAST) {
+                const EndRows* er = end_rows();
+                pr = fmax(pr, fmax(fabs(S.x[0] - er->z[0]), fabs(S.x[1] - er->z[1])));
+                nz = fmax(nz, fmax(fmax(fabs(S.x[0]), fabs(er->z[0])), fmax(fabs(S.x[1]), fabs(er->z[1]))));
+                ye0 = er->y[0]; ye1 = er->y[1];
+            }
+            double aty[6];
+            aty[0] = -S.yT[0] + gn[0] + S.yI[1] + S.yI[2] + ye0;
+            aty[1] = -S.yT[1] + gn[1] + cf * S.yI[1] + cr * S.yI[2] + ye1;
+            aty[2] = -S.yT[2] + gn[2] + S.yI[0];
+            aty[3] = S.a[5] * S.yT[2];
+            aty[4] = S.yI[1];
+            aty[5] = S.yI[2];
+            const bool colreal[6] = {real, real, real, (S.flags & F_PREV) != 0, real, real && (S.flags & F_PRECISE)};
+            double du = 0.0, nd = 0.0, bad = 0.0;
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) {
+                const double px = cost_diag(prm, S.flags, k) * S.x[k];
+                du = fmax(du, colreal[k] ? fabs(px + aty[k]) : 0.0);
+                nd = fmax(nd, colreal[k] ? fmax(fabs(px), fabs(aty[k])) : 0.0);
+                bad = (fabs(S.x[k]) <= 1e300) ? bad : 1.0;   // NaN / Inf guard
+            }
+            v[0] = real ? pr : 0.0;
+            v[1] = du;
+            v[2] = real ? nz : 0.0;
+            v[3] = nd;
+            v[4] = bad;
         });
     }
 
@@ -1237,67 +1092,52 @@ struct PathQp {
     // dual: y' = y - rho (z_0 - b) before it, y += rho (2 - alpha) (z_0 - b) after it.  dz lives in sh[lin]
     // (free between assemble and unpack).
     PQP_HD void start_transition_rows(bool have_warm) {
-        if (have_warm) {
-            ctx.phase([&](int t, Lane& ln) {
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xodd() + 3 * t + k] = ln.s[1].x[k];
-            });
-        }
         ctx.phase([&](int t, Lane& ln) {
-            double Xprev0[3];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xprev0[k] = (have_warm && t > 0) ? sh[L.xodd() + 3 * (t - 1) + k] : 0.0;
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                Slot& S = ln.s[q];
-                const int i = 2 * t + q;
-                const double* Xp = (q == 0) ? Xprev0 : ln.s[0].x;
-                double aT[3], aI[3];
-                rows_of(S, Xp, S.x, aT, aI);
-                const bool real = S.flags & F_REAL;
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                    const double dz = real ? (have_warm ? aT[k] : 0.0) - S.bT[k] : 0.0;
-                    sh[L.lin() + 3 * i + k] = dz;
-                    S.yT[k] -= S.rhoT[k] * dz;
-                    S.zI[k] = (real && have_warm) ? aI[k] : 0.0;
-                }
-                if (S.flags & F_LAST) {
-                    end_rows()->z[0] = have_warm ? S.x[0] : 0.0;
-                    end_rows()->z[1] = have_warm ? S.x[1] : 0.0;
-                }
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xbuf() + 3 * t + k] = ln.s.x[k];
+        });
+        ctx.phase([&](int t, Lane& ln) {
+            Slot& S = ln.s;
+            double Xp[3], aT[3], aI[3];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
+            rows_of(S, Xp, S.x, aT, aI);
+            const bool real = S.flags & F_REAL;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                const double dz = real ? (have_warm ? aT[k] : 0.0) - S.bT[k] : 0.0;
+                sh[L.lin() + 3 * t + k] = dz;
+                S.yT[k] -= S.rhoT[k] * dz;
+                S.zI[k] = (real && have_warm) ? aI[k] : 0.0;
+            }
+            if (S.flags & F_LAST) {
+                end_rows()->z[0] = have_warm ? S.x[0] : 0.0;
+                end_rows()->z[1] = have_warm ? S.x[1] : 0.0;
             }
         });
     }
     PQP_HD void finish_first_iteration() {
         const double f = 2.0 - A.prm.alpha;
         ctx.phase([&](int t, Lane& ln) {
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                Slot& S = ln.s[q];
-                const int i = 2 * t + q;
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.yT[k] += S.rhoT[k] * f * sh[L.lin() + 3 * i + k];
-            }
+            Slot& S = ln.s;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) S.yT[k] += S.rhoT[k] * f * sh[L.lin() + 3 * t + k];
         });
     }
 
     PQP_HD void load_warm() {
         ctx.phase([&](int t, Lane& ln) {
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                Slot& S = ln.s[q];
-                const int i = 2 * t + q;
-                const bool real = S.flags & F_REAL;
-                const size_t o = ((size_t)qp * n + (real ? i : n - 1)) * 6;
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = real ? A.wx[o + k] : 0.0;
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) { S.yT[k] = real ? A.wy[o + k] : 0.0; S.yI[k] = real ? A.wy[o + 3 + k] : 0.0; }
-                if (S.flags & F_LAST) { end_rows()->y[0] = A.wye[2 * (size_t)qp]; end_rows()->y[1] = A.wye[2 * (size_t)qp + 1]; }
-            }
+            Slot& S = ln.s;
+            const bool real = S.flags & F_REAL;
+            const size_t o = ((size_t)qp * n + (real ? t : n - 1)) * 6;
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = real ? A.wx[o + k] : 0.0;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { S.yT[k] = real ? A.wy[o + k] : 0.0; S.yI[k] = real ? A.wy[o + 3 + k] : 0.0; }
+            if (S.flags & F_LAST) { end_rows()->y[0] = A.wye[2 * (size_t)qp]; end_rows()->y[1] = A.wye[2 * (size_t)qp + 1]; }
         });
     }
 
     PQP_HD void store_warm() {
         ctx.phase([&](int t, Lane& ln) {
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                const Slot& S = ln.s[q];
-                const int i = 2 * t + q;
-                if (!(S.flags & F_REAL)) continue;
-                double* wx = A.wx + ((size_t)qp * n + i) * 6;
-                double* wy = A.wy + ((size_t)qp * n + i) * 6;
+            const Slot& S = ln.s;
+            if (S.flags & F_REAL) {
+                double* wx = A.wx + ((size_t)qp * n + t) * 6;
+                double* wy = A.wy + ((size_t)qp * n + t) * 6;
                 _Pragma("unroll") for (int k = 0; k < 6; ++k) wx[k] = S.x[k];
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) { wy[k] = S.yT[k]; wy[3 + k] = S.yI[k]; }
                 if (S.flags & F_LAST) { A.wye[2 * (size_t)qp] = end_rows()->y[0]; A.wye[2 * (size_t)qp + 1] = end_rows()->y[1]; }
@@ -1310,13 +1150,12 @@ struct PathQp {
     // ---------------------------------------------------------------------------------------------
     PQP_HD void unpack() {
         ctx.phase([&](int t, Lane& ln) {
-            sh[L.xbuf() + t] = ln.s[0].x[3];    // v of slot 0 = u of waypoint 2t-1
+            sh[L.xbuf() + t] = ln.s.x[3];    // v of waypoint t = u of waypoint t-1
         });
         ctx.phase([&](int t, Lane& ln) {
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {
-                const Slot& S = ln.s[q];
-                const int i = 2 * t + q;
-                if (!(S.flags & F_REAL)) continue;
+            const Slot& S = ln.s;
+            if (S.flags & F_REAL) {
+                const int i = t;
                 const double* r = A.ref + ((size_t)qp * n + i) * PQP_REF_STRIDE;
                 double* o = A.out + ((size_t)qp * n + i) * PQP_OUT_STRIDE;
                 const double angle = r[2];
@@ -1330,18 +1169,13 @@ struct PathQp {
                 o[3] = l;
                 o[4] = dpsi;
                 o[5] = S.x[2];
-                double dk = 0.0;
-                if (S.flags & F_NEXT) dk = (q == 0) ? ln.s[1].x[3] : sh[L.xbuf() + t + 1];
-                o[6] = dk;
+                o[6] = (S.flags & F_NEXT) ? sh[L.xbuf() + t + 1] : 0.0;
                 // input_path_ = first solution (base_solver.cpp:100): l, d_heading, k
                 sh[L.lin() + 3 * i + 0] = l; sh[L.lin() + 3 * i + 1] = dpsi; sh[L.lin() + 3 * i + 2] = S.x[2];
             }
         });
     }
 
-    // ---------------------------------------------------------------------------------------------
-    // the whole path: (warm) solve + `passes` re-linearised warm re-solves
-    // ---------------------------------------------------------------------------------------------
     PQP_HD Uni get_uni() const { return Uni{rho, cscale, kap, alpha_, kkt_solves_, factors_, polishing_ ? 1 : 0}; }
     PQP_HD void set_uni(const Uni& u) { rho = u.rho; cscale = u.cscale; kap = u.kap; alpha_ = u.alpha; kkt_solves_ = u.kkt_solves; factors_ = u.factors; polishing_ = u.polishing != 0; }
 
@@ -1359,8 +1193,7 @@ struct PathQp {
                     rho = A.wrho[qp];
                 } else {
                     ctx.phase([&](int, Lane& ln) {
-                        _Pragma("unroll") for (int q = 0; q < 2; ++q)
-                            if (ln.s[q].flags & F_LAST) { end_rows()->y[0] = 0.0; end_rows()->y[1] = 0.0; }
+                        if (ln.s.flags & F_LAST) { end_rows()->y[0] = 0.0; end_rows()->y[1] = 0.0; }
                     });
                 }
             }

@@ -35,14 +35,14 @@ extern "C" int pqp_emu_path_solve(const pqp_params* prm, int batch, int n, const
                                   int32_t* status, int32_t* iters, double* info, double* wx, double* wy,
                                   double* wye, double* wrho) {
     int T = 64;
-    while (2 * T < n) T *= 2;
+    while (T < n) T *= 2;
     pqp::PathSolveArgs a;
     std::memset(&a, 0, sizeof(a));
     a.batch = batch; a.n = n; a.passes = passes; a.warm = warm;
     a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
     a.status = status; a.iters = iters; a.info = info;
     a.wx = wx; a.wy = wy; a.wye = wye; a.wrho = wrho;
-    std::vector<double> wsave((size_t)batch * 2 * T * 44, 0.0);
+    std::vector<double> wsave((size_t)batch * T * 20, 0.0);
     a.wsave = wsave.data();
     a.prm = *prm;
     for (int q = 0; q < batch; ++q) {
@@ -58,10 +58,12 @@ extern "C" int pqp_emu_path_solve(const pqp_params* prm, int batch, int n, const
 extern "C" int pqp_emu_probe(const pqp_params* prm, int n, const double* ref, const double* bounds, const double* scal,
                              double* dump, double* endrows, double* cscale, int do_iters, double* xout) {
     int T = 64;
-    while (2 * T < n) T *= 2;
+    while (T < n) T *= 2;
     pqp::PathSolveArgs a;
     std::memset(&a, 0, sizeof(a));
     a.batch = 1; a.n = n; a.ref = ref; a.bounds = bounds; a.scal = scal; a.prm = *prm;
+    std::vector<double> wsave((size_t)T * 20, 0.0);
+    a.wsave = wsave.data();
     HostCtx ctx(T);
     pqp::PathQp<HostCtx> s(ctx, a, 0);
     s.load();
@@ -72,8 +74,8 @@ extern "C" int pqp_emu_probe(const pqp_params* prm, int n, const double* ref, co
     s.start_transition_rows(false);
     for (int it = 0; it < do_iters; ++it) { s.iterate(); if (it == 0) s.finish_first_iteration(); }
     for (int i = 0; i < n; ++i) {
-        const pqp::Slot& S = ctx.lanes[i / 2].s[i & 1];
-        const pqp::SlotSetup& W = ctx.lanes[i / 2].w[i & 1];
+        const pqp::Slot& S = ctx.lanes[i].s;
+        const pqp::SlotSetup& W = ctx.lanes[i].w;
         double* d = dump + 64 * i;
         int o = 0;
         for (int k = 0; k < 6; ++k) d[o++] = S.a[k];
