@@ -17,6 +17,9 @@
  *   PathOptimizer::optimizePath       src/path_optimizer.cpp:124-161     pqp_path_solve (passes = 1)
  *   OsqpEigen::Solver initSolver/solve (third party, called at base_solver.cpp:87-88,110)
  *                                                                 the ADMM loop inside the solve kernel
+ *   TensionSmoother2::osqpSmooth      src/reference_path_smoother/tension_smoother_2.cpp:20-158   pqp_smooth_tension2
+ *   TensionSmoother::osqpSmooth       src/reference_path_smoother/tension_smoother.cpp:49-177     pqp_smooth_tension
+ *   ReferencePathSmoother::postSmooth src/reference_path_smoother/reference_path_smoother.cpp:526-636 (QP part) pqp_post_smooth
  *
  * Conventions
  *   - plain C, no C++/torch types; all reals are IEEE fp64, all indices int32.
@@ -117,6 +120,13 @@ typedef struct pqp_params {
     int32_t reserved2;
     double polish_delta;              /* 1e-6  regularisation; active rows get penalty 1/delta */
     double polish_tol;                /* 1e-7  KKT acceptance tolerance of the polished point  */
+    /* smoother QP weights (src/config/planning_flags.cpp:51-61) */
+    double tension2_deviation_weight;        /* 0.005 */
+    double tension2_curvature_weight;        /* 1     */
+    double tension2_curvature_rate_weight;   /* 10    */
+    double cartesian_curvature_weight;       /* 1     */
+    double cartesian_curvature_rate_weight;  /* 50    */
+    double cartesian_deviation_weight;       /* 0     */
 } pqp_params;
 
 typedef struct pqp_sizes {
@@ -174,6 +184,30 @@ int pqp_path_solve_device(pqp_handle* h, int batch, int n, const double* ref, co
 /* Primal / dual solution of the handle's last solve in the REFERENCE numbering (OsqpEigen::Solver::
  * getSolution(), base_solver.cpp:89,112): x [batch][vars], y [batch][cons].  HOST buffers; either may be NULL. */
 int pqp_path_get_solution(pqp_handle* h, int batch, int n, int precise, double* x, double* y);
+
+/* ---- reference-line smoothing QPs; the solver settings of the handle apply (the reference runs
+ *      them at OSQP's default eps 1e-3: tension_smoother_2.cpp:32-36, tension_smoother.cpp:61-65, reference_path_smoother.cpp:533-537).
+ *      All lists are [batch][n] fp64; out_s is the cumulative chord length of the smoothed points. ------------------------- */
+/* TensionSmoother2::osqpSmooth   src/reference_path_smoother/tension_smoother_2.cpp:20-72 (default smoothing_method) */
+int pqp_smooth_tension2(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list,
+                        const double* k_list, const double* s_list, double* out_x, double* out_y, double* out_s, int32_t* status,
+                        int32_t* iters);
+int pqp_smooth_tension2_device(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list,
+                               const double* k_list, const double* s_list, double* out_x, double* out_y, double* out_s,
+                               int32_t* status, int32_t* iters, double* info);
+/* TensionSmoother::osqpSmooth    src/reference_path_smoother/tension_smoother.cpp:49-100; clearance = Map::getObstacleDistance
+ * at each input point (the distance-map lookup itself, tension_smoother.cpp:168, stays on the caller's side) */
+int pqp_smooth_tension(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list,
+                       const double* clearance, double* out_x, double* out_y, double* out_s, int32_t* status, int32_t* iters);
+int pqp_smooth_tension_device(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list,
+                              const double* clearance, double* out_x, double* out_y, double* out_s, int32_t* status, int32_t* iters,
+                              double* info);
+/* ReferencePathSmoother::postSmooth QP   src/reference_path_smoother/reference_path_smoother.cpp:526-558,582-636:
+ * layers_s, lb, ub [batch][m] (layers_bounds_), vehicle_l [batch] (vehicle_l_wrt_smoothed_ref_); out_l [batch][m] = QPSolution(i) */
+int pqp_post_smooth(pqp_handle* h, int batch, int m, const double* layers_s, const double* lb, const double* ub,
+                    const double* vehicle_l, double* out_l, int32_t* status, int32_t* iters);
+int pqp_post_smooth_device(pqp_handle* h, int batch, int m, const double* layers_s, const double* lb, const double* ub,
+                           const double* vehicle_l, double* out_l, int32_t* status, int32_t* iters, double* info);
 
 /* GPU time (ms, hipEvent) of the handle's last solve / assemble launch. */
 int pqp_last_kernel_ms(pqp_handle* h, float* ms);

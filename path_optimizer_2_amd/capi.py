@@ -25,6 +25,9 @@ class PqpParams(C.Structure):
         ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32),
         ("adaptive_rho_tolerance", C.c_double), ("check_termination", C.c_int32), ("polish", C.c_int32),
         ("polish_refine_iter", C.c_int32), ("polish_every", C.c_int32), ("polish_warm_set", C.c_int32), ("reserved2", C.c_int32), ("polish_delta", C.c_double), ("polish_tol", C.c_double),
+        ("tension2_deviation_weight", C.c_double), ("tension2_curvature_weight", C.c_double),
+        ("tension2_curvature_rate_weight", C.c_double), ("cartesian_curvature_weight", C.c_double),
+        ("cartesian_curvature_rate_weight", C.c_double), ("cartesian_deviation_weight", C.c_double),
     ]
 
 
@@ -36,7 +39,8 @@ EXPORTS = [
     "pqp_default_params", "pqp_last_error", "pqp_version", "pqp_create", "pqp_destroy", "pqp_set_params",
     "pqp_get_stream", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
     "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_get_solution",
-    "pqp_last_kernel_ms",
+    "pqp_last_kernel_ms", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
+    "pqp_post_smooth", "pqp_post_smooth_device",
 ]
 
 _lib = None
@@ -70,6 +74,12 @@ def load_library(path=None):
         getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.pqp_path_get_solution.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.pqp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.pqp_smooth_tension2.argtypes = [vp, C.c_int, C.c_int] + [vp] * 10
+    lib.pqp_smooth_tension2_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 11
+    lib.pqp_smooth_tension.argtypes = [vp, C.c_int, C.c_int] + [vp] * 9
+    lib.pqp_smooth_tension_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 10
+    lib.pqp_post_smooth.argtypes = [vp, C.c_int, C.c_int] + [vp] * 7
+    lib.pqp_post_smooth_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 8
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -186,6 +196,30 @@ class Handle:
         x = np.zeros((batch, nv)); y = np.zeros((batch, nc))
         self._check(self.lib.pqp_path_get_solution(self._h, batch, n, precise, _ptr(x), _ptr(y)))
         return x, y
+
+    # ---- smoother QPs (host arrays [batch][n]) ----
+    def smooth_tension2(self, x, y, angle, k, s):
+        B, n = x.shape
+        ox = np.zeros((B, n)); oy = np.zeros((B, n)); os_ = np.zeros((B, n)); st = np.zeros(B, dtype=np.int32); it = np.zeros(B, dtype=np.int32)
+        c = np.ascontiguousarray
+        self._check(self.lib.pqp_smooth_tension2(self._h, B, n, _ptr(c(x)), _ptr(c(y)), _ptr(c(angle)), _ptr(c(k)), _ptr(c(s)), _ptr(ox), _ptr(oy),
+                                                 _ptr(os_), _ptr(st), _ptr(it)))
+        return dict(x=ox, y=oy, s=os_, status=st, iters=it)
+
+    def smooth_tension(self, x, y, angle, clearance):
+        B, n = x.shape
+        ox = np.zeros((B, n)); oy = np.zeros((B, n)); os_ = np.zeros((B, n)); st = np.zeros(B, dtype=np.int32); it = np.zeros(B, dtype=np.int32)
+        c = np.ascontiguousarray
+        self._check(self.lib.pqp_smooth_tension(self._h, B, n, _ptr(c(x)), _ptr(c(y)), _ptr(c(angle)), _ptr(c(clearance)), _ptr(ox), _ptr(oy),
+                                                _ptr(os_), _ptr(st), _ptr(it)))
+        return dict(x=ox, y=oy, s=os_, status=st, iters=it)
+
+    def post_smooth(self, layers_s, lb, ub, vehicle_l):
+        B, m = layers_s.shape
+        ol = np.zeros((B, m)); st = np.zeros(B, dtype=np.int32); it = np.zeros(B, dtype=np.int32)
+        c = np.ascontiguousarray
+        self._check(self.lib.pqp_post_smooth(self._h, B, m, _ptr(c(layers_s)), _ptr(c(lb)), _ptr(c(ub)), _ptr(c(vehicle_l)), _ptr(ol), _ptr(st), _ptr(it)))
+        return dict(l=ol, status=st, iters=it)
 
     def last_kernel_ms(self):
         ms = C.c_float()

@@ -38,5 +38,11 @@ inline void default_params(pqp_params* p) {
     p->reserved2 = 0;
     p->polish_delta = 1e-6;
     p->polish_tol = 1e-7;
+    p->tension2_deviation_weight = 0.005;           // planning_flags.cpp:57
+    p->tension2_curvature_weight = 1.0;             // planning_flags.cpp:59
+    p->tension2_curvature_rate_weight = 10.0;       // planning_flags.cpp:61
+    p->cartesian_curvature_weight = 1.0;            // planning_flags.cpp:51
+    p->cartesian_curvature_rate_weight = 50.0;      // planning_flags.cpp:53
+    p->cartesian_deviation_weight = 0.0;            // planning_flags.cpp:55
 }
 }  // namespace pqp

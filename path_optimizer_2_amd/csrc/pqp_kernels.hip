@@ -20,6 +20,8 @@
 
 #include "pqp_defaults.hpp"
 #include "pqp_path_lane.hpp"
+#include "pqp_banded_qp.hpp"
+#include <vector>
 
 namespace pqp {
 
@@ -376,6 +378,8 @@ __global__ void path_gather_solution(RefIndex R, int batch, const double* __rest
 
 }  // namespace pqp
 
+#include "pqp_smoother_kernels.inc"
+
 // =========================================================================================================
 // C ABI
 // =========================================================================================================
@@ -418,6 +422,9 @@ struct pqp_handle {
     DevBuf wx, wy, wye, wrho, wsave;            // warm state (lane layout) + polish save area
     DevBuf s_ref, s_lin, s_bounds, s_scal;      // staging for the host-pointer entry points
     DevBuf s_out, s_status, s_iters, s_info, s_a, s_p, s_l, s_u, s_idx;
+    // smoother QPs: banded problem data + shared sparsity (cached per type and size) + staging
+    DevBuf b_pband, b_q, b_aval, b_lo, b_up, b_x, b_y, b_acol, b_trow, b_tslot, b_in[5], b_out[3];
+    int b_struct_type = -1, b_struct_n = -1;
 };
 
 extern "C" {
@@ -458,7 +465,9 @@ int pqp_destroy(pqp_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
-                      &h->s_status, &h->s_iters, &h->s_info, &h->s_a, &h->s_p, &h->s_l, &h->s_u, &h->s_idx})
+                      &h->s_status, &h->s_iters, &h->s_info, &h->s_a, &h->s_p, &h->s_l, &h->s_u, &h->s_idx, &h->b_pband, &h->b_q, &h->b_aval,
+                      &h->b_lo, &h->b_up, &h->b_x, &h->b_y, &h->b_acol, &h->b_trow, &h->b_tslot, &h->b_in[0], &h->b_in[1], &h->b_in[2],
+                      &h->b_in[3], &h->b_in[4], &h->b_out[0], &h->b_out[1], &h->b_out[2]})
         b->release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -674,6 +683,203 @@ int pqp_last_kernel_ms(pqp_handle* h, float* ms) {
     PQP_HIP(hipEventSynchronize(h->ev1));
     PQP_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
     return PQP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// smoother QPs
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+enum { SM_TENSION2 = 0, SM_TENSION = 1, SM_POST = 2 };
+
+struct SmShape { int nv, nc, bw, pbw, stride; };
+SmShape sm_shape(int type, int n) {
+    if (type == SM_TENSION2) return {4 * n - 1, 3 * (n - 1) + 2, 4, 4, 4};
+    if (type == SM_TENSION) return {3 * n, 3 * n, 9, 9, 3};
+    return {3 * n, 3 * n - 2, 3, 0, 3};
+}
+
+// shared sparsity of a smoother QP in the interleaved variable order: integer host logic (like pqp_path_sizes)
+int sm_upload_structure(pqp_handle* h, int type, int n) {
+    if (h->b_struct_type == type && h->b_struct_n == n) return PQP_OK;
+    const SmShape sh = sm_shape(type, n);
+    std::vector<int> acol((size_t)sh.nc * pqp::kRMax, -1), trow((size_t)sh.nv * pqp::kCMax, -1), tslot((size_t)sh.nv * pqp::kCMax, 0);
+    auto row = [&](int r, int c0, int c1, int c2) { int* a = &acol[(size_t)r * pqp::kRMax]; a[0] = c0; a[1] = c1; a[2] = c2; };
+    if (type == SM_TENSION2) {
+        for (int i = 0; i < n - 1; ++i) {
+            row(i, 4 * (i + 1), 4 * i, 4 * i + 2);
+            row(n - 1 + i, 4 * (i + 1) + 1, 4 * i + 1, 4 * i + 2);
+            row(2 * (n - 1) + i, 4 * (i + 1) + 2, 4 * i + 2, 4 * i + 3);
+        }
+        row(3 * (n - 1), 0, -1, -1);
+        row(3 * (n - 1) + 1, 1, -1, -1);
+    } else if (type == SM_TENSION) {
+        for (int i = 0; i < n; ++i) { row(i, 3 * i, 3 * i + 2, -1); row(n + i, 3 * i + 1, 3 * i + 2, -1); row(2 * n + i, 3 * i + 2, -1, -1); }
+    } else {
+        for (int i = 0; i < n; ++i) row(i, 3 * i, -1, -1);
+        for (int i = 0; i < n - 1; ++i) { row(n + i, 3 * (i + 1), 3 * i, 3 * i + 1); row(2 * n - 1 + i, 3 * (i + 1) + 1, 3 * i + 1, 3 * i + 2); }
+    }
+    std::vector<int> fill(sh.nv, 0);
+    for (int r = 0; r < sh.nc; ++r)
+        for (int s = 0; s < pqp::kRMax; ++s) {
+            const int c = acol[(size_t)r * pqp::kRMax + s];
+            if (c < 0) continue;
+            if (fill[c] >= pqp::kCMax) return fail(PQP_ERR_INVALID, "smoother structure: column overflow");
+            trow[(size_t)c * pqp::kCMax + fill[c]] = r; tslot[(size_t)c * pqp::kCMax + fill[c]] = s; ++fill[c];
+        }
+    int rc;
+    if ((rc = h->b_acol.ensure(acol.size() * 4)) || (rc = h->b_trow.ensure(trow.size() * 4)) || (rc = h->b_tslot.ensure(tslot.size() * 4))) return rc;
+    PQP_HIP(hipMemcpyAsync(h->b_acol.p, acol.data(), acol.size() * 4, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->b_trow.p, trow.data(), trow.size() * 4, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->b_tslot.p, tslot.data(), tslot.size() * 4, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipStreamSynchronize(h->stream));      // the vectors go out of scope
+    h->b_struct_type = type; h->b_struct_n = n;
+    return PQP_OK;
+}
+
+// assemble (already enqueued by the caller into b_pband ...) -> banded ADMM solve -> finish.  All device pointers.
+int sm_solve(pqp_handle* h, int type, int batch, int n, int32_t* status, int32_t* iters, double* info) {
+    const SmShape sh = sm_shape(type, n);
+    pqp::BandedQpArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.batch = batch; a.nv = sh.nv; a.nc = sh.nc; a.bw = sh.bw; a.pbw = sh.pbw;
+    a.pband = h->b_pband.as<double>(); a.q = h->b_q.as<double>(); a.acol = h->b_acol.as<int>(); a.aval = h->b_aval.as<double>();
+    a.trow = h->b_trow.as<int>(); a.tslot = h->b_tslot.as<int>(); a.lo = h->b_lo.as<double>(); a.up = h->b_up.as<double>();
+    a.x = h->b_x.as<double>(); a.y = h->b_y.as<double>(); a.status = status; a.iters = iters; a.info = info; a.prm = h->prm;
+    const size_t lds = (size_t)pqp::BqLayout{sh.nv, sh.nc, sh.bw}.total() * 8;
+    if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "smoother QP too large for one CU's LDS");
+    if (lds > 64 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::banded_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(pqp::banded_solve_kernel, dim3(batch), dim3(64), lds, h->stream, a);
+    PQP_HIP(hipGetLastError());
+    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return PQP_OK;
+}
+
+int sm_alloc(pqp_handle* h, int type, int batch, int n) {
+    const SmShape sh = sm_shape(type, n);
+    int rc;
+    if ((rc = h->b_pband.ensure((size_t)batch * (sh.pbw + 1) * sh.nv * 8)) || (rc = h->b_q.ensure((size_t)batch * sh.nv * 8)) ||
+        (rc = h->b_aval.ensure((size_t)batch * sh.nc * pqp::kRMax * 8)) || (rc = h->b_lo.ensure((size_t)batch * sh.nc * 8)) ||
+        (rc = h->b_up.ensure((size_t)batch * sh.nc * 8)) || (rc = h->b_x.ensure((size_t)batch * sh.nv * 8)) || (rc = h->b_y.ensure((size_t)batch * sh.nc * 8)))
+        return rc;
+    return sm_upload_structure(h, type, n);
+}
+}  // namespace
+
+// TensionSmoother2::osqpSmooth (tension_smoother_2.cpp:20-72), device pointers, all lists [batch][n]
+int pqp_smooth_tension2_device(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list,
+                               const double* k_list, const double* s_list, double* out_x, double* out_y, double* out_s, int32_t* status,
+                               int32_t* iters, double* info) {
+    if (!h || !x_list || !y_list || !angle_list || !k_list || !s_list || !out_x || !out_y || !out_s || batch < 1 || n < 3)
+        return fail(PQP_ERR_INVALID, "pqp_smooth_tension2: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    int rc;
+    if ((rc = sm_alloc(h, SM_TENSION2, batch, n))) return rc;
+    const int total = batch * n;
+    hipLaunchKernelGGL(pqp::tension2_assemble_kernel, dim3((total + 255) / 256), dim3(256), 0, h->stream, batch, n, x_list, y_list, angle_list,
+                       k_list, s_list, h->prm.tension2_deviation_weight, h->prm.tension2_curvature_weight, h->prm.tension2_curvature_rate_weight,
+                       h->b_pband.as<double>(), h->b_q.as<double>(), h->b_aval.as<double>(), h->b_lo.as<double>(), h->b_up.as<double>());
+    PQP_HIP(hipGetLastError());
+    if ((rc = sm_solve(h, SM_TENSION2, batch, n, status, iters, info))) return rc;
+    hipLaunchKernelGGL(pqp::tension_finish_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, batch, n, 4 * n - 1, 4, h->b_x.as<double>(), out_x, out_y, out_s);
+    PQP_HIP(hipGetLastError());
+    return PQP_OK;
+}
+
+// TensionSmoother::osqpSmooth (tension_smoother.cpp:49-100); clearance[batch][n] = Map::getObstacleDistance at each point
+int pqp_smooth_tension_device(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list,
+                              const double* clearance, double* out_x, double* out_y, double* out_s, int32_t* status, int32_t* iters, double* info) {
+    if (!h || !x_list || !y_list || !angle_list || !clearance || !out_x || !out_y || !out_s || batch < 1 || n < 4)
+        return fail(PQP_ERR_INVALID, "pqp_smooth_tension: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    int rc;
+    if ((rc = sm_alloc(h, SM_TENSION, batch, n))) return rc;
+    const int total = batch * n;
+    hipLaunchKernelGGL(pqp::tension_assemble_kernel, dim3((total + 255) / 256), dim3(256), 0, h->stream, batch, n, x_list, y_list, angle_list, clearance,
+                       h->prm.cartesian_curvature_weight, h->prm.cartesian_curvature_rate_weight, h->prm.cartesian_deviation_weight,
+                       h->b_pband.as<double>(), h->b_q.as<double>(), h->b_aval.as<double>(), h->b_lo.as<double>(), h->b_up.as<double>());
+    PQP_HIP(hipGetLastError());
+    if ((rc = sm_solve(h, SM_TENSION, batch, n, status, iters, info))) return rc;
+    hipLaunchKernelGGL(pqp::tension_finish_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, batch, n, 3 * n, 3, h->b_x.as<double>(), out_x, out_y, out_s);
+    PQP_HIP(hipGetLastError());
+    return PQP_OK;
+}
+
+// ReferencePathSmoother::postSmooth QP (reference_path_smoother.cpp:526-558): out_l[batch][m] = the lateral offsets l_i
+int pqp_post_smooth_device(pqp_handle* h, int batch, int m, const double* layers_s, const double* lb, const double* ub, const double* vehicle_l,
+                           double* out_l, int32_t* status, int32_t* iters, double* info) {
+    if (!h || !layers_s || !lb || !ub || !vehicle_l || !out_l || batch < 1 || m < 4) return fail(PQP_ERR_INVALID, "pqp_post_smooth: bad argument (m >= 4, reference_path_smoother.cpp:528)");
+    PQP_HIP(hipSetDevice(h->device));
+    int rc;
+    if ((rc = sm_alloc(h, SM_POST, batch, m))) return rc;
+    const int total = batch * m;
+    hipLaunchKernelGGL(pqp::post_assemble_kernel, dim3((total + 255) / 256), dim3(256), 0, h->stream, batch, m, layers_s, lb, ub, vehicle_l,
+                       h->b_pband.as<double>(), h->b_q.as<double>(), h->b_aval.as<double>(), h->b_lo.as<double>(), h->b_up.as<double>());
+    PQP_HIP(hipGetLastError());
+    if ((rc = sm_solve(h, SM_POST, batch, m, status, iters, info))) return rc;
+    hipLaunchKernelGGL(pqp::post_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, h->stream, batch, m, h->b_x.as<double>(), out_l);
+    PQP_HIP(hipGetLastError());
+    return PQP_OK;
+}
+
+// host-pointer conveniences: nin input lists of [batch][n] (+ optional [batch] scalar list), nout output lists
+static int sm_host_call(pqp_handle* h, int which, int batch, int n, const double* const* in, int nin, const double* scalar_in, double* const* out,
+                        int nout, int32_t* status, int32_t* iters) {
+    PQP_HIP(hipSetDevice(h->device));
+    const size_t bytes = (size_t)batch * n * 8;
+    int rc;
+    for (int k = 0; k < nin; ++k) {
+        if ((rc = h->b_in[k].ensure(bytes))) return rc;
+        PQP_HIP(hipMemcpyAsync(h->b_in[k].p, in[k], bytes, hipMemcpyHostToDevice, h->stream));
+    }
+    if (scalar_in) {
+        if ((rc = h->b_in[4].ensure((size_t)batch * 8))) return rc;
+        PQP_HIP(hipMemcpyAsync(h->b_in[4].p, scalar_in, (size_t)batch * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    for (int k = 0; k < nout; ++k) if ((rc = h->b_out[k].ensure(bytes))) return rc;
+    if ((rc = h->s_status.ensure((size_t)batch * 4)) || (rc = h->s_iters.ensure((size_t)batch * 4))) return rc;
+    double* i0 = h->b_in[0].as<double>(); double* i1 = h->b_in[1].as<double>(); double* i2 = h->b_in[2].as<double>(); double* i3 = h->b_in[3].as<double>();
+    double* o0 = h->b_out[0].as<double>(); double* o1 = h->b_out[1].as<double>(); double* o2 = h->b_out[2].as<double>();
+    if (which == SM_TENSION2) {
+        if ((rc = h->b_in[4].ensure(bytes))) return rc;
+        PQP_HIP(hipMemcpyAsync(h->b_in[4].p, in[4], bytes, hipMemcpyHostToDevice, h->stream));
+        rc = pqp_smooth_tension2_device(h, batch, n, i0, i1, i2, i3, h->b_in[4].as<double>(), o0, o1, o2, h->s_status.as<int32_t>(), h->s_iters.as<int32_t>(), nullptr);
+    } else if (which == SM_TENSION) {
+        rc = pqp_smooth_tension_device(h, batch, n, i0, i1, i2, i3, o0, o1, o2, h->s_status.as<int32_t>(), h->s_iters.as<int32_t>(), nullptr);
+    } else {
+        rc = pqp_post_smooth_device(h, batch, n, i0, i1, i2, h->b_in[4].as<double>(), o0, h->s_status.as<int32_t>(), h->s_iters.as<int32_t>(), nullptr);
+    }
+    if (rc) return rc;
+    for (int k = 0; k < nout; ++k) PQP_HIP(hipMemcpyAsync(out[k], h->b_out[k].p, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (status) PQP_HIP(hipMemcpyAsync(status, h->s_status.p, (size_t)batch * 4, hipMemcpyDeviceToHost, h->stream));
+    if (iters) PQP_HIP(hipMemcpyAsync(iters, h->s_iters.p, (size_t)batch * 4, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipStreamSynchronize(h->stream));
+    return PQP_OK;
+}
+
+int pqp_smooth_tension2(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list, const double* k_list,
+                        const double* s_list, double* out_x, double* out_y, double* out_s, int32_t* status, int32_t* iters) {
+    if (!h || !x_list || !y_list || !angle_list || !k_list || !s_list || !out_x || !out_y || !out_s || batch < 1 || n < 3)
+        return fail(PQP_ERR_INVALID, "pqp_smooth_tension2: bad argument");
+    const double* in[5] = {x_list, y_list, angle_list, k_list, s_list};
+    double* out[3] = {out_x, out_y, out_s};
+    return sm_host_call(h, SM_TENSION2, batch, n, in, 4, nullptr, out, 3, status, iters);
+}
+int pqp_smooth_tension(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list, const double* clearance,
+                       double* out_x, double* out_y, double* out_s, int32_t* status, int32_t* iters) {
+    if (!h || !x_list || !y_list || !angle_list || !clearance || !out_x || !out_y || !out_s || batch < 1 || n < 4)
+        return fail(PQP_ERR_INVALID, "pqp_smooth_tension: bad argument");
+    const double* in[4] = {x_list, y_list, angle_list, clearance};
+    double* out[3] = {out_x, out_y, out_s};
+    return sm_host_call(h, SM_TENSION, batch, n, in, 4, nullptr, out, 3, status, iters);
+}
+int pqp_post_smooth(pqp_handle* h, int batch, int m, const double* layers_s, const double* lb, const double* ub, const double* vehicle_l, double* out_l,
+                    int32_t* status, int32_t* iters) {
+    if (!h || !layers_s || !lb || !ub || !vehicle_l || !out_l || batch < 1 || m < 4) return fail(PQP_ERR_INVALID, "pqp_post_smooth: bad argument");
+    const double* in[3] = {layers_s, lb, ub};
+    double* out[1] = {out_l};
+    return sm_host_call(h, SM_POST, batch, m, in, 3, vehicle_l, out, 1, status, iters);
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@
 
 #include "../../path_optimizer_2_amd/csrc/pqp_path_lane.hpp"
 #include "../../path_optimizer_2_amd/csrc/pqp_defaults.hpp"
+#include "../../path_optimizer_2_amd/csrc/pqp_banded_qp.hpp"
 
 namespace {
 struct HostCtx {
@@ -91,5 +92,41 @@ extern "C" int pqp_emu_probe(const pqp_params* prm, int n, const double* ref, co
     }
     std::memcpy(endrows, s.end_rows(), sizeof(pqp::EndRows));
     *cscale = s.cscale;
+    return 0;
+}
+
+// ---- the generic banded-QP core (pqp_banded_qp.hpp) on the host -----------------------------------------------------
+namespace {
+struct BqHostCtx {
+    int T_;
+    std::vector<double> shm;
+    BqHostCtx(int T, int doubles) : T_(T), shm(doubles, 0.0) {}
+    int T() const { return T_; }
+    double* sh() { return shm.data(); }
+    template <class F> void phase(F f) { for (int t = 0; t < T_; ++t) f(t); }
+    template <int K, class F> void reduce_max(double (&out)[K], F f) {
+        for (int k = 0; k < K; ++k) out[k] = 0.0;
+        for (int t = 0; t < T_; ++t) { double v[K]; f(t, v); for (int k = 0; k < K; ++k) out[k] = out[k] > v[k] ? out[k] : v[k]; }
+    }
+    template <int K, class F> void reduce_sum(double (&out)[K], F f) {
+        for (int k = 0; k < K; ++k) out[k] = 0.0;
+        for (int t = 0; t < T_; ++t) { double v[K]; f(t, v); for (int k = 0; k < K; ++k) out[k] += v[k]; }
+    }
+};
+}  // namespace
+
+extern "C" int pqp_emu_banded_solve(const pqp_params* prm, int batch, int nv, int nc, int bw, int pbw, const double* pband, const double* q,
+                                    const int* acol, const double* aval, const int* trow, const int* tslot, const double* lo,
+                                    const double* up, double* x, double* y, int32_t* status, int32_t* iters, double* info) {
+    pqp::BandedQpArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.batch = batch; a.nv = nv; a.nc = nc; a.bw = bw; a.pbw = pbw;
+    a.pband = pband; a.q = q; a.acol = acol; a.aval = aval; a.trow = trow; a.tslot = tslot; a.lo = lo; a.up = up;
+    a.x = x; a.y = y; a.status = status; a.iters = iters; a.info = info; a.prm = *prm;
+    for (int qp = 0; qp < batch; ++qp) {
+        BqHostCtx ctx(64, pqp::BqLayout{nv, nc, bw}.total());
+        pqp::BandedQp<BqHostCtx> s(ctx, a, qp);
+        s.run();
+    }
     return 0;
 }

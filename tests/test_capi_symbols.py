@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     txt = open(os.path.join(ROOT, "include", "pqp.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(pqp_[a-z_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(pqp_[a-z_0-9]+)\s*\(", txt)))
 
 
 def test_header_symbols_are_exported(hip_lib):
