@@ -140,6 +140,16 @@ def main():
     avg_kernel_s = float(np.mean(ev_ms)) * 1e-3
     abytes, abytes_ext = algorithmic_bytes(n, kkt_np, fac_np, setups)
     achieved = abytes / avg_kernel_s / 1e9
+    # measured HBM bytes per launch come from separate rocprofv3 --pmc passes of THIS command (FETCH_SIZE, WRITE_SIZE; the
+    # gfx950 x2 correction of FETCH_SIZE for wide reads applied; MI355X_MICROARCH.md HBM section), committed under profiles/
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_bench_n1_pmc_per_launch.json")
+    if world == 1 and batch == 1024 and n == 80 and polish and os.path.exists(pmc_file):
+        try:
+            pmc = json.load(open(pmc_file))
+            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+        except Exception:
+            traffic = None
     if rank == 0:
         line = {
             "metric": "paths/sec (QP solves/sec) at N=80 waypoints; ADMM iters to 1e-4",
@@ -157,7 +167,7 @@ def main():
             "factorisations": {"mean": float(fac_np.mean()), "max": float(fac_np.max())},
             "solved": int((st_np == 1).sum()), "polished": int((info_np[:, 4] >= 2).sum()), "batch": batch,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "path_solve_kernel", "kernel_ms": avg_kernel_s * 1e3,
+                         "traffic": traffic, "kernel": "path_solve_kernel", "kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": abytes,
                          "achieved_incl_factor_and_scaling": abytes_ext / avg_kernel_s / 1e9,
                          "note": "SURVEY.md 8(d) streaming-model bytes; the iterates are register/LDS resident, so measured HBM "
