@@ -62,6 +62,10 @@ def main():
     ap.add_argument("--no-polish", action="store_true", help="plain OSQP termination (the reference setting), no polish")
     ap.add_argument("--rho-interval", type=int, default=25, help="adaptive_rho_interval (iterations)")
     ap.add_argument("--polish-every", type=int, default=25, help="also try the KKT-verified polish every k ADMM iterations")
+    ap.add_argument("--polish-refine", type=int, default=2, help="refinement solves per active-set round of the polish")
+    ap.add_argument("--polish-max-rounds", type=int, default=0, help="active-set rounds before a polish attempt gives up (0: max(8, n/5 - 8))")
+    ap.add_argument("--polish-warm-set", type=int, default=2, help="1: pass 2 starts with a polish on pass 1's active set; 2: and keeps its equilibration")
+    ap.add_argument("--check-termination", type=int, default=25, help="residual check interval (iterations)")
     ap.add_argument("--profile", default="uniform", choices=["uniform", "varied"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of host CPU work for the cpu_baseline sample")
@@ -96,8 +100,9 @@ def main():
     info = torch.zeros((batch, 8), dtype=torch.float64, device=dev)
 
     polish = not args.no_polish
-    prm = capi.default_params(eps_abs=args.eps, eps_rel=args.eps, polish=1 if polish else 0, polish_every=args.polish_every,
-                              adaptive_rho_interval=args.rho_interval, polish_warm_set=1 if polish else 0, polish_refine_iter=3)
+    prm = capi.production_params(eps_abs=args.eps, eps_rel=args.eps, polish=1 if polish else 0, polish_every=args.polish_every,
+                              adaptive_rho_interval=args.rho_interval, polish_warm_set=args.polish_warm_set if polish else 0, check_termination=args.check_termination, polish_refine_iter=args.polish_refine,
+                              polish_max_rounds=args.polish_max_rounds)
     h = capi.Handle(prm, device=local_rank, max_batch=batch, max_n=n)
 
     def step():
@@ -159,6 +164,7 @@ def main():
             "config": {"workload": f"configs[1]: batch={batch} QPs per GPU, N={n}, shared sparsity, synthetic obstacle bounds ({args.profile} profile)",
                        "batch_per_gpu": batch, "n_waypoints": n, "eps_abs": args.eps, "eps_rel": args.eps, "polish": polish,
                        "polish_every": args.polish_every if polish else 0, "adaptive_rho_interval": args.rho_interval,
+                       "polish_refine_iter": args.polish_refine, "polish_max_rounds": args.polish_max_rounds, "polish_warm_set": args.polish_warm_set,
                        "passes": "cold solve + 1 re-linearised warm re-solve (PathOptimizer::optimizePath)",
                        "parallelism": f"{world} independent shard(s)" + (", RCCL all_gather of results inside the timed region" if world > 1 else "")},
             "admm_iters": {"min": int(it_np.min()), "median": float(np.median(it_np)), "p99": float(np.percentile(it_np, 99)),

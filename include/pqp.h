@@ -116,10 +116,15 @@ typedef struct pqp_params {
     int32_t polish;                   /* 0 (reference) ; bench and parity tests use 1 */
     int32_t polish_refine_iter;       /* 4     */
     int32_t polish_every;             /* 0: only when the residual test passes; k: also try every k iterations */
-    int32_t polish_warm_set;          /* 1: a warm re-linearised re-solve starts with a polish on the previous pass's active set */
-    int32_t reserved2;
+    int32_t polish_warm_set;          /* 1: a warm re-linearised re-solve starts with a polish on the previous pass's active set;
+                                         2: ... and keeps that pass's equilibration (D, E, c) instead of re-running Ruiz */
+    int32_t polish_max_rounds;        /* 40: active-set correction rounds per polish attempt; <= 0: max(8, n/5 - 8) (40 for the smoothers) */
+    int32_t polish_reseed;            /* 1: a polish attempt that gives up hands its best point (smallest KKT failure) to ADMM as the
+                                         new iterate when that failure is below polish_reseed_factor x the ADMM residuals */
+    int32_t polish_diverge;           /* k > 0: an attempt gives up as soon as the KKT failure exceeds k x the smallest one seen in it */
     double polish_delta;              /* 1e-6  regularisation; active rows get penalty 1/delta */
     double polish_tol;                /* 1e-7  KKT acceptance tolerance of the polished point  */
+    double polish_reseed_factor;      /* 1.0   */
     /* smoother QP weights (src/config/planning_flags.cpp:51-61) */
     double tension2_deviation_weight;        /* 0.005 */
     double tension2_curvature_weight;        /* 1     */
@@ -136,6 +141,8 @@ typedef struct pqp_sizes {
 typedef struct pqp_handle pqp_handle;
 
 void pqp_default_params(pqp_params* p);
+/* the defaults with the engine's production solver setting (1e-4 + KKT-verified polish; pqp_defaults.hpp) */
+void pqp_production_params(pqp_params* p);
 const char* pqp_last_error(void);
 const char* pqp_version(void);
 

@@ -24,7 +24,9 @@ class PqpParams(C.Structure):
         ("alpha", C.c_double), ("max_iter", C.c_int32), ("scaling", C.c_int32),
         ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32),
         ("adaptive_rho_tolerance", C.c_double), ("check_termination", C.c_int32), ("polish", C.c_int32),
-        ("polish_refine_iter", C.c_int32), ("polish_every", C.c_int32), ("polish_warm_set", C.c_int32), ("reserved2", C.c_int32), ("polish_delta", C.c_double), ("polish_tol", C.c_double),
+        ("polish_refine_iter", C.c_int32), ("polish_every", C.c_int32), ("polish_warm_set", C.c_int32), ("polish_max_rounds", C.c_int32),
+        ("polish_reseed", C.c_int32), ("polish_diverge", C.c_int32), ("polish_delta", C.c_double), ("polish_tol", C.c_double),
+        ("polish_reseed_factor", C.c_double),
         ("tension2_deviation_weight", C.c_double), ("tension2_curvature_weight", C.c_double),
         ("tension2_curvature_rate_weight", C.c_double), ("cartesian_curvature_weight", C.c_double),
         ("cartesian_curvature_rate_weight", C.c_double), ("cartesian_deviation_weight", C.c_double),
@@ -36,7 +38,7 @@ class PqpSizes(C.Structure):
 
 
 EXPORTS = [
-    "pqp_default_params", "pqp_last_error", "pqp_version", "pqp_create", "pqp_destroy", "pqp_set_params",
+    "pqp_default_params", "pqp_production_params", "pqp_last_error", "pqp_version", "pqp_create", "pqp_destroy", "pqp_set_params",
     "pqp_get_stream", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
     "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_get_solution",
     "pqp_last_kernel_ms", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
@@ -59,6 +61,8 @@ def load_library(path=None):
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
     lib.pqp_default_params.argtypes = [C.POINTER(PqpParams)]
     lib.pqp_default_params.restype = None
+    lib.pqp_production_params.argtypes = [C.POINTER(PqpParams)]
+    lib.pqp_production_params.restype = None
     lib.pqp_last_error.restype = C.c_char_p
     lib.pqp_version.restype = C.c_char_p
     lib.pqp_create.argtypes = [C.POINTER(vp), C.POINTER(PqpParams), C.c_int, C.c_int, C.c_int]
@@ -89,6 +93,16 @@ def default_params(lib=None, **over):
     lib = lib or load_library()
     p = PqpParams()
     lib.pqp_default_params(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def production_params(lib=None, **over):
+    """pqp_production_params: the defaults + the engine's production solver setting (1e-4 + KKT-verified polish)."""
+    lib = lib or load_library()
+    p = PqpParams()
+    lib.pqp_production_params(C.byref(p))
     for k, v in over.items():
         setattr(p, k, v)
     return p

@@ -423,7 +423,7 @@ struct BandedQp {
                 bool ok = false, conservative = false;
                 double best = 1e300;
                 int stall = 0;
-                for (int round = 0; round < 40; ++round) {
+                for (int round = 0; round < (prm.polish_max_rounds > 0 ? prm.polish_max_rounds : 40); ++round) {
                     polish_apply_set();
                     factor();
                     for (int k = 0; k < prm.polish_refine_iter; ++k) iterate();

@@ -35,7 +35,10 @@ inline void default_params(pqp_params* p) {
     p->polish_refine_iter = 4;
     p->polish_every = 0;
     p->polish_warm_set = 0;
-    p->reserved2 = 0;
+    p->polish_max_rounds = 40;
+    p->polish_reseed = 0;
+    p->polish_diverge = 0;
+    p->polish_reseed_factor = 1.0;
     p->polish_delta = 1e-6;
     p->polish_tol = 1e-7;
     p->tension2_deviation_weight = 0.005;           // planning_flags.cpp:57
@@ -44,5 +47,22 @@ inline void default_params(pqp_params* p) {
     p->cartesian_curvature_weight = 1.0;            // planning_flags.cpp:51
     p->cartesian_curvature_rate_weight = 50.0;      // planning_flags.cpp:53
     p->cartesian_deviation_weight = 0.0;            // planning_flags.cpp:55
+}
+
+// The engine's production setting on top of the defaults: ADMM to 1e-4, KKT-verified polish (every returned path is the exact
+// optimum of its QP), residual check / rho adaptation / polish attempt every 25 iterations, 2 refinement solves per active-set
+// round, at most max(8, n/5 - 8) rounds per attempt, pass 2 starts from pass 1's active set and equilibration, an attempt that gives up re-seeds ADMM with its best point.  Tuned on MI355X
+// (DESIGN.md section 6); bench.py, smoke() and the parity tests run this setting.
+inline void production_params(pqp_params* p) {
+    default_params(p);
+    p->eps_abs = 1e-4;
+    p->eps_rel = 1e-4;
+    p->adaptive_rho_interval = 25;
+    p->polish = 1;
+    p->polish_refine_iter = 2;
+    p->polish_every = 25;
+    p->polish_warm_set = 2;
+    p->polish_max_rounds = 0;                       // auto: max(8, n/5 - 8)
+    p->polish_reseed = 1;
 }
 }  // namespace pqp

@@ -69,6 +69,15 @@ struct RegCtx {
         f((int)threadIdx.x, lane);
         __syncthreads();
     }
+    __device__ __forceinline__ long long clock() const { return (long long)wall_clock64(); }     // 100 MHz
+    // wave-local phase: LDS operations of one wavefront execute in program order, so lanes of the same wavefront see each
+    // other's writes without a workgroup barrier; the fence only stops the compiler from moving LDS accesses across it
+    template <class F>
+    __device__ __forceinline__ void phase_w(F f) {
+        f((int)threadIdx.x, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     template <int K, class F>
     __device__ __forceinline__ void reduce_max(double (&out)[K], F f) {
         f((int)threadIdx.x, lane, out);
@@ -106,12 +115,21 @@ struct DevCtx {
     Lane* mem;
     double* shp;
     const PathSolveArgs* args;
+    __device__ __forceinline__ long long clock() const { return (long long)wall_clock64(); }     // 100 MHz
     __device__ __forceinline__ int T() const { return 64 * NW; }
     __device__ __forceinline__ double* sh() { return shp; }
     template <class F>
     __device__ __forceinline__ void phase(F f) {
         f((int)threadIdx.x, lane);
         __syncthreads();
+    }
+    // wave-local phase: LDS operations of one wavefront execute in program order, so lanes of the same wavefront see each
+    // other's writes without a workgroup barrier; the fence only stops the compiler from moving LDS accesses across it
+    template <class F>
+    __device__ __forceinline__ void phase_w(F f) {
+        f((int)threadIdx.x, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     template <int K, class F>
     __device__ __forceinline__ void reduce_max(double (&out)[K], F f) {
@@ -430,6 +448,7 @@ struct pqp_handle {
 extern "C" {
 
 void pqp_default_params(pqp_params* p) { if (p) pqp::default_params(p); }
+void pqp_production_params(pqp_params* p) { if (p) pqp::production_params(p); }
 const char* pqp_last_error(void) { return g_last_error.c_str(); }
 const char* pqp_version(void) { return "pqp-hip 0.1 (gfx950)"; }
 
@@ -608,7 +627,7 @@ int pqp_path_solve_device(pqp_handle* h, int batch, int n, const double* ref, co
     a.prm = h->prm;
     int nw = 1;
     while (64 * nw < n) nw *= 2;           // one waypoint per lane: T = 64 * nw >= n threads per QP
-    if ((rc = h->wsave.ensure((size_t)batch * 64 * nw * 20 * 8))) return rc;
+    if ((rc = h->wsave.ensure((size_t)batch * 64 * nw * PQP_SAVE_STRIDE * 8))) return rc;
     a.wsave = h->wsave.as<double>();
     const size_t lds = (size_t)pqp::ShLayout{64 * nw}.total() * 8;
     PQP_HIP(hipEventRecord(h->ev0, h->stream));

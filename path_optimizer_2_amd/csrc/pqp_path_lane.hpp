@@ -38,6 +38,8 @@
 
 #include "../../include/pqp.h"
 
+#define PQP_SAVE_STRIDE 32   /* doubles per thread of the polish save area */
+
 #if defined(__HIPCC__)
 #define PQP_HD __host__ __device__ __forceinline__
 #else
@@ -72,7 +74,7 @@ struct PathSolveArgs {
     double* wy;             // [batch][n][6]  (yT[3], yK, yF, yR)
     double* wye;            // [batch][2]
     double* wrho;           // [batch]
-    double* wsave;          // [batch][T][20] save area: the ADMM state while a polish is tried
+    double* wsave;          // [batch][T][kSaveStride] save area: the ADMM state while a polish is tried + the best polished point
     pqp_params prm;
 };
 
@@ -271,7 +273,7 @@ struct EndRows {
     double lo[2], up[2], z[2], y[2], E[2], rb[2], rho[2], rinv[2];
     double act[2];          // polish: -1 lower-active, +1 upper-active, 0 inactive
     double sz[2], sy[2];    // ADMM state parked while a polish is tried
-    double pad[2];
+    double by[2];           // multipliers of the best polished point of the current attempt
 };
 
 // shared-memory layout in doubles, T = threads per QP = padded number of waypoints.  The per-iteration exchange
@@ -329,7 +331,8 @@ enum RefactorKind : int { RF_RESCALE = 0 /* d0 = ratio */, RF_POLISH_BEGIN = 1, 
 // The solver.  Ctx provides:
 //   int  T()                              threads per QP (power of two, >= 64)
 //   double* sh()                          shared scratch of ShLayout(T).total() doubles
-//   template<F> void phase(F f)           run f(t, Lane&) for every thread, then synchronise
+//   template<F> void phase(F f)           run f(t, Lane&) for every thread, then synchronise the workgroup
+//   template<F> void phase_w(F f)         the same, but only the lanes of one wavefront need to see each other's LDS writes
 //   template<int K,F> void reduce_max/sum(double (&out)[K], F f)   f(t, Lane&, double (&v)[K])
 //   void cold(PathQp&, op, i0, i1, d0)    run do_cold() (possibly out of line)
 // =======================================================================================================
@@ -462,7 +465,14 @@ struct PathQp {
     // modified Ruiz equilibration (OSQP paper Alg. 2) on the structured KKT -> D, E, c, then the
     // penalty metrics Sigma = sigma/(c D^2) and R = rho * class * E^2 / c for the current rho
     // ---------------------------------------------------------------------------------------------
-    PQP_HD void ruiz() {
+    // reuse = true keeps D, E, c of the previous pass of this QP (whose matrix differs only by the re-linearisation) and
+    // only rebuilds the metrics; any positive diagonal scaling is a valid metric, OSQP's own update path re-equilibrates
+    PQP_HD void ruiz(bool reuse = false) {
+        const pqp_params& prm = A.prm;
+        if (!reuse) ruiz_equilibrate();
+        ruiz_metrics();
+    }
+    PQP_HD void ruiz_equilibrate() {
         const pqp_params& prm = A.prm;
         cscale = 1.0;
         ctx.phase([&](int, Lane& ln) {
@@ -538,7 +548,9 @@ struct PathQp {
             ct = limit_scaling(ct);
             cscale = cscale / ct;
         }
-        // metrics
+    }
+    PQP_HD void ruiz_metrics() {
+        const pqp_params& prm = A.prm;
         const double c = cscale, rho_now = rho;
         const double ic = 1.0 / c;
         ctx.phase([&](int, Lane& ln) {
@@ -611,7 +623,7 @@ struct PathQp {
     //      the active rows and is stationary -> it then IS the optimum of the QP; otherwise rows that fail the test
     //      change sides (primal-dual active-set rounds) or, when that stalls, the ADMM state is restored.
     // ---------------------------------------------------------------------------------------------
-    static constexpr int kSaveStride = 20;   // x6 yT3 yI3 zI3 rhoI3 (+2 pad)
+    static constexpr int kSaveStride = PQP_SAVE_STRIDE;   // x6 yT3 yI3 zI3 rhoI3 (+2 pad) | best polished point: x6 yT3 yI3
     static constexpr int kPolishRounds = 40; // active-set correction rounds per polish attempt
 
     PQP_HD double* save_slot(int t) const { return A.wsave + ((size_t)qp * T + t) * kSaveStride; }
@@ -743,6 +755,10 @@ struct PathQp {
                 const bool move = row_violation(S, k, aI[k]) > thr;
                 const bool add_lo = move && !alo && !aup && (raw_lo(S, k) - aI[k] > aI[k] - raw_up(S, k));
                 const bool add_up = move && !alo && !aup && !add_lo;
+#ifdef PQP_EMU_DEBUG
+                if (move) printf("      row t=%d k=%d %s viol %.3e (ax %.5f lo %.5f up %.5f y %.4e)\n", t, k, (alo || aup) ? "RELEASE" : (add_lo ? "ADD_LO" : "ADD_UP"),
+                                 row_violation(S, k, aI[k]), aI[k], raw_lo(S, k), raw_up(S, k), S.yI[k]);
+#endif
                 if (move && (alo || aup)) fl &= ~((F_ACTLO0 << k) | (F_ACTUP0 << k));
                 if (add_lo) fl |= (F_ACTLO0 << k);
                 if (add_up) fl |= (F_ACTUP0 << k);
@@ -759,9 +775,21 @@ struct PathQp {
         });
     }
 
-    // --- polish piece 5: leave polish mode.  accept: keep (x, y).  reject: restore the ADMM iterate.
+    // --- polish piece 4b: remember the polished point with the smallest KKT failure seen in this attempt
+    PQP_HD void polish_save_best() {
+        ctx.phase([&](int t, Lane& ln) {
+            const Slot& S = ln.s;
+            double* w = save_slot(t) + 20;
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) w[k] = S.x[k];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { w[6 + k] = S.yT[k]; w[9 + k] = S.yI[k]; }
+            if (S.flags & F_LAST) { end_rows()->by[0] = end_rows()->y[0]; end_rows()->by[1] = end_rows()->y[1]; }
+        });
+    }
+
+    // --- polish piece 5: leave polish mode.  accept: keep (x, y).  reject: restore the ADMM iterate, or (reseed) continue
+    //     ADMM from the best polished point of the attempt: (x, y) from there, z = clip(A x) as in osqp_warm_start.
     //     Either way put the ADMM penalties back.
-    PQP_HD void polish_end(bool ok) {
+    PQP_HD void polish_end(bool ok, bool reseed = false) {
         const pqp_params& prm = A.prm;
         const double rho_now = rho;
         const double gain = 1.0 / prm.polish_delta;
@@ -772,11 +800,12 @@ struct PathQp {
             Slot& S = ln.s;
             const bool real = S.flags & F_REAL;
             const double* w = save_slot(t);
+            const double* wb = w + (reseed ? 20 : 0);
             const bool rest = real && !ok;
-            _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = rest ? w[k] : S.x[k];
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = rest ? wb[k] : S.x[k];
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                S.yT[k] = rest ? w[6 + k] : S.yT[k];
-                S.yI[k] = rest ? w[9 + k] : S.yI[k];
+                S.yT[k] = rest ? wb[6 + k] : S.yT[k];
+                S.yI[k] = rest ? wb[9 + k] : S.yI[k];
                 S.zI[k] = rest ? w[12 + k] : S.zI[k];
                 const double r = real ? w[15 + k] : 0.0;
                 S.rhoI[k] = r;
@@ -787,13 +816,31 @@ struct PathQp {
             if (S.flags & F_LAST) {
                 EndRows* er = end_rows();
                 for (int k = 0; k < 2; ++k) {
-                    if (!ok) { er->z[k] = er->sz[k]; er->y[k] = er->sy[k]; }
+                    if (!ok) { er->z[k] = er->sz[k]; er->y[k] = reseed ? er->by[k] : er->sy[k]; }
                     const double rb = er->rb[k];
                     const double r = rb < 0.0 ? -rb : rho_now * rb;
                     er->rho[k] = r; er->rinv[k] = rcp(r);
                 }
             }
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xbuf() + 3 * t + k] = S.x[k];
         });
+        if (!ok && reseed) {
+            ctx.phase([&](int t, Lane& ln) {
+                Slot& S = ln.s;
+                double Xp[3], aT[3], aI[3];
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
+                rows_of(S, Xp, S.x, aT, aI);
+                const bool real = S.flags & F_REAL;
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                    const double lo_k = raw_lo(S, k), up_k = raw_up(S, k);
+                    S.zI[k] = real ? fmin(fmax(aI[k], lo_k), up_k) : 0.0;
+                }
+                if (S.flags & F_LAST) {
+                    EndRows* er = end_rows();
+                    for (int k = 0; k < 2; ++k) er->z[k] = fmin(fmax(S.x[k], er->lo[k]), er->up[k]);
+                }
+            });
+        }
     }
 
     // ---------------------------------------------------------------------------------------------
@@ -851,25 +898,29 @@ struct PathQp {
             _Pragma("unroll") for (int k = 0; k < 6; ++k) W.Dg[k] += has ? f[k] : 0.0;
             _Pragma("unroll") for (int k = 0; k < 9; ++k) W.Rc[k] = has ? f[6 + k] : 0.0;
         });
-        // levels: receive from the level just eliminated, then eliminate the nodes t = h (mod 2h); h == T: root
+        // Cyclic-reduction tree over tp = t + 1 in [1, T]: level h eliminates tp = h (mod 2h), the root is tp = T (the last
+        // thread).  With this numbering the only node of a wavefront that talks to the next wavefront during the levels
+        // h < 64 is its LAST lane (tp = 64m), and that node only RECEIVES until its own elimination at a level >= 64 — which
+        // is what lets iterate() run the 6 in-wave levels without workgroup barriers.
         _Pragma("nounroll") for (int h = 1; h <= T; h <<= 1) {
             ctx.phase([&](int t, Lane& ln) {
                 Slot& S = ln.s;
                 SlotSetup& W = ln.w;
+                const int tp = t + 1;
                 if (h > 1) {
                     const int hp = h >> 1;   // stride of the level just eliminated
-                    const bool surv = (t & (h - 1)) == 0;
+                    const bool surv = (tp & (h - 1)) == 0;
                     const bool hr = surv && (t + hp < T), hl = surv && (t - hp >= 0);
                     const double* fr = sh + L.fbuf() + 21 * (hr ? t + hp : t);
                     const double* fl = sh + L.fbuf() + 21 * (hl ? t - hp : t);
                     _Pragma("unroll") for (int k = 0; k < 6; ++k) W.Dg[k] -= (hr ? fr[k] : 0.0) + (hl ? fl[6 + k] : 0.0);
                     _Pragma("unroll") for (int k = 0; k < 9; ++k) {
                         W.Rc[k] = surv ? (hr ? fr[12 + k] : 0.0) : W.Rc[k];
-                        W.Lc[k] = hl ? fl[12 + k] : W.Lc[k];
+                        W.Lc[k] = hl ? fl[12 + k] : (surv ? 0.0 : W.Lc[k]);
                     }
                 }
-                const bool elim = (h < T) ? ((t & (2 * h - 1)) == h) : (t == 0);
-                if (elim) {      // every thread is eliminated at exactly one level (thread 0: the root)
+                const bool elim = (h < T) ? ((tp & (2 * h - 1)) == h) : (tp == T);
+                if (elim) {      // every thread is eliminated at exactly one level (the last thread: the root)
                     sym3_inv(W.Dg, S.Dinv);
                     mat3_mul_sym3(W.Lc, S.Dinv, S.GL);
                     mat3t_mul_sym3(W.Rc, S.Dinv, S.GR);
@@ -937,23 +988,59 @@ struct PathQp {
             S.r[2] = S.sig[2] * S.x[2] - wT[2] + wI[0] + tud;
             _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufG() + 3 * t + k] = g[k];
         });
-        // forward levels: (first: add the message of the next waypoint) receive from the level just eliminated, then send
-        // if eliminated at this level; h == T: root
-        for (int h = 1; h <= T; h <<= 1) {
-            ctx.phase([&](int t, Lane& ln) {
+        // Forward pass.  Levels h < 64 stay inside a wavefront (wave-local phases: no workgroup barrier); a wave's last lane
+        // (tp = 64m, a survivor of all of them) defers what it would receive from the next wavefront - the message g of
+        // waypoint t+1 and the level messages of the nodes t + hp - and adds them after ONE barrier.  Levels h >= 64 and the
+        // root use workgroup barriers.  (T = 64: no barrier at all.)
+        const int hw = T < 64 ? T : 64;
+        for (int h = 1; h < hw; h <<= 1) {
+            ctx.phase_w([&](int t, Lane& ln) {
                 Slot& S = ln.s;
+                const int tp = t + 1;
+                const bool edge = (tp & 63) == 0;            // last lane of its wavefront
                 if (h == 1) {
-                    const bool has = t + 1 < T;
+                    const bool has = (t + 1 < T) && !edge;
                     _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += has ? sh[L.bufG() + 3 * (t + 1) + k] : 0.0;
                 } else {
                     const int hp = h >> 1;
-                    const bool surv = (t & (h - 1)) == 0;
-                    const bool hr = surv && (t + hp < T), hl = surv && (t - hp >= 0);
+                    const bool surv = (tp & (h - 1)) == 0;
+                    const bool hr = surv && (t + hp < T) && !edge, hl = surv && (t - hp >= 0);
                     _Pragma("unroll") for (int k = 0; k < 3; ++k)
                         S.r[k] -= (hr ? sh[L.bufQ() + 3 * (t + hp) + k] : 0.0) + (hl ? sh[L.bufP() + 3 * (t - hp) + k] : 0.0);
                 }
+                if ((tp & (2 * h - 1)) == h) {
+                    double p[3];
+                    mat3_vec(S.GL, S.r, p);
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufQ() + 3 * t + k] = p[k];
+                    mat3_vec(S.GR, S.r, p);
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufP() + 3 * t + k] = p[k];
+                }
+            });
+        }
+        ctx.phase([&](int, Lane&) {});      // the one barrier between the in-wave levels and the cross-wave part
+        for (int h = hw; h <= T; h <<= 1) {
+            ctx.phase([&](int t, Lane& ln) {
+                Slot& S = ln.s;
+                const int tp = t + 1;
+                const bool edge = (tp & 63) == 0;
+                if (h == hw && edge) {
+                    // deferred: message of waypoint t+1 and the right-hand level messages of all in-wave levels
+                    if (t + 1 < T) { _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += sh[L.bufG() + 3 * (t + 1) + k]; }
+                    for (int hp = 1; hp < (hw >> 1); hp <<= 1) {
+                        if (t + hp < T) { _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] -= sh[L.bufQ() + 3 * (t + hp) + k]; }
+                    }
+                }
+                if (h > 1) {
+                    const int hp = h >> 1;
+                    const bool surv = (tp & (h - 1)) == 0;
+                    const bool hr = surv && (t + hp < T), hl = surv && (t - hp >= 0);
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k)
+                        S.r[k] -= (hr ? sh[L.bufQ() + 3 * (t + hp) + k] : 0.0) + (hl ? sh[L.bufP() + 3 * (t - hp) + k] : 0.0);
+                } else if (t + 1 < T && !edge) {     // T == 1 only
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += sh[L.bufG() + 3 * (t + 1) + k];
+                }
                 if (h < T) {
-                    if ((t & (2 * h - 1)) == h) {
+                    if ((tp & (2 * h - 1)) == h) {
                         double p[3];
                         mat3_vec(S.GL, S.r, p);
                         _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufQ() + 3 * t + k] = p[k];
@@ -963,30 +1050,34 @@ struct PathQp {
                 } else {
                     double x3[3];
                     sym3_vec(S.Dinv, S.r, x3);
-                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.xt[k] = x3[k];      // only thread 0's value survives
-                    if (t == 0) { _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xbuf() + k] = x3[k]; }
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.xt[k] = x3[k];      // only the root's value survives
+                    if (tp == T) { _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xbuf() + 3 * t + k] = x3[k]; }
                 }
             });
         }
-        // backward levels
+        // Backward pass: cross-wave levels with barriers, then the in-wave levels wave-locally (what they read from another
+        // wavefront - the x of its last lane - was written before the last barrier).
         for (int h = T >> 1; h >= 1; h >>= 1) {
-            ctx.phase([&](int t, Lane& ln) {
+            auto body = [&](int t, Lane& ln) {
                 Slot& S = ln.s;
-                const bool act = (t & (2 * h - 1)) == h;
-                const bool hr = act && (t + h < T);
-                const double* xl = sh + L.xbuf() + 3 * (act ? t - h : t);
+                const int tp = t + 1;
+                const bool act = (tp & (2 * h - 1)) == h;
+                const bool hl = act && (t - h >= 0), hr = act && (t + h < T);
+                const double* xl = sh + L.xbuf() + 3 * (hl ? t - h : t);
                 const double* xr = sh + L.xbuf() + 3 * (hr ? t + h : t);
                 double x3[3], p[3], pr[3];
                 sym3_vec(S.Dinv, S.r, x3);
                 mat3t_vec(S.GL, xl, p);
                 mat3t_vec(S.GR, xr, pr);
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                    const double v = x3[k] - p[k] - (hr ? pr[k] : 0.0);
+                    const double v = x3[k] - (hl ? p[k] : 0.0) - (hr ? pr[k] : 0.0);
                     S.xt[k] = act ? v : S.xt[k];
                     if (act) sh[L.xbuf() + 3 * t + k] = v;
                 }
-            });
+            };
+            if (h >= 64) ctx.phase(body); else ctx.phase_w(body);
         }
+        ctx.phase([&](int, Lane&) {});      // X~ of every waypoint is in LDS for I3
         // I3: back-substitute v, sf, sr; z~ = A x~; relaxed updates, projection, dual update
         ctx.phase([&](int t, Lane& ln) {
             Slot& S = ln.s;
@@ -1198,7 +1289,7 @@ struct PathQp {
                 }
             }
             assemble();
-            ruiz();
+            ruiz(/*reuse=*/(i1 & 2) != 0 && prm.polish_warm_set >= 2);
             start_transition_rows(have_warm);
             if (i1 & 2) {      // warm re-solve: go straight to a polish on the active set the previous pass ended with
                 polish_begin(true);
@@ -1217,7 +1308,7 @@ struct PathQp {
                 polish_update_set(d0);
                 polish_apply_set();
             } else {   // RF_POLISH_REJECT
-                polish_end(false);
+                polish_end(false, d0 != 0.0);
                 polishing_ = false; alpha_ = prm.alpha;
             }
             factor();
@@ -1242,18 +1333,35 @@ struct PathQp {
     PQP_HD void run() {
         const pqp_params& prm = A.prm;
         int total_iters = 0, last_iters = 0, status = PQP_STATUS_UNSOLVED, polished = 0;
+        // active-set rounds per polish attempt; <= 0: sized to the path (long paths need more rounds, short ones pay for them)
+        const int auto_rounds = n / 5 - 8;
+        const int max_rounds = prm.polish_max_rounds > 0 ? prm.polish_max_rounds : (auto_rounds > 8 ? auto_rounds : 8);
         double res[5] = {0, 0, 0, 0, 0};
         int pass = 0;
         // per-pass state of the hot loop
         bool polish_mode = false, conservative = false, end_after_reject = false;
-        double eps_scale = 1.0, best = 1e300;
+        double eps_scale = 1.0, best = 1e300, best_any = 1e300, admm_merit = 1e300;
         int it = 0, refine_left = 0, round = 0, stall = 0, polish_gap = 0, next_polish = 0;
         bool direct_polish = false, last_accepted = false;
         // the pending cold operation
         int op = COLD_BEGIN_PASS, i0 = 0, i1 = A.warm ? 1 : 0;
         double d0 = 0.0;
+#ifdef PQP_TIMING
+        // debug build only (tools/kernel_timeline.py): wall-clock ticks per category, written over the info record
+        long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const long long t_begin = ctx.clock();
+#define PQP_TIC const long long tic_ = ctx.clock()
+#define PQP_TOC(k) tacc[k] += ctx.clock() - tic_
+#else
+#define PQP_TIC
+#define PQP_TOC(k)
+#endif
         for (;;) {
-            ctx.cold(*this, op, i0, i1, d0);
+            {
+                PQP_TIC;
+                ctx.cold(*this, op, i0, i1, d0);
+                PQP_TOC(op == COLD_BEGIN_PASS ? 0 : op == COLD_REFACTOR ? (i0 == RF_RESCALE ? 1 : 2) : 3);
+            }
             if (op == COLD_FINISH) break;
             if (op == COLD_END_PASS) {
                 last_iters = it;
@@ -1271,14 +1379,14 @@ struct PathQp {
                 it = 0; refine_left = 0; round = 0; stall = 0;
                 polish_gap = prm.polish_every; next_polish = prm.polish_every;
                 last_accepted = false;
-                if (direct_polish) { polish_mode = true; refine_left = prm.polish_refine_iter; }
+                if (direct_polish) { polish_mode = true; refine_left = prm.polish_refine_iter; best_any = 1e300; admm_merit = 1e300; }
             } else if (end_after_reject) {       // a rejected polish at max_iter
                 op = COLD_END_PASS; i0 = 0;
                 continue;
             }
             // ---- hot loop: runs until the next cold operation is due
             for (;;) {
-                iterate();
+                { PQP_TIC; iterate(); PQP_TOC(4); }
                 bool want_res, check = false, adapt = false;
                 if (!polish_mode) {
                     it += 1;
@@ -1294,7 +1402,7 @@ struct PathQp {
                     if (!polish_mode && it >= prm.max_iter) { op = COLD_END_PASS; i0 = 0; break; }
                     continue;
                 }
-                residuals(res);
+                { PQP_TIC; residuals(res); PQP_TOC(5); }
                 if (!polish_mode) {
                     bool start_polish = false;
                     if (res[4] != 0.0) { status = PQP_STATUS_NUMERICAL; op = COLD_END_PASS; i0 = 0; break; }
@@ -1315,8 +1423,12 @@ struct PathQp {
                         }
                     }
                     if (start_polish) {
+#ifdef PQP_EMU_DEBUG
+                        printf("  START qp %d it %d ratio_p %.3e ratio_d %.3e\n", qp, it, res[0] / (prm.eps_abs + prm.eps_rel * res[2]), res[1] / (prm.eps_abs + prm.eps_rel * res[3]));
+#endif
                         polish_mode = true;
                         refine_left = prm.polish_refine_iter; round = 0; stall = 0; best = 1e300; conservative = false;
+                        best_any = 1e300; admm_merit = fmax(res[0], res[1]);
                         op = COLD_REFACTOR; i0 = RF_POLISH_BEGIN; break;
                     }
                     bool refactor = false;
@@ -1336,25 +1448,31 @@ struct PathQp {
                 } else {
                     // KKT acceptance test of the polished point (OSQP paper 4.2 + verification)
                     const double tol = prm.polish_tol;
-                    const double viol = polish_violation();
+                    double viol;
+                    { PQP_TIC; viol = polish_violation(); PQP_TOC(6); }
                     const bool solve_ok = res[4] == 0.0 && res[0] <= tol * (1.0 + res[2]) && res[1] <= tol * (1.0 + res[3]);
                     const bool ok = solve_ok && viol <= tol;
 #ifdef PQP_EMU_DEBUG
                     printf("  polish qp %d it %d round %d: pri %.3e dua %.3e viol %.3e %s -> %s\n", qp, it, round, res[0], res[1], viol, conservative ? "(cons)" : "", ok ? "ACCEPT" : "reject");
 #endif
                     if (ok) { status = PQP_STATUS_SOLVED; polished += 1; polish_mode = false; last_accepted = true; op = COLD_END_PASS; i0 = 1; break; }
-                    bool give_up = !solve_ok;
+                    // the active-set rounds diverge: this attempt will not get there, stop paying for it
+                    const bool diverged = prm.polish_diverge > 0 && viol > (double)prm.polish_diverge * best_any;
+                    bool give_up = !solve_ok || diverged;
+                    if (solve_ok && viol < best_any) { best_any = viol; if (prm.polish_reseed) polish_save_best(); }
                     if (!give_up) {
                         // primal-dual active-set step.  A full update can cycle: when the violation stops improving only
                         // the worst offenders (>= 90 % of the maximum) move.
                         if (viol < 0.7 * best) { best = viol; stall = 0; } else { stall += 1; }
                         if (stall >= 3) conservative = true;
                         round += 1;
-                        give_up = (conservative && stall >= 16) || round >= kPolishRounds;
+                        give_up = (conservative && stall >= 16) || round >= max_rounds;
                     }
                     if (give_up) {
                         polish_mode = false;
                         end_after_reject = it >= prm.max_iter;
+                        // continue ADMM from the best polished point when it is closer to the optimum than the parked iterate
+                        d0 = (prm.polish_reseed && best_any < prm.polish_reseed_factor * admm_merit) ? 1.0 : 0.0;
                         op = COLD_REFACTOR; i0 = RF_POLISH_REJECT; break;
                     }
                     refine_left = prm.polish_refine_iter;
@@ -1373,6 +1491,10 @@ struct PathQp {
                     double* f = A.info + PQP_INFO_STRIDE * (size_t)qp;
                     f[0] = res[0]; f[1] = res[1]; f[2] = rho_final; f[3] = (double)last_iters;
                     f[4] = (double)polished; f[5] = (double)kkt_total; f[6] = (double)fac_total; f[7] = 0.0;
+#ifdef PQP_TIMING
+                    tacc[7] = ctx.clock() - t_begin;
+                    for (int k = 0; k < 8; ++k) f[k] = (double)tacc[k];
+#endif
                 }
             }
         });

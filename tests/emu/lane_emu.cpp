@@ -8,6 +8,9 @@
 #include "../../path_optimizer_2_amd/csrc/pqp_defaults.hpp"
 #include "../../path_optimizer_2_amd/csrc/pqp_banded_qp.hpp"
 
+static int g_wave_order = 1;
+extern "C" void pqp_emu_set_wave_order(int o) { g_wave_order = o; }
+
 namespace {
 struct HostCtx {
     int T_;
@@ -17,6 +20,17 @@ struct HostCtx {
     int T() const { return T_; }
     double* sh() { return shm.data(); }
     template <class F> void phase(F f) { for (int t = 0; t < T_; ++t) f(t, lanes[t]); }
+    long long clock() const { return 0; }
+    // wave-local phase: the emulation runs the wavefronts one after the other, in the order g_wave_order selects (0: first
+    // wavefront first, 1: last wavefront first), so that code relying on a workgroup barrier it does not have reads stale data
+    // in one of the two orders and fails the tests
+    template <class F> void phase_w(F f) {
+        const int nw = (T_ + 63) / 64;
+        for (int k = 0; k < nw; ++k) {
+            const int w = g_wave_order ? nw - 1 - k : k;
+            for (int t = 64 * w; t < 64 * (w + 1) && t < T_; ++t) f(t, lanes[t]);
+        }
+    }
     template <class PQ> void cold(PQ& pq, int op, int i0, int i1, double d0) { pq.do_cold(op, i0, i1, d0); }
     template <int K, class F> void reduce_max(double (&out)[K], F f) {
         for (int k = 0; k < K; ++k) out[k] = 0.0;
@@ -30,6 +44,7 @@ struct HostCtx {
 }  // namespace
 
 extern "C" void pqp_emu_default_params(pqp_params* p) { pqp::default_params(p); }
+extern "C" void pqp_emu_production_params(pqp_params* p) { pqp::production_params(p); }
 
 extern "C" int pqp_emu_path_solve(const pqp_params* prm, int batch, int n, const double* ref, const double* lin,
                                   const double* bounds, const double* scal, int passes, int warm, double* out,
@@ -43,7 +58,7 @@ extern "C" int pqp_emu_path_solve(const pqp_params* prm, int batch, int n, const
     a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
     a.status = status; a.iters = iters; a.info = info;
     a.wx = wx; a.wy = wy; a.wye = wye; a.wrho = wrho;
-    std::vector<double> wsave((size_t)batch * T * 20, 0.0);
+    std::vector<double> wsave((size_t)batch * T * PQP_SAVE_STRIDE, 0.0);
     a.wsave = wsave.data();
     a.prm = *prm;
     for (int q = 0; q < batch; ++q) {
@@ -63,7 +78,7 @@ extern "C" int pqp_emu_probe(const pqp_params* prm, int n, const double* ref, co
     pqp::PathSolveArgs a;
     std::memset(&a, 0, sizeof(a));
     a.batch = 1; a.n = n; a.ref = ref; a.bounds = bounds; a.scal = scal; a.prm = *prm;
-    std::vector<double> wsave((size_t)T * 20, 0.0);
+    std::vector<double> wsave((size_t)T * PQP_SAVE_STRIDE, 0.0);
     a.wsave = wsave.data();
     HostCtx ctx(T);
     pqp::PathQp<HostCtx> s(ctx, a, 0);

@@ -34,6 +34,14 @@ def params(**over):
     return p
 
 
+def production(**over):
+    p = PqpParams()
+    load().pqp_emu_production_params(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
 def solve(prm, ref, bounds, scal, lin=None, passes=1):
     lib = load()
     B, n = ref.shape[0], ref.shape[1]

@@ -27,8 +27,7 @@ def _tight(**kw):
 
 def _polished(**kw):
     """The production setting of bench.py: ADMM to eps 1e-4, then the KKT-verified polish."""
-    return capi.default_params(eps_abs=1e-4, eps_rel=1e-4, polish=1, polish_every=25, adaptive_rho_interval=25,
-                               polish_warm_set=1, polish_refine_iter=3, **kw)
+    return capi.production_params(**kw)
 
 
 ORACLE_TIGHT = O.OsqpSettings(eps_abs=1e-9, eps_rel=1e-9, max_iter=40000)

@@ -27,7 +27,7 @@ def test_plain_admm_follows_the_oracle_iteration_for_iteration(n, profile):
 @pytest.mark.parametrize("n,profile,batch", [(80, "uniform", 16), (200, "varied", 4), (9, "uniform", 4)])
 def test_polished_solution_is_the_converged_optimum(n, profile, batch):
     b = make_batch(batch, n, profile)
-    prm = E.params(eps_abs=1e-4, eps_rel=1e-4, polish=1, polish_every=25, adaptive_rho_interval=25)
+    prm = E.production()
     r = E.solve(prm, b["ref"], b["bounds"], b["scal"], passes=1)
     assert (r["status"] == 1).all() and (r["info"][:, 4] == 2).all()      # both passes ended in an accepted polish
     for q in range(min(batch, 4)):
@@ -41,7 +41,7 @@ def test_polished_solution_is_the_converged_optimum(n, profile, batch):
         Pd2, A2, lo2, up2, sz = O.assemble_path_qp(b["ref"][q], E.solve(prm, b["ref"][q:q + 1], b["bounds"][q:q + 1], b["scal"][q:q + 1], passes=0)["out"][0][:, 3:6], b["bounds"][q], b["scal"][q])
         cert = O.kkt_certificate(sp.diags(Pd2), np.zeros(sz["vars"]), A2, lo2, up2, x, y)
         assert cert["pri"] < 1e-8 and cert["stat"] < 1e-7 and cert["comp"] < 1e-8, cert
-    assert r["iters"].max() <= 400
+    assert r["iters"].max() <= 700      # a slow ADMM tail is cut short by the periodic polish attempts
 
 
 def test_rough_constraints_mode():
@@ -65,3 +65,19 @@ def test_given_linearisation_point():
     for q in range(2):
         ref = O.solve_path(b["ref"][q], b["bounds"][q], b["scal"][q], st=TIGHT, passes=0, lin0=lin[q])
         assert np.abs(r["out"][q][:, 3:6] - ref[-1]["out"][:, 3:6]).max() < 1e-6
+
+
+@pytest.mark.parametrize("n", [80, 200])
+def test_wave_local_phases_do_not_depend_on_wavefront_order(n):
+    """The in-wave levels of the cyclic reduction run without workgroup barriers (phase_w).  The emulation executes the
+    wavefronts of such a phase one after the other; a missing barrier shows up as a difference between the two orders."""
+    b = make_batch(3, n, "varied", seed=11)
+    prm = E.params(eps_abs=1e-5, eps_rel=1e-5, max_iter=3000)
+    lib = E.load()
+    res = []
+    for order in (0, 1):
+        lib.pqp_emu_set_wave_order(order)
+        res.append(E.solve(prm, b["ref"], b["bounds"], b["scal"], passes=1))
+    lib.pqp_emu_set_wave_order(1)
+    assert (res[0]["iters"] == res[1]["iters"]).all()
+    assert np.array_equal(res[0]["out"], res[1]["out"])

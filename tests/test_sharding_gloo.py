@@ -22,7 +22,7 @@ def _worker(rank, world, port, total, n, ret):
     from path_optimizer_2_amd.synth import make_batch
     first, count = shard_range(total, world, rank)
     b = make_batch(count, n, first_qp=first)                       # counter-based RNG: a shard is regenerated anywhere
-    prm = E.params(eps_abs=1e-4, eps_rel=1e-4, polish=1, polish_every=25, adaptive_rho_interval=25, polish_warm_set=1)
+    prm = E.production()
     r = E.solve(prm, b["ref"], b["bounds"], b["scal"], passes=1)
     full = gather_paths(torch.from_numpy(r["out"]), total)
     mx, failed = reduce_stats(torch.from_numpy(r["iters"]), int((r["status"] != 1).sum()))
@@ -43,7 +43,7 @@ def test_two_rank_shard_and_gather_equals_single_process():
     mgr = mp.Manager(); ret = mgr.dict()
     mp.spawn(_worker, args=(world, 29517, total, n, ret), nprocs=world, join=True)
     b = make_batch(total, n)
-    prm = E.params(eps_abs=1e-4, eps_rel=1e-4, polish=1, polish_every=25, adaptive_rho_interval=25, polish_warm_set=1)
+    prm = E.production()
     single = E.solve(prm, b["ref"], b["bounds"], b["scal"], passes=1)
     np.testing.assert_array_equal(ret["full"], single["out"])      # bit-identical: sharding changes nothing per QP
     assert ret["failed"] == 0 and ret["max_iters"] == int(single["iters"].max())

@@ -1,0 +1,48 @@
+"""Where the solve kernel's time goes, per QP: builds a -DPQP_TIMING variant of the library (device wall clock, 100 MHz,
+accumulated per category by thread 0 and written over the info record) and prints the mean / max microseconds per category.
+Debug tool; the timing build is never the shipped library.
+Usage: python tools/kernel_timeline.py [batch] [n] [key=value ...]      (run on the GPU box)"""
+import os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "path_optimizer_2_amd", "csrc")
+LIB = os.path.join(CSRC, "libpqp_hip_timing.so")
+
+
+def build():
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DPQP_MONOLITH", "-DPQP_TIMING", "-fPIC", "-shared",
+                    "-o", LIB, os.path.join(CSRC, "pqp_kernels.hip")], check=True, cwd=CSRC)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        build(); sys.exit(0)
+    import torch
+    from path_optimizer_2_amd import capi
+    from path_optimizer_2_amd.synth import make_batch
+    if not os.path.exists(LIB):
+        build()
+    capi.LIB_PATH = LIB
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 80
+    over = dict(eps_abs=1e-4, eps_rel=1e-4, polish=1, polish_every=25, adaptive_rho_interval=25, polish_warm_set=2, polish_refine_iter=2, polish_max_rounds=8)
+    for kv in sys.argv[3:]:
+        k, v = kv.split("=")
+        over[k] = float(v) if ("." in v or "e" in v) else int(v)
+    host = make_batch(batch, n)
+    dev = torch.device("cuda", 0)
+    ref, bounds, scal = (torch.from_numpy(host[k]).to(dev) for k in ("ref", "bounds", "scal"))
+    out = torch.zeros((batch, n, 7), dtype=torch.float64, device=dev)
+    info = torch.zeros((batch, 8), dtype=torch.float64, device=dev)
+    h = capi.Handle(capi.default_params(**over), device=0, max_batch=batch, max_n=n)
+    for _ in range(3):
+        h.solve_device(batch, n, ref, bounds, scal, out, passes=1, info=info)
+    h.sync()
+    t = info.cpu().numpy() / 100.0          # ticks of 10 ns -> microseconds
+    names = ["begin_pass(assemble+ruiz+factor)", "refactor(rho)", "refactor(polish set)", "end_pass(unpack)", "iterate", "residuals",
+             "polish_violation", "TOTAL"]
+    print(f"batch {batch} n {n} {over}: kernel {h.last_kernel_ms():.3f} ms")
+    for k, nm in enumerate(names):
+        print(f"  {nm:36s} mean {t[:, k].mean():8.1f} us   p99 {np.percentile(t[:, k], 99):8.1f}   max {t[:, k].max():8.1f}")
+    print(f"  sum of means (0..6) {t[:, :7].sum(1).mean():.1f} us")
