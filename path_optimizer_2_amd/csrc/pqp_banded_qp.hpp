@@ -4,11 +4,12 @@
 //   S3 ReferencePathSmoother::postSmooth  src/reference_path_smoother/reference_path_smoother.cpp:526-636
 // Each is  min 1/2 x'Px + q'x  s.t.  l <= Ax <= u  with a banded P and rows that touch two neighbouring points; the
 // assemble kernels emit the variables point-interleaved, which makes the reduced KKT matrix S = P + Sigma + A'RA banded
-// (half-bandwidth 4 / 9 / 3).  This core is the OSQP-paper ADMM (the same iteration as pqp_path_lane.hpp: unscaled
-// coordinates, Ruiz metrics, adaptive rho, KKT-verified polish) on that band:
-//   one workgroup (one wavefront) per QP, band factor + all vectors resident in LDS, HBM touched to read the QP and
-//   write the solution.  The band Cholesky / triangular solves are sequential in the variable index and parallel over
-//   the band; everything else is parallel over rows / columns.
+// (half-bandwidth B = 4 / 9 / 3), i.e. block tridiagonal with B x B blocks.  This core is the OSQP-paper ADMM (the same
+// iteration as pqp_path_lane.hpp: unscaled coordinates, Ruiz metrics, adaptive rho, KKT-verified polish) on that structure:
+//   one workgroup per QP, ONE LANE PER VARIABLE (lane t = variable t = row t%B of block t/B).  S is factorised and solved by
+//   block cyclic reduction over the blocks: log2(#blocks) levels instead of a chain as long as the variable count.  A lane
+//   keeps the rows of its block's factor (D^-1, D^-1 S_left, D^-1 S_right and the transposed rows) in registers; vectors and
+//   the row data of A live in LDS; HBM is touched to read the QP and write the solution.
 //
 // QP data layout (per QP unless marked shared; doubles; sparsity shared by the whole batch):
 //   pband [pbw+1][nv]   P[j+d][j] at [d][j]                      q [nv]   l, u [nc]
@@ -41,14 +42,30 @@ struct BandedQpArgs {
     pqp_params prm;
 };
 
-// LDS layout (doubles)
+// per-lane register state: the factor rows of variable t (valid at the elimination level of its block) and the
+// factorisation workspace
+template <int B>
+struct BqLane {
+    double Dinv[B], HL[B], HR[B];    // row i of D^-1, D^-1 S_{e,left}, D^-1 S_{e,right}
+    double HLt[B], HRt[B];           // column i of the latter two (rows of their transposes)
+    double Dr[B], Lr[B], Rr[B], Ag[B];   // factorisation: row i of S_ee, S_{e,left}, S_{e,right}, Gauss-Jordan augment
+    double r;                        // right-hand side entry / solution entry
+    double b0, x0;                   // polish: right-hand side and accumulated solution during iterative refinement
+};
+
+// LDS layout (doubles).  nbb = padded variable count (#blocks x B)
 struct BqLayout {
     int nv, nc, bw;
-    PQP_HD int band() const { return 0; }                          // [bw+1][nv] factor / S
-    PQP_HD int x() const { return (bw + 1) * nv; }
-    PQP_HD int xt() const { return x() + nv; }
-    PQP_HD int rhs() const { return xt() + nv; }
-    PQP_HD int sig() const { return rhs() + nv; }                  // sigma / (c D^2)
+    PQP_HD int nb() const { return (nv + bw - 1) / bw; }
+    PQP_HD int nbb() const { return nb() * bw; }
+    PQP_HD int piv() const { return 0; }                           // [nb][4B] Gauss-Jordan pivot rows
+    PQP_HD int hm() const { return piv() + nb() * 4 * bw; }        // [nb/2+1][2][B][B] D^-1 S_left / D^-1 S_right of the level's blocks
+    PQP_HD int x() const { return hm() + (nb() / 2 + 1) * 2 * bw * bw; }
+    PQP_HD int xt() const { return x() + nv; }                     // [nbb] solution of the reduced system
+    PQP_HD int rhs() const { return xt() + nbb(); }                // [nbb] right-hand side at elimination time (and Ruiz scratch)
+    PQP_HD int pl() const { return rhs() + nbb(); }                // [nbb] message of a block to its left neighbour
+    PQP_HD int pr() const { return pl() + nbb(); }                 // [nbb] ... right neighbour
+    PQP_HD int sig() const { return pr() + nbb(); }                // sigma / (c D^2)
     PQP_HD int dsc() const { return sig() + nv; }                  // D
     PQP_HD int xs() const { return dsc() + nv; }                   // polish: saved x
     PQP_HD int z() const { return xs() + nv; }
@@ -62,13 +79,14 @@ struct BqLayout {
     PQP_HD int act() const { return up() + nc; }                   // polish: -1 / 0 / +1
     PQP_HD int zs() const { return act() + nc; }                   // polish: saved z
     PQP_HD int ys() const { return zs() + nc; }                    // polish: saved y
-    PQP_HD int red() const { return ys() + nc; }                   // [64] scratch
-    PQP_HD int total() const { return red() + 64; }
+    PQP_HD int red() const { return ys() + nc; }                   // [5][16] reduction scratch
+    PQP_HD int total() const { return red() + 128; }
 };
 
-// Ctx: T(), sh(), phase(f(t)), reduce_max/sum<K>(out, f(t, v[K]))
-template <class Ctx>
+// Ctx: T(), sh(), phase(f(t, BqLane<B>&)), reduce_max/sum<K>(out, f(t, v[K]))
+template <class Ctx, int B>
 struct BandedQp {
+    typedef BqLane<B> Lane;
     Ctx& ctx;
     const BandedQpArgs& A;
     const int qp, nv, nc, bw, T;
@@ -86,8 +104,8 @@ struct BandedQp {
     PQP_HD const double* pband() const { return A.pband + (size_t)qp * (A.pbw + 1) * nv; }
     PQP_HD double pdiag(int j) const { return pband()[j]; }
 
-    template <class F> PQP_HD void rows(F f) { ctx.phase([&](int t) { for (int r = t; r < nc; r += T) f(r); }); }
-    template <class F> PQP_HD void cols(F f) { ctx.phase([&](int t) { for (int j = t; j < nv; j += T) f(j); }); }
+    template <class F> PQP_HD void rows(F f) { ctx.phase([&](int t, Lane&) { for (int r = t; r < nc; r += T) f(r); }); }
+    template <class F> PQP_HD void cols(F f) { ctx.phase([&](int t, Lane&) { for (int j = t; j < nv; j += T) f(j); }); }
 
     PQP_HD double row_dot(int r, const double* v) const {      // (A v)_r
         const double* av = aval() + (size_t)r * kRMax;
@@ -202,60 +220,170 @@ struct BandedQp {
         rows([&](int r) { const double b = sh[L.e2() + r]; sh[L.rv() + r] = b < 0.0 ? -b : rho_now * b; });
     }
 
-    // ---- factorisation: S = P + Sigma + A' R A in band storage, banded Cholesky in place --------------------------
+    // ---- factorisation: S = P + Sigma + A' R A, block cyclic reduction over the B x B blocks ----------------------------
+    // Block e = t / B, row i = t % B.  Tree over tp = e + 1: a block is eliminated at level h = lowest set bit of tp into the
+    // blocks e - h and e + h (those that exist).  Elimination of e: Gauss-Jordan on [S_ee | S_e,left | S_e,right | I] with one
+    // row per lane gives D^-1 S_e,left, D^-1 S_e,right and D^-1 row by row; the surviving neighbours then update their own
+    // rows:  S_aa -= S_ae (D^-1 S_ea),  S_a,c = -S_ae (D^-1 S_ec)  (a = e - h, c = e + h) and the mirror image for c.
+    PQP_HD static int level_of(int e) { const int tp = e + 1; return tp & (-tp); }
     PQP_HD void factor() {
         factors_ += 1;
-        double* B = sh + L.band();
+        const int nb = L.nb();
         const double* rv = sh + L.rv();
-        cols([&](int j) {      // column j of the lower band of S; deterministic: every lane owns whole columns
-            const double* pb = pband();
-            for (int d = 0; d <= bw; ++d) B[(size_t)d * nv + j] = (d <= A.pbw) ? pb[(size_t)d * nv + j] : 0.0;
-            B[j] += sh[L.sig() + j];
-            const int* tr = A.trow + (size_t)j * kCMax;
-            const int* ts = A.tslot + (size_t)j * kCMax;
-            for (int k = 0; k < kCMax; ++k) {
-                const int r = tr[k];
-                if (r < 0) continue;
-                const double* av = aval() + (size_t)r * kRMax;
-                const int* ac = A.acol + (size_t)r * kRMax;
-                const double v = rv[r] * av[ts[k]];
-                for (int s = 0; s < kRMax; ++s) {
-                    const int c2 = ac[s];
-                    if (c2 >= j) B[(size_t)(c2 - j) * nv + j] += v * av[s];
+        ctx.phase([&](int t, Lane& ln) {      // row t of S, split by block column: left / own / right block
+            const int e = t / B;
+            _Pragma("unroll") for (int k = 0; k < B; ++k) { ln.Dr[k] = 0.0; ln.Lr[k] = 0.0; ln.Rr[k] = 0.0; }
+            if (t < nv) {
+                const int j = t;
+                const double* pb = pband();
+                for (int d = -A.pbw; d <= A.pbw; ++d) {
+                    const int c = j + d;
+                    if (c < 0 || c >= nv) continue;
+                    const double v = d >= 0 ? pb[(size_t)d * nv + j] : pb[(size_t)(-d) * nv + c];
+                    add_entry(ln, e, c, v);
                 }
+                add_entry(ln, e, j, sh[L.sig() + j]);
+                const int* tr = A.trow + (size_t)j * kCMax;
+                const int* ts = A.tslot + (size_t)j * kCMax;
+                for (int k = 0; k < kCMax; ++k) {
+                    const int r = tr[k];
+                    if (r < 0) continue;
+                    const double* av = aval() + (size_t)r * kRMax;
+                    const int* ac = A.acol + (size_t)r * kRMax;
+                    const double v = rv[r] * av[ts[k]];
+                    for (int s2 = 0; s2 < kRMax; ++s2) { const int c2 = ac[s2]; if (c2 >= 0) add_entry(ln, e, c2, v * av[s2]); }
+                }
+            } else {
+                add_entry(ln, e, t, 1.0);     // padding variable of the last block: unit row
             }
         });
-        // right-looking banded Cholesky: column j is finished, then the trailing (bw x bw) window is updated in parallel
-        for (int j = 0; j < nv; ++j) {
-            ctx.phase([&](int t) { if (t == 0) B[j] = sqrt(B[j]); });
-            ctx.phase([&](int t) { if (t >= 1 && t <= bw && j + t < nv) B[(size_t)t * nv + j] *= rcp(B[j]); });   // lane d scales L[j+d][j]
-            ctx.phase([&](int t) {
-                // pairs (d1 >= d2 >= 1): S[j+d1][j+d2] -= L[j+d1][j] * L[j+d2][j]
-                const int npair = bw * (bw + 1) / 2;
-                for (int p = t; p < npair; p += T) {
-                    int d2 = 1, rem = p;
-                    while (rem >= bw - d2 + 1) { rem -= bw - d2 + 1; ++d2; }
-                    const int d1 = d2 + rem;
-                    if (j + d1 < nv) B[(size_t)(d1 - d2) * nv + j + d2] -= B[(size_t)d1 * nv + j] * B[(size_t)d2 * nv + j];
+        for (int h = 1; h <= nb; h <<= 1) {
+            // Gauss-Jordan, pivot k: the pivot lane publishes its row; then it normalises it and the other rows of the block
+            // eliminate.  (No lane field is indexed by k under a test `i == k`: there the compiler rewrites Dr[k] as Dr[i], a
+            // dynamic index into the lane struct, which would keep the whole struct in scratch memory.)
+            _Pragma("unroll") for (int k = 0; k < B; ++k) {
+                ctx.phase([&](int t, Lane& ln) {
+                    const int e = t / B, i = t - e * B;
+                    if (e < nb && level_of(e) == h) {
+                        if (k == 0) { _Pragma("unroll") for (int c = 0; c < B; ++c) ln.Ag[c] = (c == i) ? 1.0 : 0.0; }
+                        if (i == k) {
+                            double* pv = sh + L.piv() + (size_t)e * 4 * B;
+                            _Pragma("unroll") for (int c = 0; c < B; ++c) {
+                                pv[c] = ln.Dr[c]; pv[B + c] = ln.Lr[c]; pv[2 * B + c] = ln.Rr[c]; pv[3 * B + c] = ln.Ag[c];
+                            }
+                        }
+                    }
+                });
+                ctx.phase([&](int t, Lane& ln) {
+                    const int e = t / B, i = t - e * B;
+                    if (e < nb && level_of(e) == h) {
+                        const double* pv = sh + L.piv() + (size_t)e * 4 * B;
+                        const bool pivot = (i == k);
+                        const double inv = rcp(pv[k]);
+                        const double f = pivot ? 0.0 : ln.Dr[k] * inv;      // multiple of the (raw) pivot row to subtract
+                        const double sc = pivot ? inv : 1.0;               // the pivot row itself is normalised
+                        _Pragma("unroll") for (int c = 0; c < B; ++c) {
+                            ln.Dr[c] = ln.Dr[c] * sc - f * pv[c];
+                            ln.Lr[c] = ln.Lr[c] * sc - f * pv[B + c];
+                            ln.Rr[c] = ln.Rr[c] * sc - f * pv[2 * B + c];
+                            ln.Ag[c] = ln.Ag[c] * sc - f * pv[3 * B + c];
+                        }
+                    }
+                });
+            }
+            // keep the factor rows, publish D^-1 S_left / D^-1 S_right of the eliminated blocks
+            ctx.phase([&](int t, Lane& ln) {
+                const int e = t / B, i = t - e * B;
+                if (e < nb && level_of(e) == h) {
+                    double* m = sh + L.hm() + (size_t)(e / (2 * h)) * 2 * B * B;
+                    _Pragma("unroll") for (int c = 0; c < B; ++c) {
+                        ln.Dinv[c] = ln.Ag[c]; ln.HL[c] = ln.Lr[c]; ln.HR[c] = ln.Rr[c];
+                        m[i * B + c] = ln.Lr[c]; m[B * B + i * B + c] = ln.Rr[c];
+                    }
+                }
+            });
+            // (one unconditional store per lane field with selected values: if/else branches that end in stores to different
+            //  fields are merged by LLVM into a store through a pointer phi, which pushes the lane struct into scratch memory)
+            ctx.phase([&](int t, Lane& ln) {
+                const int e = t / B, i = t - e * B;
+                if (e >= nb) return;
+                const int lv = level_of(e);
+                const bool el = lv == h, sv = lv > h;
+                if (el) {   // eliminated block: transposed rows for the forward sweep.  (A plain `if` without else: selecting between
+                            //  an LDS load and a lane field would again become an address select.)
+                    const double* m = sh + L.hm() + (size_t)(e / (2 * h)) * 2 * B * B;
+                    _Pragma("unroll") for (int c = 0; c < B; ++c) { ln.HLt[c] = m[c * B + i]; ln.HRt[c] = m[B * B + c * B + i]; }
+                }
+                // survivor: fold the eliminated neighbours into the own row, couple to the next neighbours
+                double nd[B], nl[B], nr[B];
+                _Pragma("unroll") for (int c = 0; c < B; ++c) { nd[c] = ln.Dr[c]; nl[c] = 0.0; nr[c] = 0.0; }
+                if (sv && e + h < nb) {     // right neighbour e + h: own Rr is row i of S_{a,e}
+                    const double* m = sh + L.hm() + (size_t)((e + h) / (2 * h)) * 2 * B * B;
+                    _Pragma("unroll") for (int k2 = 0; k2 < B; ++k2) {
+                        const double f = ln.Rr[k2];
+                        _Pragma("unroll") for (int c = 0; c < B; ++c) { nd[c] -= f * m[k2 * B + c]; nr[c] -= f * m[B * B + k2 * B + c]; }
+                    }
+                }
+                if (sv && e - h >= 0) {     // left neighbour e - h: own Lr is row i of S_{c,e}
+                    const double* m = sh + L.hm() + (size_t)((e - h) / (2 * h)) * 2 * B * B;
+                    _Pragma("unroll") for (int k2 = 0; k2 < B; ++k2) {
+                        const double f = ln.Lr[k2];
+                        _Pragma("unroll") for (int c = 0; c < B; ++c) { nd[c] -= f * m[B * B + k2 * B + c]; nl[c] -= f * m[k2 * B + c]; }
+                    }
+                }
+                _Pragma("unroll") for (int c = 0; c < B; ++c) {
+                    ln.Dr[c] = sv ? nd[c] : ln.Dr[c]; ln.Lr[c] = sv ? nl[c] : ln.Lr[c]; ln.Rr[c] = sv ? nr[c] : ln.Rr[c];
                 }
             });
         }
     }
-
-    // solve S v = b in place on sh[rhs]
-    PQP_HD void band_solve() {
-        const double* B = sh + L.band();
-        double* b = sh + L.rhs();
-        for (int j = 0; j < nv; ++j) {       // forward, column oriented
-            ctx.phase([&](int t) { if (t == 0) b[j] = b[j] / B[j]; });
-            ctx.phase([&](int t) { if (t >= 1 && t <= bw && j + t < nv) b[j + t] -= B[(size_t)t * nv + j] * b[j]; });
+    // S[row of lane][c] += v, routed to the left / own / right block of the row (static register indices only)
+    PQP_HD static void add_entry(Lane& ln, int e, int c, double v) {
+        const int base = e * B;
+        _Pragma("unroll") for (int k = 0; k < B; ++k) {
+            ln.Dr[k] += (c == base + k) ? v : 0.0;
+            ln.Lr[k] += (c == base - B + k) ? v : 0.0;
+            ln.Rr[k] += (c == base + B + k) ? v : 0.0;
         }
-        for (int j = nv - 1; j >= 0; --j) {  // backward: row oriented dot product over the band, reduced by lane 0
-            ctx.phase([&](int t) {
-                if (t == 0) {
-                    double s = b[j];
-                    for (int d = 1; d <= bw; ++d) if (j + d < nv) s -= B[(size_t)d * nv + j] * b[j + d];
-                    b[j] = s / B[j];
+    }
+
+    // solve S v = r (r in the lanes' registers); the solution ends in sh[xt] and in ln.r
+    PQP_HD void band_solve() {
+        const int nb = L.nb();
+        double* rb = sh + L.rhs(); double* pl = sh + L.pl(); double* pr = sh + L.pr(); double* xb = sh + L.xt();
+        int hmax = 1;
+        while (2 * hmax <= nb) hmax <<= 1;
+        for (int h = 1; h <= hmax; h <<= 1) {
+            ctx.phase([&](int t, Lane& ln) {      // receive from the level just eliminated; blocks of this level publish r
+                const int e = t / B, i = t - e * B;
+                if (e >= nb) return;
+                const int lv = level_of(e);
+                if (h > 1 && lv >= h) {
+                    const int hp = h >> 1;
+                    if (e + hp < nb) ln.r -= pl[(e + hp) * B + i];
+                    if (e - hp >= 0) ln.r -= pr[(e - hp) * B + i];
+                }
+                if (lv == h) rb[t] = ln.r;
+            });
+            ctx.phase([&](int t, Lane& ln) {      // messages of the blocks eliminated at this level
+                const int e = t / B;
+                if (e < nb && level_of(e) == h) {
+                    double a = 0.0, b2 = 0.0;
+                    _Pragma("unroll") for (int k = 0; k < B; ++k) { const double re = rb[e * B + k]; a += ln.HLt[k] * re; b2 += ln.HRt[k] * re; }
+                    pl[t] = a; pr[t] = b2;
+                }
+            });
+        }
+        for (int h = hmax; h >= 1; h >>= 1) {
+            ctx.phase([&](int t, Lane& ln) {
+                const int e = t / B;
+                if (e < nb && level_of(e) == h) {
+                    double v = 0.0;
+                    _Pragma("unroll") for (int k = 0; k < B; ++k) v += ln.Dinv[k] * rb[e * B + k];
+                    if (e - h >= 0) { _Pragma("unroll") for (int k = 0; k < B; ++k) v -= ln.HL[k] * xb[(e - h) * B + k]; }
+                    if (e + h < nb) { _Pragma("unroll") for (int k = 0; k < B; ++k) v -= ln.HR[k] * xb[(e + h) * B + k]; }
+                    xb[t] = v;
+                    ln.r = v;
                 }
             });
         }
@@ -267,12 +395,24 @@ struct BandedQp {
         const double alpha = alpha_;
         const double* qv = A.q + (size_t)qp * nv;
         double* x = sh + L.x(); double* z = sh + L.z(); double* y = sh + L.y();
-        double* zt = sh + L.zt(); double* xt = sh + L.xt(); double* b = sh + L.rhs();
+        double* zt = sh + L.zt(); double* xt = sh + L.xt();
         const double* rv = sh + L.rv();
         rows([&](int r) { zt[r] = rv[r] * z[r] - y[r]; });
-        cols([&](int j) { b[j] = sh[L.sig() + j] * x[j] - qv[j] + col_dot(j, zt); });
+        ctx.phase([&](int t, Lane& ln) { ln.r = t < nv ? sh[L.sig() + t] * x[t] - qv[t] + col_dot(t, zt) : 0.0; ln.b0 = ln.r; ln.x0 = 0.0; });
         band_solve();
-        cols([&](int j) { xt[j] = b[j]; });
+        // While polishing (penalties 1/delta next to delta: condition ~1e12) the cyclic-reduction solve alone is not accurate
+        // enough (S2: |b - S x| ~ 25); iterative refinement against the exactly applied S reaches the round-off floor
+        // eps |S| |x| in one step, a second one is insurance.
+        for (int step = 0; step < (polishing_ ? 2 : 0); ++step) {
+            rows([&](int r) { zt[r] = rv[r] * row_dot(r, xt); });
+            ctx.phase([&](int t, Lane& ln) {
+                ln.x0 += ln.r;
+                ln.r = t < nv ? ln.b0 - (p_times(t, xt) + sh[L.sig() + t] * xt[t] + col_dot(t, zt)) : 0.0;
+            });
+            // xt still holds the previous solve's output; the correction overwrites it, so fold it in afterwards
+            band_solve();
+            ctx.phase([&](int t, Lane& ln) { if (t < L.nbb()) { ln.r += ln.x0; ln.x0 = 0.0; xt[t] = ln.r; } });
+        }
         rows([&](int r) {
             const double ztr = row_dot(r, xt);
             const double zh = alpha * ztr + (1.0 - alpha) * z[r];
@@ -317,9 +457,12 @@ struct BandedQp {
     }
 
     // ---- polish (same scheme as pqp_path_lane.hpp) -------------------------------------------------------------
+    // delta of the polish for these QPs: their equality rows carry the whole problem, and the multiplier update y += R (Ax - z)
+    // has a round-off floor of eps/delta * |Ax|; at the path QP's 1e-6 that floor sits above the acceptance tolerance
+    PQP_HD double polish_delta() const { return B > 4 ? A.prm.polish_delta : fmax(A.prm.polish_delta, 1e-4); }
     PQP_HD void polish_begin() {
         const pqp_params& prm = A.prm;
-        const double gain = 1.0 / prm.polish_delta, sgain = prm.polish_delta / prm.sigma;
+        const double gain = 1.0 / polish_delta(), sgain = polish_delta() / prm.sigma;
         rows([&](int r) {
             sh[L.zs() + r] = sh[L.z() + r]; sh[L.ys() + r] = sh[L.y() + r];
             const double b = sh[L.e2() + r];
@@ -334,7 +477,7 @@ struct BandedQp {
         (void)gain;
     }
     PQP_HD void polish_apply_set() {
-        const double gain = 1.0 / A.prm.polish_delta;
+        const double gain = 1.0 / polish_delta();
         rows([&](int r) {
             const double a = sh[L.act() + r];
             const double e = sh[L.esc() + r], e2 = e * e / cscale;
@@ -370,7 +513,7 @@ struct BandedQp {
         });
     }
     PQP_HD void polish_end(bool ok) {
-        const double isgain = A.prm.sigma / A.prm.polish_delta;
+        const double isgain = A.prm.sigma / polish_delta();
         rows([&](int r) {
             if (!ok) { sh[L.z() + r] = sh[L.zs() + r]; sh[L.y() + r] = sh[L.ys() + r]; }
         });
@@ -407,10 +550,10 @@ struct BandedQp {
             if (check) {
                 const double eps_p = eps_scale * (prm.eps_abs + prm.eps_rel * res[2]);
                 const double eps_d = eps_scale * (prm.eps_abs + prm.eps_rel * res[3]);
-                if (res[0] <= eps_p && res[1] <= eps_d) {
+                const bool converged = res[0] <= eps_p && res[1] <= eps_d;
+                if (converged) {
                     if (!prm.polish || eps_scale * fmax(prm.eps_abs, prm.eps_rel) < 1e-10) { status = PQP_STATUS_SOLVED; break; }
                     start_polish = true;
-                    eps_scale *= 0.1;
                 } else if (prm.polish && prm.polish_every > 0 && it >= next_polish) {
                     start_polish = true;
                     polish_gap *= 2;
@@ -418,6 +561,7 @@ struct BandedQp {
                 }
             }
             if (start_polish) {
+                const bool was_converged = res[0] <= eps_scale * (prm.eps_abs + prm.eps_rel * res[2]) && res[1] <= eps_scale * (prm.eps_abs + prm.eps_rel * res[3]);
                 polish_begin();
                 polishing_ = true; alpha_ = 1.0;
                 bool ok = false, conservative = false;
@@ -442,6 +586,9 @@ struct BandedQp {
                     const double viol = polish_violation();
                     const bool solve_ok = res[4] == 0.0 && res[0] <= tol * (1.0 + res[2]) && res[1] <= tol * (1.0 + res[3]);
                     ok = solve_ok && viol <= tol;
+#ifdef PQP_EMU_DEBUG
+                    printf("  bq polish qp %d it %d round %d: pri %.3e (norm %.2e) dua %.3e (norm %.2e) viol %.3e -> %s\n", qp, it, round, res[0], res[2], res[1], res[3], viol, ok ? "ACCEPT" : (solve_ok ? "next" : "solve failed"));
+#endif
                     if (ok || !solve_ok) break;
                     if (viol < 0.7 * best) { best = viol; stall = 0; } else { stall += 1; }
                     if (stall >= 3) conservative = true;
@@ -451,6 +598,7 @@ struct BandedQp {
                 polishing_ = false; alpha_ = prm.alpha;
                 polish_end(ok);
                 if (ok) { status = PQP_STATUS_SOLVED; polished = 1; break; }
+                if (was_converged) eps_scale *= 0.1;     // rejected: ADMM resumes one decade tighter
                 factor();
                 continue;
             }
@@ -472,7 +620,7 @@ struct BandedQp {
         rows([&](int r) { yo[r] = sh[L.y() + r]; });
         const int kk = kkt_solves_, ff = factors_;
         const double rho_final = rho;
-        ctx.phase([&](int t) {
+        ctx.phase([&](int t, Lane&) {
             if (t == 0) {
                 if (A.status) A.status[qp] = status;
                 if (A.iters) A.iters[qp] = it;

@@ -766,9 +766,22 @@ int sm_solve(pqp_handle* h, int type, int batch, int n, int32_t* status, int32_t
     a.x = h->b_x.as<double>(); a.y = h->b_y.as<double>(); a.status = status; a.iters = iters; a.info = info; a.prm = h->prm;
     const size_t lds = (size_t)pqp::BqLayout{sh.nv, sh.nc, sh.bw}.total() * 8;
     if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "smoother QP too large for one CU's LDS");
-    if (lds > 64 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::banded_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int nbb = pqp::BqLayout{sh.nv, sh.nc, sh.bw}.nbb();
+    const int threads = 64 * ((nbb + 63) / 64);        // one lane per (padded) variable
+    if (threads > 1024) return fail(PQP_ERR_CAPACITY, "smoother QP has more than 1024 variables");
+    const void* fn = nullptr;
+#define PQP_BQ_PICK(BB) fn = threads <= 256 ? (const void*)pqp::banded_solve_kernel<BB, 256> : threads <= 512 ? (const void*)pqp::banded_solve_kernel<BB, 512> : (const void*)pqp::banded_solve_kernel<BB, 1024>
+    switch (sh.bw) {
+        case 3: PQP_BQ_PICK(3); break;
+        case 4: PQP_BQ_PICK(4); break;
+        case 9: PQP_BQ_PICK(9); break;
+        default: return fail(PQP_ERR_INVALID, "unsupported smoother block size");
+    }
+#undef PQP_BQ_PICK
+    if (lds > 64 * 1024) PQP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(pqp::banded_solve_kernel, dim3(batch), dim3(64), lds, h->stream, a);
+    void* kargs[] = {(void*)&a};
+    PQP_HIP(hipLaunchKernel(fn, dim3(batch), dim3(threads), kargs, lds, h->stream));
     PQP_HIP(hipGetLastError());
     PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;

@@ -112,13 +112,15 @@ extern "C" int pqp_emu_probe(const pqp_params* prm, int n, const double* ref, co
 
 // ---- the generic banded-QP core (pqp_banded_qp.hpp) on the host -----------------------------------------------------
 namespace {
+template <int B>
 struct BqHostCtx {
     int T_;
     std::vector<double> shm;
-    BqHostCtx(int T, int doubles) : T_(T), shm(doubles, 0.0) {}
+    std::vector<pqp::BqLane<B>> lanes;
+    BqHostCtx(int T, int doubles) : T_(T), shm(doubles, 0.0), lanes(T) {}
     int T() const { return T_; }
     double* sh() { return shm.data(); }
-    template <class F> void phase(F f) { for (int t = 0; t < T_; ++t) f(t); }
+    template <class F> void phase(F f) { for (int t = 0; t < T_; ++t) f(t, lanes[t]); }
     template <int K, class F> void reduce_max(double (&out)[K], F f) {
         for (int k = 0; k < K; ++k) out[k] = 0.0;
         for (int t = 0; t < T_; ++t) { double v[K]; f(t, v); for (int k = 0; k < K; ++k) out[k] = out[k] > v[k] ? out[k] : v[k]; }
@@ -128,6 +130,17 @@ struct BqHostCtx {
         for (int t = 0; t < T_; ++t) { double v[K]; f(t, v); for (int k = 0; k < K; ++k) out[k] += v[k]; }
     }
 };
+
+template <int B>
+void bq_run(const pqp::BandedQpArgs& a) {
+    const pqp::BqLayout L{a.nv, a.nc, a.bw};
+    const int T = 64 * ((L.nbb() + 63) / 64);
+    for (int qp = 0; qp < a.batch; ++qp) {
+        BqHostCtx<B> ctx(T, L.total());
+        pqp::BandedQp<BqHostCtx<B>, B> s(ctx, a, qp);
+        s.run();
+    }
+}
 }  // namespace
 
 extern "C" int pqp_emu_banded_solve(const pqp_params* prm, int batch, int nv, int nc, int bw, int pbw, const double* pband, const double* q,
@@ -138,10 +151,11 @@ extern "C" int pqp_emu_banded_solve(const pqp_params* prm, int batch, int nv, in
     a.batch = batch; a.nv = nv; a.nc = nc; a.bw = bw; a.pbw = pbw;
     a.pband = pband; a.q = q; a.acol = acol; a.aval = aval; a.trow = trow; a.tslot = tslot; a.lo = lo; a.up = up;
     a.x = x; a.y = y; a.status = status; a.iters = iters; a.info = info; a.prm = *prm;
-    for (int qp = 0; qp < batch; ++qp) {
-        BqHostCtx ctx(64, pqp::BqLayout{nv, nc, bw}.total());
-        pqp::BandedQp<BqHostCtx> s(ctx, a, qp);
-        s.run();
+    switch (bw) {
+        case 3: bq_run<3>(a); break;
+        case 4: bq_run<4>(a); break;
+        case 9: bq_run<9>(a); break;
+        default: return -1;
     }
     return 0;
 }
