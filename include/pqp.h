@@ -20,6 +20,8 @@
  *   TensionSmoother2::osqpSmooth      src/reference_path_smoother/tension_smoother_2.cpp:20-158   pqp_smooth_tension2
  *   TensionSmoother::osqpSmooth       src/reference_path_smoother/tension_smoother.cpp:49-177     pqp_smooth_tension
  *   ReferencePathSmoother::postSmooth src/reference_path_smoother/reference_path_smoother.cpp:526-636 (QP part) pqp_post_smooth
+ *   ReferencePath::updateBounds -> ReferencePathImpl::updateBoundsImproved
+ *                                     src/data_struct/reference_path.cpp:61, reference_path_impl.cpp:177-312    pqp_corridor_bounds
  *
  * Conventions
  *   - plain C, no C++/torch types; all reals are IEEE fp64, all indices int32.
@@ -218,6 +220,40 @@ int pqp_post_smooth_device(pqp_handle* h, int batch, int m, const double* layers
 
 /* GPU time (ms, hipEvent) of the handle's last solve / assemble launch. */
 int pqp_last_kernel_ms(pqp_handle* h, float* ms);
+
+/* ---- corridor bounds from the obstacle distance map ---------------------------------------------
+ * ReferencePath::updateBounds(const Map&)  src/data_struct/reference_path.cpp:61  ->  ReferencePathImpl::updateBoundsImproved
+ * (reference_path_impl.cpp:177-230), getClearanceWithDirectionStrict (:232-312), Map::getObstacleDistance (src/tools/Map.cpp:16-22),
+ * getDirectionalProjectionByNewton (src/tools/tools.cpp:156-189).  Produces the `bounds` input of pqp_path_solve on the device. */
+typedef struct pqp_grid_geometry {       /* grid_map::GridMap geometry of the "distance" layer */
+    int32_t rows, cols;                  /* getSize(): cells along x, along y */
+    double resolution;
+    double length_x, length_y;           /* getLength() = size * resolution */
+    double pos_x, pos_y;                 /* getPosition(): map centre */
+} pqp_grid_geometry;
+
+typedef struct pqp_corridor_params {
+    double front_length, rear_length;    /* 3.9, -1.0   planning_flags.cpp:20,18 */
+    double car_width, safety_margin;     /* 2.0, 0.3    planning_flags.cpp:10,14 */
+    double epsilon;                      /* 1e-6        planning_flags.cpp:108 (isEqual) */
+    double search_radius, delta_s, smaller_ds, search_range, min_space;   /* 0.5, 0.3, 0.05, 6.0, 0.2   reference_path_impl.cpp:238-304 */
+    double projection_window;            /* 5.0         reference_path_impl.cpp:194 */
+} pqp_corridor_params;
+
+void pqp_corridor_default_params(pqp_corridor_params* p);
+/* ref      [batch][n][5]  s, k, heading, x, y of the reference states (the layout pqp_path_solve takes)
+ * spline   [batch][9][m]  row 0: knots s; rows 1-4: y, a, b, c of x(s); rows 5-8: y, a, b, c of y(s)  (tk::spline members m_y, m_a, m_b, m_c)
+ * spline_ext [batch][4]   m_b0, m_c0 of x(s), then of y(s)
+ * dist     [n_maps][cols][rows] float: the layer in Eigen's column-major order (grid_map::Matrix = Eigen::MatrixXf)
+ * map_of   [batch] map index of each scenario, or NULL (all use map 0)
+ * bounds   [batch][n][6]  f_lb f_ub r_lb r_ub c_lb c_ub for EVERY waypoint;  n_valid [batch] = index of the first waypoint whose
+ *          front or rear interval is empty (the reference cuts the path there and sets isBlocked(), :219-223), n if none */
+int pqp_corridor_bounds_device(pqp_handle* h, int batch, int n, int m, const double* ref, const double* spline, const double* spline_ext,
+                               const float* dist, const int32_t* map_of, const pqp_grid_geometry* geom, const pqp_corridor_params* prm,
+                               double* bounds, int32_t* n_valid);
+int pqp_corridor_bounds(pqp_handle* h, int batch, int n, int m, const double* ref, const double* spline, const double* spline_ext,
+                        const float* dist, int n_maps, const int32_t* map_of, const pqp_grid_geometry* geom, const pqp_corridor_params* prm,
+                        double* bounds, int32_t* n_valid);
 
 #ifdef __cplusplus
 }

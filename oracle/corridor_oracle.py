@@ -1,0 +1,359 @@
+"""corridor_oracle.py — CPU restatement of the step that produces the `bounds` input of every path QP.
+
+TEST INFRASTRUCTURE ONLY: only tests/, __graft_entry__.smoke() and bench tools' cpu_baseline legs may import this module.
+
+PARITY UNPINNED.  The reference has no tests or vectors for this path, and two of its ingredients are third-party:
+  * grid_map_core (ANYbotics/grid_map, un-pinned `find_package(grid_map_core)`; not in /root/reference, not in this image).
+    `GridMap::isInside`, `getIndex`, `getPosition` and `atPosition(..., INTER_LINEAR)` are restated below from the published
+    1.6.x sources (GridMapMath.cpp, GridMap.cpp::atPositionLinearInterpolated), including their border behaviour.
+  * libm's sin/cos/atan2 (the GPU uses ocml's): bounds agree except where a clearance sample lies within round-off of
+    the 0.5 m threshold.
+tk::spline IS in the reference tree (src/tools/spline.cpp, std-only): oracle/Makefile builds it from where it lies into
+oracle/_ref/libref_spline.so and tests/test_corridor_oracle.py checks the restatement below against it bit for bit.
+
+What is restated (reference file:line):
+  spline_fit / spline_eval / spline_deriv      tk::spline::set_points / operator() / deriv       src/tools/spline.cpp:69-318
+  directional_projection_newton                getDirectionalProjectionByNewton                  src/tools/tools.cpp:156-189
+  global2local_y                               global2Local(...).y                               src/tools/tools.cpp:57-64
+  obstacle_distance                            Map::getObstacleDistance                          src/tools/Map.cpp:16-22
+  clearance_strict                             ReferencePathImpl::getClearanceWithDirectionStrict src/data_struct/reference_path_impl.cpp:232-312
+  update_bounds_improved                       ReferencePathImpl::updateBoundsImproved           src/data_struct/reference_path_impl.cpp:177-230
+Python floats are IEEE doubles and every operation below is written in the reference's order, so the arithmetic is the
+reference's (gcc does not contract to FMA on baseline x86-64).
+"""
+import bisect
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# parameters (src/config/planning_flags.cpp)
+# ----------------------------------------------------------------------------------------------------------------------
+@dataclass
+class CorridorParams:
+    front_length: float = 3.9        # :20
+    rear_length: float = -1.0        # :18
+    car_width: float = 2.0           # :10
+    safety_margin: float = 0.3       # :14
+    epsilon: float = 1e-6            # :108  isEqual tolerance
+    search_radius: float = 0.5       # reference_path_impl.cpp:241 (static local)
+    delta_s: float = 0.3             # :238
+    smaller_ds: float = 0.05         # :277
+    search_range: float = 6.0        # :243
+    min_space: float = 0.2           # :304
+    projection_window: float = 5.0   # :194  max_s = s + 5.0
+
+
+def constrain_angle(a):              # include/tools/tools.hpp:24-35
+    while a > math.pi:
+        a -= 2 * math.pi
+    while a < -math.pi:
+        a += 2 * math.pi
+    return a
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# tk::spline (natural cubic spline; the reference never calls set_boundary)
+# ----------------------------------------------------------------------------------------------------------------------
+def spline_fit(x, y):
+    """set_points (spline.cpp:161-249) with band_matrix::lu_solve (:69-148): tridiagonal, rows pre-scaled to unit diagonal."""
+    x = [float(v) for v in x]
+    y = [float(v) for v in y]
+    n = len(x)
+    assert n > 2 and all(x[i] < x[i + 1] for i in range(n - 1))
+    lo = [0.0] * n     # A(i, i-1)
+    di = [0.0] * n     # A(i, i)
+    up = [0.0] * n     # A(i, i+1)
+    rhs = [0.0] * n
+    for i in range(1, n - 1):
+        lo[i] = 1.0 / 3.0 * (x[i] - x[i - 1])
+        di[i] = 2.0 / 3.0 * (x[i + 1] - x[i - 1])
+        up[i] = 1.0 / 3.0 * (x[i + 1] - x[i])
+        rhs[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]) - (y[i] - y[i - 1]) / (x[i] - x[i - 1])
+    di[0] = 2.0; up[0] = 0.0; rhs[0] = 0.0                  # second_deriv = 0 on the left
+    di[n - 1] = 2.0; lo[n - 1] = 0.0; rhs[n - 1] = 0.0      # ... and on the right
+    # lu_decompose: normalise every row by its diagonal (saved), then Gauss elimination
+    saved = [0.0] * n
+    for i in range(n):
+        saved[i] = 1.0 / di[i]
+        if i > 0:
+            lo[i] *= saved[i]
+        if i < n - 1:
+            up[i] *= saved[i]
+        di[i] = 1.0
+    for k in range(n - 1):
+        i = k + 1
+        xm = -lo[i] / di[k]
+        lo[i] = -xm
+        di[i] = di[i] + xm * up[k]
+    # l_solve
+    yv = [0.0] * n
+    for i in range(n):
+        s = 0.0
+        if i > 0:
+            s += lo[i] * yv[i - 1]
+        yv[i] = (rhs[i] * saved[i]) - s
+    # r_solve
+    b = [0.0] * n
+    for i in range(n - 1, -1, -1):
+        s = 0.0
+        if i < n - 1:
+            s += up[i] * b[i + 1]
+        b[i] = (yv[i] - s) / di[i]
+    a = [0.0] * n
+    c = [0.0] * n
+    for i in range(n - 1):
+        a[i] = 1.0 / 3.0 * (b[i + 1] - b[i]) / (x[i + 1] - x[i])
+        c[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]) - 1.0 / 3.0 * (2.0 * b[i] + b[i + 1]) * (x[i + 1] - x[i])
+    b0, c0 = b[0], c[0]
+    h = x[n - 1] - x[n - 2]
+    a[n - 1] = 0.0
+    c[n - 1] = 3.0 * a[n - 2] * h * h + 2.0 * b[n - 2] * h + c[n - 2]
+    return dict(x=x, y=y, a=a, b=b, c=c, b0=b0, c0=c0)
+
+
+def _segment(sp, x):
+    # std::lower_bound: first knot >= x; idx = max(that - 1, 0)
+    return max(bisect.bisect_left(sp["x"], x) - 1, 0)
+
+
+def spline_eval(sp, x):              # operator()  spline.cpp:251-272
+    n = len(sp["x"])
+    idx = _segment(sp, x)
+    h = x - sp["x"][idx]
+    if x < sp["x"][0]:
+        return (sp["b0"] * h + sp["c0"]) * h + sp["y"][0]
+    if x > sp["x"][n - 1]:
+        return (sp["b"][n - 1] * h + sp["c"][n - 1]) * h + sp["y"][n - 1]
+    return ((sp["a"][idx] * h + sp["b"][idx]) * h + sp["c"][idx]) * h + sp["y"][idx]
+
+
+def spline_deriv(sp, order, x):      # deriv  spline.cpp:274-318 (the left-extrapolated 2nd derivative is the reference's)
+    n = len(sp["x"])
+    idx = _segment(sp, x)
+    h = x - sp["x"][idx]
+    if x < sp["x"][0]:
+        return {1: 2.0 * sp["b0"] * h + sp["c0"], 2: 2.0 * sp["b0"] * h}.get(order, 0.0)
+    if x > sp["x"][n - 1]:
+        return {1: 2.0 * sp["b"][n - 1] * h + sp["c"][n - 1], 2: 2.0 * sp["b"][n - 1]}.get(order, 0.0)
+    if order == 1:
+        return (3.0 * sp["a"][idx] * h + 2.0 * sp["b"][idx]) * h + sp["c"][idx]
+    if order == 2:
+        return 6.0 * sp["a"][idx] * h + 2.0 * sp["b"][idx]
+    if order == 3:
+        return 6.0 * sp["a"][idx]
+    return 0.0
+
+
+def pack_spline(sx, sy):
+    """The flat layout the C ABI takes: [7][m] doubles = knots, then (y, a, b, c) of x(s), then of y(s) ... see include/pqp.h.
+    Row 0: knots s; rows 1-4: y, a, b, c of x(s); rows 5-8: y, a, b, c of y(s); extra[4] = b0x, c0x, b0y, c0y."""
+    m = len(sx["x"])
+    tab = np.zeros((9, m))
+    tab[0] = sx["x"]
+    tab[1], tab[2], tab[3], tab[4] = sx["y"], sx["a"], sx["b"], sx["c"]
+    tab[5], tab[6], tab[7], tab[8] = sy["y"], sy["a"], sy["b"], sy["c"]
+    return tab, np.array([sx["b0"], sx["c0"], sy["b0"], sy["c0"]])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# tools.cpp
+# ----------------------------------------------------------------------------------------------------------------------
+def directional_projection_newton(sx, sy, tx, ty, angle, max_s, hint_s):      # tools.cpp:156-189
+    hint_s = min(hint_s, max_s)
+    cur_s = hint_s
+    prev_s = hint_s
+    v1 = math.sin(angle)
+    v2 = -math.cos(angle)
+    for _ in range(20):
+        x = spline_eval(sx, cur_s)
+        y = spline_eval(sy, cur_s)
+        dx = spline_deriv(sx, 1, cur_s)
+        dy = spline_deriv(sy, 1, cur_s)
+        ddx = spline_deriv(sx, 2, cur_s)
+        ddy = spline_deriv(sy, 2, cur_s)
+        p1 = v1 * (x - tx) + v2 * (y - ty)
+        p2 = v1 * dx + v2 * dy
+        j = p1 * p2
+        h = p1 * (v1 * ddx + v2 * ddy) + p2 * p2
+        cur_s -= j / h
+        if abs(cur_s - prev_s) < 1e-5:
+            break
+        prev_s = cur_s
+    cur_s = min(cur_s, max_s)
+    return spline_eval(sx, cur_s), spline_eval(sy, cur_s), cur_s      # heading is overwritten by the caller (:207)
+
+
+def global2local_y(rx, ry, rheading, tx, ty):                                 # tools.cpp:57-64, .y only
+    dx = tx - rx
+    dy = ty - ry
+    return -dx * math.sin(rheading) + dy * math.cos(rheading)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# grid_map_core 1.6.x (restated; see the header)
+# ----------------------------------------------------------------------------------------------------------------------
+@dataclass
+class GridGeom:
+    rows: int              # cells along x  (getSize()(0))
+    cols: int              # cells along y  (getSize()(1))
+    resolution: float
+    length_x: float
+    length_y: float
+    pos_x: float           # map centre
+    pos_y: float
+
+    @staticmethod
+    def make(length_x, length_y, resolution, pos=(0.0, 0.0)):
+        # GridMap::setGeometry: size = round(length / resolution), length = size * resolution
+        rows, cols = int(round(length_x / resolution)), int(round(length_y / resolution))
+        return GridGeom(rows, cols, resolution, rows * resolution, cols * resolution, float(pos[0]), float(pos[1]))
+
+
+def grid_is_inside(g, px, py):       # checkIfPositionWithinMap: -(p - c - L/2) in [0, L)
+    tx = -(px - g.pos_x - 0.5 * g.length_x)
+    ty = -(py - g.pos_y - 0.5 * g.length_y)
+    return tx >= 0.0 and ty >= 0.0 and tx < g.length_x and ty < g.length_y
+
+
+def grid_index(g, px, py):           # getIndexFromPosition: trunc toward zero of (p - L/2 - c) / res, negated
+    vx = (px - 0.5 * g.length_x - g.pos_x) / g.resolution
+    vy = (py - 0.5 * g.length_y - g.pos_y) / g.resolution
+    return -int(vx), -int(vy)        # Python int() truncates toward zero like the C++ double -> int conversion
+
+
+def grid_cell_position(g, ix, iy):   # getPositionFromIndex: c + (L/2 - res/2) + res * (-idx)
+    ox = 0.5 * g.length_x - 0.5 * g.resolution
+    oy = 0.5 * g.length_y - 0.5 * g.resolution
+    return (g.pos_x + ox) + g.resolution * float(-ix), (g.pos_y + oy) + g.resolution * float(-iy)
+
+
+def _lin(g, ix, iy):                 # getLinearIndexFromIndex (column major), as size_t: negative values wrap to huge ones
+    v = iy * g.rows + ix
+    return v if v >= 0 else (1 << 64) + v
+
+
+def grid_at_linear(dist, g, px, py):
+    """GridMap::atPositionLinearInterpolated; `dist` is the layer as a [rows][cols] float32 array. Returns None on failure."""
+    i0 = grid_index(g, px, py)
+    cx, cy = grid_cell_position(g, *i0)
+    idx = [i0, None, None, None]
+    if px >= cx:
+        idx[1] = (i0[0] - 1, i0[1]); tmp_dir = True
+    else:
+        idx[1] = (i0[0] + 1, i0[1]); tmp_dir = False
+    if py >= cy:
+        idx[2] = (i0[0], i0[1] - 1)
+        shift = (0, 1, 2, 3) if tmp_dir else (1, 0, 3, 2)
+    else:
+        idx[2] = (i0[0], i0[1] + 1)
+        shift = (2, 3, 0, 1) if tmp_dir else (3, 2, 1, 0)
+    idx[3] = (idx[1][0], idx[2][1])
+    end_lin = g.rows * g.cols          # startIndexLin = 0 for a map that was never moved
+    f = []
+    for k in range(4):
+        ix, iy = idx[shift[k]]
+        lin = _lin(g, ix, iy)
+        if lin > end_lin:              # (the upstream test is `>`; lin == end_lin would read one past the buffer)
+            return None
+        if lin == end_lin:
+            return None                # guard the restatement against the out-of-bounds read; unreachable for inside points
+        # the quirk: a neighbour with ix = -1 and iy >= 1 passes the linear test and reads the element the wrapped linear
+        # index points at
+        f.append(float(dist.reshape(-1, order="F")[lin]))
+    qx, qy = grid_cell_position(g, *idx[shift[0]])
+    rx = (px - qx) / g.resolution
+    ry = (py - qy) / g.resolution
+    fx = 1.0 - rx
+    fy = 1.0 - ry
+    v = f[0] * fx * fy + f[1] * rx * fy + f[2] * fx * ry + f[3] * rx * ry
+    return float(np.float32(v))
+
+
+def obstacle_distance(dist, g, px, py):          # Map::getObstacleDistance (Map.cpp:16-22)
+    if not grid_is_inside(g, px, py):
+        return 0.0
+    v = grid_at_linear(dist, g, px, py)
+    if v is not None:
+        return v
+    ix, iy = grid_index(g, px, py)               # INTER_NEAREST fallback of GridMap::atPosition
+    return float(dist[ix, iy])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# reference_path_impl.cpp
+# ----------------------------------------------------------------------------------------------------------------------
+def clearance_strict(x, y, heading, dist, g, prm=CorridorParams()):          # :232-312 -> (left_bound, right_bound)
+    delta_s = prm.delta_s
+    left_angle = constrain_angle(heading + math.pi / 2)
+    right_angle = constrain_angle(heading - math.pi / 2)
+    n = int(prm.search_range / delta_s)
+    if not (obstacle_distance(dist, g, x, y) > prm.search_radius):
+        return 0.0, 0.0
+    right_s = 0.0
+    for _ in range(n):
+        right_s += delta_s
+        if obstacle_distance(dist, g, x + right_s * math.cos(right_angle), y + right_s * math.sin(right_angle)) < prm.search_radius:
+            break
+    left_s = 0.0
+    for _ in range(n):
+        left_s += delta_s
+        if obstacle_distance(dist, g, x + left_s * math.cos(left_angle), y + left_s * math.sin(left_angle)) < prm.search_radius:
+            break
+    right_bound = -(right_s - delta_s)
+    left_bound = left_s - delta_s
+    smaller_ds = prm.smaller_ds
+    steps = int(delta_s / smaller_ds)          # static_cast<int>(0.3 / 0.05) = 5: four fine steps
+    for _ in range(1, steps):
+        left_bound += smaller_ds
+        if obstacle_distance(dist, g, x + left_bound * math.cos(left_angle), y + left_bound * math.sin(left_angle)) < prm.search_radius:
+            left_bound -= smaller_ds
+            break
+    for _ in range(1, steps):
+        right_bound -= smaller_ds
+        # as written in the reference (:291-294): right_bound is negative, so this probes the LEFT side of the state
+        if obstacle_distance(dist, g, x + right_bound * math.cos(right_angle), y + right_bound * math.sin(right_angle)) < prm.search_radius:
+            right_bound += smaller_ds
+            break
+    diff_radius = prm.car_width * 0.5 - prm.search_radius
+    left_bound -= diff_radius
+    right_bound += diff_radius
+    if left_bound < right_bound:
+        return 0.0, 0.0
+    space = left_bound - right_bound
+    max_safety_margin = max(0.0, (space - prm.min_space) / 2.0)
+    safety_margin = min(prm.safety_margin, max_safety_margin)
+    left_bound -= safety_margin
+    right_bound += safety_margin
+    return left_bound, right_bound
+
+
+def update_bounds_improved(ref, sx, sy, dist, g, prm=CorridorParams()):
+    """ref [n][5] = (s, k, heading, x, y) per waypoint (the ABI layout of the path QP).  Returns (bounds [n_valid][6] in the
+    ABI order f_lb f_ub r_lb r_ub c_lb c_ub, n_valid, blocked row or None) — :177-230: the loop stops at the first
+    waypoint whose front or rear interval is empty, and the reference path is cut there."""
+    out = []
+    blocked = None
+    for i in range(len(ref)):
+        s, _, heading, x, y = (float(v) for v in ref[i])
+        fcx = x + prm.front_length * math.cos(heading)
+        fcy = y + prm.front_length * math.sin(heading)
+        rcx = x + prm.rear_length * math.cos(heading)
+        rcy = y + prm.rear_length * math.sin(heading)
+        fpx, fpy, _ = directional_projection_newton(sx, sy, fcx, fcy, heading + math.pi / 2, s + prm.projection_window, s + prm.front_length)
+        rpx, rpy, _ = directional_projection_newton(sx, sy, rcx, rcy, heading + math.pi / 2, s + prm.projection_window, s + prm.rear_length)
+        f_ub, f_lb = clearance_strict(fpx, fpy, heading, dist, g, prm)
+        off = global2local_y(fcx, fcy, heading, fpx, fpy)
+        f_ub += off; f_lb += off
+        r_ub, r_lb = clearance_strict(rpx, rpy, heading, dist, g, prm)
+        off = global2local_y(rcx, rcy, heading, rpx, rpy)
+        r_ub += off; r_lb += off
+        c_ub, c_lb = clearance_strict(x, y, heading, dist, g, prm)
+        row = [f_lb, f_ub, r_lb, r_ub, c_lb, c_ub]
+        if abs(f_ub - f_lb) < prm.epsilon or abs(r_ub - r_lb) < prm.epsilon:
+            blocked = row
+            break
+        out.append(row)
+    return np.array(out).reshape(-1, 6), len(out), blocked

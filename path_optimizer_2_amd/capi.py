@@ -33,6 +33,16 @@ class PqpParams(C.Structure):
     ]
 
 
+class PqpGridGeometry(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("resolution", C.c_double), ("length_x", C.c_double), ("length_y", C.c_double),
+                ("pos_x", C.c_double), ("pos_y", C.c_double)]
+
+
+class PqpCorridorParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("front_length", "rear_length", "car_width", "safety_margin", "epsilon", "search_radius", "delta_s",
+                                         "smaller_ds", "search_range", "min_space", "projection_window")]
+
+
 class PqpSizes(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("n", "state", "control", "precise", "slack", "vars", "cons", "nnz_a", "nnz_p")]
 
@@ -42,7 +52,7 @@ EXPORTS = [
     "pqp_get_stream", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
     "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_get_solution",
     "pqp_last_kernel_ms", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
-    "pqp_post_smooth", "pqp_post_smooth_device",
+    "pqp_post_smooth", "pqp_post_smooth_device", "pqp_corridor_default_params", "pqp_corridor_bounds", "pqp_corridor_bounds_device",
 ]
 
 _lib = None
@@ -84,6 +94,12 @@ def load_library(path=None):
     lib.pqp_smooth_tension_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 10
     lib.pqp_post_smooth.argtypes = [vp, C.c_int, C.c_int] + [vp] * 7
     lib.pqp_post_smooth_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 8
+    lib.pqp_corridor_default_params.argtypes = [C.POINTER(PqpCorridorParams)]
+    lib.pqp_corridor_default_params.restype = None
+    lib.pqp_corridor_bounds_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.POINTER(PqpGridGeometry),
+                                               C.POINTER(PqpCorridorParams), vp, vp]
+    lib.pqp_corridor_bounds.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, C.POINTER(PqpGridGeometry),
+                                        C.POINTER(PqpCorridorParams), vp, vp]
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -156,6 +172,33 @@ class Handle:
         s = C.c_void_p()
         self._check(self.lib.pqp_get_stream(self._h, C.byref(s)))
         return s.value
+
+    def corridor_params(self, **over):
+        p = PqpCorridorParams()
+        self.lib.pqp_corridor_default_params(C.byref(p))
+        for k, v in over.items():
+            setattr(p, k, v)
+        return p
+
+    def corridor_bounds(self, ref, spline, spline_ext, dist, geom, map_of=None, prm=None):
+        """pqp_corridor_bounds (host arrays): ref [B][n][5], spline [B][9][m], spline_ext [B][4], dist [n_maps][rows][cols] float32
+        (converted to the ABI's column-major order here), geom = PqpGridGeometry.  Returns (bounds [B][n][6], n_valid [B])."""
+        ref = np.ascontiguousarray(ref, dtype=np.float64)
+        spline = np.ascontiguousarray(spline, dtype=np.float64)
+        spline_ext = np.ascontiguousarray(spline_ext, dtype=np.float64)
+        dist = np.asarray(dist, dtype=np.float32)
+        if dist.ndim == 2:
+            dist = dist[None]
+        dist_cm = np.ascontiguousarray(np.transpose(dist, (0, 2, 1)))        # [n_maps][cols][rows]
+        B, n = ref.shape[0], ref.shape[1]
+        m = spline.shape[2]
+        bounds = np.zeros((B, n, 6))
+        n_valid = np.zeros(B, dtype=np.int32)
+        mo = None if map_of is None else np.ascontiguousarray(map_of, dtype=np.int32)
+        prm = prm or self.corridor_params()
+        self._check(self.lib.pqp_corridor_bounds(self._h, B, n, m, _ptr(ref), _ptr(spline), _ptr(spline_ext), _ptr(dist_cm), dist.shape[0],
+                                                 _ptr(mo), C.byref(geom), C.byref(prm), _ptr(bounds), _ptr(n_valid)))
+        return bounds, n_valid
 
     def sizes(self, n, s=None):
         out = PqpSizes()

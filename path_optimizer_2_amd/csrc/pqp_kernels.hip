@@ -397,6 +397,7 @@ __global__ void path_gather_solution(RefIndex R, int batch, const double* __rest
 }  // namespace pqp
 
 #include "pqp_smoother_kernels.inc"
+#include "pqp_corridor_kernels.inc"
 
 // =========================================================================================================
 // C ABI
@@ -441,7 +442,7 @@ struct pqp_handle {
     DevBuf s_ref, s_lin, s_bounds, s_scal;      // staging for the host-pointer entry points
     DevBuf s_out, s_status, s_iters, s_info, s_a, s_p, s_l, s_u, s_idx;
     // smoother QPs: banded problem data + shared sparsity (cached per type and size) + staging
-    DevBuf b_pband, b_q, b_aval, b_lo, b_up, b_x, b_y, b_acol, b_trow, b_tslot, b_in[5], b_out[3];
+    DevBuf b_pband, b_q, b_aval, b_lo, b_up, b_x, b_y, b_acol, b_trow, b_tslot, b_in[5], b_out[3], c_buf[7];
     int b_struct_type = -1, b_struct_n = -1;
 };
 
@@ -486,7 +487,8 @@ int pqp_destroy(pqp_handle* h) {
     for (DevBuf* b : {&h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
                       &h->s_status, &h->s_iters, &h->s_info, &h->s_a, &h->s_p, &h->s_l, &h->s_u, &h->s_idx, &h->b_pband, &h->b_q, &h->b_aval,
                       &h->b_lo, &h->b_up, &h->b_x, &h->b_y, &h->b_acol, &h->b_trow, &h->b_tslot, &h->b_in[0], &h->b_in[1], &h->b_in[2],
-                      &h->b_in[3], &h->b_in[4], &h->b_out[0], &h->b_out[1], &h->b_out[2]})
+                      &h->b_in[3], &h->b_in[4], &h->b_out[0], &h->b_out[1], &h->b_out[2], &h->c_buf[0], &h->c_buf[1], &h->c_buf[2],
+                      &h->c_buf[3], &h->c_buf[4], &h->c_buf[5], &h->c_buf[6]})
         b->release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -912,6 +914,63 @@ int pqp_post_smooth(pqp_handle* h, int batch, int m, const double* layers_s, con
     const double* in[3] = {layers_s, lb, ub};
     double* out[1] = {out_l};
     return sm_host_call(h, SM_POST, batch, m, in, 3, vehicle_l, out, 1, status, iters);
+}
+
+// ---- corridor bounds from the distance map -----------------------------------------------------------
+void pqp_corridor_default_params(pqp_corridor_params* p) {
+    if (!p) return;
+    p->front_length = 3.9; p->rear_length = -1.0;       // planning_flags.cpp:20,18
+    p->car_width = 2.0; p->safety_margin = 0.3;         // planning_flags.cpp:10,14
+    p->epsilon = 1e-6;                                  // planning_flags.cpp:108
+    p->search_radius = 0.5; p->delta_s = 0.3; p->smaller_ds = 0.05; p->search_range = 6.0; p->min_space = 0.2;   // reference_path_impl.cpp:238-304
+    p->projection_window = 5.0;                         // reference_path_impl.cpp:194
+}
+
+int pqp_corridor_bounds_device(pqp_handle* h, int batch, int n, int m, const double* ref, const double* spline, const double* spline_ext,
+                               const float* dist, const int32_t* map_of, const pqp_grid_geometry* geom, const pqp_corridor_params* prm,
+                               double* bounds, int32_t* n_valid) {
+    if (!h || !ref || !spline || !spline_ext || !dist || !geom || !prm || !bounds || !n_valid || batch < 1 || n < 1 || m < 3 ||
+        geom->rows < 2 || geom->cols < 2 || !(geom->resolution > 0.0) || !(prm->delta_s > 0.0) || !(prm->smaller_ds > 0.0))
+        return fail(PQP_ERR_INVALID, "pqp_corridor_bounds: bad argument (m >= 3 knots: spline.cpp:164)");
+    PQP_HIP(hipSetDevice(h->device));
+    pqp::CorridorArgs a;
+    a.batch = batch; a.n = n; a.m = m; a.ref = ref; a.spl = spline; a.spl_ext = spline_ext; a.dist = dist; a.map_of = map_of;
+    a.g = *geom; a.p = *prm; a.bounds = bounds; a.n_valid = n_valid;
+    int threads = 64 * ((3 * n + 63) / 64);
+    if (threads > 1024) threads = 1024;
+    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(pqp::corridor_bounds_kernel, dim3(batch), dim3(threads), 0, h->stream, a);
+    PQP_HIP(hipGetLastError());
+    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return PQP_OK;
+}
+
+int pqp_corridor_bounds(pqp_handle* h, int batch, int n, int m, const double* ref, const double* spline, const double* spline_ext,
+                        const float* dist, int n_maps, const int32_t* map_of, const pqp_grid_geometry* geom, const pqp_corridor_params* prm,
+                        double* bounds, int32_t* n_valid) {
+    if (!h || !ref || !spline || !spline_ext || !dist || !geom || !prm || !bounds || !n_valid || batch < 1 || n < 1 || m < 3 || n_maps < 1)
+        return fail(PQP_ERR_INVALID, "pqp_corridor_bounds: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    const size_t b_ref = (size_t)batch * n * PQP_REF_STRIDE * 8, b_spl = (size_t)batch * 9 * m * 8, b_ext = (size_t)batch * 4 * 8;
+    const size_t b_map = (size_t)n_maps * geom->rows * geom->cols * 4, b_of = (size_t)batch * 4;
+    const size_t b_bnd = (size_t)batch * n * PQP_BOUNDS_STRIDE * 8, b_nv = (size_t)batch * 4;
+    const size_t sizes[7] = {b_ref, b_spl, b_ext, b_map, b_of, b_bnd, b_nv};
+    int rc;
+    for (int k = 0; k < 7; ++k) if ((rc = h->c_buf[k].ensure(sizes[k]))) return rc;
+    PQP_HIP(hipMemcpyAsync(h->c_buf[0].p, ref, b_ref, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[1].p, spline, b_spl, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[2].p, spline_ext, b_ext, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[3].p, dist, b_map, hipMemcpyHostToDevice, h->stream));
+    if (map_of) PQP_HIP(hipMemcpyAsync(h->c_buf[4].p, map_of, b_of, hipMemcpyHostToDevice, h->stream));
+    if ((rc = pqp_corridor_bounds_device(h, batch, n, m, h->c_buf[0].as<double>(), h->c_buf[1].as<double>(), h->c_buf[2].as<double>(),
+                                         h->c_buf[3].as<float>(), map_of ? h->c_buf[4].as<int32_t>() : nullptr, geom, prm,
+                                         h->c_buf[5].as<double>(), h->c_buf[6].as<int32_t>())))
+        return rc;
+    PQP_HIP(hipMemcpyAsync(bounds, h->c_buf[5].p, b_bnd, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(n_valid, h->c_buf[6].p, b_nv, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipStreamSynchronize(h->stream));
+    return PQP_OK;
 }
 
 }  // extern "C"

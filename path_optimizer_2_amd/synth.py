@@ -102,3 +102,39 @@ def make_batch(batch, n, profile="uniform", seed=BASE_SEED, first_qp=0):
     scal[:, 4] = 0.0
     scal[:, 5] = np.deg2rad(_uni(seed, qp, F_STEER, 25.0, 40.0)) if varied else np.full(batch, 35.0 * np.pi / 180.0)
     return dict(ref=np.ascontiguousarray(ref), bounds=np.ascontiguousarray(bounds), scal=np.ascontiguousarray(scal))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# synthetic scenes for the corridor-bounds step (obstacle distance map + reference line), deterministic in (seed)
+# ----------------------------------------------------------------------------------------------------------------------
+def make_scene(seed=0, n=80, spacing=0.6, resolution=0.2, length=(70.0, 40.0), n_obstacles=60, knots_every=3.0):
+    """One planning scene: a float32 obstacle-distance layer dist[rows][cols] on a grid_map-style grid (cell (0,0) at the
+    +x/+y corner, indices grow towards -x/-y), a smooth reference line through it as two knot lists (s, x, y) for
+    tk::spline::set_points, and n reference states (s, k, heading, x, y) sampled every `spacing` metres.
+    Obstacles are discs scattered off the line, some close enough to squeeze the corridor."""
+    from scipy import ndimage
+    rng = np.random.default_rng(seed)
+    rows, cols = int(round(length[0] / resolution)), int(round(length[1] / resolution))
+    lx, ly = rows * resolution, cols * resolution
+    # reference line: heading wanders slowly; starts near the -x edge
+    total = (n - 1) * spacing + 8.0
+    ks = np.arange(0.0, total + knots_every, knots_every)
+    curv = 0.04 * np.sin(ks / 9.0 + rng.uniform(0, 6.28)) + rng.normal(scale=0.01, size=ks.size)
+    head = np.cumsum(curv * knots_every) + rng.uniform(-0.3, 0.3)
+    kx = -0.5 * lx + 6.0 + np.concatenate([[0.0], np.cumsum(np.cos(head[:-1]) * knots_every)])
+    ky = rng.uniform(-4.0, 4.0) + np.concatenate([[0.0], np.cumsum(np.sin(head[:-1]) * knots_every)])
+    # obstacle mask in cell coordinates; cell (i, j) centre = (lx/2 - res/2 - res i, ly/2 - res/2 - res j)
+    cx = 0.5 * lx - 0.5 * resolution - resolution * np.arange(rows)
+    cy = 0.5 * ly - 0.5 * resolution - resolution * np.arange(cols)
+    free = np.ones((rows, cols), dtype=bool)
+    for _ in range(n_obstacles):
+        k = rng.integers(0, ks.size)
+        side = rng.choice([-1.0, 1.0])
+        off = rng.uniform(2.2, 9.0)
+        ox = kx[k] - side * off * np.sin(head[k]) + rng.normal(scale=0.5)
+        oy = ky[k] + side * off * np.cos(head[k]) + rng.normal(scale=0.5)
+        rad = rng.uniform(0.3, 1.2)
+        free &= ((cx[:, None] - ox) ** 2 + (cy[None, :] - oy) ** 2) > rad * rad
+    dist = (ndimage.distance_transform_edt(free) * resolution).astype(np.float32)
+    return dict(dist=dist, rows=rows, cols=cols, resolution=resolution, length=(lx, ly), pos=(0.0, 0.0), knots_s=ks, knots_x=kx, knots_y=ky,
+                n=n, spacing=spacing)

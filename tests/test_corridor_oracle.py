@@ -1,0 +1,115 @@
+"""The CPU restatement of the corridor-bounds step (oracle/corridor_oracle.py) against what can be pinned here:
+the reference's own tk::spline compiled from /root/reference (oracle/_ref, bit for bit), and analytic known answers
+for the restated grid_map lookups and the clearance search."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+import corridor_oracle as K
+import corridor_util as U
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SPLINE = os.path.join(ROOT, "oracle", "_ref", "libref_spline.so")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SPLINE), reason="oracle/_ref not built (needs /root/reference: `make -C oracle ref`)")
+def test_spline_restatement_is_the_reference_bit_for_bit():
+    lib = C.CDLL(REF_SPLINE)
+    lib.ref_spline_new.restype = C.c_void_p; lib.ref_spline_new.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    lib.ref_spline_eval.restype = C.c_double; lib.ref_spline_eval.argtypes = [C.c_void_p, C.c_double]
+    lib.ref_spline_deriv.restype = C.c_double; lib.ref_spline_deriv.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    lib.ref_spline_free.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(0)
+    for _ in range(12):
+        n = int(rng.integers(3, 60))
+        x = np.cumsum(rng.uniform(0.2, 3.0, n)); y = np.cumsum(rng.normal(size=n))
+        sp = K.spline_fit(x, y)
+        h = lib.ref_spline_new(n, x.ctypes.data, y.ctypes.data)
+        for t in np.concatenate([x, rng.uniform(x[0] - 3, x[-1] + 3, 120)]):      # knots, interior, both extrapolations
+            t = float(t)
+            assert K.spline_eval(sp, t) == lib.ref_spline_eval(h, t)
+            for order in (1, 2, 3):
+                assert K.spline_deriv(sp, order, t) == lib.ref_spline_deriv(h, order, t)
+        lib.ref_spline_free(h)
+
+
+def test_spline_interpolates_and_is_c2():
+    x = np.array([0.0, 1.0, 2.5, 4.0, 7.0]); y = np.array([1.0, -1.0, 0.5, 0.0, 2.0])
+    sp = K.spline_fit(x, y)
+    for xi, yi in zip(x, y):
+        assert K.spline_eval(sp, float(xi)) == pytest.approx(yi, abs=1e-14)
+    for xi in x[1:-1]:
+        for order in (1, 2):
+            assert K.spline_deriv(sp, order, xi - 1e-9) == pytest.approx(K.spline_deriv(sp, order, xi + 1e-9), abs=1e-6)
+    assert K.spline_deriv(sp, 2, 0.0) == pytest.approx(0.0, abs=1e-14) and K.spline_deriv(sp, 2, 7.0) == pytest.approx(0.0, abs=1e-12)
+
+
+def _plane_map(g, a, b, c):
+    """distance layer = a + b x + c y sampled at the cell centres (bilinear interpolation reproduces a plane exactly)"""
+    d = np.zeros((g.rows, g.cols), dtype=np.float32)
+    for i in range(g.rows):
+        for j in range(g.cols):
+            x, y = K.grid_cell_position(g, i, j)
+            d[i, j] = a + b * x + c * y
+    return d
+
+
+def test_grid_conventions():
+    g = K.GridGeom.make(10.0, 6.0, 0.5, pos=(1.0, -2.0))
+    assert (g.rows, g.cols) == (20, 12)
+    # cell (0, 0) is the +x / +y corner, indices grow towards -x / -y
+    assert K.grid_cell_position(g, 0, 0) == pytest.approx((1.0 + 5.0 - 0.25, -2.0 + 3.0 - 0.25))
+    assert K.grid_index(g, 5.9, 0.9) == (0, 0) and K.grid_index(g, -3.9, -4.9) == (19, 11)
+    for i, j in ((0, 0), (3, 7), (19, 11)):
+        assert K.grid_index(g, *K.grid_cell_position(g, i, j)) == (i, j)
+    assert K.grid_is_inside(g, 5.99, 0.99) and not K.grid_is_inside(g, 6.01, 0.0) and not K.grid_is_inside(g, 0.0, -5.01)
+    assert K.obstacle_distance(np.ones((20, 12), dtype=np.float32), g, 100.0, 0.0) == 0.0          # outside -> 0 (Map.cpp:20)
+
+
+def test_bilinear_lookup_reproduces_a_plane():
+    g = K.GridGeom.make(12.0, 8.0, 0.25)
+    d = _plane_map(g, 3.0, 0.2, -0.1)
+    rng = np.random.default_rng(1)
+    for _ in range(300):
+        x, y = rng.uniform(-5.5, 5.5), rng.uniform(-3.5, 3.5)
+        assert K.obstacle_distance(d, g, x, y) == pytest.approx(3.0 + 0.2 * x - 0.1 * y, abs=2e-6)      # float32 layer
+
+
+def test_clearance_between_two_walls():
+    """Straight corridor along x between walls at y = +3 and y = -2: distance field = min(3 - y, y + 2).  The search walks
+    0.3 m steps until the field drops below 0.5, then 0.05 m steps, then subtracts car_width/2 - 0.5 and the safety margin."""
+    g = K.GridGeom.make(40.0, 16.0, 0.1)
+    d = np.zeros((g.rows, g.cols), dtype=np.float32)
+    for j in range(g.cols):
+        _, y = K.grid_cell_position(g, 0, j)
+        d[:, j] = max(min(3.0 - y, y + 2.0), 0.0)
+    left, right = K.clearance_strict(0.0, 0.0, 0.0, d, g)
+    # left: the last 0.3-step with field >= 0.5 is 2.4 (at 2.7 the field is 0.3); fine steps 2.45, 2.5 pass, 2.55 fails -> 2.5;
+    # minus (car_width/2 - 0.5) = 0.5, minus the safety margin 0.3
+    assert left == pytest.approx(2.5 - 0.5 - 0.3, abs=1e-9)
+    # right: the coarse search stops at 1.8 -> -1.5.  Two reference quirks are reproduced as written (:289-299):
+    #   int(0.3 / 0.05) = 5 (5.999...), so the fine loop makes 4 steps, not 5;
+    #   the fine probe is state + right_bound * (cos, sin)(right_angle) with right_bound NEGATIVE, i.e. it samples the LEFT
+    #   side of the road - free here, so all 4 steps pass and the right bound moves out to -1.7 although the wall is at -1.5
+    assert right == pytest.approx(-(1.5 + 4 * 0.05) + 0.5 + 0.3, abs=1e-9)
+    assert K.clearance_strict(0.0, 2.8, 0.0, d, g) == (0.0, 0.0)                  # starts inside the inflated obstacle
+
+
+def test_update_bounds_shapes_offsets_and_blocking():
+    c = U.build(seed=3, n=30)
+    bounds, n_valid, blocked = K.update_bounds_improved(c["ref"], c["sx"], c["sy"], c["dist"], c["geom"])
+    assert bounds.shape == (n_valid, 6)
+    assert (bounds[:, 1] >= bounds[:, 0]).all() and (bounds[:, 3] >= bounds[:, 2]).all()        # ub >= lb
+    # a wall across the road: everything beyond it is cut off and the blocked row has an empty front or rear interval
+    d2 = c["dist"].copy()
+    x_wall = c["ref"][20, 3]
+    g = c["geom"]
+    for i in range(g.rows):
+        x, _ = K.grid_cell_position(g, i, 0)
+        d2[i, :] = np.minimum(d2[i, :], np.float32(abs(x - x_wall)))
+    b2, nv2, blocked2 = K.update_bounds_improved(c["ref"], c["sx"], c["sy"], d2, g)
+    assert nv2 < 20 and blocked2 is not None
+    assert abs(blocked2[1] - blocked2[0]) < 1e-6 or abs(blocked2[3] - blocked2[2]) < 1e-6
