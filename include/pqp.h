@@ -22,6 +22,8 @@
  *   ReferencePathSmoother::postSmooth src/reference_path_smoother/reference_path_smoother.cpp:526-636 (QP part) pqp_post_smooth
  *   ReferencePath::updateBounds -> ReferencePathImpl::updateBoundsImproved
  *                                     src/data_struct/reference_path.cpp:61, reference_path_impl.cpp:177-312    pqp_corridor_bounds
+ *   ReferencePathImpl::buildReferenceFromSpline  reference_path_impl.cpp:314-338, PathOptimizer::processInitState path_optimizer.cpp:73-85
+ *                                                                                                         pqp_reference_states
  *
  * Conventions
  *   - plain C, no C++/torch types; all reals are IEEE fp64, all indices int32.
@@ -189,6 +191,13 @@ int pqp_path_solve(pqp_handle* h, int batch, int n, const double* ref, const dou
 int pqp_path_solve_device(pqp_handle* h, int batch, int n, const double* ref, const double* lin,
                           const double* bounds, const double* scal, int passes, int warm,
                           double* out, int32_t* status, int32_t* iters, double* info);
+/* The same with a waypoint count per QP: n_of[batch] (device pointer, each <= n_max); every array keeps the stride n_max.
+ * This is what a road cut short by an obstacle needs (ReferencePathImpl::updateBoundsImproved resizes reference_states_ to the
+ * blocked waypoint, reference_path_impl.cpp:225-228; pqp_corridor_bounds reports it as n_valid).  A QP with n_of < 2 is left
+ * untouched with status PQP_STATUS_UNSOLVED. */
+int pqp_path_solve_var_device(pqp_handle* h, int batch, int n_max, const int32_t* n_of, const double* ref, const double* lin,
+                              const double* bounds, const double* scal, int passes, int warm, double* out, int32_t* status,
+                              int32_t* iters, double* info);
 
 /* Primal / dual solution of the handle's last solve in the REFERENCE numbering (OsqpEigen::Solver::
  * getSolution(), base_solver.cpp:89,112): x [batch][vars], y [batch][cons].  HOST buffers; either may be NULL. */
@@ -246,14 +255,30 @@ void pqp_corridor_default_params(pqp_corridor_params* p);
  * spline_ext [batch][4]   m_b0, m_c0 of x(s), then of y(s)
  * dist     [n_maps][cols][rows] float: the layer in Eigen's column-major order (grid_map::Matrix = Eigen::MatrixXf)
  * map_of   [batch] map index of each scenario, or NULL (all use map 0)
- * bounds   [batch][n][6]  f_lb f_ub r_lb r_ub c_lb c_ub for EVERY waypoint;  n_valid [batch] = index of the first waypoint whose
- *          front or rear interval is empty (the reference cuts the path there and sets isBlocked(), :219-223), n if none */
-int pqp_corridor_bounds_device(pqp_handle* h, int batch, int n, int m, const double* ref, const double* spline, const double* spline_ext,
-                               const float* dist, const int32_t* map_of, const pqp_grid_geometry* geom, const pqp_corridor_params* prm,
-                               double* bounds, int32_t* n_valid);
-int pqp_corridor_bounds(pqp_handle* h, int batch, int n, int m, const double* ref, const double* spline, const double* spline_ext,
-                        const float* dist, int n_maps, const int32_t* map_of, const pqp_grid_geometry* geom, const pqp_corridor_params* prm,
-                        double* bounds, int32_t* n_valid);
+ * n_of     [batch] reference states of each scenario (<= n; n is then the array stride), or NULL (all have n)
+ * bounds   [batch][n][6]  f_lb f_ub r_lb r_ub c_lb c_ub for every waypoint of the scenario;  n_valid [batch] = index of the first
+ *          waypoint whose front or rear interval is empty (the reference cuts the path there and sets isBlocked(), :219-223),
+ *          the scenario's own count if none.  n_valid is what pqp_path_solve_var_device takes as n_of. */
+int pqp_corridor_bounds_device(pqp_handle* h, int batch, int n, int m, const double* ref, const int32_t* n_of, const double* spline,
+                               const double* spline_ext, const float* dist, const int32_t* map_of, const pqp_grid_geometry* geom,
+                               const pqp_corridor_params* prm, double* bounds, int32_t* n_valid);
+int pqp_corridor_bounds(pqp_handle* h, int batch, int n, int m, const double* ref, const int32_t* n_of, const double* spline,
+                        const double* spline_ext, const float* dist, int n_maps, const int32_t* map_of, const pqp_grid_geometry* geom,
+                        const pqp_corridor_params* prm, double* bounds, int32_t* n_valid);
+
+/* ---- reference states from the reference line's spline + the vehicle's initial error -------------------
+ * ReferencePathImpl::buildReferenceFromSpline(delta_s_smaller, delta_s_larger)  src/data_struct/reference_path_impl.cpp:314-338
+ *   (called with output_spacing / 2, output_spacing = 0.15, 0.3 at path_optimizer.cpp:119; dynamic = FLAGS_enable_dynamic_segmentation)
+ * PathOptimizer::processInitState                                              src/path_optimizer.cpp:73-85
+ * spline, spline_ext as above; max_s [batch] = ReferencePath::getLength(); start [batch][3] = vehicle start state x, y, heading (or NULL)
+ * ref [batch][n_max][5] = s, k, heading, x, y;  count [batch] = states the loop produces (when it exceeds n_max only n_max rows
+ * were written);  init_err [batch][2] = initial_offset, initial_heading_error (NULL or needs start): scal[0..1] of pqp_path_solve */
+int pqp_reference_states_device(pqp_handle* h, int batch, int n_max, int m, const double* spline, const double* spline_ext,
+                                const double* max_s, const double* start, double ds_small, double ds_large, int dynamic, double* ref,
+                                int32_t* count, double* init_err);
+int pqp_reference_states(pqp_handle* h, int batch, int n_max, int m, const double* spline, const double* spline_ext, const double* max_s,
+                         const double* start, double ds_small, double ds_large, int dynamic, double* ref, int32_t* count,
+                         double* init_err);
 
 #ifdef __cplusplus
 }

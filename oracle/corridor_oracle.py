@@ -16,6 +16,8 @@ What is restated (reference file:line):
   directional_projection_newton                getDirectionalProjectionByNewton                  src/tools/tools.cpp:156-189
   global2local_y                               global2Local(...).y                               src/tools/tools.cpp:57-64
   obstacle_distance                            Map::getObstacleDistance                          src/tools/Map.cpp:16-22
+  build_reference_from_spline                  ReferencePathImpl::buildReferenceFromSpline       src/data_struct/reference_path_impl.cpp:314-338
+  process_init_state                           PathOptimizer::processInitState                   src/path_optimizer.cpp:73-85
   clearance_strict                             ReferencePathImpl::getClearanceWithDirectionStrict src/data_struct/reference_path_impl.cpp:232-312
   update_bounds_improved                       ReferencePathImpl::updateBoundsImproved           src/data_struct/reference_path_impl.cpp:177-230
 Python floats are IEEE doubles and every operation below is written in the reference's order, so the arithmetic is the
@@ -190,6 +192,40 @@ def global2local_y(rx, ry, rheading, tx, ty):                                 # 
     dx = tx - rx
     dy = ty - ry
     return -dx * math.sin(rheading) + dy * math.cos(rheading)
+
+
+def build_reference_from_spline(sx, sy, max_s, ds_small=0.15, ds_large=0.3, dynamic=True):
+    """ReferencePathImpl::buildReferenceFromSpline (reference_path_impl.cpp:314-338), called with (output_spacing / 2,
+    output_spacing) = (0.15, 0.3) at path_optimizer.cpp:119.  Rows (s, k, heading, x, y): the ABI layout of the path QP."""
+    large_k, small_k = 0.2, 0.08
+    out = []
+    tmp_s = 0.0
+    while tmp_s <= max_s:
+        x = spline_eval(sx, tmp_s)
+        y = spline_eval(sy, tmp_s)
+        dx, dy = spline_deriv(sx, 1, tmp_s), spline_deriv(sy, 1, tmp_s)
+        ddx, ddy = spline_deriv(sx, 2, tmp_s), spline_deriv(sy, 2, tmp_s)
+        h = math.atan2(dy, dx)                                                            # getHeading   tools.cpp:32-36
+        k = (dx * ddy - dy * ddx) / math.pow(math.pow(dx, 2) + math.pow(dy, 2), 1.5)      # getCurvature tools.cpp:38-44
+        out.append((tmp_s, k, h, x, y))
+        if dynamic:
+            ak = abs(k)
+            k_share = 1 if ak > large_k else (0 if ak < small_k else (ak - small_k) / (large_k - small_k))
+            tmp_s += ds_large - k_share * (ds_large - ds_small)
+        else:
+            tmp_s += ds_large
+    return np.array(out).reshape(-1, 5)
+
+
+def process_init_state(sx, sy, start_x, start_y, start_heading):
+    """PathOptimizer::processInitState (path_optimizer.cpp:73-85) -> (initial_offset, initial_heading_error)."""
+    ix, iy = spline_eval(sx, 0.0), spline_eval(sy, 0.0)
+    ih = math.atan2(spline_deriv(sy, 1, 0.0), spline_deriv(sx, 1, 0.0))
+    dx, dy = ix - start_x, iy - start_y
+    local_y = -dx * math.sin(start_heading) + dy * math.cos(start_heading)                # global2Local(start, init_point).y
+    min_distance = math.sqrt(math.pow(start_x - ix, 2) + math.pow(start_y - iy, 2))       # distance()  tools.cpp:46-48
+    offset = min_distance if local_y < 0.0 else -min_distance
+    return offset, constrain_angle(start_heading - ih)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -50,9 +50,10 @@ class PqpSizes(C.Structure):
 EXPORTS = [
     "pqp_default_params", "pqp_production_params", "pqp_last_error", "pqp_version", "pqp_create", "pqp_destroy", "pqp_set_params",
     "pqp_get_stream", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
-    "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_get_solution",
+    "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_solve_var_device", "pqp_path_get_solution",
     "pqp_last_kernel_ms", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
     "pqp_post_smooth", "pqp_post_smooth_device", "pqp_corridor_default_params", "pqp_corridor_bounds", "pqp_corridor_bounds_device",
+    "pqp_reference_states", "pqp_reference_states_device",
 ]
 
 _lib = None
@@ -96,10 +97,13 @@ def load_library(path=None):
     lib.pqp_post_smooth_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 8
     lib.pqp_corridor_default_params.argtypes = [C.POINTER(PqpCorridorParams)]
     lib.pqp_corridor_default_params.restype = None
-    lib.pqp_corridor_bounds_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.POINTER(PqpGridGeometry),
+    lib.pqp_corridor_bounds_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(PqpGridGeometry),
                                                C.POINTER(PqpCorridorParams), vp, vp]
-    lib.pqp_corridor_bounds.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, C.POINTER(PqpGridGeometry),
+    lib.pqp_corridor_bounds.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, C.POINTER(PqpGridGeometry),
                                         C.POINTER(PqpCorridorParams), vp, vp]
+    for name in ("pqp_reference_states", "pqp_reference_states_device"):
+        getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, vp]
+    lib.pqp_path_solve_var_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -180,7 +184,21 @@ class Handle:
             setattr(p, k, v)
         return p
 
-    def corridor_bounds(self, ref, spline, spline_ext, dist, geom, map_of=None, prm=None):
+    def reference_states(self, spline, spline_ext, max_s, n_max, start=None, ds_small=0.15, ds_large=0.3, dynamic=True):
+        """pqp_reference_states (host arrays): spline [B][9][m], spline_ext [B][4], max_s [B], start [B][3] or None.
+        Returns (ref [B][n_max][5], count [B], init_err [B][2] or None)."""
+        spline = np.ascontiguousarray(spline, dtype=np.float64)
+        spline_ext = np.ascontiguousarray(spline_ext, dtype=np.float64)
+        max_s = np.ascontiguousarray(max_s, dtype=np.float64)
+        B, m = spline.shape[0], spline.shape[2]
+        st = None if start is None else np.ascontiguousarray(start, dtype=np.float64)
+        ref = np.zeros((B, n_max, 5)); count = np.zeros(B, dtype=np.int32)
+        err = None if start is None else np.zeros((B, 2))
+        self._check(self.lib.pqp_reference_states(self._h, B, n_max, m, _ptr(spline), _ptr(spline_ext), _ptr(max_s), _ptr(st), ds_small,
+                                                  ds_large, 1 if dynamic else 0, _ptr(ref), _ptr(count), _ptr(err)))
+        return ref, count, err
+
+    def corridor_bounds(self, ref, spline, spline_ext, dist, geom, map_of=None, prm=None, n_of=None):
         """pqp_corridor_bounds (host arrays): ref [B][n][5], spline [B][9][m], spline_ext [B][4], dist [n_maps][rows][cols] float32
         (converted to the ABI's column-major order here), geom = PqpGridGeometry.  Returns (bounds [B][n][6], n_valid [B])."""
         ref = np.ascontiguousarray(ref, dtype=np.float64)
@@ -196,7 +214,8 @@ class Handle:
         n_valid = np.zeros(B, dtype=np.int32)
         mo = None if map_of is None else np.ascontiguousarray(map_of, dtype=np.int32)
         prm = prm or self.corridor_params()
-        self._check(self.lib.pqp_corridor_bounds(self._h, B, n, m, _ptr(ref), _ptr(spline), _ptr(spline_ext), _ptr(dist_cm), dist.shape[0],
+        no = None if n_of is None else np.ascontiguousarray(n_of, dtype=np.int32)
+        self._check(self.lib.pqp_corridor_bounds(self._h, B, n, m, _ptr(ref), _ptr(no), _ptr(spline), _ptr(spline_ext), _ptr(dist_cm), dist.shape[0],
                                                  _ptr(mo), C.byref(geom), C.byref(prm), _ptr(bounds), _ptr(n_valid)))
         return bounds, n_valid
 
@@ -245,6 +264,15 @@ class Handle:
             return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
         self._check(self.lib.pqp_path_solve_device(self._h, batch, n, dp(ref), dp(lin), dp(bounds), dp(scal), passes,
                                                    1 if warm else 0, dp(out), dp(status), dp(iters), dp(info)))
+
+    def solve_var_device(self, batch, n_max, n_of, ref, bounds, scal, out, lin=None, passes=1, warm=False, status=None, iters=None, info=None):
+        """pqp_path_solve_var_device: like solve_device with a waypoint count per QP (n_of: device int32 [batch])."""
+        def dp(x):
+            if x is None:
+                return None
+            return C.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+        self._check(self.lib.pqp_path_solve_var_device(self._h, batch, n_max, dp(n_of), dp(ref), dp(lin), dp(bounds), dp(scal), passes,
+                                                       1 if warm else 0, dp(out), dp(status), dp(iters), dp(info)))
 
     def get_solution(self, batch, n, precise=None):
         precise = n if precise is None else precise

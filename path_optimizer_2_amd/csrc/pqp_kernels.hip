@@ -604,9 +604,8 @@ int pqp_path_assemble(pqp_handle* h, int batch, int n, int precise, const double
     return PQP_OK;
 }
 
-int pqp_path_solve_device(pqp_handle* h, int batch, int n, const double* ref, const double* lin, const double* bounds,
-                          const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters,
-                          double* info) {
+static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
+                           const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters, double* info) {
     if (!h || !ref || !bounds || !scal || !out || batch < 1 || n < 2 || passes < 0)
         return fail(PQP_ERR_INVALID, "pqp_path_solve: bad argument");
     if (n > 1024) return fail(PQP_ERR_CAPACITY, "pqp_path_solve: n > 1024 waypoints is not supported");
@@ -622,7 +621,7 @@ int pqp_path_solve_device(pqp_handle* h, int batch, int n, const double* ref, co
     }
     pqp::PathSolveArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.batch = batch; a.n = n; a.passes = passes; a.warm = warm ? 1 : 0;
+    a.batch = batch; a.n = n; a.n_of = n_of; a.passes = passes; a.warm = warm ? 1 : 0;
     a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
     a.status = status; a.iters = iters; a.info = info;
     a.wx = h->wx.as<double>(); a.wy = h->wy.as<double>(); a.wye = h->wye.as<double>(); a.wrho = h->wrho.as<double>();
@@ -648,6 +647,19 @@ int pqp_path_solve_device(pqp_handle* h, int batch, int n, const double* ref, co
     h->timed = true;
     h->warm_batch = batch; h->warm_n = n;
     return PQP_OK;
+}
+
+int pqp_path_solve_device(pqp_handle* h, int batch, int n, const double* ref, const double* lin, const double* bounds,
+                          const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters,
+                          double* info) {
+    return path_solve_impl(h, batch, n, nullptr, ref, lin, bounds, scal, passes, warm, out, status, iters, info);
+}
+
+int pqp_path_solve_var_device(pqp_handle* h, int batch, int n_max, const int32_t* n_of, const double* ref, const double* lin,
+                              const double* bounds, const double* scal, int passes, int warm, double* out, int32_t* status,
+                              int32_t* iters, double* info) {
+    if (!n_of) return fail(PQP_ERR_INVALID, "pqp_path_solve_var: n_of is null");
+    return path_solve_impl(h, batch, n_max, n_of, ref, lin, bounds, scal, passes, warm, out, status, iters, info);
 }
 
 int pqp_path_solve(pqp_handle* h, int batch, int n, const double* ref, const double* lin, const double* bounds,
@@ -926,15 +938,15 @@ void pqp_corridor_default_params(pqp_corridor_params* p) {
     p->projection_window = 5.0;                         // reference_path_impl.cpp:194
 }
 
-int pqp_corridor_bounds_device(pqp_handle* h, int batch, int n, int m, const double* ref, const double* spline, const double* spline_ext,
-                               const float* dist, const int32_t* map_of, const pqp_grid_geometry* geom, const pqp_corridor_params* prm,
-                               double* bounds, int32_t* n_valid) {
+int pqp_corridor_bounds_device(pqp_handle* h, int batch, int n, int m, const double* ref, const int32_t* n_of, const double* spline,
+                               const double* spline_ext, const float* dist, const int32_t* map_of, const pqp_grid_geometry* geom,
+                               const pqp_corridor_params* prm, double* bounds, int32_t* n_valid) {
     if (!h || !ref || !spline || !spline_ext || !dist || !geom || !prm || !bounds || !n_valid || batch < 1 || n < 1 || m < 3 ||
         geom->rows < 2 || geom->cols < 2 || !(geom->resolution > 0.0) || !(prm->delta_s > 0.0) || !(prm->smaller_ds > 0.0))
         return fail(PQP_ERR_INVALID, "pqp_corridor_bounds: bad argument (m >= 3 knots: spline.cpp:164)");
     PQP_HIP(hipSetDevice(h->device));
     pqp::CorridorArgs a;
-    a.batch = batch; a.n = n; a.m = m; a.ref = ref; a.spl = spline; a.spl_ext = spline_ext; a.dist = dist; a.map_of = map_of;
+    a.batch = batch; a.n = n; a.m = m; a.ref = ref; a.spl = spline; a.spl_ext = spline_ext; a.dist = dist; a.map_of = map_of; a.n_of = n_of;
     a.g = *geom; a.p = *prm; a.bounds = bounds; a.n_valid = n_valid;
     int threads = 64 * ((3 * n + 63) / 64);
     if (threads > 1024) threads = 1024;
@@ -946,9 +958,9 @@ int pqp_corridor_bounds_device(pqp_handle* h, int batch, int n, int m, const dou
     return PQP_OK;
 }
 
-int pqp_corridor_bounds(pqp_handle* h, int batch, int n, int m, const double* ref, const double* spline, const double* spline_ext,
-                        const float* dist, int n_maps, const int32_t* map_of, const pqp_grid_geometry* geom, const pqp_corridor_params* prm,
-                        double* bounds, int32_t* n_valid) {
+int pqp_corridor_bounds(pqp_handle* h, int batch, int n, int m, const double* ref, const int32_t* n_of, const double* spline,
+                        const double* spline_ext, const float* dist, int n_maps, const int32_t* map_of, const pqp_grid_geometry* geom,
+                        const pqp_corridor_params* prm, double* bounds, int32_t* n_valid) {
     if (!h || !ref || !spline || !spline_ext || !dist || !geom || !prm || !bounds || !n_valid || batch < 1 || n < 1 || m < 3 || n_maps < 1)
         return fail(PQP_ERR_INVALID, "pqp_corridor_bounds: bad argument");
     PQP_HIP(hipSetDevice(h->device));
@@ -963,12 +975,60 @@ int pqp_corridor_bounds(pqp_handle* h, int batch, int n, int m, const double* re
     PQP_HIP(hipMemcpyAsync(h->c_buf[2].p, spline_ext, b_ext, hipMemcpyHostToDevice, h->stream));
     PQP_HIP(hipMemcpyAsync(h->c_buf[3].p, dist, b_map, hipMemcpyHostToDevice, h->stream));
     if (map_of) PQP_HIP(hipMemcpyAsync(h->c_buf[4].p, map_of, b_of, hipMemcpyHostToDevice, h->stream));
-    if ((rc = pqp_corridor_bounds_device(h, batch, n, m, h->c_buf[0].as<double>(), h->c_buf[1].as<double>(), h->c_buf[2].as<double>(),
+    if (n_of) PQP_HIP(hipMemcpyAsync(h->c_buf[6].p, n_of, b_nv, hipMemcpyHostToDevice, h->stream));     // n_valid is written after n_of is read
+    if ((rc = pqp_corridor_bounds_device(h, batch, n, m, h->c_buf[0].as<double>(), n_of ? h->c_buf[6].as<int32_t>() : nullptr,
+                                         h->c_buf[1].as<double>(), h->c_buf[2].as<double>(),
                                          h->c_buf[3].as<float>(), map_of ? h->c_buf[4].as<int32_t>() : nullptr, geom, prm,
                                          h->c_buf[5].as<double>(), h->c_buf[6].as<int32_t>())))
         return rc;
     PQP_HIP(hipMemcpyAsync(bounds, h->c_buf[5].p, b_bnd, hipMemcpyDeviceToHost, h->stream));
     PQP_HIP(hipMemcpyAsync(n_valid, h->c_buf[6].p, b_nv, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipStreamSynchronize(h->stream));
+    return PQP_OK;
+}
+
+// ---- reference states + initial error ----------------------------------------------------------------
+int pqp_reference_states_device(pqp_handle* h, int batch, int n_max, int m, const double* spline, const double* spline_ext,
+                                const double* max_s, const double* start, double ds_small, double ds_large, int dynamic, double* ref,
+                                int32_t* count, double* init_err) {
+    if (!h || !spline || !spline_ext || !max_s || !ref || !count || batch < 1 || n_max < 1 || m < 3 || !(ds_small > 0.0) ||
+        !(ds_large >= ds_small) || (init_err && !start))
+        return fail(PQP_ERR_INVALID, "pqp_reference_states: bad argument (0 < ds_small <= ds_large: reference_path_impl.cpp:315)");
+    PQP_HIP(hipSetDevice(h->device));
+    pqp::RefStatesArgs a;
+    a.batch = batch; a.n_max = n_max; a.m = m; a.spl = spline; a.spl_ext = spline_ext; a.max_s = max_s; a.start = start;
+    a.ds_small = ds_small; a.ds_large = ds_large; a.dynamic = dynamic ? 1 : 0; a.ref = ref; a.count = count; a.init_err = init_err;
+    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(pqp::reference_states_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, a);
+    PQP_HIP(hipGetLastError());
+    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return PQP_OK;
+}
+
+int pqp_reference_states(pqp_handle* h, int batch, int n_max, int m, const double* spline, const double* spline_ext, const double* max_s,
+                         const double* start, double ds_small, double ds_large, int dynamic, double* ref, int32_t* count,
+                         double* init_err) {
+    if (!h || !spline || !spline_ext || !max_s || !ref || !count || batch < 1 || n_max < 1 || m < 3)
+        return fail(PQP_ERR_INVALID, "pqp_reference_states: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    const size_t b_spl = (size_t)batch * 9 * m * 8, b_ext = (size_t)batch * 4 * 8, b_s = (size_t)batch * 8, b_st = (size_t)batch * 3 * 8;
+    const size_t b_ref = (size_t)batch * n_max * PQP_REF_STRIDE * 8, b_cnt = (size_t)batch * 4, b_err = (size_t)batch * 2 * 8;
+    const size_t sizes[7] = {b_ref, b_spl, b_ext, b_s, b_st, b_err, b_cnt};
+    int rc;
+    for (int k = 0; k < 7; ++k) if ((rc = h->c_buf[k].ensure(sizes[k]))) return rc;
+    PQP_HIP(hipMemcpyAsync(h->c_buf[1].p, spline, b_spl, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[2].p, spline_ext, b_ext, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[3].p, max_s, b_s, hipMemcpyHostToDevice, h->stream));
+    if (start) PQP_HIP(hipMemcpyAsync(h->c_buf[4].p, start, b_st, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemsetAsync(h->c_buf[0].p, 0, b_ref, h->stream));
+    if ((rc = pqp_reference_states_device(h, batch, n_max, m, h->c_buf[1].as<double>(), h->c_buf[2].as<double>(), h->c_buf[3].as<double>(),
+                                          start ? h->c_buf[4].as<double>() : nullptr, ds_small, ds_large, dynamic, h->c_buf[0].as<double>(),
+                                          h->c_buf[6].as<int32_t>(), (init_err && start) ? h->c_buf[5].as<double>() : nullptr)))
+        return rc;
+    PQP_HIP(hipMemcpyAsync(ref, h->c_buf[0].p, b_ref, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(count, h->c_buf[6].p, b_cnt, hipMemcpyDeviceToHost, h->stream));
+    if (init_err && start) PQP_HIP(hipMemcpyAsync(init_err, h->c_buf[5].p, b_err, hipMemcpyDeviceToHost, h->stream));
     PQP_HIP(hipStreamSynchronize(h->stream));
     return PQP_OK;
 }

@@ -61,6 +61,7 @@ constexpr double kPi2 = 1.57079632679489661923;  // M_PI_2
 // ---- device-side argument block of one solve launch ---------------------------------------------
 struct PathSolveArgs {
     int batch, n, passes, warm;
+    const int32_t* n_of;    // [batch] waypoints of each QP (<= n; n is then only the array stride), or nullptr: all have n
     const double* ref;      // [batch][n][5]
     const double* lin;      // [batch][n][3] or nullptr
     const double* bounds;   // [batch][n][6]
@@ -341,7 +342,8 @@ struct PathQp {
     Ctx& ctx;
     const PathSolveArgs& A;
     const int qp;
-    const int n;
+    const int stride;         // waypoints per QP in the batch arrays
+    const int n;              // waypoints of THIS QP
     const int T;
     const ShLayout L;
     double* const sh;
@@ -352,7 +354,7 @@ struct PathQp {
     int factors_;             // factor() executions
 
     PQP_HD PathQp(Ctx& c, const PathSolveArgs& a, int q)
-        : ctx(c), A(a), qp(q), n(a.n), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false), kkt_solves_(0), factors_(0) {}
+        : ctx(c), A(a), qp(q), stride(a.n), n(a.n_of ? (a.n_of[q] < a.n ? a.n_of[q] : a.n) : a.n), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false), kkt_solves_(0), factors_(0) {}
 
     PQP_HD EndRows* end_rows() const { return reinterpret_cast<EndRows*>(sh + L.end()); }
 
@@ -371,14 +373,14 @@ struct PathQp {
             const int i = t;
             const bool real = i < n;
             const int ic = real ? i : n - 1;
-            const double* r = A.ref + ((size_t)qp * n + ic) * PQP_REF_STRIDE;
+            const double* r = A.ref + ((size_t)qp * stride + ic) * PQP_REF_STRIDE;
             const double r0 = r[0], r1 = r[1];
             // base_solver.cpp:25-34: precise planning size = lower_bound(s, precise_planning_length)
             const bool precise = !prm.rough_constraints_far_away || r0 < prm.precise_planning_length;
             S.flags = real ? (F_REAL | (i > 0 ? F_PREV : 0) | (i < n - 1 ? F_NEXT : 0) | (i == n - 1 ? F_LAST : 0) | (precise ? F_PRECISE : 0)) : 0;
             double l0 = 0.0, l1 = 0.0, l2 = r1;      // path_optimizer.cpp:128-137: (0, 0, k_ref)
             if (A.lin) {
-                const double* li = A.lin + ((size_t)qp * n + ic) * PQP_LIN_STRIDE;
+                const double* li = A.lin + ((size_t)qp * stride + ic) * PQP_LIN_STRIDE;
                 l0 = li[0]; l1 = li[1]; l2 = li[2];
             }
             if (real) {
@@ -415,7 +417,7 @@ struct PathQp {
             _Pragma("unroll") for (int k = 0; k < 3; ++k) S.bT[k] = !real ? 0.0 : (prev ? -c3[k] : -sc[k]);
             // collision boxes (:232-248); rough: one row l + s_c on the centre box, the R row and sr are dummies
             const int ic = real ? i : n - 1;
-            const double* b = A.bounds + ((size_t)qp * n + ic) * PQP_BOUNDS_STRIDE;
+            const double* b = A.bounds + ((size_t)qp * stride + ic) * PQP_BOUNDS_STRIDE;
             const double f_lb = precise ? b[0] : b[4], f_ub = precise ? b[1] : b[5];
             double flo, fup, rlo, rup;
             soft_bounds(f_lb, f_ub, prm.expected_safety_margin, prm.min_clearance, flo, fup);
@@ -426,7 +428,7 @@ struct PathQp {
                 EndRows* er = end_rows();
                 double elo = -kInfty, eup = kInfty;
                 if (prm.constraint_end_heading && sc[4] == 0.0) {
-                    const double heading = A.ref[((size_t)qp * n + i) * PQP_REF_STRIDE + 2];
+                    const double heading = A.ref[((size_t)qp * stride + i) * PQP_REF_STRIDE + 2];
                     const double end_psi = constrain_angle(sc[3] - heading);
                     if (end_psi < prm.end_psi_max) {     // signed compare, no fabs (:256)
                         elo = end_psi - prm.end_psi_tol;
@@ -1216,7 +1218,7 @@ struct PathQp {
         ctx.phase([&](int t, Lane& ln) {
             Slot& S = ln.s;
             const bool real = S.flags & F_REAL;
-            const size_t o = ((size_t)qp * n + (real ? t : n - 1)) * 6;
+            const size_t o = ((size_t)qp * stride + (real ? t : n - 1)) * 6;
             _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = real ? A.wx[o + k] : 0.0;
             _Pragma("unroll") for (int k = 0; k < 3; ++k) { S.yT[k] = real ? A.wy[o + k] : 0.0; S.yI[k] = real ? A.wy[o + 3 + k] : 0.0; }
             if (S.flags & F_LAST) { end_rows()->y[0] = A.wye[2 * (size_t)qp]; end_rows()->y[1] = A.wye[2 * (size_t)qp + 1]; }
@@ -1227,8 +1229,8 @@ struct PathQp {
         ctx.phase([&](int t, Lane& ln) {
             const Slot& S = ln.s;
             if (S.flags & F_REAL) {
-                double* wx = A.wx + ((size_t)qp * n + t) * 6;
-                double* wy = A.wy + ((size_t)qp * n + t) * 6;
+                double* wx = A.wx + ((size_t)qp * stride + t) * 6;
+                double* wy = A.wy + ((size_t)qp * stride + t) * 6;
                 _Pragma("unroll") for (int k = 0; k < 6; ++k) wx[k] = S.x[k];
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) { wy[k] = S.yT[k]; wy[3 + k] = S.yI[k]; }
                 if (S.flags & F_LAST) { A.wye[2 * (size_t)qp] = end_rows()->y[0]; A.wye[2 * (size_t)qp + 1] = end_rows()->y[1]; }
@@ -1247,8 +1249,8 @@ struct PathQp {
             const Slot& S = ln.s;
             if (S.flags & F_REAL) {
                 const int i = t;
-                const double* r = A.ref + ((size_t)qp * n + i) * PQP_REF_STRIDE;
-                double* o = A.out + ((size_t)qp * n + i) * PQP_OUT_STRIDE;
+                const double* r = A.ref + ((size_t)qp * stride + i) * PQP_REF_STRIDE;
+                double* o = A.out + ((size_t)qp * stride + i) * PQP_OUT_STRIDE;
                 const double angle = r[2];
                 const double l = S.x[0], dpsi = S.x[1];
                 const double new_angle = constrain_angle(angle + kPi2);
@@ -1334,6 +1336,15 @@ struct PathQp {
         const pqp_params& prm = A.prm;
         int total_iters = 0, last_iters = 0, status = PQP_STATUS_UNSOLVED, polished = 0;
         // active-set rounds per polish attempt; <= 0: sized to the path (long paths need more rounds, short ones pay for them)
+        if (n < 2) {        // nothing to optimise (a road blocked at the first waypoints): the reference does not get this far
+            ctx.phase([&](int t, Lane&) {
+                if (t == 0) {
+                    if (A.status) A.status[qp] = PQP_STATUS_UNSOLVED;
+                    if (A.iters) A.iters[qp] = 0;
+                }
+            });
+            return;
+        }
         const int auto_rounds = n / 5 - 8;
         const int max_rounds = prm.polish_max_rounds > 0 ? prm.polish_max_rounds : (auto_rounds > 8 ? auto_rounds : 8);
         double res[5] = {0, 0, 0, 0, 0};

@@ -9,6 +9,8 @@
 #include "../../path_optimizer_2_amd/csrc/pqp_banded_qp.hpp"
 
 static int g_wave_order = 1;
+static const int32_t* g_n_of = nullptr;      // per-QP waypoint counts of the next pqp_emu_path_solve call (nullptr: all n)
+extern "C" void pqp_emu_set_counts(const int32_t* n_of) { g_n_of = n_of; }
 extern "C" void pqp_emu_set_wave_order(int o) { g_wave_order = o; }
 
 namespace {
@@ -61,6 +63,7 @@ extern "C" int pqp_emu_path_solve(const pqp_params* prm, int batch, int n, const
     std::vector<double> wsave((size_t)batch * T * PQP_SAVE_STRIDE, 0.0);
     a.wsave = wsave.data();
     a.prm = *prm;
+    a.n_of = g_n_of;
     for (int q = 0; q < batch; ++q) {
         HostCtx ctx(T);
         pqp::PathQp<HostCtx> s(ctx, a, q);

@@ -42,7 +42,7 @@ def production(**over):
     return p
 
 
-def solve(prm, ref, bounds, scal, lin=None, passes=1):
+def solve(prm, ref, bounds, scal, lin=None, passes=1, n_of=None):
     lib = load()
     B, n = ref.shape[0], ref.shape[1]
     vp = lambda a: None if a is None else np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
@@ -50,8 +50,11 @@ def solve(prm, ref, bounds, scal, lin=None, passes=1):
     wx = np.zeros((B, n, 6)); wy = np.zeros((B, n, 6)); wye = np.zeros((B, 2)); wrho = np.zeros(B)
     ref = np.ascontiguousarray(ref); bounds = np.ascontiguousarray(bounds); scal = np.ascontiguousarray(scal)
     lin_c = None if lin is None else np.ascontiguousarray(lin)
+    n_of_c = None if n_of is None else np.ascontiguousarray(n_of, dtype=np.int32)
+    lib.pqp_emu_set_counts(None if n_of_c is None else n_of_c.ctypes.data_as(C.c_void_p))
     lib.pqp_emu_path_solve(C.byref(prm), B, n, vp(ref), vp(lin_c), vp(bounds), vp(scal), passes, 0, vp(out), vp(st), vp(it),
                            vp(info), vp(wx), vp(wy), vp(wye), vp(wrho))
+    lib.pqp_emu_set_counts(None)
     return dict(out=out, status=st, iters=it, info=info, wx=wx, wy=wy, wye=wye)
 
 

@@ -113,3 +113,28 @@ def test_update_bounds_shapes_offsets_and_blocking():
     b2, nv2, blocked2 = K.update_bounds_improved(c["ref"], c["sx"], c["sy"], d2, g)
     assert nv2 < 20 and blocked2 is not None
     assert abs(blocked2[1] - blocked2[0]) < 1e-6 or abs(blocked2[3] - blocked2[2]) < 1e-6
+
+
+def test_reference_state_sampling():
+    """buildReferenceFromSpline: on a circle of radius R the curvature is 1/R everywhere (up to the spline's error), the
+    heading turns with s, and the spacing follows the curvature rule (0.3 below k = 0.08, 0.15 above 0.2, linear between)."""
+    for R, step in ((50.0, 0.3), (4.0, 0.15), (1.0 / 0.14, 0.3 - 0.5 * 0.15)):
+        s = np.linspace(0.0, 12.0, 25)
+        sx = K.spline_fit(s, R * np.sin(s / R)); sy = K.spline_fit(s, R * (1.0 - np.cos(s / R)))
+        ref = K.build_reference_from_spline(sx, sy, 9.0)
+        inner = ref[(ref[:, 0] > 3.0) & (ref[:, 0] < 7.0)]          # away from the natural spline's end effects
+        assert np.abs(inner[:, 1] - 1.0 / R).max() < 2e-3
+        assert np.abs(inner[:, 2] - inner[:, 0] / R).max() < 2e-3
+        assert np.abs(np.diff(inner[:, 0]) - step).max() < 5e-3
+        assert ref[0, 0] == 0.0 and ref[-1, 0] <= 9.0 < ref[-1, 0] + 0.3
+    fixed = K.build_reference_from_spline(sx, sy, 9.0, dynamic=False)
+    assert np.allclose(np.diff(fixed[:, 0]), 0.3)
+
+
+def test_initial_error():
+    s = np.linspace(0.0, 10.0, 11)
+    sx = K.spline_fit(s, s); sy = K.spline_fit(s, 0.0 * s)          # the x axis
+    off, dpsi = K.process_init_state(sx, sy, 0.0, 0.7, 0.2)         # vehicle 0.7 m to the left of the line, heading +0.2
+    assert off == pytest.approx(0.7) and dpsi == pytest.approx(0.2)
+    off, dpsi = K.process_init_state(sx, sy, 0.0, -0.4, -0.1)
+    assert off == pytest.approx(-0.4) and dpsi == pytest.approx(-0.1)

@@ -84,3 +84,74 @@ def test_feeds_the_path_qp(handle):
     want = O.solve_path(ref[0], got[0, :n], scal[0], st=O.OsqpSettings(eps_abs=1e-9, eps_rel=1e-9, max_iter=40000))
     assert np.abs(res["out"][0][:, 3:5] - want[-1]["out"][:, 3:5]).max() < 1e-6
     hp.close()
+
+
+def test_reference_states_and_initial_error(handle):
+    cs = [U.build(seed=s, n=10) for s in (20, 21, 22)]
+    max_s = np.array([30.0, 41.7, 18.3])
+    start = np.array([[c["ref"][0, 3] + 0.3, c["ref"][0, 4] - 0.2, c["ref"][0, 2] + 0.1] for c in cs])
+    ref, count, err = handle.reference_states(np.stack([c["tab"] for c in cs]), np.stack([c["ext"] for c in cs]), max_s, 400, start=start)
+    for q, c in enumerate(cs):
+        want = K.build_reference_from_spline(c["sx"], c["sy"], float(max_s[q]))
+        assert count[q] == len(want)
+        np.testing.assert_allclose(ref[q, :count[q]], want, rtol=0, atol=1e-11)       # pow / atan2: ocml vs libm
+        assert np.all(ref[q, count[q]:] == 0.0)
+        off, dpsi = K.process_init_state(c["sx"], c["sy"], *start[q])
+        assert err[q, 0] == pytest.approx(off, abs=1e-12) and err[q, 1] == pytest.approx(dpsi, abs=1e-12)
+    # fixed spacing, and a capacity smaller than the line needs: count still reports what the loop produces
+    ref2, count2, _ = handle.reference_states(cs[0]["tab"][None], cs[0]["ext"][None], max_s[:1], 50, dynamic=False)
+    want2 = K.build_reference_from_spline(cs[0]["sx"], cs[0]["sy"], 30.0, dynamic=False)
+    assert count2[0] == len(want2) == 100          # 100 additions of 0.3 give 30.000000000000004 > 30
+    np.testing.assert_allclose(ref2[0], want2[:50], rtol=0, atol=1e-11)
+
+
+def test_pipeline_spline_to_path_on_the_device(handle):
+    """spline coefficients -> reference states -> corridor bounds -> path QP with a waypoint count per scenario, all on the
+    device, against the same chain of oracles (reference call order: path_optimizer.cpp:110-161)."""
+    import torch
+    import pqp_oracle as O
+    dev = torch.device("cuda", 0)
+    cs = [U.build(seed=s, n=10) for s in (30, 31, 33)]
+    g = cs[0]["geom"]
+    B, n_max = len(cs), 128
+    max_s = np.array([24.0, 30.0, 36.0])
+    tab = torch.from_numpy(np.stack([c["tab"] for c in cs])).to(dev); ext = torch.from_numpy(np.stack([c["ext"] for c in cs])).to(dev)
+    dist = torch.from_numpy(np.ascontiguousarray(np.transpose(np.stack([c["dist"] for c in cs]), (0, 2, 1)))).to(dev)
+    start = np.array([[c["ref"][0, 3] + 0.1, c["ref"][0, 4] + 0.15, c["ref"][0, 2] - 0.05] for c in cs])
+    t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+    ref = torch.zeros((B, n_max, 5), dtype=torch.float64, device=dev); count = torch.zeros(B, dtype=torch.int32, device=dev)
+    err = torch.zeros((B, 2), dtype=torch.float64, device=dev)
+    bounds = torch.zeros((B, n_max, 6), dtype=torch.float64, device=dev); nv = torch.zeros(B, dtype=torch.int32, device=dev)
+    out = torch.zeros((B, n_max, 7), dtype=torch.float64, device=dev); status = torch.zeros(B, dtype=torch.int32, device=dev)
+    p = lambda x: capi.C.c_void_p(x.data_ptr())
+    hp = capi.Handle(capi.production_params(), device=0, max_batch=B, max_n=n_max)
+    lib, hh = hp.lib, hp._h
+    m = tab.shape[2]
+    ms, st_d, mo = t(max_s), t(start), torch.arange(B, dtype=torch.int32, device=dev)
+    assert lib.pqp_reference_states_device(hh, B, n_max, m, p(tab), p(ext), p(ms), p(st_d), 0.15, 0.3, 1, p(ref), p(count), p(err)) == 0
+    geom = _geom(g); prm = hp.corridor_params()
+    assert lib.pqp_corridor_bounds_device(hh, B, n_max, m, p(ref), p(count), p(tab), p(ext), p(dist), p(mo), capi.C.byref(geom), capi.C.byref(prm), p(bounds), p(nv)) == 0
+    hp.sync()
+    ref_h, nv_h, err_h = ref.cpu().numpy(), nv.cpu().numpy(), err.cpu().numpy()
+    scal = np.zeros((B, 6))
+    for q in range(B):
+        nq = int(nv_h[q])
+        scal[q] = (err_h[q, 0], err_h[q, 1], ref_h[q, 0, 1], ref_h[q, max(nq - 1, 0), 2], 1.0 if nq < int(count[q]) else 0.0, 35.0 * np.pi / 180.0)
+    hp.solve_var_device(B, n_max, nv, ref, bounds, t(scal), out, passes=1, status=status)
+    hp.sync()
+    out_h, bounds_h = out.cpu().numpy(), bounds.cpu().numpy()
+    solved = 0
+    for q, c in enumerate(cs):
+        want_ref = K.build_reference_from_spline(c["sx"], c["sy"], float(max_s[q]))
+        assert int(count[q]) == len(want_ref) <= n_max
+        want_b, want_nv, _ = K.update_bounds_improved(want_ref, c["sx"], c["sy"], c["dist"], g)
+        assert nv_h[q] == want_nv
+        nq = int(want_nv)
+        if nq < 2:
+            continue
+        assert status[q] == 1
+        want = O.solve_path(ref_h[q, :nq], bounds_h[q, :nq], scal[q], st=O.OsqpSettings(eps_abs=1e-9, eps_rel=1e-9, max_iter=40000))
+        assert np.abs(out_h[q, :nq, 3:5] - want[-1]["out"][:, 3:5]).max() < 1e-6
+        solved += 1
+    assert solved >= 2
+    hp.close()

@@ -81,3 +81,21 @@ def test_wave_local_phases_do_not_depend_on_wavefront_order(n):
     lib.pqp_emu_set_wave_order(1)
     assert (res[0]["iters"] == res[1]["iters"]).all()
     assert np.array_equal(res[0]["out"], res[1]["out"])
+
+
+def test_waypoint_count_per_qp():
+    """pqp_path_solve_var: a batch whose arrays have stride 80 but whose QPs have 80, 47, 64 and 1 waypoints gives, QP by QP,
+    what solving the truncated scenario on its own gives (a road cut short by an obstacle: reference_path_impl.cpp:225-228)."""
+    b = make_batch(4, 80, "varied")
+    counts = np.array([80, 47, 64, 1], dtype=np.int32)
+    prm = E.production()
+    r = E.solve(prm, b["ref"], b["bounds"], b["scal"], passes=1, n_of=counts)
+    for q, nq in enumerate(counts):
+        if nq < 2:
+            assert r["status"][q] == 0 and np.all(r["out"][q] == 0.0)
+            continue
+        alone = E.solve(prm, b["ref"][q:q + 1, :nq].copy(), b["bounds"][q:q + 1, :nq].copy(), b["scal"][q:q + 1], passes=1)
+        assert r["status"][q] == 1 and alone["status"][0] == 1
+        assert r["iters"][q] == alone["iters"][0]
+        assert np.array_equal(r["out"][q, :nq], alone["out"][0])
+        assert np.all(r["out"][q, nq:] == 0.0)            # rows beyond the QP's last waypoint are not written

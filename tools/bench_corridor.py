@@ -28,7 +28,7 @@ p = lambda t: capi.C.c_void_p(t.data_ptr())
 m = tab.shape[2]
 ms = []
 for _ in range(10):
-    assert h.lib.pqp_corridor_bounds_device(h._h, batch, n, m, p(ref), p(tab), p(ext), p(dist), p(map_of), capi.C.byref(geom), capi.C.byref(prm), p(bounds), p(nv)) == 0
+    assert h.lib.pqp_corridor_bounds_device(h._h, batch, n, m, p(ref), None, p(tab), p(ext), p(dist), p(map_of), capi.C.byref(geom), capi.C.byref(prm), p(bounds), p(nv)) == 0
     ms.append(h.last_kernel_ms())
 h.sync()
 k_ms = float(np.median(ms[2:]))
