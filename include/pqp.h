@@ -24,6 +24,7 @@
  *                                     src/data_struct/reference_path.cpp:61, reference_path_impl.cpp:177-312    pqp_corridor_bounds
  *   ReferencePathImpl::buildReferenceFromSpline  reference_path_impl.cpp:314-338, PathOptimizer::processInitState path_optimizer.cpp:73-85
  *                                                                                                         pqp_reference_states
+ *   tk::spline::set_points            src/tools/spline.cpp:161-249                                         pqp_spline_fit
  *
  * Conventions
  *   - plain C, no C++/torch types; all reals are IEEE fp64, all indices int32.
@@ -279,6 +280,15 @@ int pqp_reference_states_device(pqp_handle* h, int batch, int n_max, int m, cons
 int pqp_reference_states(pqp_handle* h, int batch, int n_max, int m, const double* spline, const double* spline_ext, const double* max_s,
                          const double* start, double ds_small, double ds_large, int dynamic, double* ref, int32_t* count,
                          double* init_err);
+
+/* ---- natural cubic spline through the knots ----------------------------------------------------------
+ * tk::spline::set_points  src/tools/spline.cpp:161-249 (+ band_matrix::lu_solve :69-148), as called on the smoothed reference line
+ * (tension_smoother.cpp:36-38, reference_path_smoother.cpp:58-59,574-576, reference_path_impl.cpp:349-350).
+ * s, x, y [batch][m] (s strictly increasing, m >= 3)  ->  spline [batch][9][m], spline_ext [batch][4] in the layout
+ * pqp_reference_states / pqp_corridor_bounds take.  Coefficients are the reference's bit for bit. */
+int pqp_spline_fit_device(pqp_handle* h, int batch, int m, const double* s, const double* x, const double* y, double* spline,
+                          double* spline_ext);
+int pqp_spline_fit(pqp_handle* h, int batch, int m, const double* s, const double* x, const double* y, double* spline, double* spline_ext);
 
 #ifdef __cplusplus
 }

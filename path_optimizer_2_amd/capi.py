@@ -53,7 +53,7 @@ EXPORTS = [
     "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_solve_var_device", "pqp_path_get_solution",
     "pqp_last_kernel_ms", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
     "pqp_post_smooth", "pqp_post_smooth_device", "pqp_corridor_default_params", "pqp_corridor_bounds", "pqp_corridor_bounds_device",
-    "pqp_reference_states", "pqp_reference_states_device",
+    "pqp_reference_states", "pqp_reference_states_device", "pqp_spline_fit", "pqp_spline_fit_device",
 ]
 
 _lib = None
@@ -103,6 +103,8 @@ def load_library(path=None):
                                         C.POINTER(PqpCorridorParams), vp, vp]
     for name in ("pqp_reference_states", "pqp_reference_states_device"):
         getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, vp]
+    for name in ("pqp_spline_fit", "pqp_spline_fit_device"):
+        getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     lib.pqp_path_solve_var_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     if path == LIB_PATH:
         _lib = lib
@@ -183,6 +185,14 @@ class Handle:
         for k, v in over.items():
             setattr(p, k, v)
         return p
+
+    def spline_fit(self, s, x, y):
+        """pqp_spline_fit (host arrays [B][m]) -> (spline [B][9][m], spline_ext [B][4])."""
+        s = np.ascontiguousarray(s, dtype=np.float64); x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+        B, m = s.shape
+        tab = np.zeros((B, 9, m)); ext = np.zeros((B, 4))
+        self._check(self.lib.pqp_spline_fit(self._h, B, m, _ptr(s), _ptr(x), _ptr(y), _ptr(tab), _ptr(ext)))
+        return tab, ext
 
     def reference_states(self, spline, spline_ext, max_s, n_max, start=None, ds_small=0.15, ds_large=0.3, dynamic=True):
         """pqp_reference_states (host arrays): spline [B][9][m], spline_ext [B][4], max_s [B], start [B][3] or None.

@@ -442,7 +442,7 @@ struct pqp_handle {
     DevBuf s_ref, s_lin, s_bounds, s_scal;      // staging for the host-pointer entry points
     DevBuf s_out, s_status, s_iters, s_info, s_a, s_p, s_l, s_u, s_idx;
     // smoother QPs: banded problem data + shared sparsity (cached per type and size) + staging
-    DevBuf b_pband, b_q, b_aval, b_lo, b_up, b_x, b_y, b_acol, b_trow, b_tslot, b_in[5], b_out[3], c_buf[7];
+    DevBuf b_pband, b_q, b_aval, b_lo, b_up, b_x, b_y, b_acol, b_trow, b_tslot, b_in[5], b_out[3], c_buf[7], sp_work;
     int b_struct_type = -1, b_struct_n = -1;
 };
 
@@ -488,7 +488,7 @@ int pqp_destroy(pqp_handle* h) {
                       &h->s_status, &h->s_iters, &h->s_info, &h->s_a, &h->s_p, &h->s_l, &h->s_u, &h->s_idx, &h->b_pband, &h->b_q, &h->b_aval,
                       &h->b_lo, &h->b_up, &h->b_x, &h->b_y, &h->b_acol, &h->b_trow, &h->b_tslot, &h->b_in[0], &h->b_in[1], &h->b_in[2],
                       &h->b_in[3], &h->b_in[4], &h->b_out[0], &h->b_out[1], &h->b_out[2], &h->c_buf[0], &h->c_buf[1], &h->c_buf[2],
-                      &h->c_buf[3], &h->c_buf[4], &h->c_buf[5], &h->c_buf[6]})
+                      &h->c_buf[3], &h->c_buf[4], &h->c_buf[5], &h->c_buf[6], &h->sp_work})
         b->release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1029,6 +1029,43 @@ int pqp_reference_states(pqp_handle* h, int batch, int n_max, int m, const doubl
     PQP_HIP(hipMemcpyAsync(ref, h->c_buf[0].p, b_ref, hipMemcpyDeviceToHost, h->stream));
     PQP_HIP(hipMemcpyAsync(count, h->c_buf[6].p, b_cnt, hipMemcpyDeviceToHost, h->stream));
     if (init_err && start) PQP_HIP(hipMemcpyAsync(init_err, h->c_buf[5].p, b_err, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipStreamSynchronize(h->stream));
+    return PQP_OK;
+}
+
+// ---- spline fit ---------------------------------------------------------------------------------------
+int pqp_spline_fit_device(pqp_handle* h, int batch, int m, const double* s, const double* x, const double* y, double* spline,
+                          double* spline_ext) {
+    if (!h || !s || !x || !y || !spline || !spline_ext || batch < 1 || m < 3)
+        return fail(PQP_ERR_INVALID, "pqp_spline_fit: bad argument (m >= 3: spline.cpp:164)");
+    PQP_HIP(hipSetDevice(h->device));
+    int rc;
+    if ((rc = h->sp_work.ensure((size_t)batch * 4 * m * 8))) return rc;
+    pqp::SplineFitArgs a;
+    a.batch = batch; a.m = m; a.s = s; a.vx = x; a.vy = y; a.spl = spline; a.spl_ext = spline_ext; a.work = h->sp_work.as<double>();
+    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(pqp::spline_fit_kernel, dim3((2 * batch + 63) / 64), dim3(64), 0, h->stream, a);
+    PQP_HIP(hipGetLastError());
+    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return PQP_OK;
+}
+
+int pqp_spline_fit(pqp_handle* h, int batch, int m, const double* s, const double* x, const double* y, double* spline, double* spline_ext) {
+    if (!h || !s || !x || !y || !spline || !spline_ext || batch < 1 || m < 3) return fail(PQP_ERR_INVALID, "pqp_spline_fit: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    const size_t b_in = (size_t)batch * m * 8, b_spl = (size_t)batch * 9 * m * 8, b_ext = (size_t)batch * 4 * 8;
+    const size_t sizes[5] = {b_in, b_in, b_in, b_spl, b_ext};
+    int rc;
+    for (int k = 0; k < 5; ++k) if ((rc = h->c_buf[k].ensure(sizes[k]))) return rc;
+    PQP_HIP(hipMemcpyAsync(h->c_buf[0].p, s, b_in, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[1].p, x, b_in, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[2].p, y, b_in, hipMemcpyHostToDevice, h->stream));
+    if ((rc = pqp_spline_fit_device(h, batch, m, h->c_buf[0].as<double>(), h->c_buf[1].as<double>(), h->c_buf[2].as<double>(),
+                                    h->c_buf[3].as<double>(), h->c_buf[4].as<double>())))
+        return rc;
+    PQP_HIP(hipMemcpyAsync(spline, h->c_buf[3].p, b_spl, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(spline_ext, h->c_buf[4].p, b_ext, hipMemcpyDeviceToHost, h->stream));
     PQP_HIP(hipStreamSynchronize(h->stream));
     return PQP_OK;
 }

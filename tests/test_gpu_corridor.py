@@ -155,3 +155,21 @@ def test_pipeline_spline_to_path_on_the_device(handle):
         solved += 1
     assert solved >= 2
     hp.close()
+
+
+def test_spline_fit_is_bit_exact(handle):
+    """tk::spline::set_points on the device: the coefficient table equals the restatement bit for bit (and the restatement
+    equals the reference build, tests/test_corridor_oracle.py)."""
+    rng = np.random.default_rng(5)
+    B, m = 6, 37
+    s = np.cumsum(rng.uniform(0.2, 3.0, (B, m)), axis=1)
+    x = np.cumsum(rng.normal(size=(B, m)), axis=1); y = np.cumsum(rng.normal(size=(B, m)), axis=1)
+    tab, ext = handle.spline_fit(s, x, y)
+    for q in range(B):
+        want_tab, want_ext = K.pack_spline(K.spline_fit(s[q], x[q]), K.spline_fit(s[q], y[q]))
+        assert np.array_equal(tab[q], want_tab)
+        assert np.array_equal(ext[q], want_ext)
+    # smallest legal size
+    tab3, ext3 = handle.spline_fit(s[:1, :3], x[:1, :3], y[:1, :3])
+    w3, e3 = K.pack_spline(K.spline_fit(s[0, :3], x[0, :3]), K.spline_fit(s[0, :3], y[0, :3]))
+    assert np.array_equal(tab3[0], w3) and np.array_equal(ext3[0], e3)
