@@ -951,7 +951,11 @@ int pqp_corridor_bounds_device(pqp_handle* h, int batch, int n, int m, const dou
     int threads = 64 * ((3 * n + 63) / 64);
     if (threads > 1024) threads = 1024;
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(pqp::corridor_bounds_kernel, dim3(batch), dim3(threads), 0, h->stream, a);
+    const size_t lds = pqp::CorridorLds{m, n}.total_bytes();
+    if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_corridor_bounds: scenario too large for one CU's LDS (about 9 m + 31 n doubles)");
+    if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::corridor_bounds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    threads = 1024;                  // the sample loops are strided: a full workgroup keeps more gathers in flight
+    hipLaunchKernelGGL(pqp::corridor_bounds_kernel, dim3(batch), dim3(threads), lds, h->stream, a);
     PQP_HIP(hipGetLastError());
     PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
@@ -999,7 +1003,10 @@ int pqp_reference_states_device(pqp_handle* h, int batch, int n_max, int m, cons
     a.batch = batch; a.n_max = n_max; a.m = m; a.spl = spline; a.spl_ext = spline_ext; a.max_s = max_s; a.start = start;
     a.ds_small = ds_small; a.ds_large = ds_large; a.dynamic = dynamic ? 1 : 0; a.ref = ref; a.count = count; a.init_err = init_err;
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(pqp::reference_states_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, a);
+    const size_t lds = ((size_t)9 * m + n_max) * 8;
+    if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_reference_states: 9 m + n_max doubles exceed one CU's LDS");
+    if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::reference_states_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(pqp::reference_states_kernel, dim3(batch), dim3(64), lds, h->stream, a);
     PQP_HIP(hipGetLastError());
     PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
