@@ -608,7 +608,7 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
                            const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters, double* info) {
     if (!h || !ref || !bounds || !scal || !out || batch < 1 || n < 2 || passes < 0)
         return fail(PQP_ERR_INVALID, "pqp_path_solve: bad argument");
-    if (n > 1024) return fail(PQP_ERR_CAPACITY, "pqp_path_solve: n > 1024 waypoints is not supported");
+    if (n > 512) return fail(PQP_ERR_CAPACITY, "pqp_path_solve: more than 512 waypoints per path (one lane per waypoint, 26 T + 152 doubles of LDS per QP)");
     PQP_HIP(hipSetDevice(h->device));
     if (warm && (h->warm_batch != batch || h->warm_n != n))
         return fail(PQP_ERR_INVALID, "pqp_path_solve: warm == 1 needs a previous solve with the same batch and n");
@@ -636,10 +636,9 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
         case 1: hipLaunchKernelGGL(pqp::path_solve_kernel<1>, dim3(batch), dim3(64), lds, h->stream, a); break;
         case 2: hipLaunchKernelGGL(pqp::path_solve_kernel<2>, dim3(batch), dim3(128), lds, h->stream, a); break;
         case 4: hipLaunchKernelGGL(pqp::path_solve_kernel<4>, dim3(batch), dim3(256), lds, h->stream, a); break;
-        case 8: hipLaunchKernelGGL(pqp::path_solve_kernel<8>, dim3(batch), dim3(512), lds, h->stream, a); break;
         default: {
-            PQP_HIP(hipFuncSetAttribute((const void*)pqp::path_solve_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(pqp::path_solve_kernel<16>, dim3(batch), dim3(1024), lds, h->stream, a);
+            PQP_HIP(hipFuncSetAttribute((const void*)pqp::path_solve_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(pqp::path_solve_kernel<8>, dim3(batch), dim3(512), lds, h->stream, a);
         }
     }
     PQP_HIP(hipGetLastError());

@@ -221,6 +221,21 @@ def test_golden_fixtures_through_the_hip_path(hip_lib):
         h.close()
 
 
+@pytest.mark.parametrize("n", [2, 3, 300, 512])
+def test_smallest_and_largest_paths(hip_lib, n):
+    """n = 2 is the smallest QP the reference can form (one transition); 512 waypoints is the engine's limit (8 wavefronts
+    per QP); 300 exercises a partly filled 512-lane workgroup."""
+    b = make_batch(2, n, "varied")
+    if n <= 3:
+        b["scal"][:, 4] = 1.0      # no end-heading row (as for a blocked road): one or two steps cannot turn the initial heading error
+    h = capi.Handle(_polished(), max_batch=2, max_n=n)
+    r = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    assert (r["status"] == 1).all()
+    ref = O.solve_path(b["ref"][0], b["bounds"][0], b["scal"][0], st=ORACLE_TIGHT)
+    assert np.abs(r["out"][0][:, 3:5] - ref[-1]["out"][:, 3:5]).max() < (5e-6 if n <= 300 else 5e-5)
+    h.close()
+
+
 def test_error_paths(hip_lib):
     h = capi.Handle(capi.default_params(hip_lib), max_batch=2, max_n=16)
     b = make_batch(2, 16)
@@ -228,4 +243,7 @@ def test_error_paths(hip_lib):
         h.solve(b["ref"], b["bounds"], b["scal"], passes=0, warm=True)       # warm without a previous solve
     with pytest.raises(capi.PqpError):
         h.pattern(1)
+    big = make_batch(1, 513)
+    with pytest.raises(capi.PqpError):
+        h.solve(big["ref"], big["bounds"], big["scal"], passes=0)           # more than 512 waypoints
     h.close()
