@@ -78,7 +78,8 @@ typedef enum pqp_status {
     PQP_STATUS_SOLVED = 1,         /* both residual tests passed (and, with polish on, the KKT-verified polish
                                       was accepted or ADMM reached 1e-10)             -> solve() == true  */
     PQP_STATUS_MAX_ITER = 2,       /* max_iter reached                                  -> solve() == false */
-    PQP_STATUS_NUMERICAL = 3       /* NaN/Inf in the iterates                           -> solve() == false */
+    PQP_STATUS_NUMERICAL = 3,      /* NaN/Inf in the iterates                           -> solve() == false */
+    PQP_STATUS_PRIMAL_INFEASIBLE = 4   /* OSQP's primal infeasibility certificate holds  -> solve() == false */
 } pqp_status;
 
 /* The scalars the path reads.  Defaults (pqp_default_params) are the reference's gflags defaults
@@ -130,6 +131,7 @@ typedef struct pqp_params {
     double polish_delta;              /* 1e-6  regularisation; active rows get penalty 1/delta */
     double polish_tol;                /* 1e-7  KKT acceptance tolerance of the polished point  */
     double polish_reseed_factor;      /* 1.0   */
+    double eps_prim_inf;              /* 1e-4  OSQP's primal infeasibility tolerance; <= 0: no certificate test */
     /* smoother QP weights (src/config/planning_flags.cpp:51-61) */
     double tension2_deviation_weight;        /* 0.005 */
     double tension2_curvature_weight;        /* 1     */

@@ -75,6 +75,8 @@ class OsqpSettings:
     adaptive_rho_interval: int = 100   # OSQP "auto" without profiling = 4*check_termination
     adaptive_rho_tolerance: float = 5.0
     check_termination: int = 25
+    eps_prim_inf: float = 1e-4     # OSQP default
+    eps_dual_inf: float = 1e-4     # OSQP default
 
 
 def constrain_angle(a):
@@ -373,7 +375,10 @@ def osqp_admm(P, q, A, l, u, st=None, warm_x=None, warm_y=None, rho_init=None):
     n_refactor = 0
     it = 0
     pri = dua = float("nan")
+    inf_u = us > OSQP_INFTY * MIN_SCALING
+    inf_l = ls < -OSQP_INFTY * MIN_SCALING
     for it in range(1, st.max_iter + 1):
+        x_prev, y_prev = x, y
         rhs = np.concatenate([st.sigma * x - qs, z - y / rv])
         sol = lu.solve(rhs)
         xt = sol[:n]
@@ -402,6 +407,26 @@ def osqp_admm(P, q, A, l, u, st=None, warm_x=None, warm_y=None, rho_init=None):
                 if pri <= eps_p and dua <= eps_d:
                     status = "solved"
                     break
+                # infeasibility certificates (OSQP paper section 3.4; osqp/src/auxil.c is_primal_infeasible / is_dual_infeasible)
+                # on the difference of the last two iterates, norms unscaled
+                dy = y - y_prev
+                dy = np.where(inf_u & inf_l, 0.0, np.where(inf_u, np.minimum(dy, 0.0), np.where(inf_l, np.maximum(dy, 0.0), dy)))
+                n_dy = np.max(np.abs(E * dy)) if m else 0.0
+                if n_dy > st.eps_prim_inf:
+                    lhs = float(np.sum(np.where(dy > 0, us * dy, 0.0)) + np.sum(np.where(dy < 0, ls * dy, 0.0)))
+                    if lhs < -st.eps_prim_inf * n_dy and np.max(np.abs(Dinv * (As.T @ dy))) < st.eps_prim_inf * n_dy:
+                        status = "primal_infeasible"
+                        break
+                dx = x - x_prev
+                n_dx = np.max(np.abs(D * dx))
+                if n_dx > st.eps_dual_inf and float(qs @ dx) < -c * st.eps_dual_inf * n_dx:
+                    if np.max(np.abs(Dinv * (Ps @ dx))) < c * st.eps_dual_inf * n_dx:
+                        Adx = Einv * (As @ dx)
+                        tol = st.eps_dual_inf * n_dx
+                        ok = np.all(np.where(inf_u, True, Adx < tol) & np.where(inf_l, True, Adx > -tol))
+                        if ok:
+                            status = "dual_infeasible"
+                            break
             if adapt:
                 pn = pri / (max(n_ax, n_z) + 1e-10)
                 dn = dua / (max(n_px, n_aty, n_q) + 1e-10)
@@ -451,6 +476,8 @@ def solve_path(ref, bounds, scal, prm=None, st=None, passes=1, lin0=None):
         r["out"] = out
         r["qp"] = (Pd, A, lo, up)
         res.append(r)
+        if r["status"] != "solved":       # solve() == false: optimizePath returns (path_optimizer.cpp:143-146,154-157)
+            break
         lin = out[:, 3:6].copy()          # input_path_ = first solution (base_solver.cpp:100)
         warm_x, warm_y, rho = r["x"], r["y"], r["rho"]
     return res

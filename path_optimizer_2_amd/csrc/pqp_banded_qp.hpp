@@ -79,7 +79,8 @@ struct BqLayout {
     PQP_HD int act() const { return up() + nc; }                   // polish: -1 / 0 / +1
     PQP_HD int zs() const { return act() + nc; }                   // polish: saved z
     PQP_HD int ys() const { return zs() + nc; }                    // polish: saved y
-    PQP_HD int red() const { return ys() + nc; }                   // [5][16] reduction scratch
+    PQP_HD int yp() const { return ys() + nc; }                    // multipliers one iteration before a termination check
+    PQP_HD int red() const { return yp() + nc; }                   // [5][16] reduction scratch
     PQP_HD int total() const { return red() + 128; }
 };
 
@@ -456,6 +457,30 @@ struct BandedQp {
         res[0] = a[0]; res[2] = a[1]; res[1] = b[0]; res[3] = b[1]; res[4] = b[2];
     }
 
+    // ---- primal infeasibility certificate on dy = y_k - y_{k-1} (OSQP paper 3.4; see pqp_path_lane.hpp::primal_infeasible) ----
+    PQP_HD bool primal_infeasible() {
+        double* dy = sh + L.yp();
+        const double* y = sh + L.y();
+        rows([&](int r) {
+            const double d = y[r] - dy[r];
+            const bool fr = sh[L.e2() + r] < 0.0, inf_u = sh[L.up() + r] > 1e19, inf_l = sh[L.lo() + r] < -1e19;
+            dy[r] = (fr || (inf_u && inf_l)) ? 0.0 : (inf_u ? fmin(d, 0.0) : (inf_l ? fmax(d, 0.0) : d));
+        });
+        double nm[2], lhs[1];
+        ctx.template reduce_max<2>(nm, [&](int t, double (&v)[2]) {
+            v[0] = 0.0; v[1] = 0.0;
+            for (int r = t; r < nc; r += T) v[0] = fmax(v[0], fabs(dy[r]));
+            for (int j = t; j < nv; j += T) v[1] = fmax(v[1], fabs(col_dot(j, dy)));
+        });
+        ctx.template reduce_sum<1>(lhs, [&](int t, double (&v)[1]) {
+            double acc = 0.0;
+            for (int r = t; r < nc; r += T) { const double d = dy[r]; acc += d > 0.0 ? sh[L.up() + r] * d : (d < 0.0 ? sh[L.lo() + r] * d : 0.0); }
+            v[0] = acc;
+        });
+        const double eps = A.prm.eps_prim_inf;
+        return cscale * nm[0] > eps && lhs[0] < -eps * nm[0] && nm[1] < eps * nm[0];
+    }
+
     // ---- polish (same scheme as pqp_path_lane.hpp) -------------------------------------------------------------
     // delta of the polish for these QPs: their equality rows carry the whole problem, and the multiplier update y += R (Ax - z)
     // has a round-off floor of eps/delta * |Ax|; at the path QP's 1e-6 that floor sits above the acceptance tolerance
@@ -540,6 +565,8 @@ struct BandedQp {
         double eps_scale = 1.0;
         int polish_gap = prm.polish_every, next_polish = prm.polish_every;
         for (it = 1; it <= prm.max_iter; ++it) {
+            if (prm.eps_prim_inf > 0.0 && prm.check_termination > 0 && (it % prm.check_termination) == 0)
+                rows([&](int r) { sh[L.yp() + r] = sh[L.y() + r]; });
             iterate();
             const bool check = prm.check_termination > 0 && (it % prm.check_termination) == 0;
             const bool adapt = prm.adaptive_rho && prm.adaptive_rho_interval > 0 && (it % prm.adaptive_rho_interval) == 0;
@@ -554,6 +581,8 @@ struct BandedQp {
                 if (converged) {
                     if (!prm.polish || eps_scale * fmax(prm.eps_abs, prm.eps_rel) < 1e-10) { status = PQP_STATUS_SOLVED; break; }
                     start_polish = true;
+                } else if (prm.eps_prim_inf > 0.0 && it > 1 && primal_infeasible()) {
+                    status = PQP_STATUS_PRIMAL_INFEASIBLE; break;
                 } else if (prm.polish && prm.polish_every > 0 && it >= next_polish) {
                     start_polish = true;
                     polish_gap *= 2;

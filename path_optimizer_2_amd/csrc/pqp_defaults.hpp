@@ -39,6 +39,7 @@ inline void default_params(pqp_params* p) {
     p->polish_reseed = 0;
     p->polish_diverge = 0;
     p->polish_reseed_factor = 1.0;
+    p->eps_prim_inf = 1e-4;
     p->polish_delta = 1e-6;
     p->polish_tol = 1e-7;
     p->tension2_deviation_weight = 0.005;           // planning_flags.cpp:57
@@ -51,7 +52,8 @@ inline void default_params(pqp_params* p) {
 
 // The engine's production setting on top of the defaults: ADMM to 1e-4, KKT-verified polish (every returned path is the exact
 // optimum of its QP), residual check / rho adaptation / polish attempt every 25 iterations, 2 refinement solves per active-set
-// round, at most max(8, n/5 - 8) rounds per attempt, pass 2 starts from pass 1's active set and equilibration, an attempt that gives up re-seeds ADMM with its best point.  Tuned on MI355X
+// round, at most max(8, n/5 - 8) rounds per attempt, pass 2 starts from pass 1's active set and equilibration, an attempt that gives up re-seeds ADMM with its best point, no
+// infeasibility certificate (set eps_prim_inf = 1e-4 to get OSQP's behaviour back).  Tuned on MI355X
 // (DESIGN.md section 6); bench.py, smoke() and the parity tests run this setting.
 inline void production_params(pqp_params* p) {
     default_params(p);
@@ -64,5 +66,7 @@ inline void production_params(pqp_params* p) {
     p->polish_warm_set = 2;
     p->polish_max_rounds = 0;                       // auto: max(8, n/5 - 8)
     p->polish_reseed = 1;
+    p->eps_prim_inf = 0.0;                          // the kernel variant without OSQP's infeasibility certificate: 12 % faster
+                                                    // iterations; an infeasible QP then ends with PQP_STATUS_MAX_ITER
 }
 }  // namespace pqp

@@ -56,6 +56,34 @@ __device__ __forceinline__ void wg_reduce(double (&v)[K], double* shp) {
     __syncthreads();
 }
 
+// Lane-less context + out-of-line evaluation of the infeasibility certificate (all data in LDS): nothing of it lives in the
+// registers of the ADMM loop.
+template <int NW>
+struct LaneLessCtx {
+    double* shp;
+    __device__ __forceinline__ int T() const { return 64 * NW; }
+    template <class F>
+    __device__ __forceinline__ void phase(F f) {
+        f((int)threadIdx.x);
+        __syncthreads();
+    }
+    template <int K, class F>
+    __device__ __forceinline__ void reduce_max(double (&out)[K], F f) {
+        f((int)threadIdx.x, out);
+        wg_reduce<NW, K, true>(out, shp);
+    }
+    template <int K, class F>
+    __device__ __forceinline__ void reduce_sum(double (&out)[K], F f) {
+        f((int)threadIdx.x, out);
+        wg_reduce<NW, K, false>(out, shp);
+    }
+};
+template <int NW>
+__device__ __noinline__ bool dev_certificate(double* sh, double fl, double rl, double kap, double eps, double cscale) {
+    LaneLessCtx<NW> c{sh};
+    return primal_certificate(c, sh, 64 * NW, fl, rl, kap, eps, cscale);
+}
+
 // Context whose lane state is a local struct (SROA -> registers).  A phase is the code between two workgroup
 // barriers (for a one-wave workgroup the barrier is only a wait on outstanding LDS traffic).
 template <int NW>
@@ -70,6 +98,9 @@ struct RegCtx {
         __syncthreads();
     }
     __device__ __forceinline__ long long clock() const { return (long long)wall_clock64(); }     // 100 MHz
+    __device__ __forceinline__ bool certificate(double* sh, int, double fl, double rl, double kap, double eps, double cscale) {
+        return dev_certificate<NW>(sh, fl, rl, kap, eps, cscale);
+    }
     // wave-local phase: LDS operations of one wavefront execute in program order, so lanes of the same wavefront see each
     // other's writes without a workgroup barrier; the fence only stops the compiler from moving LDS accesses across it
     template <class F>
@@ -95,12 +126,12 @@ struct RegCtx {
 // The rare, register-hungry part of the solver (assemble, Ruiz, factorisation, polish bookkeeping, unpack) runs
 // here, out of line, one function per operation: the lane state comes in through memory, lives in registers
 // inside, goes back through memory.  Whatever these functions spill never touches the ADMM loop.
-template <int NW, int OP>
+template <int NW, int OP, bool CERT = true>
 __device__ __noinline__ Uni cold_entry(const PathSolveArgs* args, int qp, double* shp, Lane* mem, Uni u, int i0, int i1, double d0) {
     RegCtx<NW> cctx;
     cctx.shp = shp;
     cctx.lane.s = mem->s;
-    PathQp<RegCtx<NW>> c(cctx, *args, qp);
+    PathQp<RegCtx<NW>, CERT> c(cctx, *args, qp);
     c.set_uni(u);
     c.do_cold(OP, i0, i1, d0);
     mem->s = cctx.lane.s;
@@ -116,6 +147,9 @@ struct DevCtx {
     double* shp;
     const PathSolveArgs* args;
     __device__ __forceinline__ long long clock() const { return (long long)wall_clock64(); }     // 100 MHz
+    __device__ __forceinline__ bool certificate(double* sh, int, double fl, double rl, double kap, double eps, double cscale) {
+        return dev_certificate<NW>(sh, fl, rl, kap, eps, cscale);
+    }
     __device__ __forceinline__ int T() const { return 64 * NW; }
     __device__ __forceinline__ double* sh() { return shp; }
     template <class F>
@@ -154,6 +188,7 @@ struct DevCtx {
             case COLD_BEGIN_PASS: u = cold_entry<NW, COLD_BEGIN_PASS>(args, pq.qp, shp, mem, pq.get_uni(), i0, i1, d0); break;
             case COLD_REFACTOR: u = cold_entry<NW, COLD_REFACTOR>(args, pq.qp, shp, mem, pq.get_uni(), i0, i1, d0); break;
             case COLD_END_PASS: u = cold_entry<NW, COLD_END_PASS>(args, pq.qp, shp, mem, pq.get_uni(), i0, i1, d0); break;
+            case COLD_CERT: u = cold_entry<NW, COLD_CERT>(args, pq.qp, shp, mem, pq.get_uni(), i0, i1, d0); break;
             default: u = cold_entry<NW, COLD_FINISH>(args, pq.qp, shp, mem, pq.get_uni(), i0, i1, d0); break;
         }
         copy_hot(lane, *mem);
@@ -165,7 +200,7 @@ struct DevCtx {
     }
 };
 
-template <int NW>
+template <int NW, bool CERT>
 __global__ void __launch_bounds__(64 * NW) path_solve_kernel(const PathSolveArgs args) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
 #ifndef PQP_MONOLITH
@@ -180,7 +215,7 @@ __global__ void __launch_bounds__(64 * NW) path_solve_kernel(const PathSolveArgs
 #endif
         ctx.shp = smem;
         ctx.args = &args;
-        PathQp<DevCtx<NW>> solver(ctx, args, qp);
+        PathQp<DevCtx<NW>, CERT> solver(ctx, args, qp);
         solver.run();
         __syncthreads();
     }
@@ -632,15 +667,18 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     a.wsave = h->wsave.as<double>();
     const size_t lds = (size_t)pqp::ShLayout{64 * nw}.total() * 8;
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    // two variants of every kernel: with and without OSQP's primal infeasibility certificate (prm.eps_prim_inf > 0)
+    const bool cert = h->prm.eps_prim_inf > 0.0;
+    const void* fn = nullptr;
     switch (nw) {
-        case 1: hipLaunchKernelGGL(pqp::path_solve_kernel<1>, dim3(batch), dim3(64), lds, h->stream, a); break;
-        case 2: hipLaunchKernelGGL(pqp::path_solve_kernel<2>, dim3(batch), dim3(128), lds, h->stream, a); break;
-        case 4: hipLaunchKernelGGL(pqp::path_solve_kernel<4>, dim3(batch), dim3(256), lds, h->stream, a); break;
-        default: {
-            PQP_HIP(hipFuncSetAttribute((const void*)pqp::path_solve_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(pqp::path_solve_kernel<8>, dim3(batch), dim3(512), lds, h->stream, a);
-        }
+        case 1: fn = cert ? (const void*)pqp::path_solve_kernel<1, true> : (const void*)pqp::path_solve_kernel<1, false>; break;
+        case 2: fn = cert ? (const void*)pqp::path_solve_kernel<2, true> : (const void*)pqp::path_solve_kernel<2, false>; break;
+        case 4: fn = cert ? (const void*)pqp::path_solve_kernel<4, true> : (const void*)pqp::path_solve_kernel<4, false>; break;
+        default: fn = cert ? (const void*)pqp::path_solve_kernel<8, true> : (const void*)pqp::path_solve_kernel<8, false>; break;
     }
+    if (lds > 64 * 1024) PQP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void* kargs[] = {(void*)&a};
+    PQP_HIP(hipLaunchKernel(fn, dim3(batch), dim3(64 * nw), kargs, lds, h->stream));
     PQP_HIP(hipGetLastError());
     PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;

@@ -275,6 +275,8 @@ struct EndRows {
     double act[2];          // polish: -1 lower-active, +1 upper-active, 0 inactive
     double sz[2], sy[2];    // ADMM state parked while a polish is tried
     double by[2];           // multipliers of the best polished point of the current attempt
+    double yp[2];           // y_k - y_{k-1} of the last iteration (infeasibility certificate)
+    double pad[6];
 };
 
 // shared-memory layout in doubles, T = threads per QP = padded number of waypoints.  The per-iteration exchange
@@ -291,9 +293,17 @@ struct ShLayout {
     // persistent
     PQP_HD int lin() const { return 21 * T; }               // [T][3] linearisation point / first-iteration dz
     PQP_HD int sk() const { return 24 * T; }                // [T][2] s, k_ref
-    PQP_HD int end() const { return 26 * T; }               // EndRows (24 doubles)
-    PQP_HD int red() const { return 26 * T + 24; }          // reduction scratch [8][16]
-    PQP_HD int total() const { return 26 * T + 24 + 128; }
+    PQP_HD int end() const { return 26 * T; }               // EndRows (32 doubles)
+    PQP_HD int red() const { return 26 * T + 32; }          // reduction scratch [8][16]
+    PQP_HD int total() const { return 26 * T + 32 + 128; }
+    // y_k - y_{k-1} of the last iteration, [T][6] (infeasibility certificate): lives in the part of the factor-time buffer
+    // the iteration does not use; every iteration rewrites it, and a check never follows a factorisation directly
+    PQP_HD int yprev() const { return 12 * T; }
+    // pass constants of the lanes staged for the certificate (free at a termination check: CR buffers, tail of the factor
+    // buffer, linearisation point): [T][9] a(6) bT(3), [T][3] flags lo0 lo1, [T][3] up0 up1 -
+    PQP_HD int stageA() const { return 3 * T; }
+    PQP_HD int stageB() const { return 18 * T; }
+    PQP_HD int stageC() const { return 21 * T; }
 };
 
 // diagonal of P by variable slot (base_solver.cpp:123-143); dummy variables (padding waypoints, v of waypoint 0,
@@ -312,19 +322,101 @@ PQP_HD double cost_diag(const pqp_params& prm, int flags, int k) {
 PQP_HD double coef_front(const pqp_params& prm, int flags) { return ((flags & F_REAL) && (flags & F_PRECISE)) ? prm.front_length : 0.0; }
 PQP_HD double coef_rear(const pqp_params& prm, int flags) { return ((flags & F_REAL) && (flags & F_PRECISE)) ? prm.rear_length : 0.0; }
 
+// ---------------------------------------------------------------------------------------------------------
+// primal infeasibility certificate from LDS (see PathQp::primal_infeasible).  LC: lane-less context with T(),
+// phase(f(t)), reduce_max<K>(out, f(t, v)), reduce_sum<K>(out, f(t, v)).
+//   dy            sh[yprev]  [T][6]   y_k - y_{k-1} (rows T0 T1 T2 K F R), EndRows::yp for the two end rows
+//   staged lanes  sh[stageA/B/C]      a(6) bT(3) | flags lo0 lo1 | up0 up1
+// ---------------------------------------------------------------------------------------------------------
+template <class LC>
+PQP_HD bool primal_certificate(LC& c, double* sh, int T, double front_length, double rear_length, double kap, double eps, double cscale) {
+    const ShLayout L{T};
+    EndRows* er = reinterpret_cast<EndRows*>(sh + L.end());
+    c.phase([&](int t) {        // project dy on the polar of the recession cone of [l, u] (in place); message A_in' dyT to the previous waypoint
+        double* dy = sh + L.yprev() + 6 * t;
+        const double* pa = sh + L.stageA() + 9 * t;
+        const double* pb = sh + L.stageB() + 3 * t;
+        const double* pc = sh + L.stageC() + 3 * t;
+        const int flags = (int)pb[0];
+        const bool real = flags & F_REAL;
+        const double lo[3] = {real ? -kap : 0.0, pb[1], pb[2]}, up[3] = {real ? kap : 0.0, pc[0], pc[1]};
+        for (int k = 0; k < 3; ++k) {
+            const double d = dy[3 + k];
+            const bool fr = flags & (F_FREE0 << k), inf_u = up[k] > 1e19, inf_l = lo[k] < -1e19;
+            dy[3 + k] = (fr || (inf_u && inf_l)) ? 0.0 : (inf_u ? fmin(d, 0.0) : (inf_l ? fmax(d, 0.0) : d));
+        }
+        sh[L.bufG() + 3 * t + 0] = pa[0] * dy[0] + pa[2] * dy[1];
+        sh[L.bufG() + 3 * t + 1] = pa[1] * dy[0] + pa[3] * dy[1];
+        sh[L.bufG() + 3 * t + 2] = pa[4] * dy[1] + ((flags & F_PREV) ? dy[2] : 0.0);
+        if (flags & F_LAST) {
+            for (int k = 0; k < 2; ++k) {
+                const double d = er->yp[k];
+                const bool inf_u = er->up[k] > 1e19, inf_l = er->lo[k] < -1e19;
+                er->yp[k] = (er->rb[k] < 0.0 || (inf_u && inf_l)) ? 0.0 : (inf_u ? fmin(d, 0.0) : (inf_l ? fmax(d, 0.0) : d));
+            }
+        }
+    });
+    double nm[2], lhs[1];
+    c.template reduce_max<2>(nm, [&](int t, double (&v)[2]) {
+        const double* dy = sh + L.yprev() + 6 * t;
+        const double* pa = sh + L.stageA() + 9 * t;
+        const int flags = (int)sh[L.stageB() + 3 * t];
+        const bool real = flags & F_REAL, precise = flags & F_PRECISE;
+        const double cf = (real && precise) ? front_length : 0.0, cr = (real && precise) ? rear_length : 0.0;
+        double gn[3];
+        for (int k = 0; k < 3; ++k) gn[k] = (t + 1 < T) ? sh[L.bufG() + 3 * (t + 1) + k] : 0.0;
+        double de0 = 0.0, de1 = 0.0;
+        if (flags & F_LAST) { de0 = er->yp[0]; de1 = er->yp[1]; }
+        double at[6];
+        at[0] = -dy[0] + gn[0] + dy[4] + dy[5] + de0;
+        at[1] = -dy[1] + gn[1] + cf * dy[4] + cr * dy[5] + de1;
+        at[2] = -dy[2] + gn[2] + dy[3];
+        at[3] = pa[5] * dy[2];
+        at[4] = dy[4];
+        at[5] = dy[5];
+        const bool colreal[6] = {real, real, real, (flags & F_PREV) != 0, real, real && precise};
+        double n_dy = 0.0, n_at = 0.0;
+        for (int k = 0; k < 6; ++k) {
+            n_dy = fmax(n_dy, real ? fabs(dy[k]) : 0.0);
+            n_at = fmax(n_at, colreal[k] ? fabs(at[k]) : 0.0);
+        }
+        v[0] = fmax(n_dy, fmax(fabs(de0), fabs(de1)));
+        v[1] = n_at;
+    });
+    c.template reduce_sum<1>(lhs, [&](int t, double (&v)[1]) {
+        const double* dy = sh + L.yprev() + 6 * t;
+        const double* pa = sh + L.stageA() + 9 * t;
+        const double* pb = sh + L.stageB() + 3 * t;
+        const double* pc = sh + L.stageC() + 3 * t;
+        const int flags = (int)pb[0];
+        double acc = 0.0;
+        if (flags & F_REAL) {
+            for (int k = 0; k < 3; ++k) acc += pa[6 + k] * dy[k];                       // l = u = b on the transition rows
+            const double lo[3] = {-kap, pb[1], pb[2]}, up[3] = {kap, pc[0], pc[1]};
+            for (int k = 0; k < 3; ++k) { const double d = dy[3 + k]; acc += d > 0.0 ? up[k] * d : (d < 0.0 ? lo[k] * d : 0.0); }
+        }
+        if (flags & F_LAST)
+            for (int k = 0; k < 2; ++k) { const double d = er->yp[k]; acc += d > 0.0 ? er->up[k] * d : (d < 0.0 ? er->lo[k] * d : 0.0); }
+        v[0] = acc;
+    });
+    return cscale * nm[0] > eps && lhs[0] < -eps * nm[0] && nm[1] < eps * nm[0];
+}
+
 // uniform (per-QP) solver scalars; handed by value across the hot / cold boundary
 struct Uni {
     double rho, cscale, kap, alpha;
     int kkt_solves;
     int factors;
     int polishing;
+    int cert;
 };
 // cold operations (rare, register-hungry): executed out of line on a memory-resident copy of the lane state
 enum ColdOp : int {
     COLD_BEGIN_PASS = 0,     // i0 = pass index, i1 = have_warm: [load, warm-load], assemble, Ruiz, start rows, factor
     COLD_REFACTOR = 1,       // i0 = RefactorKind, d0 = parameter: penalty change + factor
     COLD_END_PASS = 2,       // i0 = polish accepted: [polish_end(true)], unpack
-    COLD_FINISH = 3          // store the warm state
+    COLD_FINISH = 3,         // store the warm state
+    COLD_CERT = 4            // primal infeasibility certificate on the last dy -> PathQp::cert_
 };
 enum RefactorKind : int { RF_RESCALE = 0 /* d0 = ratio */, RF_POLISH_BEGIN = 1, RF_POLISH_UPDATE = 2 /* d0 = threshold */, RF_POLISH_REJECT = 3 };
 
@@ -337,7 +429,10 @@ enum RefactorKind : int { RF_RESCALE = 0 /* d0 = ratio */, RF_POLISH_BEGIN = 1, 
 //   template<int K,F> void reduce_max/sum(double (&out)[K], F f)   f(t, Lane&, double (&v)[K])
 //   void cold(PathQp&, op, i0, i1, d0)    run do_cold() (possibly out of line)
 // =======================================================================================================
-template <class Ctx>
+// CERT: compile the primal infeasibility certificate in.  It is a template parameter because its mere presence in the kernel
+// (one more cold operation + six LDS stores per iteration) costs the ADMM iteration 12 % through register allocation;
+// the launcher picks the variant from prm.eps_prim_inf > 0.
+template <class Ctx, bool CERT = true>
 struct PathQp {
     Ctx& ctx;
     const PathSolveArgs& A;
@@ -350,11 +445,12 @@ struct PathQp {
     // uniform per-QP scalars
     double rho, cscale, kap, alpha_;
     bool polishing_;
+    bool cert_;               // result of the last COLD_CERT
     int kkt_solves_;          // iterate() executions: ADMM iterations + polish refinement solves
     int factors_;             // factor() executions
 
     PQP_HD PathQp(Ctx& c, const PathSolveArgs& a, int q)
-        : ctx(c), A(a), qp(q), stride(a.n), n(a.n_of ? (a.n_of[q] < a.n ? a.n_of[q] : a.n) : a.n), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false), kkt_solves_(0), factors_(0) {}
+        : ctx(c), A(a), qp(q), stride(a.n), n(a.n_of ? (a.n_of[q] < a.n ? a.n_of[q] : a.n) : a.n), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false), cert_(false), kkt_solves_(0), factors_(0) {}
 
     PQP_HD EndRows* end_rows() const { return reinterpret_cast<EndRows*>(sh + L.end()); }
 
@@ -1094,12 +1190,19 @@ struct PathQp {
             double zT[3], zI[3];
             rows_of(S, Xp, xt, zT, zI);
             _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = alpha * xt[k] + (1.0 - alpha) * S.x[k];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) S.yT[k] += S.rhoT[k] * alpha * (zT[k] - S.bT[k]);
+            double* dyp = sh + L.yprev() + 6 * t;       // y_k - y_{k-1} of this iteration, for the infeasibility certificate
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                const double d = S.rhoT[k] * alpha * (zT[k] - S.bT[k]);
+                S.yT[k] += d;
+                if (CERT) dyp[k] = d;
+            }
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                 const double zh = alpha * zI[k] + (1.0 - alpha) * S.zI[k];
                 const double v = zh + S.yI[k] * S.rinvI[k];
                 const double zn = fmin(fmax(v, box_lo(S, k)), box_up(S, k));
-                S.yI[k] += S.rhoI[k] * (zh - zn);
+                const double d = S.rhoI[k] * (zh - zn);
+                S.yI[k] += d;
+                if (CERT) dyp[3 + k] = d;
                 S.zI[k] = zn;
             }
             if (S.flags & F_LAST) {
@@ -1114,7 +1217,9 @@ struct PathQp {
                         eup = er->act[k] != 0.0 ? bnd : kInfty;
                     }
                     const double zn = fmin(fmax(v, elo), eup);
-                    er->y[k] += er->rho[k] * (zh - zn);
+                    const double d = er->rho[k] * (zh - zn);
+                    er->y[k] += d;
+                    if (CERT) er->yp[k] = d;
                     er->z[k] = zn;
                 }
             }
@@ -1175,6 +1280,30 @@ struct PathQp {
             v[3] = nd;
             v[4] = bad;
         });
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // primal infeasibility certificate (OSQP paper section 3.4; osqp/src/auxil.c is_primal_infeasible), evaluated at a
+    // termination check on dy = y_k - y_{k-1}:   ||A' dy|| <= eps ||dy||   and   u'(dy)+ + l'(dy)- <= -eps ||dy||.
+    // In the scaled variables OSQP uses all three quantities carry the same factor c, so the test reads the same in
+    // unscaled ones; only "||dy|| is not zero" needs c.  The path QP has q = 0, so the dual certificate (q'dx < 0) can
+    // never fire and is not evaluated.
+    // ---------------------------------------------------------------------------------------------
+    // The certificate itself is evaluated by primal_certificate() below from LDS only: the lanes first stage the pass
+    // constants it needs.  Keeping the lane struct out of that code (on the device it is an out-of-line function) keeps its
+    // register needs out of the ADMM loop - inline, it cost the loop 100 spilled VGPRs and 40 % of its speed.
+    PQP_HD bool primal_infeasible() {
+        ctx.phase([&](int t, Lane& ln) {
+            const Slot& S = ln.s;
+            double* pa = sh + L.stageA() + 9 * t;
+            double* pb = sh + L.stageB() + 3 * t;
+            double* pc = sh + L.stageC() + 3 * t;
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) pa[k] = S.a[k];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) pa[6 + k] = S.bT[k];
+            pb[0] = (double)S.flags; pb[1] = S.lo[0]; pb[2] = S.lo[1];
+            pc[0] = S.up[0]; pc[1] = S.up[1]; pc[2] = 0.0;
+        });
+        return ctx.certificate(sh, T, A.prm.front_length, A.prm.rear_length, kap, A.prm.eps_prim_inf, cscale);
     }
 
     // ---------------------------------------------------------------------------------------------
@@ -1269,8 +1398,8 @@ struct PathQp {
         });
     }
 
-    PQP_HD Uni get_uni() const { return Uni{rho, cscale, kap, alpha_, kkt_solves_, factors_, polishing_ ? 1 : 0}; }
-    PQP_HD void set_uni(const Uni& u) { rho = u.rho; cscale = u.cscale; kap = u.kap; alpha_ = u.alpha; kkt_solves_ = u.kkt_solves; factors_ = u.factors; polishing_ = u.polishing != 0; }
+    PQP_HD Uni get_uni() const { return Uni{rho, cscale, kap, alpha_, kkt_solves_, factors_, polishing_ ? 1 : 0, cert_ ? 1 : 0}; }
+    PQP_HD void set_uni(const Uni& u) { rho = u.rho; cscale = u.cscale; kap = u.kap; alpha_ = u.alpha; kkt_solves_ = u.kkt_solves; factors_ = u.factors; polishing_ = u.polishing != 0; cert_ = u.cert != 0; }
 
     // The cold side of the solver.  On the device this runs inside a __noinline__ function on a copy of the lane
     // state that lives in memory (DevCtx::cold), so its register needs never leak into the ADMM loop.
@@ -1314,6 +1443,8 @@ struct PathQp {
                 polishing_ = false; alpha_ = prm.alpha;
             }
             factor();
+        } else if (op == COLD_CERT) {
+            if (CERT) cert_ = primal_infeasible();
         } else if (op == COLD_END_PASS) {
             if (i0) {
                 polish_end(true);
@@ -1371,9 +1502,10 @@ struct PathQp {
             {
                 PQP_TIC;
                 ctx.cold(*this, op, i0, i1, d0);
-                PQP_TOC(op == COLD_BEGIN_PASS ? 0 : op == COLD_REFACTOR ? (i0 == RF_RESCALE ? 1 : 2) : 3);
+                PQP_TOC(op == COLD_BEGIN_PASS ? 0 : op == COLD_REFACTOR ? (i0 == RF_RESCALE ? 1 : 2) : op == COLD_CERT ? 5 : 3);
             }
             if (op == COLD_FINISH) break;
+            if (CERT && op == COLD_CERT && cert_) { status = PQP_STATUS_PRIMAL_INFEASIBLE; op = COLD_END_PASS; i0 = 0; continue; }
             if (op == COLD_END_PASS) {
                 last_iters = it;
                 total_iters += it;
@@ -1456,6 +1588,9 @@ struct PathQp {
                     }
                     if (it >= prm.max_iter) { op = COLD_END_PASS; i0 = 0; break; }
                     if (refactor) { op = COLD_REFACTOR; i0 = RF_RESCALE; break; }
+                    // not converged, nothing else due at this check: is the problem infeasible?  (a cold operation: evaluated
+                    // inside this loop the test costs the ADMM iteration 14 % through register pressure alone)
+                    if (CERT && check && prm.eps_prim_inf > 0.0 && it > 1) { op = COLD_CERT; break; }
                 } else {
                     // KKT acceptance test of the polished point (OSQP paper 4.2 + verification)
                     const double tol = prm.polish_tol;

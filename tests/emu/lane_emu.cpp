@@ -34,6 +34,24 @@ struct HostCtx {
         }
     }
     template <class PQ> void cold(PQ& pq, int op, int i0, int i1, double d0) { pq.do_cold(op, i0, i1, d0); }
+    // lane-less context of the infeasibility certificate
+    struct LaneLess {
+        int T_;
+        int T() const { return T_; }
+        template <class F> void phase(F f) { for (int t = 0; t < T_; ++t) f(t); }
+        template <int K, class F> void reduce_max(double (&out)[K], F f) {
+            for (int k = 0; k < K; ++k) out[k] = 0.0;
+            for (int t = 0; t < T_; ++t) { double v[K]; f(t, v); for (int k = 0; k < K; ++k) out[k] = out[k] > v[k] ? out[k] : v[k]; }
+        }
+        template <int K, class F> void reduce_sum(double (&out)[K], F f) {
+            for (int k = 0; k < K; ++k) out[k] = 0.0;
+            for (int t = 0; t < T_; ++t) { double v[K]; f(t, v); for (int k = 0; k < K; ++k) out[k] += v[k]; }
+        }
+    };
+    bool certificate(double* sh, int T, double fl, double rl, double kap, double eps, double cscale) {
+        LaneLess c{T};
+        return pqp::primal_certificate(c, sh, T, fl, rl, kap, eps, cscale);
+    }
     template <int K, class F> void reduce_max(double (&out)[K], F f) {
         for (int k = 0; k < K; ++k) out[k] = 0.0;
         for (int t = 0; t < T_; ++t) { double v[K]; f(t, lanes[t], v); for (int k = 0; k < K; ++k) out[k] = out[k] > v[k] ? out[k] : v[k]; }
@@ -66,8 +84,8 @@ extern "C" int pqp_emu_path_solve(const pqp_params* prm, int batch, int n, const
     a.n_of = g_n_of;
     for (int q = 0; q < batch; ++q) {
         HostCtx ctx(T);
-        pqp::PathQp<HostCtx> s(ctx, a, q);
-        s.run();
+        if (prm->eps_prim_inf > 0.0) { pqp::PathQp<HostCtx, true> s(ctx, a, q); s.run(); }       // the two variants the launcher picks from
+        else { pqp::PathQp<HostCtx, false> s(ctx, a, q); s.run(); }
     }
     return 0;
 }

@@ -247,3 +247,21 @@ def test_error_paths(hip_lib):
     with pytest.raises(capi.PqpError):
         h.solve(big["ref"], big["bounds"], big["scal"], passes=0)           # more than 512 waypoints
     h.close()
+
+
+def test_primal_infeasibility_certificate_on_the_gpu(hip_lib):
+    """OSQP's certificate (kernel variant with eps_prim_inf > 0, the default parameters): a start curvature outside the
+    curvature box ends with PQP_STATUS_PRIMAL_INFEASIBLE at the same termination check as the restatement; the production
+    variant (no certificate) runs the same QP to max_iter; feasible neighbours are not affected."""
+    b = make_batch(4, 80)
+    b["scal"][2, 2] = 0.5
+    h = capi.Handle(capi.default_params(hip_lib), max_batch=4, max_n=80)
+    r = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    assert list(r["status"]) == [1, 1, 4, 1]
+    ref = O.solve_path(b["ref"][2], b["bounds"][2], b["scal"][2])
+    assert [x["status"] for x in ref] == ["primal_infeasible"] and r["iters"][2] == ref[0]["iters"]
+    h.close()
+    h2 = capi.Handle(capi.production_params(max_iter=300), max_batch=4, max_n=80)
+    r2 = h2.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    assert list(r2["status"]) == [1, 1, 2, 1]
+    h2.close()

@@ -99,3 +99,18 @@ def test_waypoint_count_per_qp():
         assert r["iters"][q] == alone["iters"][0]
         assert np.array_equal(r["out"][q, :nq], alone["out"][0])
         assert np.all(r["out"][q, nq:] == 0.0)            # rows beyond the QP's last waypoint are not written
+
+
+def test_primal_infeasibility_certificate():
+    """A start curvature outside the curvature box makes the QP infeasible (rows 2 and 3N pin and box the same variable).
+    OSQP's certificate on y_k - y_{k-1} fires at the same termination check as in the restatement, instead of 4000 iterations."""
+    b = make_batch(3, 80)
+    b["scal"][1, 2] = 0.5                       # |k0| > tan(35 deg) / 2.5
+    for prm in (E.params(), E.production(eps_prim_inf=1e-4)):       # (the production setting ships without the certificate)
+        r = E.solve(prm, b["ref"], b["bounds"], b["scal"], passes=1)
+        assert list(r["status"]) == [1, 4, 1]
+    ref = O.solve_path(b["ref"][1], b["bounds"][1], b["scal"][1])
+    assert [x["status"] for x in ref] == ["primal_infeasible"]
+    assert E.solve(E.params(), b["ref"], b["bounds"], b["scal"])["iters"][1] == ref[0]["iters"]
+    off = E.solve(E.params(eps_prim_inf=0.0, max_iter=300), b["ref"], b["bounds"], b["scal"])
+    assert off["status"][1] == 2 and off["iters"][1] == 300        # without the test: max_iter
