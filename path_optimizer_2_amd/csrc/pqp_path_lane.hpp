@@ -450,7 +450,11 @@ struct PathQp {
     int factors_;             // factor() executions
 
     PQP_HD PathQp(Ctx& c, const PathSolveArgs& a, int q)
-        : ctx(c), A(a), qp(q), stride(a.n), n(a.n_of ? (a.n_of[q] < a.n ? a.n_of[q] : a.n) : a.n), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false), cert_(false), kkt_solves_(0), factors_(0) {}
+        : ctx(c), A(a), qp(q), stride(a.n), n(count_of(a, q)), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false), cert_(false), kkt_solves_(0), factors_(0) {}
+
+    // waypoints of QP q; fewer than 2: nothing to optimise (a road blocked at the first waypoints; the reference does not get
+    // this far) - the caller skips the QP with status PQP_STATUS_UNSOLVED instead of constructing a solver
+    PQP_HD static int count_of(const PathSolveArgs& a, int q) { return a.n_of ? (a.n_of[q] < a.n ? a.n_of[q] : a.n) : a.n; }
 
     PQP_HD EndRows* end_rows() const { return reinterpret_cast<EndRows*>(sh + L.end()); }
 
@@ -1467,15 +1471,6 @@ struct PathQp {
         const pqp_params& prm = A.prm;
         int total_iters = 0, last_iters = 0, status = PQP_STATUS_UNSOLVED, polished = 0;
         // active-set rounds per polish attempt; <= 0: sized to the path (long paths need more rounds, short ones pay for them)
-        if (n < 2) {        // nothing to optimise (a road blocked at the first waypoints): the reference does not get this far
-            ctx.phase([&](int t, Lane&) {
-                if (t == 0) {
-                    if (A.status) A.status[qp] = PQP_STATUS_UNSOLVED;
-                    if (A.iters) A.iters[qp] = 0;
-                }
-            });
-            return;
-        }
         const int auto_rounds = n / 5 - 8;
         const int max_rounds = prm.polish_max_rounds > 0 ? prm.polish_max_rounds : (auto_rounds > 8 ? auto_rounds : 8);
         double res[5] = {0, 0, 0, 0, 0};

@@ -83,6 +83,11 @@ extern "C" int pqp_emu_path_solve(const pqp_params* prm, int batch, int n, const
     a.prm = *prm;
     a.n_of = g_n_of;
     for (int q = 0; q < batch; ++q) {
+        if (pqp::PathQp<HostCtx, true>::count_of(a, q) < 2) {
+            if (status) status[q] = PQP_STATUS_UNSOLVED;
+            if (iters) iters[q] = 0;
+            continue;
+        }
         HostCtx ctx(T);
         if (prm->eps_prim_inf > 0.0) { pqp::PathQp<HostCtx, true> s(ctx, a, q); s.run(); }       // the two variants the launcher picks from
         else { pqp::PathQp<HostCtx, false> s(ctx, a, q); s.run(); }
