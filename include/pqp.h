@@ -25,6 +25,7 @@
  *   ReferencePathImpl::buildReferenceFromSpline  reference_path_impl.cpp:314-338, PathOptimizer::processInitState path_optimizer.cpp:73-85
  *                                                                                                         pqp_reference_states
  *   tk::spline::set_points            src/tools/spline.cpp:161-249                                         pqp_spline_fit
+ *   ReferencePathSmoother::graphSearchDp  src/reference_path_smoother/reference_path_smoother.cpp:142-295   pqp_dp_corridor
  *
  * Conventions
  *   - plain C, no C++/torch types; all reals are IEEE fp64, all indices int32.
@@ -291,6 +292,27 @@ int pqp_reference_states(pqp_handle* h, int batch, int n_max, int m, const doubl
 int pqp_spline_fit_device(pqp_handle* h, int batch, int m, const double* s, const double* x, const double* y, double* spline,
                           double* spline_ext);
 int pqp_spline_fit(pqp_handle* h, int batch, int m, const double* s, const double* x, const double* y, double* spline, double* spline_ext);
+
+/* ---- layered DP corridor search --------------------------------------------------------------------
+ * ReferencePathSmoother::graphSearchDp  src/reference_path_smoother/reference_path_smoother.cpp:142-295 (+ calculateCostAt :107-140),
+ * between the smoother QP and the postSmooth QP: its outputs layers_s / lb / ub / vehicle_l are the inputs of pqp_post_smooth. */
+typedef struct pqp_dp_params {
+    double lateral_range;            /* 10.0  FLAGS_search_lateral_range        planning_flags.cpp:38 */
+    double longitudinal_spacing;     /* 1.5   FLAGS_search_longitudial_spacing  :40 */
+    double lateral_spacing;          /* 0.6   FLAGS_search_lateral_spacing      :42 */
+    double car_width;                /* 2.0   :10  (search_threshold = car_width / 2 + 0.2) */
+} pqp_dp_params;
+void pqp_dp_default_params(pqp_dp_params* p);
+/* spline, spline_ext, dist, map_of, geom as for pqp_corridor_bounds; length [batch] = reference->getLength(); start [batch][3] = vehicle
+ * start state x, y, heading.  layers_s, lb, ub [batch][max_layers]; count [batch] = layers of the corridor (0: graphSearchDp returns
+ * false or no node of the first layer is reachable; -1: the line needs more than max_layers layers); vehicle_l [batch]. */
+int pqp_dp_corridor_device(pqp_handle* h, int batch, int m, int max_layers, const double* spline, const double* spline_ext,
+                           const double* length, const double* start, const float* dist, const int32_t* map_of,
+                           const pqp_grid_geometry* geom, const pqp_dp_params* prm, double* layers_s, double* lb, double* ub,
+                           int32_t* count, double* vehicle_l);
+int pqp_dp_corridor(pqp_handle* h, int batch, int m, int max_layers, const double* spline, const double* spline_ext, const double* length,
+                    const double* start, const float* dist, int n_maps, const int32_t* map_of, const pqp_grid_geometry* geom,
+                    const pqp_dp_params* prm, double* layers_s, double* lb, double* ub, int32_t* count, double* vehicle_l);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,8 @@ What is restated (reference file:line):
   obstacle_distance                            Map::getObstacleDistance                          src/tools/Map.cpp:16-22
   build_reference_from_spline                  ReferencePathImpl::buildReferenceFromSpline       src/data_struct/reference_path_impl.cpp:314-338
   process_init_state                           PathOptimizer::processInitState                   src/path_optimizer.cpp:73-85
+  projection / projection_newton               getProjection / getProjectionByNewton             src/tools/tools.cpp:66-126
+  graph_search_dp                              ReferencePathSmoother::graphSearchDp (+ calculateCostAt)  src/reference_path_smoother/reference_path_smoother.cpp:107-295
   clearance_strict                             ReferencePathImpl::getClearanceWithDirectionStrict src/data_struct/reference_path_impl.cpp:232-312
   update_bounds_improved                       ReferencePathImpl::updateBoundsImproved           src/data_struct/reference_path_impl.cpp:177-230
 Python floats are IEEE doubles and every operation below is written in the reference's order, so the arithmetic is the
@@ -393,3 +395,165 @@ def update_bounds_improved(ref, sx, sy, dist, g, prm=CorridorParams()):
             break
         out.append(row)
     return np.array(out).reshape(-1, 6), len(out), blocked
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# layered DP corridor search between the smoother QP and the postSmooth QP
+# ----------------------------------------------------------------------------------------------------------------------
+DBL_MAX = 1.7976931348623157e308
+
+
+@dataclass
+class DpParams:
+    lateral_range: float = 10.0          # FLAGS_search_lateral_range         planning_flags.cpp:38
+    longitudinal_spacing: float = 1.5    # FLAGS_search_longitudial_spacing   :40
+    lateral_spacing: float = 0.6         # FLAGS_search_lateral_spacing       :42
+    car_width: float = 2.0               # :10  -> search_threshold = car_width / 2 + 0.2   reference_path_smoother.cpp:171
+
+
+def projection_newton(sx, sy, tx, ty, max_s, hint_s):                        # tools.cpp:98-126
+    hint_s = min(hint_s, max_s)
+    cur_s = hint_s
+    prev_s = hint_s
+    for _ in range(20):
+        x, y = spline_eval(sx, cur_s), spline_eval(sy, cur_s)
+        dx, dy = spline_deriv(sx, 1, cur_s), spline_deriv(sy, 1, cur_s)
+        ddx, ddy = spline_deriv(sx, 2, cur_s), spline_deriv(sy, 2, cur_s)
+        j = (x - tx) * dx + (y - ty) * dy
+        h = dx * dx + (x - tx) * ddx + dy * dy + (y - ty) * ddy
+        cur_s -= j / h
+        if abs(cur_s - prev_s) < 1e-5:
+            break
+        prev_s = cur_s
+    return min(cur_s, max_s)
+
+
+def projection(sx, sy, tx, ty, max_s, start_s=0.0):                           # getProjection tools.cpp:66-96 -> s
+    if max_s <= start_s:
+        return 0.0                                # State{xs(start_s), ys(start_s)}: s stays 0
+    tmp_s, min_dis_s, min_dis = start_s, start_s, DBL_MAX
+    while tmp_s <= max_s:
+        d = math.sqrt(math.pow(spline_eval(sx, tmp_s) - tx, 2) + math.pow(spline_eval(sy, tmp_s) - ty, 2))
+        if d < min_dis:
+            min_dis, min_dis_s = d, tmp_s
+        tmp_s += 1.0
+    d_end = math.sqrt(math.pow(spline_eval(sx, max_s) - tx, 2) + math.pow(spline_eval(sy, max_s) - ty, 2))
+    if d_end < min_dis:
+        return max_s
+    return projection_newton(sx, sy, tx, ty, max_s, min_dis_s)
+
+
+def graph_search_dp(sx, sy, length, start, dist, g, prm=DpParams()):
+    """graphSearchDp (reference_path_smoother.cpp:142-295) with calculateCostAt (:107-140).
+    start = (x, y, heading) of the vehicle.  Returns None when the reference returns false, else a dict with
+    layers_s, lb, ub (layers_bounds_), vehicle_l (vehicle_l_wrt_smoothed_ref_): the inputs of the postSmooth QP."""
+    thr = prm.car_width / 2.0 + 0.2
+    tmp_s = projection(sx, sy, start[0], start[1], length)
+    layers = []
+    search_ds = prm.longitudinal_spacing if length > 6 else 0.5
+    while tmp_s < length:
+        layers.append(tmp_s)
+        tmp_s += search_ds
+    layers.append(length)
+    vs = layers[0]
+    px, py = spline_eval(sx, vs), spline_eval(sy, vs)
+    ph = math.atan2(spline_deriv(sy, 1, vs), spline_deriv(sx, 1, vs))
+    vehicle_l = global2local_y(px, py, ph, start[0], start[1])
+    if abs(vehicle_l) > prm.lateral_range:
+        return None
+    start_idx = int((prm.lateral_range + vehicle_l) / prm.lateral_spacing)
+    samples = []
+    for i, cur_s in enumerate(layers):
+        rx, ry = spline_eval(sx, cur_s), spline_eval(sy, cur_s)
+        dx, dy = spline_deriv(sx, 1, cur_s), spline_deriv(sy, 1, cur_s)
+        ddx, ddy = spline_deriv(sx, 2, cur_s), spline_deriv(sy, 2, cur_s)
+        rh = math.atan2(dy, dx)
+        rk = (dx * ddy - dy * ddx) / math.pow(math.pow(dx, 2) + math.pow(dy, 2), 1.5)
+        rr = math.inf if rk == 0.0 else 1 / rk
+        pts = []
+        cur_l = -prm.lateral_range
+        j = 0
+        while cur_l <= prm.lateral_range:
+            x = rx + cur_l * math.cos(rh + math.pi / 2)
+            y = ry + cur_l * math.sin(rh + math.pi / 2)
+            d = obstacle_distance(dist, g, x, y) if grid_is_inside(g, x, y) else -1.0
+            feas = not ((rk < 0 and cur_l < rr) or (rk > 0 and cur_l > rr) or d < thr)
+            pt = dict(x=x, y=y, heading=rh, s=cur_s, l=cur_l, cost=DBL_MAX, dir=0.0, dis=d, parent=None, feas=feas, j=j, i=i)
+            if i == 0:
+                pt["feas"] = j == start_idx
+                if j == start_idx:
+                    pt["dir"], pt["cost"] = start[2], 0.0
+            pts.append(pt)
+            cur_l += prm.lateral_spacing
+            j += 1
+        for j in range(len(pts)):
+            pts[j]["rlo"] = pts[j]["l"] if (j == 0 or not pts[j - 1]["feas"] or not pts[j]["feas"]) else pts[j - 1]["rlo"]
+        for j in range(len(pts) - 1, -1, -1):
+            pts[j]["rup"] = pts[j]["l"] if (j == len(pts) - 1 or not pts[j + 1]["feas"] or not pts[j]["feas"]) else pts[j + 1]["rup"]
+        samples.append(pts)
+    # costs (calculateCostAt)
+    max_layer = 0
+    for i, layer in enumerate(samples):
+        layer_feasible = False
+        for pt in layer:
+            if i > 0 and pt["feas"]:
+                self_cost = 0.0
+                if pt["dis"] < 3.0:
+                    self_cost += (3.0 - pt["dis"]) / 3.0 * 0.5
+                self_cost += abs(pt["l"]) / prm.lateral_range * 1.0
+                min_cost = DBL_MAX
+                for pre in samples[i - 1]:
+                    if not pre["feas"]:
+                        continue
+                    if abs(pre["l"] - pt["l"]) > (pt["s"] - pre["s"]):
+                        continue
+                    direction = math.atan2(pt["y"] - pre["y"], pt["x"] - pre["x"])
+                    edge = abs(constrain_angle(direction - pre["dir"])) / (math.pi / 2) * 16.0 \
+                        + abs(constrain_angle(direction - pt["heading"])) / (math.pi / 2) * 0.5
+                    total = self_cost + edge + pre["cost"]
+                    if total < min_cost:
+                        min_cost = total
+                        pt["parent"] = pre
+                        pt["dir"] = direction
+                if pt["parent"] is not None:
+                    pt["cost"] = min_cost
+            if pt["parent"] is not None:
+                layer_feasible = True
+        if i != 0 and not layer_feasible:
+            break
+        max_layer = i
+    # retrieve
+    ptr, min_cost = None, DBL_MAX
+    for pt in samples[max_layer]:
+        if pt["cost"] < min_cost:
+            ptr, min_cost = pt, pt["cost"]
+    bounds = []
+    while ptr is not None:
+        if ptr["i"] == 0:
+            bounds.append((-10.0, 10.0))
+        else:
+            check_s, limit = 0.2, 6.0
+            ub = check_s + ptr["rup"]
+            lb = -check_s + ptr["rlo"]
+            rx, ry = spline_eval(sx, ptr["s"]), spline_eval(sy, ptr["s"])
+            ca, sa = math.cos(ptr["heading"] + math.pi / 2), math.sin(ptr["heading"] + math.pi / 2)
+            while ub < limit:
+                x, y = rx + ub * ca, ry + ub * sa
+                if grid_is_inside(g, x, y) and obstacle_distance(dist, g, x, y) > thr:
+                    ub += check_s
+                else:
+                    ub -= check_s
+                    break
+            while lb > -limit:
+                x, y = rx + lb * ca, ry + lb * sa
+                if grid_is_inside(g, x, y) and obstacle_distance(dist, g, x, y) > thr:
+                    lb -= check_s
+                else:
+                    lb += check_s
+                    break
+            bounds.append((lb, ub))
+        ptr = ptr["parent"]
+    bounds.reverse()
+    n = len(bounds)
+    return dict(layers_s=np.array(layers[:n]), lb=np.array([b[0] for b in bounds]), ub=np.array([b[1] for b in bounds]), vehicle_l=vehicle_l,
+                path=[None] * n, n_layers_sampled=len(layers))

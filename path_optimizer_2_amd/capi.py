@@ -43,6 +43,10 @@ class PqpCorridorParams(C.Structure):
                                          "smaller_ds", "search_range", "min_space", "projection_window")]
 
 
+class PqpDpParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("lateral_range", "longitudinal_spacing", "lateral_spacing", "car_width")]
+
+
 class PqpSizes(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("n", "state", "control", "precise", "slack", "vars", "cons", "nnz_a", "nnz_p")]
 
@@ -53,7 +57,8 @@ EXPORTS = [
     "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_solve_var_device", "pqp_path_get_solution",
     "pqp_last_kernel_ms", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
     "pqp_post_smooth", "pqp_post_smooth_device", "pqp_corridor_default_params", "pqp_corridor_bounds", "pqp_corridor_bounds_device",
-    "pqp_reference_states", "pqp_reference_states_device", "pqp_spline_fit", "pqp_spline_fit_device",
+    "pqp_reference_states", "pqp_reference_states_device", "pqp_spline_fit", "pqp_spline_fit_device", "pqp_dp_default_params",
+    "pqp_dp_corridor", "pqp_dp_corridor_device",
 ]
 
 _lib = None
@@ -105,6 +110,12 @@ def load_library(path=None):
         getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, vp]
     for name in ("pqp_spline_fit", "pqp_spline_fit_device"):
         getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    lib.pqp_dp_default_params.argtypes = [C.POINTER(PqpDpParams)]
+    lib.pqp_dp_default_params.restype = None
+    lib.pqp_dp_corridor_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(PqpGridGeometry), C.POINTER(PqpDpParams),
+                                           vp, vp, vp, vp, vp]
+    lib.pqp_dp_corridor.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, C.POINTER(PqpGridGeometry), C.POINTER(PqpDpParams),
+                                    vp, vp, vp, vp, vp]
     lib.pqp_path_solve_var_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     if path == LIB_PATH:
         _lib = lib
@@ -185,6 +196,25 @@ class Handle:
         for k, v in over.items():
             setattr(p, k, v)
         return p
+
+    def dp_corridor(self, spline, spline_ext, length, start, dist, geom, max_layers=128, map_of=None, prm=None):
+        """pqp_dp_corridor (host arrays) -> (layers_s [B][max_layers], lb, ub, count [B], vehicle_l [B])."""
+        spline = np.ascontiguousarray(spline, dtype=np.float64); spline_ext = np.ascontiguousarray(spline_ext, dtype=np.float64)
+        length = np.ascontiguousarray(length, dtype=np.float64); start = np.ascontiguousarray(start, dtype=np.float64)
+        dist = np.asarray(dist, dtype=np.float32)
+        if dist.ndim == 2:
+            dist = dist[None]
+        dist_cm = np.ascontiguousarray(np.transpose(dist, (0, 2, 1)))
+        B, m = spline.shape[0], spline.shape[2]
+        ls = np.zeros((B, max_layers)); lb = np.zeros((B, max_layers)); ub = np.zeros((B, max_layers))
+        count = np.zeros(B, dtype=np.int32); vl = np.zeros(B)
+        mo = None if map_of is None else np.ascontiguousarray(map_of, dtype=np.int32)
+        if prm is None:
+            prm = PqpDpParams()
+            self.lib.pqp_dp_default_params(C.byref(prm))
+        self._check(self.lib.pqp_dp_corridor(self._h, B, m, max_layers, _ptr(spline), _ptr(spline_ext), _ptr(length), _ptr(start), _ptr(dist_cm),
+                                             dist.shape[0], _ptr(mo), C.byref(geom), C.byref(prm), _ptr(ls), _ptr(lb), _ptr(ub), _ptr(count), _ptr(vl)))
+        return ls, lb, ub, count, vl
 
     def spline_fit(self, s, x, y):
         """pqp_spline_fit (host arrays [B][m]) -> (spline [B][9][m], spline_ext [B][4])."""

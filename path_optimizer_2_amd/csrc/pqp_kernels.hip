@@ -484,7 +484,7 @@ struct pqp_handle {
     DevBuf s_ref, s_lin, s_bounds, s_scal;      // staging for the host-pointer entry points
     DevBuf s_out, s_status, s_iters, s_info, s_a, s_p, s_l, s_u, s_idx;
     // smoother QPs: banded problem data + shared sparsity (cached per type and size) + staging
-    DevBuf b_pband, b_q, b_aval, b_lo, b_up, b_x, b_y, b_acol, b_trow, b_tslot, b_in[5], b_out[3], c_buf[7], sp_work;
+    DevBuf b_pband, b_q, b_aval, b_lo, b_up, b_x, b_y, b_acol, b_trow, b_tslot, b_in[5], b_out[3], c_buf[12], sp_work;
     int b_struct_type = -1, b_struct_n = -1;
 };
 
@@ -530,7 +530,8 @@ int pqp_destroy(pqp_handle* h) {
                       &h->s_status, &h->s_iters, &h->s_info, &h->s_a, &h->s_p, &h->s_l, &h->s_u, &h->s_idx, &h->b_pband, &h->b_q, &h->b_aval,
                       &h->b_lo, &h->b_up, &h->b_x, &h->b_y, &h->b_acol, &h->b_trow, &h->b_tslot, &h->b_in[0], &h->b_in[1], &h->b_in[2],
                       &h->b_in[3], &h->b_in[4], &h->b_out[0], &h->b_out[1], &h->b_out[2], &h->c_buf[0], &h->c_buf[1], &h->c_buf[2],
-                      &h->c_buf[3], &h->c_buf[4], &h->c_buf[5], &h->c_buf[6], &h->sp_work})
+                      &h->c_buf[3], &h->c_buf[4], &h->c_buf[5], &h->c_buf[6], &h->c_buf[7], &h->c_buf[8], &h->c_buf[9], &h->c_buf[10],
+                      &h->c_buf[11], &h->sp_work})
         b->release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1117,6 +1118,68 @@ int pqp_spline_fit(pqp_handle* h, int batch, int m, const double* s, const doubl
         return rc;
     PQP_HIP(hipMemcpyAsync(spline, h->c_buf[3].p, b_spl, hipMemcpyDeviceToHost, h->stream));
     PQP_HIP(hipMemcpyAsync(spline_ext, h->c_buf[4].p, b_ext, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipStreamSynchronize(h->stream));
+    return PQP_OK;
+}
+
+// ---- layered DP corridor search ------------------------------------------------------------------------
+void pqp_dp_default_params(pqp_dp_params* p) {
+    if (!p) return;
+    p->lateral_range = 10.0; p->longitudinal_spacing = 1.5; p->lateral_spacing = 0.6; p->car_width = 2.0;      // planning_flags.cpp:38-42,10
+}
+
+int pqp_dp_corridor_device(pqp_handle* h, int batch, int m, int max_layers, const double* spline, const double* spline_ext,
+                           const double* length, const double* start, const float* dist, const int32_t* map_of,
+                           const pqp_grid_geometry* geom, const pqp_dp_params* prm, double* layers_s, double* lb, double* ub,
+                           int32_t* count, double* vehicle_l) {
+    if (!h || !spline || !spline_ext || !length || !start || !dist || !geom || !prm || !layers_s || !lb || !ub || !count || !vehicle_l ||
+        batch < 1 || m < 3 || max_layers < 2 || !(prm->lateral_spacing > 0.0) || !(prm->longitudinal_spacing > 0.0) ||
+        2.0 * prm->lateral_range / prm->lateral_spacing + 1.0 > 64.0)
+        return fail(PQP_ERR_INVALID, "pqp_dp_corridor: bad argument (at most 64 lateral samples per layer)");
+    PQP_HIP(hipSetDevice(h->device));
+    pqp::DpArgs a;
+    a.batch = batch; a.m = m; a.max_layers = max_layers; a.spl = spline; a.spl_ext = spline_ext; a.length = length; a.start = start;
+    a.dist = dist; a.map_of = map_of; a.g = *geom; a.p = *prm; a.layers_s = layers_s; a.lb = lb; a.ub = ub; a.count = count; a.vehicle_l = vehicle_l;
+    const size_t lds = pqp::DpLds{m, max_layers}.total_bytes();
+    if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_dp_corridor: 9 m + 17 max_layers doubles exceed one CU's LDS");
+    if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::dp_corridor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(pqp::dp_corridor_kernel, dim3(batch), dim3(64), lds, h->stream, a);
+    PQP_HIP(hipGetLastError());
+    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return PQP_OK;
+}
+
+int pqp_dp_corridor(pqp_handle* h, int batch, int m, int max_layers, const double* spline, const double* spline_ext, const double* length,
+                    const double* start, const float* dist, int n_maps, const int32_t* map_of, const pqp_grid_geometry* geom,
+                    const pqp_dp_params* prm, double* layers_s, double* lb, double* ub, int32_t* count, double* vehicle_l) {
+    if (!h || !spline || !spline_ext || !length || !start || !dist || !geom || !prm || !layers_s || !lb || !ub || !count || !vehicle_l ||
+        batch < 1 || m < 3 || max_layers < 2 || n_maps < 1)
+        return fail(PQP_ERR_INVALID, "pqp_dp_corridor: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    const size_t b_spl = (size_t)batch * 9 * m * 8, b_ext = (size_t)batch * 4 * 8, b_len = (size_t)batch * 8, b_st = (size_t)batch * 3 * 8;
+    const size_t b_map = (size_t)n_maps * geom->rows * geom->cols * 4, b_of = (size_t)batch * 4, b_out = (size_t)batch * max_layers * 8;
+    const size_t sizes[11] = {b_spl, b_ext, b_len, b_st, b_map, b_of, b_out, b_out, b_out, b_of, b_len};
+    int rc;
+    for (int k = 0; k < 11; ++k) if ((rc = h->c_buf[k].ensure(sizes[k]))) return rc;
+    PQP_HIP(hipMemcpyAsync(h->c_buf[0].p, spline, b_spl, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[1].p, spline_ext, b_ext, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[2].p, length, b_len, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[3].p, start, b_st, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[4].p, dist, b_map, hipMemcpyHostToDevice, h->stream));
+    if (map_of) PQP_HIP(hipMemcpyAsync(h->c_buf[5].p, map_of, b_of, hipMemcpyHostToDevice, h->stream));
+    for (int k = 6; k < 9; ++k) PQP_HIP(hipMemsetAsync(h->c_buf[k].p, 0, b_out, h->stream));
+    if ((rc = pqp_dp_corridor_device(h, batch, m, max_layers, h->c_buf[0].as<double>(), h->c_buf[1].as<double>(), h->c_buf[2].as<double>(),
+                                     h->c_buf[3].as<double>(), h->c_buf[4].as<float>(), map_of ? h->c_buf[5].as<int32_t>() : nullptr, geom, prm,
+                                     h->c_buf[6].as<double>(), h->c_buf[7].as<double>(), h->c_buf[8].as<double>(), h->c_buf[9].as<int32_t>(),
+                                     h->c_buf[10].as<double>())))
+        return rc;
+    PQP_HIP(hipMemcpyAsync(layers_s, h->c_buf[6].p, b_out, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(lb, h->c_buf[7].p, b_out, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(ub, h->c_buf[8].p, b_out, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(count, h->c_buf[9].p, b_of, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(vehicle_l, h->c_buf[10].p, b_len, hipMemcpyDeviceToHost, h->stream));
     PQP_HIP(hipStreamSynchronize(h->stream));
     return PQP_OK;
 }

@@ -138,3 +138,29 @@ def test_initial_error():
     assert off == pytest.approx(0.7) and dpsi == pytest.approx(0.2)
     off, dpsi = K.process_init_state(sx, sy, 0.0, -0.4, -0.1)
     assert off == pytest.approx(-0.4) and dpsi == pytest.approx(-0.1)
+
+
+def test_dp_search_on_an_empty_map_and_past_a_single_obstacle():
+    g = K.GridGeom.make(80.0, 40.0, 0.2)
+    s = np.linspace(0.0, 40.0, 21)
+    sx = K.spline_fit(s, s - 30.0); sy = K.spline_fit(s, 0.0 * s)                     # the x axis from x = -30
+    free = np.full((g.rows, g.cols), 20.0, dtype=np.float32)
+    r = K.graph_search_dp(sx, sy, 30.0, (-30.0, 0.0, 0.0), free, g)
+    # layers every 1.5 m from the projection of the vehicle (s = 0) plus the end; the vehicle starts on sample 16 (l = -0.4) and
+    # stays there: a lateral move of 0.6 m over 1.5 m costs 16 * atan(0.4) / (pi/2) = 3.9, the offset only 0.04
+    assert len(r["layers_s"]) == 21 and r["layers_s"][1] == 1.5 and r["layers_s"][-1] == 30.0
+    assert r["vehicle_l"] == pytest.approx(0.0, abs=1e-12)
+    assert (r["lb"][0], r["ub"][0]) == (-10.0, 10.0)
+    # everything is free: the rough bounds are the whole +-10 m range, already beyond the 6 m refinement limit
+    assert np.allclose(r["ub"][1:], 0.2 + (-10.0 + 33 * 0.6)) and np.allclose(r["lb"][1:], -0.2 - 10.0)
+    # a disc of radius 1 at (-15, 0.5): samples closer than 1.2 m to it are infeasible, the corridor passes on the lower side
+    d = free.copy()
+    for i in range(g.rows):
+        for j in range(g.cols):
+            x, y = K.grid_cell_position(g, i, j)
+            d[i, j] = max(math.hypot(x + 15.0, y - 0.5) - 1.0, 0.0)
+    r2 = K.graph_search_dp(sx, sy, 30.0, (-30.0, 0.0, 0.0), d, g)
+    k = int(np.argmin(np.abs(r2["layers_s"] - 15.0)))
+    assert r2["ub"][k] < -1.0 and r2["lb"][k] < r2["ub"][k]                            # squeezed below the obstacle
+    assert len(r2["layers_s"]) == 21
+    assert K.graph_search_dp(sx, sy, 30.0, (-30.0, 12.0, 0.0), free, g) is None        # vehicle more than 10 m off the line

@@ -173,3 +173,44 @@ def test_spline_fit_is_bit_exact(handle):
     tab3, ext3 = handle.spline_fit(s[:1, :3], x[:1, :3], y[:1, :3])
     w3, e3 = K.pack_spline(K.spline_fit(s[0, :3], x[0, :3]), K.spline_fit(s[0, :3], y[0, :3]))
     assert np.array_equal(tab3[0], w3) and np.array_equal(ext3[0], e3)
+
+
+@pytest.mark.parametrize("seed,length", [(0, 40.0), (1, 33.0), (2, 40.0), (6, 5.0), (12, 25.7)])
+def test_dp_corridor_search(handle, seed, length):
+    """graphSearchDp on the device against the restatement: same number of layers, same layer abscissae, same bounds
+    (they are sums of 0.6 m and 0.2 m steps: equal to round-off unless a sample sits on the 1.2 m threshold)."""
+    c = U.build(seed=seed, n=10)
+    start = np.array([[c["ref"][0, 3] + 0.2, c["ref"][0, 4] + 0.5, c["ref"][0, 2] + 0.05]])
+    ls, lb, ub, count, vl = handle.dp_corridor(c["tab"][None], c["ext"][None], np.array([length]), start, c["dist"], _geom(c["geom"]))
+    want = K.graph_search_dp(c["sx"], c["sy"], length, tuple(start[0]), c["dist"], c["geom"])
+    assert want is not None and count[0] == len(want["layers_s"])
+    k = int(count[0])
+    assert vl[0] == pytest.approx(want["vehicle_l"], abs=1e-12)
+    np.testing.assert_allclose(ls[0, :k], want["layers_s"], rtol=0, atol=1e-11)
+    same = (np.abs(lb[0, :k] - want["lb"]) < 1e-9) & (np.abs(ub[0, :k] - want["ub"]) < 1e-9)
+    assert same.mean() > 0.95, (lb[0, :k], want["lb"], ub[0, :k], want["ub"])
+
+
+def test_dp_corridor_edge_cases(handle):
+    c = U.build(seed=3, n=10)
+    g = _geom(c["geom"])
+    far = np.array([[c["ref"][0, 3], c["ref"][0, 4] + 15.0, c["ref"][0, 2]]])            # vehicle 15 m off the line: graphSearchDp returns false
+    _, _, _, count, vl = handle.dp_corridor(c["tab"][None], c["ext"][None], np.array([30.0]), far, c["dist"], g)
+    assert count[0] == 0 and abs(vl[0]) > 10.0
+    assert K.graph_search_dp(c["sx"], c["sy"], 30.0, tuple(far[0]), c["dist"], c["geom"]) is None
+    near = np.array([[c["ref"][0, 3], c["ref"][0, 4], c["ref"][0, 2]]])
+    _, _, _, count, _ = handle.dp_corridor(c["tab"][None], c["ext"][None], np.array([30.0]), near, c["dist"], g, max_layers=8)
+    assert count[0] == -1                                                               # 21 layers do not fit 8
+
+
+def test_dp_corridor_feeds_post_smooth(handle):
+    """layers_s / lb / ub / vehicle_l of the search are the inputs of the postSmooth QP (reference_path_smoother.cpp:44)"""
+    c = U.build(seed=1, n=10)
+    start = np.array([[c["ref"][0, 3] + 0.1, c["ref"][0, 4] + 0.3, c["ref"][0, 2]]])
+    ls, lb, ub, count, vl = handle.dp_corridor(c["tab"][None], c["ext"][None], np.array([33.0]), start, c["dist"], _geom(c["geom"]))
+    k = int(count[0])
+    assert k >= 4
+    res = handle.post_smooth(ls[:, :k].copy(), lb[:, :k].copy(), ub[:, :k].copy(), vl.copy())
+    assert res["status"][0] == 1
+    l = res["l"][0]
+    assert abs(l[0] - vl[0]) < 1e-3 and np.all(l[1:] >= lb[0, 1:k] - 1e-3) and np.all(l[1:] <= ub[0, 1:k] + 1e-3)
