@@ -42,6 +42,31 @@ def make(name, n, batch, profile):
     print(name, "cert max", np.max(cert))
 
 
+def make_scene_fixture(name, seed, length):
+    """The chain around the QPs (SURVEY.md 8f): knots -> tk::spline coefficients -> reference states -> corridor bounds, and the
+    DP corridor search on the same scene.  The distance layer is stored as float16-safe float32 cropped to the part the line uses."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import corridor_oracle as K
+    from path_optimizer_2_amd.synth import make_scene
+    sc = make_scene(seed=seed, n=10, length=(50.0, 30.0), n_obstacles=30)
+    sx = K.spline_fit(sc["knots_s"], sc["knots_x"]); sy = K.spline_fit(sc["knots_s"], sc["knots_y"])
+    g = K.GridGeom(sc["rows"], sc["cols"], sc["resolution"], sc["length"][0], sc["length"][1], sc["pos"][0], sc["pos"][1])
+    tab, ext = K.pack_spline(sx, sy)
+    ref = K.build_reference_from_spline(sx, sy, length)
+    start = np.array([ref[0, 3] + 0.2, ref[0, 4] + 0.4, ref[0, 2] + 0.03])
+    init_err = np.array(K.process_init_state(sx, sy, *start))
+    bounds, n_valid, blocked = K.update_bounds_improved(ref, sx, sy, sc["dist"], g)
+    dp = K.graph_search_dp(sx, sy, length, tuple(start), sc["dist"], g)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), knots_s=sc["knots_s"], knots_x=sc["knots_x"], knots_y=sc["knots_y"], spline=tab,
+                        spline_ext=ext, dist=sc["dist"], geom=np.array([g.rows, g.cols, g.resolution, g.length_x, g.length_y, g.pos_x, g.pos_y]),
+                        length=length, start=start, ref=ref, init_err=init_err, bounds=bounds, n_valid=n_valid,
+                        blocked_row=np.array(blocked if blocked is not None else []), dp_layers_s=dp["layers_s"], dp_lb=dp["lb"], dp_ub=dp["ub"],
+                        dp_vehicle_l=dp["vehicle_l"])
+    print(name, "states", len(ref), "usable", n_valid, "dp layers", len(dp["layers_s"]))
+
+
 if __name__ == "__main__":
     make("path_n8", 8, 4, "varied")
     make("path_n80", 80, 4, "uniform")
+    make_scene_fixture("scene_a", 0, 24.0)
+    make_scene_fixture("scene_b", 5, 30.0)

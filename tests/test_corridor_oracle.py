@@ -164,3 +164,20 @@ def test_dp_search_on_an_empty_map_and_past_a_single_obstacle():
     assert r2["ub"][k] < -1.0 and r2["lb"][k] < r2["ub"][k]                            # squeezed below the obstacle
     assert len(r2["layers_s"]) == 21
     assert K.graph_search_dp(sx, sy, 30.0, (-30.0, 12.0, 0.0), free, g) is None        # vehicle more than 10 m off the line
+
+
+@pytest.mark.parametrize("name", ["scene_a", "scene_b"])
+def test_scene_fixtures_are_reproduced(name):
+    """tests/golden/scene_*.npz (made by tests/golden/make_golden.py) pin the restatement against silent changes."""
+    f = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    sx = K.spline_fit(f["knots_s"], f["knots_x"]); sy = K.spline_fit(f["knots_s"], f["knots_y"])
+    tab, ext = K.pack_spline(sx, sy)
+    assert np.array_equal(tab, f["spline"]) and np.array_equal(ext, f["spline_ext"])
+    gv = f["geom"]
+    g = K.GridGeom(int(gv[0]), int(gv[1]), *[float(v) for v in gv[2:]])
+    ref = K.build_reference_from_spline(sx, sy, float(f["length"]))
+    assert np.array_equal(ref, f["ref"])
+    bounds, n_valid, _ = K.update_bounds_improved(ref, sx, sy, f["dist"], g)
+    assert n_valid == int(f["n_valid"]) and np.array_equal(bounds, f["bounds"])
+    dp = K.graph_search_dp(sx, sy, float(f["length"]), tuple(f["start"]), f["dist"], g)
+    assert np.array_equal(dp["layers_s"], f["dp_layers_s"]) and np.array_equal(dp["lb"], f["dp_lb"]) and np.array_equal(dp["ub"], f["dp_ub"])

@@ -214,3 +214,29 @@ def test_dp_corridor_feeds_post_smooth(handle):
     assert res["status"][0] == 1
     l = res["l"][0]
     assert abs(l[0] - vl[0]) < 1e-3 and np.all(l[1:] >= lb[0, 1:k] - 1e-3) and np.all(l[1:] <= ub[0, 1:k] + 1e-3)
+
+
+@pytest.mark.parametrize("name", ["scene_a", "scene_b"])
+def test_golden_scene_fixtures_through_the_hip_chain(handle, name):
+    """tests/golden/scene_*.npz: knots -> spline -> states -> bounds, and the DP search, all through the C ABI (no oracle here)."""
+    import os
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    gv = f["geom"]
+    geom = capi.PqpGridGeometry(int(gv[0]), int(gv[1]), *[float(v) for v in gv[2:]])
+    tab, ext = handle.spline_fit(f["knots_s"][None], f["knots_x"][None], f["knots_y"][None])
+    assert np.array_equal(tab[0], f["spline"]) and np.array_equal(ext[0], f["spline_ext"])
+    ref, count, err = handle.reference_states(tab, ext, np.array([float(f["length"])]), 128, start=f["start"][None])
+    n = int(count[0])
+    assert n == len(f["ref"])
+    np.testing.assert_allclose(ref[0, :n], f["ref"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(err[0], f["init_err"], rtol=0, atol=1e-12)
+    bounds, nv = handle.corridor_bounds(ref, tab, ext, f["dist"], geom, n_of=count)
+    assert int(nv[0]) == int(f["n_valid"])
+    k = int(nv[0])
+    assert (np.abs(bounds[0, :k] - f["bounds"]) < 1e-9).mean() > 0.99
+    ls, lb, ub, cnt, vl = handle.dp_corridor(tab, ext, np.array([float(f["length"])]), f["start"][None], f["dist"], geom)
+    c = int(cnt[0])
+    assert c == len(f["dp_layers_s"])
+    np.testing.assert_allclose(ls[0, :c], f["dp_layers_s"], rtol=0, atol=1e-11)
+    assert ((np.abs(lb[0, :c] - f["dp_lb"]) < 1e-9) & (np.abs(ub[0, :c] - f["dp_ub"]) < 1e-9)).mean() > 0.95
+    assert vl[0] == pytest.approx(float(f["dp_vehicle_l"]), abs=1e-12)

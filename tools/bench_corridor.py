@@ -3,26 +3,24 @@
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
-import corridor_oracle as K
-import corridor_util as U
+import scenes
 from path_optimizer_2_amd import capi
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 80
 n_maps = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-cs = [U.build(seed=s, n=n) for s in range(n_maps)]
-g = cs[0]["geom"]
+h = capi.Handle(capi.default_params(), device=0, max_batch=batch, max_n=n)
+sc = scenes.build(h, range(n_maps), n)
+geom = sc["geom"]
 dev = torch.device("cuda", 0)
-rep = lambda key: torch.from_numpy(np.stack([cs[b % n_maps][key] for b in range(batch)])).to(dev)
+rep = lambda key: torch.from_numpy(np.stack([sc[key][b % n_maps] for b in range(batch)])).to(dev)
 ref, tab, ext = rep("ref"), rep("tab"), rep("ext")
-dist = torch.from_numpy(np.ascontiguousarray(np.transpose(np.stack([c["dist"] for c in cs]), (0, 2, 1)))).to(dev)     # column major
+dist = torch.from_numpy(np.ascontiguousarray(np.transpose(sc["dist"], (0, 2, 1)))).to(dev)     # column major
 map_of = torch.arange(batch, dtype=torch.int32, device=dev) % n_maps
 bounds = torch.zeros((batch, n, 6), dtype=torch.float64, device=dev)
 nv = torch.zeros(batch, dtype=torch.int32, device=dev)
-h = capi.Handle(capi.default_params(), device=0, max_batch=batch, max_n=n)
-geom = capi.PqpGridGeometry(g.rows, g.cols, g.resolution, g.length_x, g.length_y, g.pos_x, g.pos_y)
 prm = h.corridor_params()
 p = lambda t: capi.C.c_void_p(t.data_ptr())
 m = tab.shape[2]
@@ -32,11 +30,6 @@ for _ in range(10):
     ms.append(h.last_kernel_ms())
 h.sync()
 k_ms = float(np.median(ms[2:]))
-# CPU: the Python restatement on one scenario (the reference's C++ would be roughly 50-100x faster than CPython)
-t0 = time.perf_counter()
-K.update_bounds_improved(cs[0]["ref"], cs[0]["sx"], cs[0]["sy"], cs[0]["dist"], g)
-cpu_s = time.perf_counter() - t0
 samples = batch * n * 3 * 2 * 25     # upper bound: 3 circles x 2 sides x (20 coarse + 5 fine) bilinear samples
-print(f"corridor bounds: batch {batch} n {n} maps {n_maps} ({g.rows}x{g.cols} cells): {k_ms * 1e3:.1f} us per launch = {batch / k_ms * 1e3:.0f} scenarios/s, "
-      f"{batch * n / k_ms * 1e3 / 1e6:.1f} M waypoints/s; <= {samples * 16 / k_ms / 1e6:.1f} GB/s of 4-float gathers; blocked {int((nv < n).sum())}/{batch}; "
-      f"CPython oracle {cpu_s * 1e3:.0f} ms per scenario")
+print(f"corridor bounds: batch {batch} n {n} maps {n_maps} ({geom.rows}x{geom.cols} cells): {k_ms * 1e3:.1f} us per launch = {batch / k_ms * 1e3:.0f} scenarios/s, "
+      f"{batch * n / k_ms * 1e3 / 1e6:.1f} M waypoints/s; <= {samples * 16 / k_ms / 1e6:.1f} GB/s of 4-float gathers; blocked {int((nv < n).sum())}/{batch}")

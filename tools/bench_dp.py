@@ -3,32 +3,31 @@ Usage: python tools/bench_dp.py [batch] [n_maps] [length]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
-import corridor_util as U
+import scenes
 from path_optimizer_2_amd import capi
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n_maps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 length = float(sys.argv[3]) if len(sys.argv) > 3 else 40.0
 Lmax = 64
-cs = [U.build(seed=s, n=10) for s in range(n_maps)]
-g = cs[0]["geom"]
+h = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3), device=0, max_batch=batch, max_n=Lmax)
+sc = scenes.build(h, range(n_maps), 10)
+geom = sc["geom"]
 dev = torch.device("cuda", 0)
 t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
-rep = lambda f: np.stack([f(cs[b % n_maps]) for b in range(batch)])
-tab, ext = t(rep(lambda c: c["tab"])), t(rep(lambda c: c["ext"]))
+rep = lambda key: np.stack([sc[key][b % n_maps] for b in range(batch)])
+tab, ext = t(rep("tab")), t(rep("ext"))
 m = tab.shape[2]
-dist = t(np.transpose(np.stack([c["dist"] for c in cs]), (0, 2, 1)), torch.float32)
+dist = t(np.transpose(sc["dist"], (0, 2, 1)), torch.float32)
 map_of = torch.arange(batch, dtype=torch.int32, device=dev) % n_maps
 lens = torch.full((batch,), length, dtype=torch.float64, device=dev)
-start = t(rep(lambda c: np.array([c["ref"][0, 3] + 0.2, c["ref"][0, 4] + 0.5, c["ref"][0, 2]])))
+start = t(np.stack([np.array([sc["ref"][b % n_maps][0, 3] + 0.2, sc["ref"][b % n_maps][0, 4] + 0.5, sc["ref"][b % n_maps][0, 2]]) for b in range(batch)]))
 z = lambda *shape, dt=torch.float64: torch.zeros(shape, dtype=dt, device=dev)
 ls, lb, ub, vl, cnt = z(batch, Lmax), z(batch, Lmax), z(batch, Lmax), z(batch), z(batch, dt=torch.int32)
-h = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3), device=0, max_batch=batch, max_n=Lmax)
 lib, hh = h.lib, h._h
 p = lambda x: capi.C.c_void_p(x.data_ptr())
-geom = capi.PqpGridGeometry(g.rows, g.cols, g.resolution, g.length_x, g.length_y, g.pos_x, g.pos_y)
 prm = capi.PqpDpParams(); lib.pqp_dp_default_params(capi.C.byref(prm))
 ms = []
 for _ in range(8):
