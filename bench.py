@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--polish-max-rounds", type=int, default=0, help="active-set rounds before a polish attempt gives up (0: max(8, n/5 - 8))")
     ap.add_argument("--polish-warm-set", type=int, default=2, help="1: pass 2 starts with a polish on pass 1's active set; 2: and keeps its equilibration")
     ap.add_argument("--check-termination", type=int, default=25, help="residual check interval (iterations)")
+    ap.add_argument("--inflight", type=int, default=1, help="batches in flight: k > 1 runs consecutive steps on k handles / HIP streams "
+                    "(what a server does with independent batches; the next batch fills the slots the slow tail of this one leaves idle)")
     ap.add_argument("--profile", default="uniform", choices=["uniform", "varied"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of host CPU work for the cpu_baseline sample")
@@ -106,20 +108,31 @@ def main():
                               adaptive_rho_interval=args.rho_interval, polish_warm_set=args.polish_warm_set if polish else 0, check_termination=args.check_termination, polish_refine_iter=args.polish_refine,
                               polish_max_rounds=args.polish_max_rounds)
     h = capi.Handle(prm, device=local_rank, max_batch=batch, max_n=n)
+    # --inflight k: k - 1 more handles (own stream, own warm state, own outputs) used round-robin
+    extra = [(capi.Handle(prm, device=local_rank, max_batch=batch, max_n=n), torch.zeros_like(out), torch.zeros_like(status),
+              torch.zeros_like(iters), torch.zeros_like(info)) for _ in range(max(args.inflight, 1) - 1)]
+    lanes = [(h, out, status, iters, info)] + extra
+    counter = [0]
 
     def step():
-        h.solve_device(batch, n, ref, bounds, scal, out, passes=1, status=status, iters=iters, info=info)
+        hh, o, st, it, inf = lanes[counter[0] % len(lanes)]
+        counter[0] += 1
+        hh.solve_device(batch, n, ref, bounds, scal, o, passes=1, status=st, iters=it, info=inf)
+
+    def sync_all():
+        for hh, *_ in lanes:
+            hh.sync()
 
     for _ in range(args.warmup):
         step()
-    h.sync()
+    sync_all()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    h.sync()
+    sync_all()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -168,7 +181,7 @@ def main():
                        "polish_every": args.polish_every if polish else 0, "adaptive_rho_interval": args.rho_interval,
                        "polish_refine_iter": args.polish_refine, "polish_max_rounds": args.polish_max_rounds, "polish_warm_set": args.polish_warm_set,
                        "passes": "cold solve + 1 re-linearised warm re-solve (PathOptimizer::optimizePath)",
-                       "parallelism": f"{world} independent shard(s), no collective in the timed region"},
+                       "parallelism": f"{world} independent shard(s), no collective in the timed region", "batches_in_flight": max(args.inflight, 1)},
             "admm_iters": {"min": int(it_np.min()), "median": float(np.median(it_np)), "p99": float(np.percentile(it_np, 99)),
                            "max": int(it_np.max()), "mean": float(it_np.mean())},
             "kkt_solves": {"mean": float(kkt_np.mean()), "p99": float(np.percentile(kkt_np, 99)), "max": float(kkt_np.max())},
