@@ -207,7 +207,8 @@ __global__ void __launch_bounds__(64 * NW) path_solve_kernel(const PathSolveArgs
     Lane memlane;
 #endif
     for (int qp = blockIdx.x; qp < args.batch; qp += gridDim.x) {
-        if (PathQp<DevCtx<NW>, CERT>::count_of(args, qp) < 2) {
+        // (written out rather than through PathQp::count_of: with the call here the register allocator spills 170 VGPRs of the loop)
+        if ((args.n_of ? args.n_of[qp] : args.n) < 2) {
             if (threadIdx.x == 0) {
                 if (args.status) args.status[qp] = PQP_STATUS_UNSOLVED;
                 if (args.iters) args.iters[qp] = 0;

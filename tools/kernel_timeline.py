@@ -21,7 +21,8 @@ if __name__ == "__main__":
     import torch
     from path_optimizer_2_amd import capi
     from path_optimizer_2_amd.synth import make_batch
-    if not os.path.exists(LIB):
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".inc"))] + [os.path.join(ROOT, "include", "pqp.h")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         build()
     capi.LIB_PATH = LIB
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
