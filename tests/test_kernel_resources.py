@@ -1,0 +1,56 @@
+"""Register / scratch budget of the HIP kernels, from the compiler's own report written by the build
+(__graft_entry__.build_hip -> csrc/libpqp_hip.resources.txt).  The solve kernels keep 86 doubles of lane state in registers;
+LLVM gives that up silently for innocent-looking source changes, and the kernel then runs several times
+slower while every parity test still passes.  This test is the tripwire."""
+import os
+import re
+
+import pytest
+
+import __graft_entry__ as g
+
+
+def _report():
+    g.build_hip()
+    if not os.path.exists(g.RESOURCES):
+        g.build_hip(force=True)
+    kernels, cur = {}, None
+    for line in open(g.RESOURCES):
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[\w/]+\])?: (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    return kernels
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    return _report()
+
+
+def _find(kernels, *parts):
+    hits = [(k, v) for k, v in kernels.items() if all(p in k for p in parts)]
+    assert len(hits) == 1, (parts, [k for k, _ in hits])
+    return hits[0][1]
+
+
+@pytest.mark.parametrize("nw", [1, 2, 4])
+@pytest.mark.parametrize("cert", [0, 1])
+def test_path_solve_kernel_keeps_its_lane_state_in_registers(kernels, nw, cert):
+    r = _find(kernels, "path_solve_kernel", f"ILi{nw}ELb{cert}E")
+    assert r["ScratchSize"] <= 64, r          # 32 B today: a few SGPR-spill slots; the lane struct would be 1 KB
+    assert r["Occupancy"] >= 1
+
+
+@pytest.mark.parametrize("b,maxt", [(3, 256), (4, 256), (9, 256), (3, 512), (4, 512)])
+def test_banded_solve_kernel_registers(kernels, b, maxt):
+    r = _find(kernels, "banded_solve_kernel", f"ILi{b}ELi{maxt}E")
+    assert r["ScratchSize"] <= 256, r         # a BqLane<9> in scratch would be 700 B
+
+
+def test_kernels_around_the_qps_do_not_use_scratch(kernels):
+    for name in ("corridor_bounds_kernel", "reference_states_kernel", "spline_fit_kernel", "dp_corridor_kernel"):
+        assert _find(kernels, name)["ScratchSize"] == 0, name
