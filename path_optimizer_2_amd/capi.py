@@ -69,7 +69,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("PQP_LIB") or LIB_PATH        # PQP_LIB: an alternative build of the library (experiments)
     if not os.path.exists(path):
         raise OSError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
