@@ -1064,8 +1064,9 @@ struct PathQp {
         const pqp_params& prm = A.prm;
         kkt_solves_ += 1;
         const double alpha = alpha_;
-        // I1: w = R z - y, reduced right-hand side pieces, message to the previous waypoint
-        ctx.phase([&](int t, Lane& ln) {
+        // I1: w = R z - y, reduced right-hand side pieces, message to the previous waypoint.  Wave-local: the message is read
+        // by the previous lane (the last lane of a wavefront reads its neighbour's after the barrier below).
+        ctx.phase_w([&](int t, Lane& ln) {
             Slot& S = ln.s;
             const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
             double wT[3], wI[3];
@@ -1179,9 +1180,11 @@ struct PathQp {
             };
             if (h >= 64) ctx.phase(body); else ctx.phase_w(body);
         }
-        ctx.phase([&](int, Lane&) {});      // X~ of every waypoint is in LDS for I3
-        // I3: back-substitute v, sf, sr; z~ = A x~; relaxed updates, projection, dual update
-        ctx.phase([&](int t, Lane& ln) {
+        // I3: back-substitute v, sf, sr; z~ = A x~; relaxed updates, projection, dual update.  Wave-local: a lane reads the X~ of the
+        // previous one; the first lane of a wavefront reads the last lane of the previous wavefront, which wrote its X~ before
+        // the last workgroup barrier of the backward pass.  iterate() therefore ENDS WITHOUT A BARRIER: the next iterate() may
+        // follow directly, anything else (residuals, cold operations) must synchronise first - sync_after_iterate().
+        ctx.phase_w([&](int t, Lane& ln) {
             Slot& S = ln.s;
             double Xp[3];
             _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
@@ -1229,6 +1232,8 @@ struct PathQp {
             }
         });
     }
+
+    PQP_HD void sync_after_iterate() { ctx.phase([&](int, Lane&) {}); }
 
     // ---------------------------------------------------------------------------------------------
     // residuals (unscaled inf-norms, OSQP termination quantities):
@@ -1537,9 +1542,10 @@ struct PathQp {
                     want_res = refine_left <= 0;
                 }
                 if (!want_res) {
-                    if (!polish_mode && it >= prm.max_iter) { op = COLD_END_PASS; i0 = 0; break; }
+                    if (!polish_mode && it >= prm.max_iter) { sync_after_iterate(); op = COLD_END_PASS; i0 = 0; break; }
                     continue;
                 }
+                sync_after_iterate();
                 { PQP_TIC; residuals(res); PQP_TOC(5); }
                 if (!polish_mode) {
                     bool start_polish = false;

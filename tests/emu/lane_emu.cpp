@@ -115,6 +115,7 @@ extern "C" int pqp_emu_probe(const pqp_params* prm, int n, const double* ref, co
     s.factor();
     s.start_transition_rows(false);
     for (int it = 0; it < do_iters; ++it) { s.iterate(); if (it == 0) s.finish_first_iteration(); }
+    s.sync_after_iterate();
     for (int i = 0; i < n; ++i) {
         const pqp::Slot& S = ctx.lanes[i].s;
         const pqp::SlotSetup& W = ctx.lanes[i].w;

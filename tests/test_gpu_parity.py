@@ -265,3 +265,17 @@ def test_primal_infeasibility_certificate_on_the_gpu(hip_lib):
     r2 = h2.solve(b["ref"], b["bounds"], b["scal"], passes=1)
     assert list(r2["status"]) == [1, 1, 2, 1]
     h2.close()
+
+
+@pytest.mark.parametrize("n,batch", [(80, 1024), (200, 256), (300, 64)])
+def test_solve_is_deterministic_run_to_run(hip_lib, n, batch):
+    """The solve kernel synchronises its wavefronts with as few workgroup barriers as the data flow allows (wave-local phases);
+    a missing one would show up as run-to-run differences when thousands of QPs share the machine.  Bit-identical, every time."""
+    b = make_batch(batch, n, "varied")
+    h = capi.Handle(_polished(), max_batch=batch, max_n=n)
+    first = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    for _ in range(4):
+        again = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+        assert np.array_equal(first["out"], again["out"]) and np.array_equal(first["iters"], again["iters"])
+        assert np.array_equal(first["info"][:, 5:7], again["info"][:, 5:7])
+    h.close()
