@@ -188,7 +188,11 @@ int pqp_path_assemble_device(pqp_handle* h, int batch, int n, int precise, const
  *   status[batch], iters[batch] (total ADMM iterations over all passes) may be NULL.
  *   info (may be NULL) [batch][PQP_INFO_STRIDE]: primal residual, dual residual, final rho, ADMM iterations of the
  *   last pass, number of accepted polishes, total reduced-KKT solves (ADMM iterations + polish refinement),
- *   number of factorisations, reserved. */
+ *   number of factorisations, reserved.
+ *   2 <= n <= 512 waypoints (one lane per waypoint: 1, 2, 4 or 8 wavefronts per QP); any batch.  Which solver runs is decided
+ *   by the handle's pqp_params: pqp_default_params = the reference's OSQP setting (eps 2e-3, no polish, infeasibility certificate),
+ *   pqp_production_params = eps 1e-4 + KKT-verified polish.  out[q] holds the last iterate also when status[q] != SOLVED (the
+ *   reference's solve() returns false there and leaves its output vector untouched). */
 int pqp_path_solve(pqp_handle* h, int batch, int n, const double* ref, const double* lin,
                    const double* bounds, const double* scal, int passes, int warm,
                    double* out, int32_t* status, int32_t* iters, double* info);
