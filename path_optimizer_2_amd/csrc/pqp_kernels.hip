@@ -652,7 +652,7 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
                            const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters, double* info) {
     if (!h || !ref || !bounds || !scal || !out || batch < 1 || n < 2 || passes < 0)
         return fail(PQP_ERR_INVALID, "pqp_path_solve: bad argument");
-    if (n > 512) return fail(PQP_ERR_CAPACITY, "pqp_path_solve: more than 512 waypoints per path (one lane per waypoint, 26 T + 152 doubles of LDS per QP)");
+    if (n > 512) return fail(PQP_ERR_CAPACITY, "pqp_path_solve: more than 512 waypoints per path (one lane per waypoint, 26 T + 160 doubles of LDS per QP)");
     PQP_HIP(hipSetDevice(h->device));
     if (warm && (h->warm_batch != batch || h->warm_n != n))
         return fail(PQP_ERR_INVALID, "pqp_path_solve: warm == 1 needs a previous solve with the same batch and n");
