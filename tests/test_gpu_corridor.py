@@ -240,3 +240,22 @@ def test_golden_scene_fixtures_through_the_hip_chain(handle, name):
     np.testing.assert_allclose(ls[0, :c], f["dp_layers_s"], rtol=0, atol=1e-11)
     assert ((np.abs(lb[0, :c] - f["dp_lb"]) < 1e-9) & (np.abs(ub[0, :c] - f["dp_ub"]) < 1e-9)).mean() > 0.95
     assert vl[0] == pytest.approx(float(f["dp_vehicle_l"]), abs=1e-12)
+
+
+def test_argument_errors(handle):
+    """bad arguments come back as PQP_ERR_INVALID / PQP_ERR_CAPACITY (no exception crosses the ABI, nothing is launched)"""
+    c = U.build(seed=0, n=8)
+    g = _geom(c["geom"])
+    with pytest.raises(capi.PqpError):
+        handle.spline_fit(np.zeros((1, 2)), np.zeros((1, 2)), np.zeros((1, 2)))                      # fewer than 3 knots (spline.cpp:164)
+    with pytest.raises(capi.PqpError):
+        handle.reference_states(c["tab"][None], c["ext"][None], np.array([10.0]), 64, ds_small=0.3, ds_large=0.1)   # CHECK_LE (:315)
+    bad = capi.PqpGridGeometry(1, 1, 0.2, 0.2, 0.2, 0.0, 0.0)
+    with pytest.raises(capi.PqpError):
+        handle.corridor_bounds(c["ref"][None], c["tab"][None], c["ext"][None], np.zeros((1, 1), dtype=np.float32), bad)
+    with pytest.raises(capi.PqpError):
+        prm = capi.PqpDpParams(10.0, 1.5, 0.1, 2.0)                                                # 201 lateral samples: more than one wavefront
+        handle.dp_corridor(c["tab"][None], c["ext"][None], np.array([10.0]), np.zeros((1, 3)), c["dist"], g, prm=prm)
+    # a batch of one and a line shorter than one step are fine
+    ref, count, _ = handle.reference_states(c["tab"][None], c["ext"][None], np.array([0.1]), 8)
+    assert count[0] == 1 and ref[0, 0, 0] == 0.0
