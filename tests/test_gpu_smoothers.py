@@ -46,7 +46,7 @@ def test_tension2(hip_lib, n, batch):
     h.close(); h2.close()
 
 
-@pytest.mark.parametrize("n,batch", [(20, 4), (80, 2)])
+@pytest.mark.parametrize("n,batch", [(20, 4), (80, 2), (150, 1)])
 def test_tension(hip_lib, n, batch):
     cases = [tension_inputs(n, seed=20 + b) for b in range(batch)]
     x, y, ang, cl = (np.stack([c[k] for c in cases]) for k in (0, 1, 2, 5))
@@ -62,7 +62,16 @@ def test_tension(hip_lib, n, batch):
     h.close()
 
 
-@pytest.mark.parametrize("m,batch", [(18, 4), (60, 2)])
+def test_tension_too_large_for_one_cu_is_an_error(hip_lib):
+    """750 variables in 9 x 9 blocks need more LDS than a CU has: PQP_ERR_CAPACITY, nothing launched"""
+    xs, ys, ang, kk, ss, cl = tension_inputs(250, seed=1)
+    h = capi.Handle(_polished(), max_batch=1, max_n=250)
+    with pytest.raises(capi.PqpError):
+        h.smooth_tension(xs[None], ys[None], ang[None], cl[None])
+    h.close()
+
+
+@pytest.mark.parametrize("m,batch", [(18, 4), (60, 2), (150, 1)])
 def test_post_smooth(hip_lib, m, batch):
     cases = [post_inputs(m, seed=30 + b) for b in range(batch)]
     s = np.stack([c[0] for c in cases]); lb = np.stack([c[1] for c in cases]); ub = np.stack([c[2] for c in cases])
