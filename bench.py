@@ -194,7 +194,7 @@ def main():
                          "note": "SURVEY.md 8(d) streaming-model bytes; the iterates are register/LDS resident, so measured HBM "
                                  "traffic is far below this (profiles/, DESIGN.md 5)"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(lambda k: make_batch(k, n, args.profile), n, args.eps, args.cpu_budget)
         print(json.dumps(line))
     if dist is not None:
