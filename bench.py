@@ -145,12 +145,13 @@ def main():
         full = gather_paths(out, total)              # untimed: what a caller that wants every path on every rank would do
         gathered_ok = bool(full.shape[0] == total and torch.equal(full[rank * batch:(rank + 1) * batch], out))
 
-    # per-launch duration of the dominant kernel from HIP events recorded on the stream it is launched on
+    # per-launch duration of the dominant kernel over the timed region: HIP events the handle recorded around every launch on the
+    # stream it launched on, read back now (nothing was synchronised between the launches)
     ev_ms = []
-    for _ in range(min(args.steps, 20)):
-        h.solve_device(batch, n, ref, bounds, scal, out, passes=1, status=status, iters=iters, info=info)
-        ev_ms.append(h.last_kernel_ms())
-    h.sync()
+    for li, (hh, *_) in enumerate(lanes):
+        k = min(sum(1 for i in range(args.steps) if (args.warmup + i) % len(lanes) == li), 256)      # timed launches of this handle
+        if k > 0:
+            ev_ms.extend(hh.kernel_ms_history(k).tolist())
 
     it_np = iters.cpu().numpy()
     st_np = status.cpu().numpy()

@@ -237,6 +237,9 @@ int pqp_post_smooth_device(pqp_handle* h, int batch, int m, const double* layers
 
 /* GPU time (ms, hipEvent) of the handle's last solve / assemble launch. */
 int pqp_last_kernel_ms(pqp_handle* h, float* ms);
+/* the same for the last `count` launches of this handle (oldest first; at most 256): the events are recorded on the handle's stream
+ * around every launch and read here after a stream synchronise, so measuring puts nothing between the launches themselves */
+int pqp_kernel_ms_history(pqp_handle* h, float* ms, int count);
 
 /* ---- corridor bounds from the obstacle distance map ---------------------------------------------
  * ReferencePath::updateBounds(const Map&)  src/data_struct/reference_path.cpp:61  ->  ReferencePathImpl::updateBoundsImproved

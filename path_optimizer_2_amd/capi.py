@@ -55,7 +55,7 @@ EXPORTS = [
     "pqp_default_params", "pqp_production_params", "pqp_last_error", "pqp_version", "pqp_create", "pqp_destroy", "pqp_set_params",
     "pqp_get_stream", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
     "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_solve_var_device", "pqp_path_get_solution",
-    "pqp_last_kernel_ms", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
+    "pqp_last_kernel_ms", "pqp_kernel_ms_history", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
     "pqp_post_smooth", "pqp_post_smooth_device", "pqp_corridor_default_params", "pqp_corridor_bounds", "pqp_corridor_bounds_device",
     "pqp_reference_states", "pqp_reference_states_device", "pqp_spline_fit", "pqp_spline_fit_device", "pqp_dp_default_params",
     "pqp_dp_corridor", "pqp_dp_corridor_device",
@@ -94,6 +94,7 @@ def load_library(path=None):
         getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.pqp_path_get_solution.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.pqp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.pqp_kernel_ms_history.argtypes = [vp, vp, C.c_int]
     lib.pqp_smooth_tension2.argtypes = [vp, C.c_int, C.c_int] + [vp] * 10
     lib.pqp_smooth_tension2_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 11
     lib.pqp_smooth_tension.argtypes = [vp, C.c_int, C.c_int] + [vp] * 9
@@ -345,6 +346,12 @@ class Handle:
         c = np.ascontiguousarray
         self._check(self.lib.pqp_post_smooth(self._h, B, m, _ptr(c(layers_s)), _ptr(c(lb)), _ptr(c(ub)), _ptr(c(vehicle_l)), _ptr(ol), _ptr(st), _ptr(it)))
         return dict(l=ol, status=st, iters=it)
+
+    def kernel_ms_history(self, count):
+        """HIP-event durations of the last `count` launches of this handle (oldest first)."""
+        ms = np.zeros(count, dtype=np.float32)
+        self._check(self.lib.pqp_kernel_ms_history(self._h, _ptr(ms), count))
+        return ms
 
     def last_kernel_ms(self):
         ms = C.c_float()

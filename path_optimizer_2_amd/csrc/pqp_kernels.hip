@@ -478,8 +478,14 @@ struct pqp_handle {
     int device = 0;
     pqp_params prm;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // HIP events around the dominant kernel of every call, on the stream it is launched on: a ring of the last kEvRing launches,
+    // read back (after the work is done) by pqp_last_kernel_ms / pqp_kernel_ms_history without putting a sync between launches
+    static constexpr int kEvRing = 256;
+    hipEvent_t evs0[kEvRing] = {}, evs1[kEvRing] = {};
+    long long ev_count = 0;          // launches recorded so far
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;      // the pair of the launch being recorded
     bool timed = false;
+    void next_event_pair() { ev0 = evs0[ev_count % kEvRing]; ev1 = evs1[ev_count % kEvRing]; ev_count += 1; }
     int warm_batch = 0, warm_n = 0;
     DevBuf wx, wy, wye, wrho, wsave;            // warm state (lane layout) + polish save area
     DevBuf s_ref, s_lin, s_bounds, s_scal;      // staging for the host-pointer entry points
@@ -509,8 +515,7 @@ int pqp_create(pqp_handle** out, const pqp_params* params, int device, int max_b
     h->device = device;
     if (params) h->prm = *params; else pqp::default_params(&h->prm);
     PQP_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    PQP_HIP(hipEventCreate(&h->ev0));
-    PQP_HIP(hipEventCreate(&h->ev1));
+    for (int k = 0; k < pqp_handle::kEvRing; ++k) { PQP_HIP(hipEventCreate(&h->evs0[k])); PQP_HIP(hipEventCreate(&h->evs1[k])); }
     if (max_batch > 0 && max_n > 0) {
         const size_t bn = (size_t)max_batch * max_n;
         int rc;
@@ -534,8 +539,7 @@ int pqp_destroy(pqp_handle* h) {
                       &h->c_buf[3], &h->c_buf[4], &h->c_buf[5], &h->c_buf[6], &h->c_buf[7], &h->c_buf[8], &h->c_buf[9], &h->c_buf[10],
                       &h->c_buf[11], &h->sp_work})
         b->release();
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (int k = 0; k < pqp_handle::kEvRing; ++k) { if (h->evs0[k]) (void)hipEventDestroy(h->evs0[k]); if (h->evs1[k]) (void)hipEventDestroy(h->evs1[k]); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PQP_OK;
@@ -610,6 +614,7 @@ int pqp_path_assemble_device(pqp_handle* h, int batch, int n, int precise, const
     if (stage && lds > 64 * 1024)
         PQP_HIP(hipFuncSetAttribute((const void*)pqp::path_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = batch < 4096 ? batch : 4096;
+    h->next_event_pair();
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(pqp::path_assemble_kernel, dim3(grid), dim3(256), stage ? lds : 0, h->stream, R, batch, ref, lin, bounds,
                        scal, h->prm, a_val, p_val, lower, upper, stage);
@@ -675,6 +680,7 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     if ((rc = h->wsave.ensure((size_t)batch * 64 * nw * PQP_SAVE_STRIDE * 8))) return rc;
     a.wsave = h->wsave.as<double>();
     const size_t lds = (size_t)pqp::ShLayout{64 * nw}.total() * 8;
+    h->next_event_pair();
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
     // two variants of every kernel: with and without OSQP's primal infeasibility certificate (prm.eps_prim_inf > 0)
     const bool cert = h->prm.eps_prim_inf > 0.0;
@@ -764,6 +770,19 @@ int pqp_last_kernel_ms(pqp_handle* h, float* ms) {
     return PQP_OK;
 }
 
+int pqp_kernel_ms_history(pqp_handle* h, float* ms, int count) {
+    if (!h || !ms || count < 1) return fail(PQP_ERR_INVALID, "pqp_kernel_ms_history: bad argument");
+    if (count > pqp_handle::kEvRing || (long long)count > h->ev_count)
+        return fail(PQP_ERR_INVALID, "pqp_kernel_ms_history: more launches asked for than the ring holds (256) or were made");
+    PQP_HIP(hipSetDevice(h->device));
+    PQP_HIP(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < count; ++k) {          // oldest of the requested launches first
+        const long long idx = (h->ev_count - count + k) % pqp_handle::kEvRing;
+        PQP_HIP(hipEventElapsedTime(ms + k, h->evs0[idx], h->evs1[idx]));
+    }
+    return PQP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // smoother QPs
 // ---------------------------------------------------------------------------------------------------------
@@ -839,6 +858,7 @@ int sm_solve(pqp_handle* h, int type, int batch, int n, int32_t* status, int32_t
     }
 #undef PQP_BQ_PICK
     if (lds > 64 * 1024) PQP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->next_event_pair();
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
     void* kargs[] = {(void*)&a};
     PQP_HIP(hipLaunchKernel(fn, dim3(batch), dim3(threads), kargs, lds, h->stream));
@@ -996,6 +1016,7 @@ int pqp_corridor_bounds_device(pqp_handle* h, int batch, int n, int m, const dou
     a.g = *geom; a.p = *prm; a.bounds = bounds; a.n_valid = n_valid;
     int threads = 64 * ((3 * n + 63) / 64);
     if (threads > 1024) threads = 1024;
+    h->next_event_pair();
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
     const size_t lds = pqp::CorridorLds{m, n}.total_bytes();
     if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_corridor_bounds: scenario too large for one CU's LDS (about 9 m + 31 n doubles)");
@@ -1048,6 +1069,7 @@ int pqp_reference_states_device(pqp_handle* h, int batch, int n_max, int m, cons
     pqp::RefStatesArgs a;
     a.batch = batch; a.n_max = n_max; a.m = m; a.spl = spline; a.spl_ext = spline_ext; a.max_s = max_s; a.start = start;
     a.ds_small = ds_small; a.ds_large = ds_large; a.dynamic = dynamic ? 1 : 0; a.ref = ref; a.count = count; a.init_err = init_err;
+    h->next_event_pair();
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
     const size_t lds = ((size_t)9 * m + n_max) * 8;
     if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_reference_states: 9 m + n_max doubles exceed one CU's LDS");
@@ -1096,6 +1118,7 @@ int pqp_spline_fit_device(pqp_handle* h, int batch, int m, const double* s, cons
     if ((rc = h->sp_work.ensure((size_t)batch * 4 * m * 8))) return rc;
     pqp::SplineFitArgs a;
     a.batch = batch; a.m = m; a.s = s; a.vx = x; a.vy = y; a.spl = spline; a.spl_ext = spline_ext; a.work = h->sp_work.as<double>();
+    h->next_event_pair();
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(pqp::spline_fit_kernel, dim3((2 * batch + 63) / 64), dim3(64), 0, h->stream, a);
     PQP_HIP(hipGetLastError());
@@ -1144,6 +1167,7 @@ int pqp_dp_corridor_device(pqp_handle* h, int batch, int m, int max_layers, cons
     const size_t lds = pqp::DpLds{m, max_layers}.total_bytes();
     if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_dp_corridor: 9 m + 17 max_layers doubles exceed one CU's LDS");
     if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::dp_corridor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->next_event_pair();
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(pqp::dp_corridor_kernel, dim3(batch), dim3(64), lds, h->stream, a);
     PQP_HIP(hipGetLastError());
