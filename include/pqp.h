@@ -206,6 +206,9 @@ int pqp_path_solve_device(pqp_handle* h, int batch, int n, const double* ref, co
 int pqp_path_solve_var_device(pqp_handle* h, int batch, int n_max, const int32_t* n_of, const double* ref, const double* lin,
                               const double* bounds, const double* scal, int passes, int warm, double* out, int32_t* status,
                               int32_t* iters, double* info);
+/* host pointers (n_of included); rows of `out` beyond a QP's own count come back as zeros */
+int pqp_path_solve_var(pqp_handle* h, int batch, int n_max, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
+                       const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters, double* info);
 
 /* Primal / dual solution of the handle's last solve in the REFERENCE numbering (OsqpEigen::Solver::
  * getSolution(), base_solver.cpp:89,112): x [batch][vars], y [batch][cons].  HOST buffers; either may be NULL. */

@@ -54,7 +54,7 @@ class PqpSizes(C.Structure):
 EXPORTS = [
     "pqp_default_params", "pqp_production_params", "pqp_last_error", "pqp_version", "pqp_create", "pqp_destroy", "pqp_set_params",
     "pqp_get_stream", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
-    "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_solve_var_device", "pqp_path_get_solution",
+    "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_solve_var_device", "pqp_path_solve_var", "pqp_path_get_solution",
     "pqp_last_kernel_ms", "pqp_kernel_ms_history", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
     "pqp_post_smooth", "pqp_post_smooth_device", "pqp_corridor_default_params", "pqp_corridor_bounds", "pqp_corridor_bounds_device",
     "pqp_reference_states", "pqp_reference_states_device", "pqp_spline_fit", "pqp_spline_fit_device", "pqp_dp_default_params",
@@ -117,7 +117,8 @@ def load_library(path=None):
                                            vp, vp, vp, vp, vp]
     lib.pqp_dp_corridor.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, C.POINTER(PqpGridGeometry), C.POINTER(PqpDpParams),
                                     vp, vp, vp, vp, vp]
-    lib.pqp_path_solve_var_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    for name in ("pqp_path_solve_var_device", "pqp_path_solve_var"):
+        getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -294,6 +295,16 @@ class Handle:
         iters = np.zeros(batch, dtype=np.int32); info = np.zeros((batch, 8))
         self._check(self.lib.pqp_path_solve(self._h, batch, n, _ptr(ref), _ptr(lin), _ptr(bounds), _ptr(scal),
                                             passes, 1 if warm else 0, _ptr(out), _ptr(status), _ptr(iters), _ptr(info)))
+        return dict(out=out, status=status, iters=iters, info=info)
+
+    def solve_var(self, n_of, ref, bounds, scal, lin=None, passes=1, warm=False):
+        """pqp_path_solve_var (host arrays): a waypoint count per QP, arrays of stride n_max = ref.shape[1]."""
+        batch, n = ref.shape[0], ref.shape[1]
+        counts = np.ascontiguousarray(n_of, dtype=np.int32)
+        out = np.zeros((batch, n, 7)); status = np.zeros(batch, dtype=np.int32)
+        iters = np.zeros(batch, dtype=np.int32); info = np.zeros((batch, 8))
+        self._check(self.lib.pqp_path_solve_var(self._h, batch, n, _ptr(counts), _ptr(ref), _ptr(lin), _ptr(bounds), _ptr(scal),
+                                                passes, 1 if warm else 0, _ptr(out), _ptr(status), _ptr(iters), _ptr(info)))
         return dict(out=out, status=status, iters=iters, info=info)
 
     def solve_device(self, batch, n, ref, bounds, scal, out, lin=None, passes=1, warm=False, status=None,

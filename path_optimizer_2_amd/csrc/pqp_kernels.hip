@@ -714,13 +714,17 @@ int pqp_path_solve_var_device(pqp_handle* h, int batch, int n_max, const int32_t
     return path_solve_impl(h, batch, n_max, n_of, ref, lin, bounds, scal, passes, warm, out, status, iters, info);
 }
 
-int pqp_path_solve(pqp_handle* h, int batch, int n, const double* ref, const double* lin, const double* bounds,
-                   const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters, double* info) {
+static int path_solve_host(pqp_handle* h, int batch, int n, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
+                           const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters, double* info) {
     if (!h || !ref || !bounds || !scal || !out || batch < 1 || n < 2 || passes < 0)
         return fail(PQP_ERR_INVALID, "pqp_path_solve: bad argument");
     PQP_HIP(hipSetDevice(h->device));
     const size_t bn = (size_t)batch * n;
     int rc;
+    if (n_of) {
+        if ((rc = h->c_buf[11].ensure((size_t)batch * 4))) return rc;
+        PQP_HIP(hipMemcpyAsync(h->c_buf[11].p, n_of, (size_t)batch * 4, hipMemcpyHostToDevice, h->stream));
+    }
     if ((rc = h->s_ref.ensure(bn * 5 * 8)) || (rc = h->s_bounds.ensure(bn * 6 * 8)) || (rc = h->s_scal.ensure((size_t)batch * 6 * 8)) ||
         (rc = h->s_out.ensure(bn * 7 * 8)) || (rc = h->s_status.ensure((size_t)batch * 4)) || (rc = h->s_iters.ensure((size_t)batch * 4)) ||
         (rc = h->s_info.ensure((size_t)batch * PQP_INFO_STRIDE * 8)))
@@ -730,9 +734,10 @@ int pqp_path_solve(pqp_handle* h, int batch, int n, const double* ref, const dou
     PQP_HIP(hipMemcpyAsync(h->s_bounds.p, bounds, bn * 6 * 8, hipMemcpyHostToDevice, h->stream));
     PQP_HIP(hipMemcpyAsync(h->s_scal.p, scal, (size_t)batch * 6 * 8, hipMemcpyHostToDevice, h->stream));
     if (lin) PQP_HIP(hipMemcpyAsync(h->s_lin.p, lin, bn * 3 * 8, hipMemcpyHostToDevice, h->stream));
-    rc = pqp_path_solve_device(h, batch, n, h->s_ref.as<double>(), lin ? h->s_lin.as<double>() : nullptr, h->s_bounds.as<double>(),
-                               h->s_scal.as<double>(), passes, warm, h->s_out.as<double>(), h->s_status.as<int32_t>(),
-                               h->s_iters.as<int32_t>(), h->s_info.as<double>());
+    if (n_of) PQP_HIP(hipMemsetAsync(h->s_out.p, 0, bn * 7 * 8, h->stream));        // rows beyond a QP's own count are not written
+    rc = path_solve_impl(h, batch, n, n_of ? h->c_buf[11].as<int32_t>() : nullptr, h->s_ref.as<double>(), lin ? h->s_lin.as<double>() : nullptr,
+                         h->s_bounds.as<double>(), h->s_scal.as<double>(), passes, warm, h->s_out.as<double>(), h->s_status.as<int32_t>(),
+                         h->s_iters.as<int32_t>(), h->s_info.as<double>());
     if (rc) return rc;
     PQP_HIP(hipMemcpyAsync(out, h->s_out.p, bn * 7 * 8, hipMemcpyDeviceToHost, h->stream));
     if (status) PQP_HIP(hipMemcpyAsync(status, h->s_status.p, (size_t)batch * 4, hipMemcpyDeviceToHost, h->stream));
@@ -740,6 +745,17 @@ int pqp_path_solve(pqp_handle* h, int batch, int n, const double* ref, const dou
     if (info) PQP_HIP(hipMemcpyAsync(info, h->s_info.p, (size_t)batch * PQP_INFO_STRIDE * 8, hipMemcpyDeviceToHost, h->stream));
     PQP_HIP(hipStreamSynchronize(h->stream));
     return PQP_OK;
+}
+
+int pqp_path_solve(pqp_handle* h, int batch, int n, const double* ref, const double* lin, const double* bounds,
+                   const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters, double* info) {
+    return path_solve_host(h, batch, n, nullptr, ref, lin, bounds, scal, passes, warm, out, status, iters, info);
+}
+
+int pqp_path_solve_var(pqp_handle* h, int batch, int n_max, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
+                       const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters, double* info) {
+    if (!n_of) return fail(PQP_ERR_INVALID, "pqp_path_solve_var: n_of is null");
+    return path_solve_host(h, batch, n_max, n_of, ref, lin, bounds, scal, passes, warm, out, status, iters, info);
 }
 
 int pqp_path_get_solution(pqp_handle* h, int batch, int n, int precise, double* x, double* y) {

@@ -279,3 +279,22 @@ def test_solve_is_deterministic_run_to_run(hip_lib, n, batch):
         assert np.array_equal(first["out"], again["out"]) and np.array_equal(first["iters"], again["iters"])
         assert np.array_equal(first["info"][:, 5:7], again["info"][:, 5:7])
     h.close()
+
+
+def test_waypoint_count_per_qp_on_the_gpu(hip_lib):
+    """pqp_path_solve_var: QPs of 80, 47, 64 and 1 waypoints in arrays of stride 80 give, one by one, what the truncated scenario
+    gives on its own (same iterations, same path to round-off of a different launch geometry), and a QP with fewer than two
+    waypoints is skipped with PQP_STATUS_UNSOLVED."""
+    b = make_batch(4, 80, "varied")
+    counts = np.array([80, 47, 64, 1], dtype=np.int32)
+    h = capi.Handle(_polished(), max_batch=4, max_n=80)
+    r = h.solve_var(counts, b["ref"], b["bounds"], b["scal"], passes=1)
+    for q, nq in enumerate(counts):
+        if nq < 2:
+            assert r["status"][q] == 0 and np.all(r["out"][q] == 0.0)
+            continue
+        alone = h.solve(b["ref"][q:q + 1, :nq].copy(), b["bounds"][q:q + 1, :nq].copy(), b["scal"][q:q + 1], passes=1)
+        assert r["status"][q] == 1 and alone["status"][0] == 1 and r["iters"][q] == alone["iters"][0]
+        assert np.abs(r["out"][q, :nq] - alone["out"][0]).max() < 1e-9
+        assert np.all(r["out"][q, nq:] == 0.0)
+    h.close()
