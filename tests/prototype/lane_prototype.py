@@ -1,7 +1,7 @@
 """numpy prototype of the per-waypoint ("lane") formulation the HIP kernel implements.
 Design aid only (not product, not oracle): checks the structured Ruiz metrics, the metric-form
 ADMM, the analytic slack/control elimination and the block cyclic reduction against the generic
-oracle in oracle/pqp_oracle.py.   Run: python tools/lane_prototype.py
+oracle in oracle/pqp_oracle.py.   Run: python tests/prototype/lane_prototype.py
 """
 import math, sys
 import numpy as np
