@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--polish-every", type=int, default=25, help="also try the KKT-verified polish every k ADMM iterations")
     ap.add_argument("--polish-refine", type=int, default=2, help="refinement solves per active-set round of the polish")
     ap.add_argument("--polish-max-rounds", type=int, default=0, help="active-set rounds before a polish attempt gives up (0: max(8, n/5 - 8))")
+    ap.add_argument("--polish-max-moves", type=int, default=-4, help="an attempt whose first active-set round moves more rows than this gives up at once (0: off; k < 0: n / |k|)")
+    ap.add_argument("--seed", type=int, default=None, help="seed of the synthetic scenarios (default: synth.BASE_SEED)")
+    ap.add_argument("--rho-tolerance", type=float, default=2.0, help="adaptive_rho_tolerance")
     ap.add_argument("--polish-warm-set", type=int, default=2, help="1: pass 2 starts with a polish on pass 1's active set; 2: and keeps its equilibration")
     ap.add_argument("--check-termination", type=int, default=25, help="residual check interval (iterations)")
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight: k > 1 runs consecutive steps on k handles / HIP streams "
@@ -78,7 +81,9 @@ def main():
     import torch
     from path_optimizer_2_amd import capi
     from path_optimizer_2_amd.shard import gather_paths
-    from path_optimizer_2_amd.synth import make_batch
+    from path_optimizer_2_amd.synth import BASE_SEED, make_batch
+    if args.seed is None:
+        args.seed = BASE_SEED
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -94,7 +99,7 @@ def main():
 
     batch, n = args.batch, args.n
     total = batch * world
-    host = make_batch(batch, n, args.profile, first_qp=rank * batch)          # this rank's shard of the global batch
+    host = make_batch(batch, n, args.profile, seed=args.seed, first_qp=rank * batch)          # this rank's shard of the global batch
     ref = torch.from_numpy(host["ref"]).to(dev)
     bounds = torch.from_numpy(host["bounds"]).to(dev)
     scal = torch.from_numpy(host["scal"]).to(dev)
@@ -106,7 +111,7 @@ def main():
     polish = not args.no_polish
     prm = capi.production_params(eps_abs=args.eps, eps_rel=args.eps, polish=1 if polish else 0, polish_every=args.polish_every,
                               adaptive_rho_interval=args.rho_interval, polish_warm_set=args.polish_warm_set if polish else 0, check_termination=args.check_termination, polish_refine_iter=args.polish_refine,
-                              polish_max_rounds=args.polish_max_rounds)
+                              polish_max_rounds=args.polish_max_rounds, polish_max_moves=args.polish_max_moves if polish else 0, adaptive_rho_tolerance=args.rho_tolerance)
     h = capi.Handle(prm, device=local_rank, max_batch=batch, max_n=n)
     # --inflight k: k - 1 more handles (own stream, own warm state, own outputs) used round-robin
     extra = [(capi.Handle(prm, device=local_rank, max_batch=batch, max_n=n), torch.zeros_like(out), torch.zeros_like(status),
@@ -180,7 +185,7 @@ def main():
             "config": {"workload": f"configs[1]: batch={batch} QPs per GPU, N={n}, shared sparsity, synthetic obstacle bounds ({args.profile} profile)",
                        "batch_per_gpu": batch, "n_waypoints": n, "eps_abs": args.eps, "eps_rel": args.eps, "polish": polish,
                        "polish_every": args.polish_every if polish else 0, "adaptive_rho_interval": args.rho_interval,
-                       "polish_refine_iter": args.polish_refine, "polish_max_rounds": args.polish_max_rounds, "polish_warm_set": args.polish_warm_set,
+                       "polish_refine_iter": args.polish_refine, "polish_max_rounds": args.polish_max_rounds, "polish_warm_set": args.polish_warm_set, "polish_max_moves": args.polish_max_moves,
                        "passes": "cold solve + 1 re-linearised warm re-solve (PathOptimizer::optimizePath)",
                        "parallelism": f"{world} independent shard(s), no collective in the timed region", "batches_in_flight": max(args.inflight, 1)},
             "admm_iters": {"min": int(it_np.min()), "median": float(np.median(it_np)), "p99": float(np.percentile(it_np, 99)),
@@ -196,7 +201,7 @@ def main():
                                  "traffic is far below this (profiles/, DESIGN.md 5)"},
         }
         if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(lambda k: make_batch(k, n, args.profile), n, args.eps, args.cpu_budget)
+            line["cpu_baseline"] = cpu_baseline(lambda k: make_batch(k, n, args.profile, seed=args.seed), n, args.eps, args.cpu_budget)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

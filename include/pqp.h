@@ -133,6 +133,9 @@ typedef struct pqp_params {
     double polish_tol;                /* 1e-7  KKT acceptance tolerance of the polished point  */
     double polish_reseed_factor;      /* 1.0   */
     double eps_prim_inf;              /* 1e-4  OSQP's primal infeasibility tolerance; <= 0: no certificate test */
+    int32_t polish_max_moves;         /* 0: off; k > 0: a polish attempt whose first active-set round finds more than k rows failing the KKT test
+                                         gives up at once (ADMM works on); k < 0: more than n / |k| rows */
+    int32_t reserved1;                /* padding, 0 */
     /* smoother QP weights (src/config/planning_flags.cpp:51-61) */
     double tension2_deviation_weight;        /* 0.005 */
     double tension2_curvature_weight;        /* 1     */

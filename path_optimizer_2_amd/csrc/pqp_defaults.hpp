@@ -40,6 +40,8 @@ inline void default_params(pqp_params* p) {
     p->polish_diverge = 0;
     p->polish_reseed_factor = 1.0;
     p->eps_prim_inf = 1e-4;
+    p->polish_max_moves = 0;
+    p->reserved1 = 0;
     p->polish_delta = 1e-6;
     p->polish_tol = 1e-7;
     p->tension2_deviation_weight = 0.005;           // planning_flags.cpp:57
@@ -66,6 +68,8 @@ inline void production_params(pqp_params* p) {
     p->polish_warm_set = 2;
     p->polish_max_rounds = 0;                       // auto: max(8, n/5 - 8)
     p->polish_reseed = 1;
+    p->adaptive_rho_tolerance = 2.0;                // re-balance rho sooner: the few slow QPs of a batch need 175 instead of 350 iterations
+    p->polish_max_moves = -4;                       // a first round that moves more than n/4 rows started from a poor guess
     p->eps_prim_inf = 0.0;                          // the kernel variant without OSQP's infeasibility certificate: 12 % faster
                                                     // iterations; an infeasible QP then ends with PQP_STATUS_MAX_ITER
 }

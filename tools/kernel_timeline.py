@@ -27,7 +27,7 @@ if __name__ == "__main__":
     capi.LIB_PATH = LIB
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 80
-    over = dict(eps_abs=1e-4, eps_rel=1e-4, polish=1, polish_every=25, adaptive_rho_interval=25, polish_warm_set=2, polish_refine_iter=2, polish_max_rounds=8)
+    over = {}                       # the production setting (bench.py's) unless overridden on the command line: key=value ...
     for kv in sys.argv[3:]:
         k, v = kv.split("=")
         over[k] = float(v) if ("." in v or "e" in v) else int(v)
@@ -36,7 +36,7 @@ if __name__ == "__main__":
     ref, bounds, scal = (torch.from_numpy(host[k]).to(dev) for k in ("ref", "bounds", "scal"))
     out = torch.zeros((batch, n, 7), dtype=torch.float64, device=dev)
     info = torch.zeros((batch, 8), dtype=torch.float64, device=dev)
-    h = capi.Handle(capi.default_params(**over), device=0, max_batch=batch, max_n=n)
+    h = capi.Handle(capi.production_params(**over), device=0, max_batch=batch, max_n=n)
     for _ in range(3):
         h.solve_device(batch, n, ref, bounds, scal, out, passes=1, info=info)
     h.sync()

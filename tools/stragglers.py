@@ -13,7 +13,8 @@ over = {}
 for kv in sys.argv[4:]:
     k, v = kv.split("=")
     over[k] = float(v) if ("." in v or "e" in v) else int(v)
-host = make_batch(batch, n, profile)
+seed = int(over.pop("seed", -1))
+host = make_batch(batch, n, profile) if seed < 0 else make_batch(batch, n, profile, seed=seed)
 res = capi.Handle(capi.production_params(**over), device=0, max_batch=batch, max_n=n).solve(host["ref"], host["bounds"], host["scal"], passes=1)
 kkt, fac = res["info"][:, 5], res["info"][:, 6]
 order = np.argsort(-kkt)[:12]
