@@ -1634,7 +1634,12 @@ struct PathQp {
                     // twice (eps_scale tightened to <= 0.05) only the periodic speculative attempts are still cut short, so a
                     // degenerate QP with many marginal rows cannot be locked out of its polish.
                     const bool gate = eps_scale > 0.05 || speculative;
-                    if (!give_up && gate && round == 0 && max_moves > 0 && polish_count_failing(tol) > max_moves) give_up = true;
+                    if (!give_up && gate && round == 0 && max_moves > 0 && polish_count_failing(tol) > max_moves) {
+                        give_up = true;
+                        // a cut attempt was cheap (one factorisation, no rounds): it does not let the gap to the next one grow
+                        // beyond 8 x polish_every, so a slow QP is not left iterating long after its active set has settled
+                        if (polish_gap > 8 * prm.polish_every) { polish_gap = 8 * prm.polish_every; next_polish = it + polish_gap; }
+                    }
                     if (solve_ok && viol < best_any) { best_any = viol; if (prm.polish_reseed) polish_save_best(); }
                     if (!give_up) {
                         // primal-dual active-set step.  A full update can cycle: when the violation stops improving only
