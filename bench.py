@@ -62,15 +62,15 @@ def main():
     ap.add_argument("--n", type=int, default=80, help="waypoints per path")
     ap.add_argument("--eps", type=float, default=1e-4, help="eps_abs = eps_rel of the ADMM termination test")
     ap.add_argument("--no-polish", action="store_true", help="plain OSQP termination (the reference setting), no polish")
-    ap.add_argument("--rho-interval", type=int, default=25, help="adaptive_rho_interval (iterations)")
-    ap.add_argument("--polish-every", type=int, default=25, help="also try the KKT-verified polish every k ADMM iterations")
+    ap.add_argument("--rho-interval", type=int, default=15, help="adaptive_rho_interval (iterations)")
+    ap.add_argument("--polish-every", type=int, default=15, help="also try the KKT-verified polish every k ADMM iterations")
     ap.add_argument("--polish-refine", type=int, default=2, help="refinement solves per active-set round of the polish")
-    ap.add_argument("--polish-max-rounds", type=int, default=0, help="active-set rounds before a polish attempt gives up (0: max(8, n/5 - 8))")
+    ap.add_argument("--polish-max-rounds", type=int, default=0, help="active-set rounds before a polish attempt gives up (0: max(24, n/5 - 8))")
     ap.add_argument("--polish-max-moves", type=int, default=-4, help="an attempt whose first active-set round moves more rows than this gives up at once (0: off; k < 0: n / |k|)")
     ap.add_argument("--seed", type=int, default=None, help="seed of the synthetic scenarios (default: synth.BASE_SEED)")
     ap.add_argument("--rho-tolerance", type=float, default=2.0, help="adaptive_rho_tolerance")
     ap.add_argument("--polish-warm-set", type=int, default=2, help="1: pass 2 starts with a polish on pass 1's active set; 2: and keeps its equilibration")
-    ap.add_argument("--check-termination", type=int, default=25, help="residual check interval (iterations)")
+    ap.add_argument("--check-termination", type=int, default=15, help="residual check interval (iterations)")
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight: k > 1 runs consecutive steps on k handles / HIP streams "
                     "(what a server does with independent batches; the next batch fills the slots the slow tail of this one leaves idle)")
     ap.add_argument("--profile", default="uniform", choices=["uniform", "varied"])

@@ -125,7 +125,7 @@ typedef struct pqp_params {
     int32_t polish_every;             /* 0: only when the residual test passes; k: also try every k iterations */
     int32_t polish_warm_set;          /* 1: a warm re-linearised re-solve starts with a polish on the previous pass's active set;
                                          2: ... and keeps that pass's equilibration (D, E, c) instead of re-running Ruiz */
-    int32_t polish_max_rounds;        /* 40: active-set correction rounds per polish attempt; <= 0: max(8, n/5 - 8) (40 for the smoothers) */
+    int32_t polish_max_rounds;        /* 40: active-set correction rounds per polish attempt; <= 0: max(24, n/5 - 8) (40 for the smoothers) */
     int32_t polish_reseed;            /* 1: a polish attempt that gives up hands its best point (smallest KKT failure) to ADMM as the
                                          new iterate when that failure is below polish_reseed_factor x the ADMM residuals */
     int32_t polish_diverge;           /* k > 0: an attempt gives up as soon as the KKT failure exceeds k x the smallest one seen in it */

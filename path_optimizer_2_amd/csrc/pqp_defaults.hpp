@@ -54,19 +54,20 @@ inline void default_params(pqp_params* p) {
 
 // The engine's production setting on top of the defaults: ADMM to 1e-4, KKT-verified polish (every returned path is the exact
 // optimum of its QP), residual check / rho adaptation / polish attempt every 25 iterations, 2 refinement solves per active-set
-// round, at most max(8, n/5 - 8) rounds per attempt, pass 2 starts from pass 1's active set and equilibration, an attempt that gives up re-seeds ADMM with its best point, no
+// round, at most max(24, n/5 - 8) rounds per attempt, pass 2 starts from pass 1's active set and equilibration, an attempt that gives up re-seeds ADMM with its best point, no
 // infeasibility certificate (set eps_prim_inf = 1e-4 to get OSQP's behaviour back).  Tuned on MI355X
 // (DESIGN.md section 6); bench.py, smoke() and the parity tests run this setting.
 inline void production_params(pqp_params* p) {
     default_params(p);
     p->eps_abs = 1e-4;
     p->eps_rel = 1e-4;
-    p->adaptive_rho_interval = 25;
+    p->adaptive_rho_interval = 15;
+    p->check_termination = 15;
     p->polish = 1;
     p->polish_refine_iter = 2;
-    p->polish_every = 25;
+    p->polish_every = 15;
     p->polish_warm_set = 2;
-    p->polish_max_rounds = 0;                       // auto: max(8, n/5 - 8)
+    p->polish_max_rounds = 0;                       // auto: max(24, n/5 - 8)
     p->polish_reseed = 1;
     p->adaptive_rho_tolerance = 2.0;                // re-balance rho sooner: the few slow QPs of a batch need 175 instead of 350 iterations
     p->polish_max_moves = -4;                       // a first round that moves more than n/4 rows started from a poor guess

@@ -844,8 +844,32 @@ struct PathQp {
         return viol[0];
     }
 
-    // --- polish piece 3b: how many rows fail the KKT test by more than thr (the size of the next active-set step)
+    // --- polish piece 3b: the inactive rows that fail the test by more than thr, published per waypoint and row kind (0: none).
+    //     A run of violated neighbouring rows of one kind is ONE bump of the path over its bound: pinning its peak removes it,
+    //     pinning the whole run over-constrains the path and the surplus rows then have to be peeled off one end at a time.
+    //     So only the local maxima of a run are added (ties: both).
+    PQP_HD void polish_publish_adds(double thr) {
+        ctx.phase([&](int t, Lane& ln) {
+            const Slot& S = ln.s;
+            double Xp[3], aT[3], aI[3];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
+            rows_of(S, Xp, S.x, aT, aI);
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                const bool inactive = !(S.flags & ((F_ACTLO0 << k) | (F_ACTUP0 << k)));
+                const double v = row_violation(S, k, aI[k]);
+                sh[L.bufQ() + 3 * t + k] = (inactive && v > thr) ? v : 0.0;
+            }
+        });
+    }
+    PQP_HD bool polish_is_peak(int t, int k, double v) const {
+        const double l = t > 0 ? sh[L.bufQ() + 3 * (t - 1) + k] : 0.0;
+        const double r = t + 1 < T ? sh[L.bufQ() + 3 * (t + 1) + k] : 0.0;
+        return v >= l && v >= r;
+    }
+
+    // --- polish piece 3c: how many rows the next active-set step with threshold thr would move
     PQP_HD int polish_count_failing(double thr) {
+        polish_publish_adds(thr);
         double cnt[1];
         ctx.template reduce_sum<1>(cnt, [&](int t, Lane& ln, double (&v)[1]) {
             const Slot& S = ln.s;
@@ -853,7 +877,11 @@ struct PathQp {
             _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
             rows_of(S, Xp, S.x, aT, aI);
             double c = 0.0;
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) c += row_violation(S, k, aI[k]) > thr ? 1.0 : 0.0;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                const bool active = S.flags & ((F_ACTLO0 << k) | (F_ACTUP0 << k));
+                const double w = row_violation(S, k, aI[k]);
+                c += (w > thr && (active || polish_is_peak(t, k, w))) ? 1.0 : 0.0;
+            }
             if (S.flags & F_LAST) {
                 const EndRows* er = end_rows();
                 for (int k = 0; k < 2; ++k) c += end_violation(er, k, S.x[k]) > thr ? 1.0 : 0.0;
@@ -865,6 +893,7 @@ struct PathQp {
 
     // --- polish piece 4: primal-dual active-set step: rows failing the test by more than thr change sides
     PQP_HD void polish_update_set(double thr) {
+        polish_publish_adds(thr);
         ctx.phase([&](int t, Lane& ln) {
             Slot& S = ln.s;
             double Xp[3], aT[3], aI[3];
@@ -873,7 +902,8 @@ struct PathQp {
             int fl = S.flags;
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                 const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
-                const bool move = row_violation(S, k, aI[k]) > thr;
+                const double w = row_violation(S, k, aI[k]);
+                const bool move = w > thr && (alo || aup || polish_is_peak(t, k, w));
                 const bool add_lo = move && !alo && !aup && (raw_lo(S, k) - aI[k] > aI[k] - raw_up(S, k));
                 const bool add_up = move && !alo && !aup && !add_lo;
 #ifdef PQP_EMU_DEBUG
@@ -1497,7 +1527,7 @@ struct PathQp {
         // active-set rounds per polish attempt; <= 0: sized to the path (long paths need more rounds, short ones pay for them)
         const int auto_rounds = n / 5 - 8;
         const int max_moves = prm.polish_max_moves >= 0 ? prm.polish_max_moves : n / (-prm.polish_max_moves);      // < 0: a fraction of the path
-        const int max_rounds = prm.polish_max_rounds > 0 ? prm.polish_max_rounds : (auto_rounds > 8 ? auto_rounds : 8);
+        const int max_rounds = prm.polish_max_rounds > 0 ? prm.polish_max_rounds : (auto_rounds > 24 ? auto_rounds : 24);
         double res[5] = {0, 0, 0, 0, 0};
         int pass = 0;
         // per-pass state of the hot loop
@@ -1645,9 +1675,11 @@ struct PathQp {
                         // primal-dual active-set step.  A full update can cycle: when the violation stops improving only
                         // the worst offenders (>= 90 % of the maximum) move.
                         if (viol < 0.7 * best) { best = viol; stall = 0; } else { stall += 1; }
-                        if (stall >= 3) conservative = true;
+                        // (progress of the cautious rounds is measured from where they start: the full rounds before them may
+                        // have passed through a smaller violation on their way out)
+                        if (stall >= 3 && !conservative) { conservative = true; best = viol; stall = 0; }
                         round += 1;
-                        give_up = (conservative && stall >= 16) || round >= max_rounds;
+                        give_up = (conservative && stall >= 8) || round >= max_rounds;
                     }
                     if (give_up) {
                         polish_mode = false;
