@@ -864,7 +864,10 @@ struct PathQp {
     PQP_HD bool polish_is_peak(int t, int k, double v) const {
         const double l = t > 0 ? sh[L.bufQ() + 3 * (t - 1) + k] : 0.0;
         const double r = t + 1 < T ? sh[L.bufQ() + 3 * (t + 1) + k] : 0.0;
-        return v >= l && v >= r;
+        // the front and the rear circle of one waypoint (rows 1, 2) over the same bound are one bump too: pinning both fixes
+        // offset and heading there, and the two then push each other out again round after round
+        const bool other = k == 0 ? true : (k == 1 ? v >= sh[L.bufQ() + 3 * t + 2] : v > sh[L.bufQ() + 3 * t + 1]);
+        return v >= l && v >= r && other;
     }
 
     // --- polish piece 3c: how many rows the next active-set step with threshold thr would move
