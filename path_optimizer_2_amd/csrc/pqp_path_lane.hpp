@@ -859,15 +859,29 @@ struct PathQp {
                 const double v = row_violation(S, k, aI[k]);
                 sh[L.bufQ() + 3 * t + k] = (inactive && v > thr) ? v : 0.0;
             }
+            if (S.flags & F_LAST) {
+                EndRows* er = end_rows();
+                for (int k = 0; k < 2; ++k) {
+                    const double v = end_violation(er, k, S.x[k]);
+                    er->pad[k] = (er->act[k] == 0.0 && v > thr) ? v : 0.0;
+                }
+            }
         });
     }
-    PQP_HD bool polish_is_peak(int t, int k, double v) const {
+    PQP_HD bool polish_is_peak(int t, int k, double v, bool last) const {
         const double l = t > 0 ? sh[L.bufQ() + 3 * (t - 1) + k] : 0.0;
         const double r = t + 1 < T ? sh[L.bufQ() + 3 * (t + 1) + k] : 0.0;
         // the front and the rear circle of one waypoint (rows 1, 2) over the same bound are one bump too: pinning both fixes
         // offset and heading there, and the two then push each other out again round after round
-        const bool other = k == 0 ? true : (k == 1 ? v >= sh[L.bufQ() + 3 * t + 2] : v > sh[L.bufQ() + 3 * t + 1]);
+        bool other = k == 0 ? true : (k == 1 ? v >= sh[L.bufQ() + 3 * t + 2] : v > sh[L.bufQ() + 3 * t + 1]);
+        // ... and so are the end-state rows (offset, heading of the last waypoint) together with its two circle rows
+        if (last && k >= 1) other = other && v >= end_rows()->pad[0] && v >= end_rows()->pad[1];
         return v >= l && v >= r && other;
+    }
+    PQP_HD bool polish_end_is_peak(int t, int k, double v) const {
+        const EndRows* er = end_rows();
+        const bool other = k == 0 ? v >= er->pad[1] : v > er->pad[0];
+        return other && v > sh[L.bufQ() + 3 * t + 1] && v > sh[L.bufQ() + 3 * t + 2];
     }
 
     // --- polish piece 3c: how many rows the next active-set step with threshold thr would move
@@ -883,11 +897,14 @@ struct PathQp {
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                 const bool active = S.flags & ((F_ACTLO0 << k) | (F_ACTUP0 << k));
                 const double w = row_violation(S, k, aI[k]);
-                c += (w > thr && (active || polish_is_peak(t, k, w))) ? 1.0 : 0.0;
+                c += (w > thr && (active || polish_is_peak(t, k, w, S.flags & F_LAST))) ? 1.0 : 0.0;
             }
             if (S.flags & F_LAST) {
                 const EndRows* er = end_rows();
-                for (int k = 0; k < 2; ++k) c += end_violation(er, k, S.x[k]) > thr ? 1.0 : 0.0;
+                for (int k = 0; k < 2; ++k) {
+                    const double w = end_violation(er, k, S.x[k]);
+                    c += (w > thr && (er->act[k] != 0.0 || polish_end_is_peak(t, k, w))) ? 1.0 : 0.0;
+                }
             }
             v[0] = c;
         });
@@ -906,7 +923,7 @@ struct PathQp {
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                 const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
                 const double w = row_violation(S, k, aI[k]);
-                const bool move = w > thr && (alo || aup || polish_is_peak(t, k, w));
+                const bool move = w > thr && (alo || aup || polish_is_peak(t, k, w, S.flags & F_LAST));
                 const bool add_lo = move && !alo && !aup && (raw_lo(S, k) - aI[k] > aI[k] - raw_up(S, k));
                 const bool add_up = move && !alo && !aup && !add_lo;
 #ifdef PQP_EMU_DEBUG
@@ -921,7 +938,11 @@ struct PathQp {
             if (S.flags & F_LAST) {
                 EndRows* er = end_rows();
                 for (int k = 0; k < 2; ++k) {
-                    if (!(end_violation(er, k, S.x[k]) > thr)) continue;
+                    const double w = end_violation(er, k, S.x[k]);
+                    if (!(w > thr) || (er->act[k] == 0.0 && !polish_end_is_peak(t, k, w))) continue;
+#ifdef PQP_EMU_DEBUG
+                    printf("      end row k=%d %s viol %.3e (x %.5f lo %.5f up %.5f y %.4e)\n", k, er->act[k] != 0.0 ? "RELEASE" : "ADD", end_violation(er, k, S.x[k]), S.x[k], er->lo[k], er->up[k], er->y[k]);
+#endif
                     if (er->act[k] != 0.0) er->act[k] = 0.0;
                     else er->act[k] = (er->lo[k] - S.x[k] > S.x[k] - er->up[k]) ? -1.0 : 1.0;
                 }
