@@ -168,12 +168,17 @@ def main():
     achieved = abytes / avg_kernel_s / 1e9
     # measured HBM bytes per launch come from separate rocprofv3 --pmc passes of THIS command (FETCH_SIZE, WRITE_SIZE; the
     # gfx950 x2 correction of FETCH_SIZE for wide reads applied; MI355X_MICROARCH.md HBM section), committed under profiles/
-    traffic = None
+    traffic, issue = None, None
     pmc_file = os.path.join(ROOT, "profiles", "r01_bench_n1_pmc_per_launch.json")
     if world == 1 and batch == 1024 and n == 80 and polish and os.path.exists(pmc_file):
         try:
             pmc = json.load(open(pmc_file))
             traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+            # what does bound the kernel (SURVEY.md 8d "secondary ceilings"): share of the wave cycles spent issuing fp64 VALU /
+            # LDS instructions and waiting, from the same PMC passes
+            wc = pmc["SQ_WAVE_CYCLES"]
+            issue = {"valu_active_frac": pmc["SQ_ACTIVE_INST_VALU"] / wc, "lds_active_frac": pmc["SQ_ACTIVE_INST_LDS"] / wc,
+                     "any_active_frac": pmc["SQ_ACTIVE_INST_ANY"] / wc, "wait_frac": pmc["SQ_WAIT_ANY"] / wc, "waves_per_simd": 1}
         except Exception:
             traffic = None
     if rank == 0:
@@ -195,7 +200,7 @@ def main():
             "gather_check": gathered_ok, "solved": int((st_np == 1).sum()), "polished": int((info_np[:, 4] >= 2).sum()), "batch": batch,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "path_solve_kernel", "kernel_ms": avg_kernel_s * 1e3,
-                         "algorithmic_bytes_per_launch": abytes,
+                         "algorithmic_bytes_per_launch": abytes, "issue": issue,
                          "achieved_incl_factor_and_scaling": abytes_ext / avg_kernel_s / 1e9,
                          "note": "SURVEY.md 8(d) streaming-model bytes; the iterates are register/LDS resident, so measured HBM "
                                  "traffic is far below this (profiles/, DESIGN.md 5)"},
