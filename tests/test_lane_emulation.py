@@ -114,3 +114,25 @@ def test_primal_infeasibility_certificate():
     assert E.solve(E.params(), b["ref"], b["bounds"], b["scal"])["iters"][1] == ref[0]["iters"]
     off = E.solve(E.params(eps_prim_inf=0.0, max_iter=300), b["ref"], b["bounds"], b["scal"])
     assert off["status"][1] == 2 and off["iters"][1] == 300        # without the test: max_iter
+
+
+# Scenarios that defeated the active-set rounds of the polish before the local-maximum rule: adding a
+# whole run of violated rows over-constrained the path and ADMM then iterated for hundreds of iterations.  (seed, first_qp, n,
+# profile, what went wrong, reduced-KKT solves it took then)
+STRAGGLERS = [
+    (None, 4009, 200, "uniform", "70 rows of two bumps added at once, peeled off two per round", 2237),
+    (3, 216, 80, "uniform", "front and rear circle row of the last waypoint added together, released together, 3-cycle", 236),
+    (None, 7215, 120, "varied", "end-state offset row and the last waypoint's circle row pushing each other out", 356),
+    (0, 907, 80, "uniform", "eight-round attempts failing at iterations 25 / 75 / 175", 404),
+]
+
+
+@pytest.mark.parametrize("seed,qp,n,profile,what,before", STRAGGLERS)
+def test_former_stragglers_finish_in_the_first_attempts(seed, qp, n, profile, what, before):
+    b = make_batch(1, n, profile, first_qp=qp) if seed is None else make_batch(1, n, profile, seed=seed, first_qp=qp)
+    r = E.solve(E.production(), b["ref"], b["bounds"], b["scal"], passes=1)
+    assert r["status"][0] == 1 and r["info"][0, 4] == 2
+    assert r["info"][0, 5] <= 110 and r["info"][0, 5] < before / 3, what
+    ref = O.solve_path(b["ref"][0], b["bounds"][0], b["scal"][0], st=TIGHT)
+    # (the ADMM oracle at eps 1e-9 is itself only good to ~1e-6 on the weakly determined end of these paths)
+    assert np.abs(r["out"][0][:, 3:5] - ref[-1]["out"][:, 3:5]).max() < 5e-6
