@@ -66,7 +66,6 @@ def main():
     ap.add_argument("--polish-every", type=int, default=15, help="also try the KKT-verified polish every k ADMM iterations")
     ap.add_argument("--polish-refine", type=int, default=2, help="refinement solves per active-set round of the polish")
     ap.add_argument("--polish-max-rounds", type=int, default=0, help="active-set rounds before a polish attempt gives up (0: max(24, n/5 - 8))")
-    ap.add_argument("--polish-max-moves", type=int, default=-4, help="an attempt whose first active-set round moves more rows than this gives up at once (0: off; k < 0: n / |k|)")
     ap.add_argument("--seed", type=int, default=None, help="seed of the synthetic scenarios (default: synth.BASE_SEED)")
     ap.add_argument("--rho-tolerance", type=float, default=2.0, help="adaptive_rho_tolerance")
     ap.add_argument("--polish-warm-set", type=int, default=2, help="1: pass 2 starts with a polish on pass 1's active set; 2: and keeps its equilibration")
@@ -111,7 +110,7 @@ def main():
     polish = not args.no_polish
     prm = capi.production_params(eps_abs=args.eps, eps_rel=args.eps, polish=1 if polish else 0, polish_every=args.polish_every,
                               adaptive_rho_interval=args.rho_interval, polish_warm_set=args.polish_warm_set if polish else 0, check_termination=args.check_termination, polish_refine_iter=args.polish_refine,
-                              polish_max_rounds=args.polish_max_rounds, polish_max_moves=args.polish_max_moves if polish else 0, adaptive_rho_tolerance=args.rho_tolerance)
+                              polish_max_rounds=args.polish_max_rounds, adaptive_rho_tolerance=args.rho_tolerance)
     h = capi.Handle(prm, device=local_rank, max_batch=batch, max_n=n)
     # --inflight k: k - 1 more handles (own stream, own warm state, own outputs) used round-robin
     extra = [(capi.Handle(prm, device=local_rank, max_batch=batch, max_n=n), torch.zeros_like(out), torch.zeros_like(status),
@@ -190,7 +189,7 @@ def main():
             "config": {"workload": f"configs[1]: batch={batch} QPs per GPU, N={n}, shared sparsity, synthetic obstacle bounds ({args.profile} profile)",
                        "batch_per_gpu": batch, "n_waypoints": n, "eps_abs": args.eps, "eps_rel": args.eps, "polish": polish,
                        "polish_every": args.polish_every if polish else 0, "adaptive_rho_interval": args.rho_interval,
-                       "polish_refine_iter": args.polish_refine, "polish_max_rounds": args.polish_max_rounds, "polish_warm_set": args.polish_warm_set, "polish_max_moves": args.polish_max_moves,
+                       "polish_refine_iter": args.polish_refine, "polish_max_rounds": args.polish_max_rounds, "polish_warm_set": args.polish_warm_set,
                        "passes": "cold solve + 1 re-linearised warm re-solve (PathOptimizer::optimizePath)",
                        "parallelism": f"{world} independent shard(s), no collective in the timed region", "batches_in_flight": max(args.inflight, 1)},
             "admm_iters": {"min": int(it_np.min()), "median": float(np.median(it_np)), "p99": float(np.percentile(it_np, 99)),

@@ -133,9 +133,11 @@ typedef struct pqp_params {
     double polish_tol;                /* 1e-7  KKT acceptance tolerance of the polished point  */
     double polish_reseed_factor;      /* 1.0   */
     double eps_prim_inf;              /* 1e-4  OSQP's primal infeasibility tolerance; <= 0: no certificate test */
-    int32_t polish_max_moves;         /* 0: off; k > 0: a polish attempt whose first active-set round finds more than k rows failing the KKT test
-                                         gives up at once (ADMM works on); k < 0: more than n / |k| rows */
-    int32_t reserved1;                /* padding, 0 */
+    int32_t polish_patience;          /* 0: a pass ends only with an accepted polish (or max_iter).  k > 0: once ADMM has met its
+                                         residual test and the gap between polish attempts has doubled k times without an accepted
+                                         polish, the ADMM point is returned as PQP_STATUS_SOLVED without polish - OSQP's behaviour when
+                                         its polish fails (info[4] counts the polished passes).  With polish_every = 0: at once. */
+    int32_t reserved0;                /* padding, 0 */
     /* smoother QP weights (src/config/planning_flags.cpp:51-61) */
     double tension2_deviation_weight;        /* 0.005 */
     double tension2_curvature_weight;        /* 1     */

@@ -40,8 +40,8 @@ inline void default_params(pqp_params* p) {
     p->polish_diverge = 0;
     p->polish_reseed_factor = 1.0;
     p->eps_prim_inf = 1e-4;
-    p->polish_max_moves = 0;
-    p->reserved1 = 0;
+    p->polish_patience = 0;
+    p->reserved0 = 0;
     p->polish_delta = 1e-6;
     p->polish_tol = 1e-7;
     p->tension2_deviation_weight = 0.005;           // planning_flags.cpp:57
@@ -52,11 +52,12 @@ inline void default_params(pqp_params* p) {
     p->cartesian_deviation_weight = 0.0;            // planning_flags.cpp:55
 }
 
-// The engine's production setting on top of the defaults: ADMM to 1e-4, KKT-verified polish (every returned path is the exact
-// optimum of its QP), residual check / rho adaptation / polish attempt every 25 iterations, 2 refinement solves per active-set
-// round, at most max(24, n/5 - 8) rounds per attempt, pass 2 starts from pass 1's active set and equilibration, an attempt that gives up re-seeds ADMM with its best point, no
-// infeasibility certificate (set eps_prim_inf = 1e-4 to get OSQP's behaviour back).  Tuned on MI355X
-// (DESIGN.md section 6); bench.py, smoke() and the parity tests run this setting.
+// The engine's production setting on top of the defaults: ADMM to 1e-4, KKT-verified polish (a returned path is the exact
+// optimum of its QP), residual check / rho adaptation / polish attempt every 15 iterations, 2 refinement solves per active-set
+// round, at most max(24, n/5 - 8) rounds per attempt, pass 2 starts from pass 1's active set and equilibration, an attempt that
+// gives up re-seeds ADMM with its best point, a QP whose polish cannot be verified ends like OSQP's (ADMM point, unpolished), no
+// infeasibility certificate (set eps_prim_inf = 1e-4 to get OSQP's behaviour back).  Tuned on MI355X (DESIGN.md sections 2, 5);
+// bench.py, smoke() and the parity tests run this setting.
 inline void production_params(pqp_params* p) {
     default_params(p);
     p->eps_abs = 1e-4;
@@ -70,7 +71,8 @@ inline void production_params(pqp_params* p) {
     p->polish_max_rounds = 0;                       // auto: max(24, n/5 - 8)
     p->polish_reseed = 1;
     p->adaptive_rho_tolerance = 2.0;                // re-balance rho sooner: the few slow QPs of a batch need 175 instead of 350 iterations
-    p->polish_max_moves = -4;                       // a first round that moves more than n/4 rows started from a poor guess
+    p->polish_patience = 5;                         // a QP whose polish cannot be verified (e.g. infeasible by 1e-5) ends like OSQP's,
+                                                    // after attempts at 15, 45, 105, 225, 465 iterations
     p->eps_prim_inf = 0.0;                          // the kernel variant without OSQP's infeasibility certificate: 12 % faster
                                                     // iterations; an infeasible QP then ends with PQP_STATUS_MAX_ITER
 }

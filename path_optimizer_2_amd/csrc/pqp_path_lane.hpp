@@ -884,33 +884,6 @@ struct PathQp {
         return other && v > sh[L.bufQ() + 3 * t + 1] && v > sh[L.bufQ() + 3 * t + 2];
     }
 
-    // --- polish piece 3c: how many rows the next active-set step with threshold thr would move
-    PQP_HD int polish_count_failing(double thr) {
-        polish_publish_adds(thr);
-        double cnt[1];
-        ctx.template reduce_sum<1>(cnt, [&](int t, Lane& ln, double (&v)[1]) {
-            const Slot& S = ln.s;
-            double Xp[3], aT[3], aI[3];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
-            rows_of(S, Xp, S.x, aT, aI);
-            double c = 0.0;
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                const bool active = S.flags & ((F_ACTLO0 << k) | (F_ACTUP0 << k));
-                const double w = row_violation(S, k, aI[k]);
-                c += (w > thr && (active || polish_is_peak(t, k, w, S.flags & F_LAST))) ? 1.0 : 0.0;
-            }
-            if (S.flags & F_LAST) {
-                const EndRows* er = end_rows();
-                for (int k = 0; k < 2; ++k) {
-                    const double w = end_violation(er, k, S.x[k]);
-                    c += (w > thr && (er->act[k] != 0.0 || polish_end_is_peak(t, k, w))) ? 1.0 : 0.0;
-                }
-            }
-            v[0] = c;
-        });
-        return (int)(cnt[0] + 0.5);
-    }
-
     // --- polish piece 4: primal-dual active-set step: rows failing the test by more than thr change sides
     PQP_HD void polish_update_set(double thr) {
         polish_publish_adds(thr);
@@ -1550,15 +1523,14 @@ struct PathQp {
         int total_iters = 0, last_iters = 0, status = PQP_STATUS_UNSOLVED, polished = 0;
         // active-set rounds per polish attempt; <= 0: sized to the path (long paths need more rounds, short ones pay for them)
         const int auto_rounds = n / 5 - 8;
-        const int max_moves = prm.polish_max_moves >= 0 ? prm.polish_max_moves : n / (-prm.polish_max_moves);      // < 0: a fraction of the path
         const int max_rounds = prm.polish_max_rounds > 0 ? prm.polish_max_rounds : (auto_rounds > 24 ? auto_rounds : 24);
         double res[5] = {0, 0, 0, 0, 0};
         int pass = 0;
         // per-pass state of the hot loop
         bool polish_mode = false, conservative = false, end_after_reject = false;
-        bool speculative = false;        // the running polish attempt was started before ADMM met its residual test
         double eps_scale = 1.0, best = 1e300, best_any = 1e300, admm_merit = 1e300;
         int it = 0, refine_left = 0, round = 0, stall = 0, polish_gap = 0, next_polish = 0;
+        int extra_refine = 0;            // extra pairs of refinement solves spent on the current polish round
         bool direct_polish = false, last_accepted = false;
         // the pending cold operation
         int op = COLD_BEGIN_PASS, i0 = 0, i1 = A.warm ? 1 : 0;
@@ -1597,7 +1569,7 @@ struct PathQp {
                 it = 0; refine_left = 0; round = 0; stall = 0;
                 polish_gap = prm.polish_every; next_polish = prm.polish_every;
                 last_accepted = false;
-                if (direct_polish) { polish_mode = true; speculative = false; refine_left = prm.polish_refine_iter; best_any = 1e300; admm_merit = 1e300; }
+                if (direct_polish) { polish_mode = true; refine_left = prm.polish_refine_iter; best_any = 1e300; admm_merit = 1e300; }
             } else if (end_after_reject) {       // a rejected polish at max_iter
                 op = COLD_END_PASS; i0 = 0;
                 continue;
@@ -1628,17 +1600,21 @@ struct PathQp {
                     if (check) {
                         const double eps_p = eps_scale * (prm.eps_abs + prm.eps_rel * res[2]);
                         const double eps_d = eps_scale * (prm.eps_abs + prm.eps_rel * res[3]);
+                        // the polish of this QP cannot be verified (typically: infeasible by less than eps, so that the tightened
+                        // residual tests below are never met): what OSQP does when its polish fails - return the ADMM point
+                        if (prm.polish_patience > 0 && eps_scale < 1.0 && polish_gap >= (prm.polish_every << prm.polish_patience) &&
+                            res[0] <= prm.eps_abs + prm.eps_rel * res[2] && res[1] <= prm.eps_abs + prm.eps_rel * res[3]) {
+                            status = PQP_STATUS_SOLVED; op = COLD_END_PASS; i0 = 0; break;
+                        }
                         if (res[0] <= eps_p && res[1] <= eps_d) {
                             if (!prm.polish || eps_scale * fmax(prm.eps_abs, prm.eps_rel) < 1e-10) {
                                 status = PQP_STATUS_SOLVED; op = COLD_END_PASS; i0 = 0; break;
                             }
                             start_polish = true;
-                            speculative = false;
                             eps_scale *= 0.1;      // if this polish is rejected ADMM resumes one decade tighter
                         } else if (prm.polish && prm.polish_every > 0 && it >= next_polish) {
                             // a slow ADMM tail: the active set is often already right long before the residuals say so
                             start_polish = true;
-                            speculative = polish_gap == prm.polish_every;      // only the first such attempt of a pass may be cut short
                             polish_gap *= 2;       // back off if it is rejected
                             next_polish = it + polish_gap;
                         }
@@ -1676,6 +1652,11 @@ struct PathQp {
                     { PQP_TIC; viol = polish_violation(); PQP_TOC(6); }
                     const bool solve_ok = res[4] == 0.0 && res[0] <= tol * (1.0 + res[2]) && res[1] <= tol * (1.0 + res[3]);
                     const bool ok = solve_ok && viol <= tol;
+                    // the refinement solves start from the ADMM iterate; from a distant one the budgeted number of them may leave the
+                    // polished point short of the accuracy the KKT test needs: up to 3 more pairs of solves instead of throwing the
+                    // attempt away
+                    if (!solve_ok && res[4] == 0.0 && extra_refine < 3) { extra_refine += 1; refine_left = 2; continue; }
+                    extra_refine = 0;
 #ifdef PQP_EMU_DEBUG
                     printf("  polish qp %d it %d round %d: pri %.3e dua %.3e viol %.3e %s -> %s\n", qp, it, round, res[0], res[1], viol, conservative ? "(cons)" : "", ok ? "ACCEPT" : "reject");
 #endif
@@ -1683,17 +1664,6 @@ struct PathQp {
                     // the active-set rounds diverge: this attempt will not get there, stop paying for it
                     const bool diverged = prm.polish_diverge > 0 && viol > (double)prm.polish_diverge * best_any;
                     bool give_up = !solve_ok || diverged;
-                    // an attempt whose first round wants to move many rows started from a poor active-set guess: such attempts
-                    // mostly fail after all their rounds, so it stops right away and ADMM works on.  Once ADMM itself has converged
-                    // twice (eps_scale tightened to <= 0.05) only the periodic speculative attempts are still cut short, so a
-                    // degenerate QP with many marginal rows cannot be locked out of its polish.
-                    const bool gate = eps_scale > 0.05 || speculative;
-                    if (!give_up && gate && round == 0 && max_moves > 0 && polish_count_failing(tol) > max_moves) {
-                        give_up = true;
-                        // a cut attempt was cheap (one factorisation, no rounds): it does not let the gap to the next one grow
-                        // beyond 8 x polish_every, so a slow QP is not left iterating long after its active set has settled
-                        if (polish_gap > 8 * prm.polish_every) { polish_gap = 8 * prm.polish_every; next_polish = it + polish_gap; }
-                    }
                     if (solve_ok && viol < best_any) { best_any = viol; if (prm.polish_reseed) polish_save_best(); }
                     if (!give_up) {
                         // primal-dual active-set step.  A full update can cycle: when the violation stops improving only

@@ -124,6 +124,8 @@ STRAGGLERS = [
     (3, 216, 80, "uniform", "front and rear circle row of the last waypoint added together, released together, 3-cycle", 236),
     (None, 7215, 120, "varied", "end-state offset row and the last waypoint's circle row pushing each other out", 356),
     (0, 907, 80, "uniform", "eight-round attempts failing at iterations 25 / 75 / 175", 404),
+    (1011, 1720, 300, "varied", "two refinement solves from a distant ADMM iterate left the polished point too inaccurate for the KKT test", 4028),
+    (1015, 5821, 37, "varied", "the same, at every attempt until ADMM itself had converged", 3381),
 ]
 
 
@@ -132,7 +134,22 @@ def test_former_stragglers_finish_in_the_first_attempts(seed, qp, n, profile, wh
     b = make_batch(1, n, profile, first_qp=qp) if seed is None else make_batch(1, n, profile, seed=seed, first_qp=qp)
     r = E.solve(E.production(), b["ref"], b["bounds"], b["scal"], passes=1)
     assert r["status"][0] == 1 and r["info"][0, 4] == 2
-    assert r["info"][0, 5] <= 110 and r["info"][0, 5] < before / 3, what
+    assert r["info"][0, 5] <= 150 and r["info"][0, 5] < before / 3, what
     ref = O.solve_path(b["ref"][0], b["bounds"][0], b["scal"][0], st=TIGHT)
-    # (the ADMM oracle at eps 1e-9 is itself only good to ~1e-6 on the weakly determined end of these paths)
-    assert np.abs(r["out"][0][:, 3:5] - ref[-1]["out"][:, 3:5]).max() < 5e-6
+    # (the parity bar is 1e-4; these are the ill-conditioned QPs of the distribution - the ADMM oracle at eps 1e-9 is itself only
+    # good to ~1e-6 on their weakly determined ends, and a KKT residual of 1e-7 leaves up to 2e-5 in l on the worst of them)
+    assert np.abs(r["out"][0][:, 3:5] - ref[-1]["out"][:, 3:5]).max() < 5e-5
+
+
+def test_a_polish_that_cannot_be_verified_ends_like_osqp():
+    """This scenario's start curvature lies 1.6e-5 outside the curvature box: ADMM meets eps = 1e-4, no tighter test, and no
+    polished point passes the KKT check.  polish_patience = 5: solved, unpolished, after the attempt at iteration 465 of each
+    pass (without it: 4000 iterations and PQP_STATUS_MAX_ITER)."""
+    b = make_batch(1, 80, "varied", seed=1007, first_qp=6640)
+    r = E.solve(E.production(), b["ref"], b["bounds"], b["scal"], passes=1)
+    assert r["status"][0] == 1 and r["info"][0, 4] == 0 and r["iters"][0] <= 2 * 495
+    ref = O.solve_path(b["ref"][0], b["bounds"][0], b["scal"][0], st=O.OsqpSettings(eps_abs=1e-4, eps_rel=1e-4))
+    assert [x["status"] for x in ref] == ["solved", "solved"]                  # the plain algorithm calls it solved too
+    assert np.abs(r["out"][0][:, 3:5] - ref[-1]["out"][:, 3:5]).max() < 2e-3   # two eps-1e-4 ADMM points of one QP
+    r0 = E.solve(E.production(polish_patience=0, max_iter=1500), b["ref"], b["bounds"], b["scal"], passes=1)
+    assert r0["status"][0] == 2
