@@ -298,3 +298,21 @@ def test_waypoint_count_per_qp_on_the_gpu(hip_lib):
         assert np.abs(r["out"][q, :nq] - alone["out"][0]).max() < 1e-9
         assert np.all(r["out"][q, nq:] == 0.0)
     h.close()
+
+
+@pytest.mark.parametrize("n,profile,batch", [(80, "uniform", 1024), (120, "varied", 512), (200, "uniform", 256)])
+def test_the_bench_workload_itself_against_the_c_oracle(hip_lib, n, profile, batch):
+    """Every path of bench.py's own batches (production setting, KKT-verified polish) against the C restatement of the
+    OSQP-paper algorithm run to eps 1e-9 on the host cores: the north_star bar is 1e-4 in lateral offset and heading;
+    the ADMM oracle is itself only good to ~1e-6 on the weakly determined ends of the ill-conditioned paths."""
+    import pqp_oracle_c as OC
+    b = make_batch(batch, n, profile)
+    h = capi.Handle(_polished(), max_batch=batch, max_n=n)
+    r = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    h.close()
+    ref = OC.solve_batch(OC.params(eps_abs=1e-9, eps_rel=1e-9, max_iter=200000), b["ref"], b["bounds"], b["scal"], passes=1)
+    assert ref["solved"] == batch and (r["status"] == 1).all() and (r["info"][:, 4] == 2).all()
+    err = np.abs(r["out"][:, :, 3:5] - ref["out"][:, :, 3:5]).reshape(batch, -1).max(axis=1)
+    assert err.max() < 1e-4
+    assert np.percentile(err, 99) < 2e-5 and np.median(err) < 1e-6
+    assert np.abs(r["out"][:, :, 0:2] - ref["out"][:, :, 0:2]).max() < 1e-4          # x, y of the optimised path
