@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight: k > 1 runs consecutive steps on k handles / HIP streams "
                     "(what a server does with independent batches; the next batch fills the slots the slow tail of this one leaves idle)")
     ap.add_argument("--profile", default="uniform", choices=["uniform", "varied"])
+    ap.add_argument("--reference-setting", action="store_true", help="the reference's solver setting instead of the production one: "
+                    "pqp_default_params (OSQP defaults, no polish, infeasibility certificate on) at --eps (the reference runs 2e-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of host CPU work for the cpu_baseline sample")
     args = ap.parse_args()
@@ -107,8 +109,8 @@ def main():
     iters = torch.zeros(batch, dtype=torch.int32, device=dev)
     info = torch.zeros((batch, 8), dtype=torch.float64, device=dev)
 
-    polish = not args.no_polish
-    prm = capi.production_params(eps_abs=args.eps, eps_rel=args.eps, polish=1 if polish else 0, polish_every=args.polish_every,
+    polish = not args.no_polish and not args.reference_setting
+    prm = capi.default_params(eps_abs=args.eps, eps_rel=args.eps) if args.reference_setting else capi.production_params(eps_abs=args.eps, eps_rel=args.eps, polish=1 if polish else 0, polish_every=args.polish_every,
                               adaptive_rho_interval=args.rho_interval, polish_warm_set=args.polish_warm_set if polish else 0, check_termination=args.check_termination, polish_refine_iter=args.polish_refine,
                               polish_max_rounds=args.polish_max_rounds, adaptive_rho_tolerance=args.rho_tolerance)
     h = capi.Handle(prm, device=local_rank, max_batch=batch, max_n=n)
@@ -188,7 +190,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: batch={batch} QPs per GPU, N={n}, shared sparsity, synthetic obstacle bounds ({args.profile} profile)",
                        "batch_per_gpu": batch, "n_waypoints": n, "eps_abs": args.eps, "eps_rel": args.eps, "polish": polish,
-                       "polish_every": args.polish_every if polish else 0, "adaptive_rho_interval": args.rho_interval,
+                       "setting": "reference (pqp_default_params)" if args.reference_setting else "production (pqp_production_params)",
+                       "polish_every": args.polish_every if polish else 0, "adaptive_rho_interval": 100 if args.reference_setting else args.rho_interval,
                        "polish_refine_iter": args.polish_refine, "polish_max_rounds": args.polish_max_rounds, "polish_warm_set": args.polish_warm_set,
                        "passes": "cold solve + 1 re-linearised warm re-solve (PathOptimizer::optimizePath)",
                        "parallelism": f"{world} independent shard(s), no collective in the timed region", "batches_in_flight": max(args.inflight, 1)},
