@@ -1602,7 +1602,7 @@ struct PathQp {
                         const double eps_d = eps_scale * (prm.eps_abs + prm.eps_rel * res[3]);
                         // the polish of this QP cannot be verified (typically: infeasible by less than eps, so that the tightened
                         // residual tests below are never met): what OSQP does when its polish fails - return the ADMM point
-                        if (prm.polish_patience > 0 && eps_scale < 1.0 && polish_gap >= (prm.polish_every << prm.polish_patience) &&
+                        if (prm.polish_patience > 0 && eps_scale < 1.0 && polish_gap >= (prm.polish_every << (prm.polish_patience < 16 ? prm.polish_patience : 16)) &&
                             res[0] <= prm.eps_abs + prm.eps_rel * res[2] && res[1] <= prm.eps_abs + prm.eps_rel * res[3]) {
                             status = PQP_STATUS_SOLVED; op = COLD_END_PASS; i0 = 0; break;
                         }
