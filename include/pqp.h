@@ -197,7 +197,10 @@ int pqp_path_assemble_device(pqp_handle* h, int batch, int n, int precise, const
  *   2 <= n <= 512 waypoints (one lane per waypoint: 1, 2, 4 or 8 wavefronts per QP); any batch.  Which solver runs is decided
  *   by the handle's pqp_params: pqp_default_params = the reference's OSQP setting (eps 2e-3, no polish, infeasibility certificate),
  *   pqp_production_params = eps 1e-4 + KKT-verified polish.  out[q] holds the last iterate also when status[q] != SOLVED (the
- *   reference's solve() returns false there and leaves its output vector untouched). */
+ *   reference's solve() returns false there and leaves its output vector untouched).
+ *   A QP with a collision box whose lower bound exceeds its upper bound is refused as OSQP refuses it at setup: the host-pointer
+ *   entry points do not launch it and report PQP_STATUS_PRIMAL_INFEASIBLE (out[q] = 0); the *_device entry points do not
+ *   validate their inputs (there such a row is pinned to its upper bound). */
 int pqp_path_solve(pqp_handle* h, int batch, int n, const double* ref, const double* lin,
                    const double* bounds, const double* scal, int passes, int warm,
                    double* out, int32_t* status, int32_t* iters, double* info);

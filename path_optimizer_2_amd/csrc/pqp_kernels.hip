@@ -721,6 +721,27 @@ static int path_solve_host(pqp_handle* h, int batch, int n, const int32_t* n_of,
     PQP_HIP(hipSetDevice(h->device));
     const size_t bn = (size_t)batch * n;
     int rc;
+    // A box with lower > upper bound: OSQP refuses such data at setup (OsqpEigen's initSolver() fails and BaseSolver::solve returns
+    // false, base_solver.cpp:76-80).  The host-pointer entry points see the data anyway: such a QP is not launched (waypoint count 0)
+    // and comes back PQP_STATUS_PRIMAL_INFEASIBLE.  (The device-pointer entry points do not validate: there the row would be
+    // pinned to its upper bound.)
+    std::vector<int32_t> counts;
+    bool any_invalid = false;
+    for (int q = 0; q < batch; ++q) {
+        const int cnt = n_of ? n_of[q] : n;
+        bool bad = false;
+        for (int i = 0; i < cnt && i < n && !bad; ++i) {
+            const double* b = bounds + ((size_t)q * n + i) * PQP_BOUNDS_STRIDE;
+            bad = b[0] > b[1] || b[2] > b[3] || b[4] > b[5];
+        }
+        if (bad && !any_invalid) {
+            counts.assign(batch, n);
+            if (n_of) counts.assign(n_of, n_of + batch);
+            any_invalid = true;
+        }
+        if (bad) counts[q] = -1;
+    }
+    if (any_invalid) n_of = counts.data();
     if (n_of) {
         if ((rc = h->c_buf[11].ensure((size_t)batch * 4))) return rc;
         PQP_HIP(hipMemcpyAsync(h->c_buf[11].p, n_of, (size_t)batch * 4, hipMemcpyHostToDevice, h->stream));
@@ -744,6 +765,9 @@ static int path_solve_host(pqp_handle* h, int batch, int n, const int32_t* n_of,
     if (iters) PQP_HIP(hipMemcpyAsync(iters, h->s_iters.p, (size_t)batch * 4, hipMemcpyDeviceToHost, h->stream));
     if (info) PQP_HIP(hipMemcpyAsync(info, h->s_info.p, (size_t)batch * PQP_INFO_STRIDE * 8, hipMemcpyDeviceToHost, h->stream));
     PQP_HIP(hipStreamSynchronize(h->stream));
+    if (any_invalid && status)
+        for (int q = 0; q < batch; ++q)
+            if (counts[q] < 0) status[q] = PQP_STATUS_PRIMAL_INFEASIBLE;
     return PQP_OK;
 }
 

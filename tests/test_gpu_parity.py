@@ -316,3 +316,16 @@ def test_the_bench_workload_itself_against_the_c_oracle(hip_lib, n, profile, bat
     assert err.max() < 1e-4
     assert np.percentile(err, 99) < 2e-5 and np.median(err) < 1e-6
     assert np.abs(r["out"][:, :, 0:2] - ref["out"][:, :, 0:2]).max() < 1e-4          # x, y of the optimised path
+
+
+def test_inverted_box_is_refused_by_the_host_entry_points(hip_lib):
+    """lower > upper bound on a collision row: OSQP refuses the data at setup and the reference's solve() returns false
+    (base_solver.cpp:76-80).  pqp_path_solve does not launch that QP and reports it primal infeasible; its neighbours solve."""
+    b = make_batch(3, 40)
+    b["bounds"][1, 20, 0], b["bounds"][1, 20, 1] = 5.0, -5.0
+    h = capi.Handle(_polished(), max_batch=3, max_n=40)
+    r = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    assert list(r["status"]) == [1, 4, 1] and r["iters"][1] == 0 and not r["out"][1].any()
+    ok = capi.Handle(_polished(), max_batch=3, max_n=40).solve(b["ref"][[0, 2]], b["bounds"][[0, 2]], b["scal"][[0, 2]], passes=1)
+    np.testing.assert_array_equal(r["out"][[0, 2]], ok["out"])
+    h.close()

@@ -153,3 +153,4 @@ def test_a_polish_that_cannot_be_verified_ends_like_osqp():
     assert np.abs(r["out"][0][:, 3:5] - ref[-1]["out"][:, 3:5]).max() < 2e-3   # two eps-1e-4 ADMM points of one QP
     r0 = E.solve(E.production(polish_patience=0, max_iter=1500), b["ref"], b["bounds"], b["scal"], passes=1)
     assert r0["status"][0] == 2
+
