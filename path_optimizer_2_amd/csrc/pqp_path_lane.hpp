@@ -570,7 +570,6 @@ struct PathQp {
     // reuse = true keeps D, E, c of the previous pass of this QP (whose matrix differs only by the re-linearisation) and
     // only rebuilds the metrics; any positive diagonal scaling is a valid metric, OSQP's own update path re-equilibrates
     PQP_HD void ruiz(bool reuse = false) {
-        const pqp_params& prm = A.prm;
         if (!reuse) ruiz_equilibrate();
         ruiz_metrics();
     }
