@@ -24,6 +24,7 @@
  *                                     src/data_struct/reference_path.cpp:61, reference_path_impl.cpp:177-312    pqp_corridor_bounds
  *   ReferencePathImpl::buildReferenceFromSpline  reference_path_impl.cpp:314-338, PathOptimizer::processInitState path_optimizer.cpp:73-85
  *                                                                                                         pqp_reference_states
+ *   ReferencePathSmoother::segmentRawReference  reference_path_smoother.cpp:48-85                           pqp_segment_raw_reference
  *   tk::spline::set_points            src/tools/spline.cpp:161-249                                         pqp_spline_fit
  *   ReferencePathSmoother::graphSearchDp  src/reference_path_smoother/reference_path_smoother.cpp:142-295   pqp_dp_corridor
  *
@@ -301,6 +302,19 @@ int pqp_reference_states_device(pqp_handle* h, int batch, int n_max, int m, cons
 int pqp_reference_states(pqp_handle* h, int batch, int n_max, int m, const double* spline, const double* spline_ext, const double* max_s,
                          const double* start, double ds_small, double ds_large, int dynamic, double* ref, int32_t* count,
                          double* init_err);
+
+/* ---- raw reference line -> the input lists of the smoother QPs ---------------------------------------------------------------
+ * ReferencePathSmoother::segmentRawReference  src/reference_path_smoother/reference_path_smoother.cpp:48-85 (called by
+ * TensionSmoother::smooth, tension_smoother.cpp:21-26): the splines of the raw point list (pqp_spline_fit of s_list_, x_list_,
+ * y_list_) sampled at 0, delta_s, 2 delta_s, ... up to AND INCLUDING the first abscissa >= max_s (the reference's loop, :64-67, with
+ * delta_s = 1.0: the last sample lies beyond the line and is extrapolated), angle = atan2(dy, dx), k = (dx ddy - dy ddx) / pow(dx^2 + dy^2, 1.5).
+ * x, y, s, angle, k [batch][n_max] are exactly pqp_smooth_tension2 / pqp_smooth_tension's inputs; count [batch] = samples the
+ * loop produces (when it exceeds n_max only n_max were written). */
+int pqp_segment_raw_reference_device(pqp_handle* h, int batch, int n_max, int m, const double* spline, const double* spline_ext,
+                                     const double* max_s, double delta_s, double* x, double* y, double* s, double* angle, double* k,
+                                     int32_t* count);
+int pqp_segment_raw_reference(pqp_handle* h, int batch, int n_max, int m, const double* spline, const double* spline_ext, const double* max_s,
+                              double delta_s, double* x, double* y, double* s, double* angle, double* k, int32_t* count);
 
 /* ---- natural cubic spline through the knots ----------------------------------------------------------
  * tk::spline::set_points  src/tools/spline.cpp:161-249 (+ band_matrix::lu_solve :69-148), as called on the smoothed reference line

@@ -219,6 +219,27 @@ def build_reference_from_spline(sx, sy, max_s, ds_small=0.15, ds_large=0.3, dyna
     return np.array(out).reshape(-1, 5)
 
 
+def segment_raw_reference(sx, sy, max_s, delta_s=1.0):
+    """ReferencePathSmoother::segmentRawReference (reference_path_smoother.cpp:48-85): the raw point list's splines sampled
+    every delta_s = 1.0 for the smoother QPs.  The loop (:64-67) pushes back + delta_s while back < max_s, so the last abscissa is
+    the first one >= max_s - beyond the line unless max_s is a multiple of delta_s - and the test of :68-70 can never hold
+    after it; both kept as written.  Returns x, y, s, angle, k lists (the argument order of osqpSmooth)."""
+    s_list = [0.0]
+    while s_list[-1] < max_s:
+        s_list.append(s_list[-1] + delta_s)
+    if max_s - s_list[-1] > 1:
+        s_list.append(max_s)
+    x, y, angle, k = [], [], [], []
+    for s in s_list:
+        dx, dy = spline_deriv(sx, 1, s), spline_deriv(sy, 1, s)
+        ddx, ddy = spline_deriv(sx, 2, s), spline_deriv(sy, 2, s)
+        angle.append(math.atan2(dy, dx))
+        k.append((dx * ddy - dy * ddx) / math.pow(dx * dx + dy * dy, 1.5))
+        x.append(spline_eval(sx, s))
+        y.append(spline_eval(sy, s))
+    return np.array(x), np.array(y), np.array(s_list), np.array(angle), np.array(k)
+
+
 def process_init_state(sx, sy, start_x, start_y, start_heading):
     """PathOptimizer::processInitState (path_optimizer.cpp:73-85) -> (initial_offset, initial_heading_error)."""
     ix, iy = spline_eval(sx, 0.0), spline_eval(sy, 0.0)

@@ -58,7 +58,7 @@ EXPORTS = [
     "pqp_last_kernel_ms", "pqp_kernel_ms_history", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
     "pqp_post_smooth", "pqp_post_smooth_device", "pqp_corridor_default_params", "pqp_corridor_bounds", "pqp_corridor_bounds_device",
     "pqp_reference_states", "pqp_reference_states_device", "pqp_spline_fit", "pqp_spline_fit_device", "pqp_dp_default_params",
-    "pqp_dp_corridor", "pqp_dp_corridor_device",
+    "pqp_dp_corridor", "pqp_dp_corridor_device", "pqp_segment_raw_reference", "pqp_segment_raw_reference_device",
 ]
 
 _lib = None
@@ -109,6 +109,8 @@ def load_library(path=None):
                                         C.POINTER(PqpCorridorParams), vp, vp]
     for name in ("pqp_reference_states", "pqp_reference_states_device"):
         getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, vp]
+    for name in ("pqp_segment_raw_reference", "pqp_segment_raw_reference_device"):
+        getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, vp, vp, vp, vp, vp]
     for name in ("pqp_spline_fit", "pqp_spline_fit_device"):
         getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     lib.pqp_dp_default_params.argtypes = [C.POINTER(PqpDpParams)]
@@ -239,6 +241,20 @@ class Handle:
         self._check(self.lib.pqp_reference_states(self._h, B, n_max, m, _ptr(spline), _ptr(spline_ext), _ptr(max_s), _ptr(st), ds_small,
                                                   ds_large, 1 if dynamic else 0, _ptr(ref), _ptr(count), _ptr(err)))
         return ref, count, err
+
+    def segment_raw_reference(self, spline, spline_ext, max_s, n_max, delta_s=1.0):
+        """pqp_segment_raw_reference (host arrays): spline [B][9][m], spline_ext [B][4], max_s [B].
+        Returns dict(x, y, s, angle, k: [B][n_max], count [B]) - the smoother QPs' input lists."""
+        spline = np.ascontiguousarray(spline, dtype=np.float64)
+        spline_ext = np.ascontiguousarray(spline_ext, dtype=np.float64)
+        max_s = np.ascontiguousarray(max_s, dtype=np.float64)
+        B, m = spline.shape[0], spline.shape[2]
+        o = {k: np.zeros((B, n_max)) for k in ("x", "y", "s", "angle", "k")}
+        count = np.zeros(B, dtype=np.int32)
+        self._check(self.lib.pqp_segment_raw_reference(self._h, B, n_max, m, _ptr(spline), _ptr(spline_ext), _ptr(max_s), delta_s,
+                                                       _ptr(o["x"]), _ptr(o["y"]), _ptr(o["s"]), _ptr(o["angle"]), _ptr(o["k"]), _ptr(count)))
+        o["count"] = count
+        return o
 
     def corridor_bounds(self, ref, spline, spline_ext, dist, geom, map_of=None, prm=None, n_of=None):
         """pqp_corridor_bounds (host arrays): ref [B][n][5], spline [B][9][m], spline_ext [B][4], dist [n_maps][rows][cols] float32

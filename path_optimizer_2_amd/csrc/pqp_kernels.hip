@@ -1109,6 +1109,7 @@ int pqp_reference_states_device(pqp_handle* h, int batch, int n_max, int m, cons
     pqp::RefStatesArgs a;
     a.batch = batch; a.n_max = n_max; a.m = m; a.spl = spline; a.spl_ext = spline_ext; a.max_s = max_s; a.start = start;
     a.ds_small = ds_small; a.ds_large = ds_large; a.dynamic = dynamic ? 1 : 0; a.ref = ref; a.count = count; a.init_err = init_err;
+    a.lx = a.ly = a.ls = a.langle = a.lk = nullptr;
     h->next_event_pair();
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
     const size_t lds = ((size_t)9 * m + n_max) * 8;
@@ -1118,6 +1119,55 @@ int pqp_reference_states_device(pqp_handle* h, int batch, int n_max, int m, cons
     PQP_HIP(hipGetLastError());
     PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
+    return PQP_OK;
+}
+
+// ---- raw reference line -> the smoother QPs' input lists (ReferencePathSmoother::segmentRawReference) ------------------------------
+int pqp_segment_raw_reference_device(pqp_handle* h, int batch, int n_max, int m, const double* spline, const double* spline_ext,
+                                     const double* max_s, double delta_s, double* x, double* y, double* s, double* angle, double* k,
+                                     int32_t* count) {
+    if (!h || !spline || !spline_ext || !max_s || !x || !y || !s || !angle || !k || !count || batch < 1 || n_max < 1 || m < 3 || !(delta_s > 0.0))
+        return fail(PQP_ERR_INVALID, "pqp_segment_raw_reference: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    pqp::RefStatesArgs a;
+    a.batch = batch; a.n_max = n_max; a.m = m; a.spl = spline; a.spl_ext = spline_ext; a.max_s = max_s; a.start = nullptr;
+    a.ds_small = delta_s; a.ds_large = delta_s; a.dynamic = 2; a.ref = nullptr; a.count = count; a.init_err = nullptr;
+    a.lx = x; a.ly = y; a.ls = s; a.langle = angle; a.lk = k;
+    h->next_event_pair();
+    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    const size_t lds = ((size_t)9 * m + n_max) * 8;
+    if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_segment_raw_reference: 9 m + n_max doubles exceed one CU's LDS");
+    if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::reference_states_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(pqp::reference_states_kernel, dim3(batch), dim3(64), lds, h->stream, a);
+    PQP_HIP(hipGetLastError());
+    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return PQP_OK;
+}
+
+int pqp_segment_raw_reference(pqp_handle* h, int batch, int n_max, int m, const double* spline, const double* spline_ext, const double* max_s,
+                              double delta_s, double* x, double* y, double* s, double* angle, double* k, int32_t* count) {
+    if (!h || !spline || !spline_ext || !max_s || !x || !y || !s || !angle || !k || !count || batch < 1 || n_max < 1 || m < 3)
+        return fail(PQP_ERR_INVALID, "pqp_segment_raw_reference: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    const size_t b_spl = (size_t)batch * 9 * m * 8, b_ext = (size_t)batch * 4 * 8, b_s = (size_t)batch * 8;
+    const size_t b_list = (size_t)batch * n_max * 8, b_cnt = (size_t)batch * 4;
+    const size_t sizes[5] = {5 * b_list, b_spl, b_ext, b_s, b_cnt};
+    int rc;
+    for (int j = 0; j < 5; ++j) if ((rc = h->c_buf[j].ensure(sizes[j]))) return rc;
+    PQP_HIP(hipMemcpyAsync(h->c_buf[1].p, spline, b_spl, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[2].p, spline_ext, b_ext, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[3].p, max_s, b_s, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemsetAsync(h->c_buf[0].p, 0, 5 * b_list, h->stream));
+    double* l = h->c_buf[0].as<double>();
+    const size_t bn = (size_t)batch * n_max;
+    if ((rc = pqp_segment_raw_reference_device(h, batch, n_max, m, h->c_buf[1].as<double>(), h->c_buf[2].as<double>(), h->c_buf[3].as<double>(),
+                                               delta_s, l, l + bn, l + 2 * bn, l + 3 * bn, l + 4 * bn, h->c_buf[4].as<int32_t>())))
+        return rc;
+    double* outs[5] = {x, y, s, angle, k};
+    for (int j = 0; j < 5; ++j) PQP_HIP(hipMemcpyAsync(outs[j], l + j * bn, b_list, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(count, h->c_buf[4].p, b_cnt, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipStreamSynchronize(h->stream));
     return PQP_OK;
 }
 

@@ -131,6 +131,21 @@ def test_reference_state_sampling():
     assert np.allclose(np.diff(fixed[:, 0]), 0.3)
 
 
+def test_raw_reference_segmentation():
+    """segmentRawReference: samples every metre from 0 up to and including the first abscissa >= max_s (the reference's loop
+    overshoots the line unless its length is a whole number of metres); on a circle: angle = s / R, k = 1 / R."""
+    R = 20.0
+    s = np.linspace(0.0, 30.0, 61)
+    sx = K.spline_fit(s, R * np.sin(s / R)); sy = K.spline_fit(s, R * (1.0 - np.cos(s / R)))
+    x, y, sl, ang, k = K.segment_raw_reference(sx, sy, 24.3)
+    assert list(sl) == [float(i) for i in range(26)]                 # 0 .. 25: the last one lies 0.7 m beyond max_s
+    inner = (sl > 3) & (sl < 22)
+    assert np.abs(ang[inner] - sl[inner] / R).max() < 1e-4 and np.abs(k[inner] - 1 / R).max() < 1e-4
+    assert np.abs(x - R * np.sin(sl / R)).max() < 1e-4 and np.abs(y - R * (1 - np.cos(sl / R))).max() < 1e-4
+    assert len(K.segment_raw_reference(sx, sy, 24.0)[2]) == 25       # a whole number of metres: 0 .. 24, no overshoot
+    assert list(K.segment_raw_reference(sx, sy, 2.1, delta_s=0.5)[2]) == [0.0, 0.5, 1.0, 1.5, 2.0, 2.5]
+
+
 def test_initial_error():
     s = np.linspace(0.0, 10.0, 11)
     sx = K.spline_fit(s, s); sy = K.spline_fit(s, 0.0 * s)          # the x axis

@@ -105,6 +105,40 @@ def test_reference_states_and_initial_error(handle):
     np.testing.assert_allclose(ref2[0], want2[:50], rtol=0, atol=1e-11)
 
 
+def test_raw_reference_segmentation_feeds_the_tension_smoother(handle):
+    """pqp_segment_raw_reference against the restatement of segmentRawReference, then the chain TensionSmoother::smooth runs
+    (tension_smoother.cpp:21-39): raw points -> spline -> 1 m samples -> TensionSmoother2 QP -> spline of the smoothed points."""
+    import scipy.sparse as sp
+    import pqp_oracle as O
+    cs = [U.build(seed=s, n=10) for s in (30, 31, 32)]
+    max_s = np.array([24.3, 24.0, 24.9])                    # 26, 25, 26 samples (the reference's loop overshoots the line)
+    tab, ext = np.stack([c["tab"] for c in cs]), np.stack([c["ext"] for c in cs])
+    seg = handle.segment_raw_reference(tab, ext, max_s, 40)
+    for q, c in enumerate(cs):
+        x, y, s, ang, k = K.segment_raw_reference(c["sx"], c["sy"], float(max_s[q]))
+        n = len(s)
+        assert seg["count"][q] == n
+        np.testing.assert_array_equal(seg["s"][q, :n], s)
+        for name, want in (("x", x), ("y", y), ("angle", ang), ("k", k)):
+            np.testing.assert_allclose(seg[name][q, :n], want, rtol=0, atol=1e-11)      # pow / atan2: ocml vs libm
+            assert np.all(seg[name][q, n:] == 0.0)
+    # a capacity smaller than the line needs: count still reports what the loop produces
+    assert handle.segment_raw_reference(tab[:1], ext[:1], max_s[:1], 10)["count"][0] == 26
+    # the two 26-sample lines as one smoother batch (shared sparsity needs equal n), checked against the converged oracle QP
+    idx, n = [0, 2], 26
+    hs = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3, polish=1, polish_every=25, adaptive_rho_interval=25), max_batch=2, max_n=n)
+    r = hs.smooth_tension2(*(seg[k][idx, :n] for k in ("x", "y", "angle", "k", "s")))
+    assert (r["status"] == 1).all()
+    for j, q in enumerate(idx):
+        P, qv, A, lo, up = O.assemble_tension2(*(seg[k][q, :n] for k in ("x", "y", "angle", "k", "s")))
+        ref = O.osqp_admm(sp.csc_matrix(P), qv, A, lo, up, O.OsqpSettings(eps_abs=1e-9, eps_rel=1e-9, max_iter=100000))
+        assert np.abs(r["x"][j] - ref["x"][:n]).max() < 1e-5 and np.abs(r["y"][j] - ref["x"][n:2 * n]).max() < 1e-5
+    fit_tab, fit_ext = handle.spline_fit(r["s"], r["x"], r["y"])                         # tension_smoother.cpp:36-38
+    sx = K.spline_fit(r["s"][0], r["x"][0])
+    np.testing.assert_array_equal(fit_tab[0], K.pack_spline(sx, K.spline_fit(r["s"][0], r["y"][0]))[0])
+    hs.close()
+
+
 def test_pipeline_spline_to_path_on_the_device(handle):
     """spline coefficients -> reference states -> corridor bounds -> path QP with a waypoint count per scenario, all on the
     device, against the same chain of oracles (reference call order: path_optimizer.cpp:110-161)."""
