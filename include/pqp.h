@@ -24,6 +24,7 @@
  *                                     src/data_struct/reference_path.cpp:61, reference_path_impl.cpp:177-312    pqp_corridor_bounds
  *   ReferencePathImpl::buildReferenceFromSpline  reference_path_impl.cpp:314-338, PathOptimizer::processInitState path_optimizer.cpp:73-85
  *                                                                                                         pqp_reference_states
+ *   ReferencePathSmoother::bSpline              reference_path_smoother.cpp:490-521                         pqp_bspline_resample
  *   ReferencePathSmoother::segmentRawReference  reference_path_smoother.cpp:48-85                           pqp_segment_raw_reference
  *   tk::spline::set_points            src/tools/spline.cpp:161-249                                         pqp_spline_fit
  *   ReferencePathSmoother::graphSearchDp  src/reference_path_smoother/reference_path_smoother.cpp:142-295   pqp_dp_corridor
@@ -302,6 +303,20 @@ int pqp_reference_states_device(pqp_handle* h, int batch, int n_max, int m, cons
 int pqp_reference_states(pqp_handle* h, int batch, int n_max, int m, const double* spline, const double* spline_ext, const double* max_s,
                          const double* start, double ds_small, double ds_large, int dynamic, double* ref, int32_t* count,
                          double* init_err);
+
+/* ---- input points -> dense raw reference line ----------------------------------------------------------------------------------
+ * ReferencePathSmoother::bSpline  src/reference_path_smoother/reference_path_smoother.cpp:490-521 (first step of
+ * ReferencePathSmoother::solve, :31-45): the input points are the control points of a clamped B-spline of degree 3 / 4 / 5 (average
+ * point spacing > 10 m / > 5 m / else), sampled at t = 0, 1/length, 2/length, ... while t < 1 and at t = 1 (about one point per
+ * metre); s = accumulated chord length.  The spline itself is the third-party tinyspline (not in the reference tree): its clamped
+ * knot vector and de Boor evaluation are restated, see oracle/corridor_oracle.py.
+ * points [batch][p_max][2], n_points [batch] (fewer than 4: count = 0, the reference's "Few reference points")
+ *   ->  x, y, s [batch][n_max] = x_list_, y_list_, s_list_;  count [batch] = points the loop produces (when it exceeds n_max only
+ * n_max were written).  pqp_spline_fit of (s, x, y) then gives the splines pqp_segment_raw_reference samples. */
+int pqp_bspline_resample_device(pqp_handle* h, int batch, int p_max, int n_max, const double* points, const int32_t* n_points, double* x,
+                                double* y, double* s, int32_t* count);
+int pqp_bspline_resample(pqp_handle* h, int batch, int p_max, int n_max, const double* points, const int32_t* n_points, double* x, double* y,
+                         double* s, int32_t* count);
 
 /* ---- raw reference line -> the input lists of the smoother QPs ---------------------------------------------------------------
  * ReferencePathSmoother::segmentRawReference  src/reference_path_smoother/reference_path_smoother.cpp:48-85 (called by

@@ -219,6 +219,68 @@ def build_reference_from_spline(sx, sy, max_s, ds_small=0.15, ds_large=0.3, dyna
     return np.array(out).reshape(-1, 5)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# ReferencePathSmoother::bSpline (reference_path_smoother.cpp:490-521) over tinyspline
+# PARITY UNPINNED: tinyspline (the un-vendored, un-pinned ROS package qutas/tinyspline_ros, CMakeLists.txt:12, package.xml:56) is
+# not in /root/reference and not in this image.  What is restated here is its published behaviour for the one call pattern the
+# reference uses - tinyspline::BSpline(n_control_points, 2, degree) [type TS_CLAMPED], setControlPoints, eval(u).result():
+#   knots of a clamped spline on [0, 1]: `order` zeros, then (i - degree) / (n_knots - 2 degree - 1) for the interior ones, then
+#   `order` ones (ts_bspline_new / fill_knots); eval = de Boor's algorithm on the knot span containing u; u = 0 and u = 1 return the
+#   first and the last control point.  tinyspline treats u within 1e-4 of a knot as lying on it, which changes the result by
+#   O(1e-4 ^ degree) only (the pieces join with degree - 1 continuous derivatives) and is not reproduced.
+# ----------------------------------------------------------------------------------------------------------------------
+def clamped_knots(n_ctrl, degree):
+    order = degree + 1
+    n_knots = n_ctrl + order
+    fac = 1.0 / (n_knots - 2 * degree - 1)
+    return np.array([0.0] * order + [(i - degree) * fac for i in range(order, n_knots - order)] + [1.0] * order)
+
+
+def bspline_eval(ctrl, knots, degree, u):
+    """de Boor: the point of the B-spline with control points ctrl [n][2] at parameter u in [0, 1]."""
+    n = len(ctrl)
+    if u <= knots[0]:
+        return np.array(ctrl[0], dtype=float)
+    if u >= knots[-1]:
+        return np.array(ctrl[n - 1], dtype=float)
+    k = degree
+    while knots[k + 1] <= u:               # knots[k] <= u < knots[k + 1], degree <= k <= n - 1
+        k += 1
+    d = [np.array(ctrl[j + k - degree], dtype=float) for j in range(degree + 1)]
+    for r in range(1, degree + 1):
+        for j in range(degree, r - 1, -1):
+            i = j + k - degree
+            a = (u - knots[i]) / (knots[i + degree - r + 1] - knots[i])
+            d[j] = (1.0 - a) * d[j - 1] + a * d[j]
+    return d[degree]
+
+
+def bspline_resample(points):
+    """ReferencePathSmoother::bSpline (reference_path_smoother.cpp:490-521): the input points are the control points of a clamped
+    B-spline whose degree depends on their average spacing (> 10 m: 3, > 5 m: 4, else 5); it is sampled at t = 0, 1/length,
+    2/length, ... while t < 1 (t accumulated as written) and at t = 1; s is the accumulated chord length.  Returns x, y, s."""
+    pts = np.asarray(points, dtype=float)
+    length = 0.0
+    for i in range(len(pts) - 1):
+        length += math.sqrt(math.pow(pts[i, 0] - pts[i + 1, 0], 2) + math.pow(pts[i, 1] - pts[i + 1, 1], 2))     # tools.hpp distance()
+    average_length = length / (len(pts) - 1)
+    degree = 3 if average_length > 10 else (4 if average_length > 5 else 5)
+    knots = clamped_knots(len(pts), degree)
+    delta_t = 1.0 / length
+    xs, ys = [], []
+    tmp_t = 0.0
+    while tmp_t < 1:
+        p = bspline_eval(pts, knots, degree, tmp_t)
+        xs.append(p[0]); ys.append(p[1])
+        tmp_t += delta_t
+    p = bspline_eval(pts, knots, degree, 1.0)
+    xs.append(p[0]); ys.append(p[1])
+    s = [0.0]
+    for i in range(1, len(xs)):
+        s.append(s[-1] + math.sqrt(math.pow(xs[i] - xs[i - 1], 2) + math.pow(ys[i] - ys[i - 1], 2)))
+    return np.array(xs), np.array(ys), np.array(s)
+
+
 def segment_raw_reference(sx, sy, max_s, delta_s=1.0):
     """ReferencePathSmoother::segmentRawReference (reference_path_smoother.cpp:48-85): the raw point list's splines sampled
     every delta_s = 1.0 for the smoother QPs.  The loop (:64-67) pushes back + delta_s while back < max_s, so the last abscissa is

@@ -1198,6 +1198,51 @@ int pqp_reference_states(pqp_handle* h, int batch, int n_max, int m, const doubl
     return PQP_OK;
 }
 
+// ---- input points -> dense raw reference line (ReferencePathSmoother::bSpline) --------------------------------------------------
+int pqp_bspline_resample_device(pqp_handle* h, int batch, int p_max, int n_max, const double* points, const int32_t* n_points, double* x,
+                                double* y, double* s, int32_t* count) {
+    if (!h || !points || !n_points || !x || !y || !s || !count || batch < 1 || p_max < 4 || n_max < 2)
+        return fail(PQP_ERR_INVALID, "pqp_bspline_resample: bad argument (at least 4 input points: reference_path_smoother.cpp:33)");
+    PQP_HIP(hipSetDevice(h->device));
+    pqp::BsplineArgs a;
+    a.batch = batch; a.p_max = p_max; a.n_max = n_max; a.pts = points; a.n_pts = n_points; a.x = x; a.y = y; a.s = s; a.count = count;
+    const size_t lds = ((size_t)3 * p_max + 6 + (size_t)3 * n_max) * 8;
+    if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_bspline_resample: 3 p_max + 3 n_max doubles exceed one CU's LDS");
+    if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::bspline_resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->next_event_pair();
+    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(pqp::bspline_resample_kernel, dim3(batch), dim3(64), lds, h->stream, a);
+    PQP_HIP(hipGetLastError());
+    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return PQP_OK;
+}
+
+int pqp_bspline_resample(pqp_handle* h, int batch, int p_max, int n_max, const double* points, const int32_t* n_points, double* x, double* y,
+                         double* s, int32_t* count) {
+    if (!h || !points || !n_points || !x || !y || !s || !count || batch < 1 || p_max < 4 || n_max < 2)
+        return fail(PQP_ERR_INVALID, "pqp_bspline_resample: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    const size_t b_pts = (size_t)batch * p_max * 2 * 8, b_n = (size_t)batch * 4, b_list = (size_t)batch * n_max * 8;
+    const size_t sizes[4] = {3 * b_list, b_pts, b_n, b_n};
+    int rc;
+    for (int j = 0; j < 4; ++j) if ((rc = h->c_buf[j].ensure(sizes[j]))) return rc;
+    PQP_HIP(hipMemcpyAsync(h->c_buf[1].p, points, b_pts, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[2].p, n_points, b_n, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemsetAsync(h->c_buf[0].p, 0, 3 * b_list, h->stream));
+    double* l = h->c_buf[0].as<double>();
+    const size_t bn = (size_t)batch * n_max;
+    if ((rc = pqp_bspline_resample_device(h, batch, p_max, n_max, h->c_buf[1].as<double>(), h->c_buf[2].as<int32_t>(), l, l + bn, l + 2 * bn,
+                                          h->c_buf[3].as<int32_t>())))
+        return rc;
+    PQP_HIP(hipMemcpyAsync(x, l, b_list, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(y, l + bn, b_list, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(s, l + 2 * bn, b_list, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(count, h->c_buf[3].p, b_n, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipStreamSynchronize(h->stream));
+    return PQP_OK;
+}
+
 // ---- spline fit ---------------------------------------------------------------------------------------
 int pqp_spline_fit_device(pqp_handle* h, int batch, int m, const double* s, const double* x, const double* y, double* spline,
                           double* spline_ext) {

@@ -131,6 +131,30 @@ def test_reference_state_sampling():
     assert np.allclose(np.diff(fixed[:, 0]), 0.3)
 
 
+def test_bspline_resampling():
+    """bSpline(): the restated clamped knot vector + de Boor against scipy's independent B-spline evaluation (tinyspline itself is
+    not in this image: parity unpinned, see the oracle), the degree rule, the sampling loop and the chord-length abscissae."""
+    from scipy.interpolate import BSpline
+    rng = np.random.default_rng(5)
+    for n, spacing, degree in ((7, 4.0, 5), (9, 7.0, 4), (6, 12.0, 3)):
+        pts = np.cumsum(np.column_stack([np.full(n, spacing), rng.uniform(-1.0, 1.0, n)]), axis=0)
+        kn = K.clamped_knots(n, degree)
+        assert len(kn) == n + degree + 1 and list(kn[:degree + 1]) == [0.0] * (degree + 1) and list(kn[-degree - 1:]) == [1.0] * (degree + 1)
+        assert np.allclose(np.diff(kn[degree:n + 1]), 1.0 / (n - degree))               # uniform interior knots
+        sp = BSpline(kn, pts, degree)
+        for t in np.linspace(0.0, 1.0, 41):
+            assert np.abs(K.bspline_eval(pts, kn, degree, t) - sp(t)).max() < 1e-12
+        x, y, s = K.bspline_resample(pts)
+        length = np.hypot(*np.diff(pts, axis=0).T).sum()
+        assert len(x) in (int(np.ceil(length)) + 1, int(np.ceil(length)) + 2)           # t = k / length while < 1 (accumulated), then t = 1
+        assert (x[0], y[0]) == tuple(pts[0]) and (x[-1], y[-1]) == tuple(pts[-1])        # a clamped spline starts and ends on its polygon
+        assert np.abs(K.bspline_eval(pts, kn, degree, 3.0 / length) - (x[3], y[3])).max() < 1e-9
+        assert s[0] == 0.0 and np.all(np.diff(s) > 0) and s[-1] <= length + 1e-9 and s[-1] > 0.9 * length
+    line = np.column_stack([np.linspace(0.0, 30.0, 8), np.linspace(0.0, 15.0, 8)])
+    x, y, s = K.bspline_resample(line)                                                  # collinear control points: the spline is the segment
+    assert np.abs(y - 0.5 * x).max() < 1e-12 and np.all(np.diff(x) > 0)
+
+
 def test_raw_reference_segmentation():
     """segmentRawReference: samples every metre from 0 up to and including the first abscissa >= max_s (the reference's loop
     overshoots the line unless its length is a whole number of metres); on a circle: angle = s / R, k = 1 / R."""

@@ -105,6 +105,39 @@ def test_reference_states_and_initial_error(handle):
     np.testing.assert_allclose(ref2[0], want2[:50], rtol=0, atol=1e-11)
 
 
+def test_bspline_resampling_of_the_input_points(handle):
+    """pqp_bspline_resample against the restatement of ReferencePathSmoother::bSpline (all three degrees, ragged point counts, a
+    scenario with too few points), then on into pqp_spline_fit -> pqp_segment_raw_reference as ReferencePathSmoother::solve chains them."""
+    rng = np.random.default_rng(11)
+    sets = []
+    for n, spacing in ((7, 4.0), (12, 3.0), (9, 7.0), (6, 12.0), (3, 5.0)):
+        sets.append(np.cumsum(np.column_stack([np.full(n, spacing), rng.uniform(-1.5, 1.5, n)]), axis=0))
+    p_max = 12
+    pts = np.zeros((len(sets), p_max, 2)); n_pts = np.array([len(p) for p in sets], dtype=np.int32)
+    for q, p in enumerate(sets):
+        pts[q, :len(p)] = p
+    r = handle.bspline_resample(pts, n_pts, 96)
+    assert r["count"][4] == 0                                                  # "Few reference points" (reference_path_smoother.cpp:33)
+    for q, p in enumerate(sets[:4]):
+        x, y, s = K.bspline_resample(p)
+        n = len(x)
+        assert r["count"][q] == n
+        np.testing.assert_allclose(r["x"][q, :n], x, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(r["y"][q, :n], y, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(r["s"][q, :n], s, rtol=0, atol=1e-11)
+        assert np.all(r["x"][q, n:] == 0.0) and np.all(r["s"][q, n:] == 0.0)
+    assert handle.bspline_resample(pts[:1], n_pts[:1], 10)["count"][0] == r["count"][0]         # capacity smaller than the line needs
+    q, n = 1, int(r["count"][1])                                               # on into the next two steps of the chain
+    tab, ext = handle.spline_fit(r["s"][q:q + 1, :n], r["x"][q:q + 1, :n], r["y"][q:q + 1, :n])
+    seg = handle.segment_raw_reference(tab, ext, r["s"][q:q + 1, n - 1], 64)
+    sx, sy = K.spline_fit(r["s"][q, :n], r["x"][q, :n]), K.spline_fit(r["s"][q, :n], r["y"][q, :n])
+    want = K.segment_raw_reference(sx, sy, float(r["s"][q, n - 1]))
+    m = len(want[2])
+    assert seg["count"][0] == m
+    np.testing.assert_allclose(seg["x"][0, :m], want[0], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(seg["k"][0, :m], want[4], rtol=0, atol=1e-11)
+
+
 def test_raw_reference_segmentation_feeds_the_tension_smoother(handle):
     """pqp_segment_raw_reference against the restatement of segmentRawReference, then the chain TensionSmoother::smooth runs
     (tension_smoother.cpp:21-39): raw points -> spline -> 1 m samples -> TensionSmoother2 QP -> spline of the smoothed points."""
