@@ -24,6 +24,7 @@
  *                                     src/data_struct/reference_path.cpp:61, reference_path_impl.cpp:177-312    pqp_corridor_bounds
  *   ReferencePathImpl::buildReferenceFromSpline  reference_path_impl.cpp:314-338, PathOptimizer::processInitState path_optimizer.cpp:73-85
  *                                                                                                         pqp_reference_states
+ *   PathOptimizer::setReferencePathLength       path_optimizer.cpp:87-104                                   pqp_reference_length
  *   ReferencePathSmoother::bSpline              reference_path_smoother.cpp:490-521                         pqp_bspline_resample
  *   ReferencePathSmoother::segmentRawReference  reference_path_smoother.cpp:48-85                           pqp_segment_raw_reference
  *   tk::spline::set_points            src/tools/spline.cpp:161-249                                         pqp_spline_fit
@@ -303,6 +304,17 @@ int pqp_reference_states_device(pqp_handle* h, int batch, int n_max, int m, cons
 int pqp_reference_states(pqp_handle* h, int batch, int n_max, int m, const double* spline, const double* spline_ext, const double* max_s,
                          const double* start, double ds_small, double ds_large, int dynamic, double* ref, int32_t* count,
                          double* init_err);
+
+/* ---- length of the reference line up to the target state ----------------------------------------------------------------------
+ * PathOptimizer::setReferencePathLength  src/path_optimizer.cpp:87-104 (called in processReferencePath, :117, before
+ * buildReferenceFromSpline): when the target state lies behind the end of the line - x <= 0 in the frame of the line's end state,
+ * global2Local tools.cpp:57-64 - the line is cut at the target's projection (getProjection tools.cpp:66-126).
+ * length [batch] = ReferencePath::getLength(), target [batch][3] = x, y, heading  ->  length_out [batch], the max_s of
+ * pqp_reference_states. */
+int pqp_reference_length_device(pqp_handle* h, int batch, int m, const double* spline, const double* spline_ext, const double* length,
+                                const double* target, double* length_out);
+int pqp_reference_length(pqp_handle* h, int batch, int m, const double* spline, const double* spline_ext, const double* length,
+                         const double* target, double* length_out);
 
 /* ---- input points -> dense raw reference line ----------------------------------------------------------------------------------
  * ReferencePathSmoother::bSpline  src/reference_path_smoother/reference_path_smoother.cpp:490-521 (first step of

@@ -526,6 +526,17 @@ def projection(sx, sy, tx, ty, max_s, start_s=0.0):                           # 
     return projection_newton(sx, sy, tx, ty, max_s, min_dis_s)
 
 
+def reference_length(sx, sy, length, tx, ty):
+    """PathOptimizer::setReferencePathLength (path_optimizer.cpp:87-104): the line's length, or the abscissa of the target state's
+    projection when the target lies behind the line's end (x <= 0 in the end state's frame)."""
+    ex, ey = spline_eval(sx, length), spline_eval(sy, length)
+    eh = math.atan2(spline_deriv(sy, 1, length), spline_deriv(sx, 1, length))
+    local_x = (tx - ex) * math.cos(eh) + (ty - ey) * math.sin(eh)              # global2Local(...).x  tools.cpp:57-64
+    if local_x > 0.0:
+        return length
+    return projection(sx, sy, tx, ty, length, 0.0)
+
+
 def graph_search_dp(sx, sy, length, start, dist, g, prm=DpParams()):
     """graphSearchDp (reference_path_smoother.cpp:142-295) with calculateCostAt (:107-140).
     start = (x, y, heading) of the vehicle.  Returns None when the reference returns false, else a dict with

@@ -1198,6 +1198,47 @@ int pqp_reference_states(pqp_handle* h, int batch, int n_max, int m, const doubl
     return PQP_OK;
 }
 
+// ---- length of the reference line up to the target state (PathOptimizer::setReferencePathLength) ---------------------------------
+int pqp_reference_length_device(pqp_handle* h, int batch, int m, const double* spline, const double* spline_ext, const double* length,
+                                const double* target, double* length_out) {
+    if (!h || !spline || !spline_ext || !length || !target || !length_out || batch < 1 || m < 3)
+        return fail(PQP_ERR_INVALID, "pqp_reference_length: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    pqp::RefLengthArgs a;
+    a.batch = batch; a.m = m; a.spl = spline; a.spl_ext = spline_ext; a.length = length; a.target = target; a.length_out = length_out;
+    const size_t lds = (size_t)9 * m * 8;
+    if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_reference_length: 9 m doubles exceed one CU's LDS");
+    if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::reference_length_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->next_event_pair();
+    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(pqp::reference_length_kernel, dim3(batch), dim3(64), lds, h->stream, a);
+    PQP_HIP(hipGetLastError());
+    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return PQP_OK;
+}
+
+int pqp_reference_length(pqp_handle* h, int batch, int m, const double* spline, const double* spline_ext, const double* length,
+                         const double* target, double* length_out) {
+    if (!h || !spline || !spline_ext || !length || !target || !length_out || batch < 1 || m < 3)
+        return fail(PQP_ERR_INVALID, "pqp_reference_length: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    const size_t b_spl = (size_t)batch * 9 * m * 8, b_ext = (size_t)batch * 4 * 8, b_s = (size_t)batch * 8, b_t = (size_t)batch * 3 * 8;
+    const size_t sizes[5] = {b_s, b_spl, b_ext, b_s, b_t};
+    int rc;
+    for (int j = 0; j < 5; ++j) if ((rc = h->c_buf[j].ensure(sizes[j]))) return rc;
+    PQP_HIP(hipMemcpyAsync(h->c_buf[1].p, spline, b_spl, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[2].p, spline_ext, b_ext, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[3].p, length, b_s, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[4].p, target, b_t, hipMemcpyHostToDevice, h->stream));
+    if ((rc = pqp_reference_length_device(h, batch, m, h->c_buf[1].as<double>(), h->c_buf[2].as<double>(), h->c_buf[3].as<double>(),
+                                          h->c_buf[4].as<double>(), h->c_buf[0].as<double>())))
+        return rc;
+    PQP_HIP(hipMemcpyAsync(length_out, h->c_buf[0].p, b_s, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipStreamSynchronize(h->stream));
+    return PQP_OK;
+}
+
 // ---- input points -> dense raw reference line (ReferencePathSmoother::bSpline) --------------------------------------------------
 int pqp_bspline_resample_device(pqp_handle* h, int batch, int p_max, int n_max, const double* points, const int32_t* n_points, double* x,
                                 double* y, double* s, int32_t* count) {

@@ -131,6 +131,21 @@ def test_reference_state_sampling():
     assert np.allclose(np.diff(fixed[:, 0]), 0.3)
 
 
+def test_reference_length_up_to_the_target():
+    """setReferencePathLength: a target beyond the end of the line leaves the length alone, a target beside the line cuts it at
+    the target's projection (on a straight line: the target's own abscissa)."""
+    s = np.linspace(0.0, 40.0, 41)
+    sx = K.spline_fit(s, s.copy()); sy = K.spline_fit(s, np.zeros_like(s))
+    assert K.reference_length(sx, sy, 40.0, 45.0, 1.0) == 40.0
+    assert K.reference_length(sx, sy, 40.0, 40.0, -2.0) == 40.0                # x == 0 in the end frame: cut ... at the end itself
+    assert abs(K.reference_length(sx, sy, 40.0, 27.3, 1.5) - 27.3) < 1e-9
+    R = 30.0
+    cx = K.spline_fit(s, R * np.sin(s / R)); cy = K.spline_fit(s, R * (1 - np.cos(s / R)))
+    phi = 22.0 / R
+    got = K.reference_length(cx, cy, 40.0, (R - 2.0) * np.sin(phi), R - (R - 2.0) * np.cos(phi))    # 2 m inside the arc at s = 22
+    assert abs(got - 22.0) < 1e-3
+
+
 def test_bspline_resampling():
     """bSpline(): the restated clamped knot vector + de Boor against scipy's independent B-spline evaluation (tinyspline itself is
     not in this image: parity unpinned, see the oracle), the degree rule, the sampling loop and the chord-length abscissae."""

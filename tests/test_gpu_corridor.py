@@ -105,6 +105,27 @@ def test_reference_states_and_initial_error(handle):
     np.testing.assert_allclose(ref2[0], want2[:50], rtol=0, atol=1e-11)
 
 
+def test_reference_length_up_to_the_target(handle):
+    """pqp_reference_length against the restatement of setReferencePathLength: targets beyond the end, beside the line, at its
+    start, and the cut length fed to pqp_reference_states."""
+    cs = [U.build(seed=s, n=10) for s in (40, 41, 42, 43)]
+    tab, ext = np.stack([c["tab"] for c in cs]), np.stack([c["ext"] for c in cs])
+    length = np.array([30.0, 30.0, 25.5, 28.0])
+    def at(c, s, off):
+        x, y = K.spline_eval(c["sx"], s), K.spline_eval(c["sy"], s)
+        h = np.arctan2(K.spline_deriv(c["sy"], 1, s), K.spline_deriv(c["sx"], 1, s))
+        return [x - off * np.sin(h), y + off * np.cos(h), h]
+    target = np.array([at(cs[0], 30.0, 0.0)[:2] + [0.0], at(cs[1], 17.4, 1.2), at(cs[2], 0.3, -0.8), at(cs[3], 27.9, 0.5)])
+    target[0, 0] += 3.0 * np.cos(at(cs[0], 30.0, 0.0)[2]); target[0, 1] += 3.0 * np.sin(at(cs[0], 30.0, 0.0)[2])      # 3 m beyond the end
+    got = handle.reference_length(tab, ext, length, target)
+    for q, c in enumerate(cs):
+        want = K.reference_length(c["sx"], c["sy"], float(length[q]), target[q, 0], target[q, 1])
+        assert got[q] == pytest.approx(want, abs=1e-9)
+    assert got[0] == 30.0 and abs(got[1] - 17.4) < 1e-3 and abs(got[2] - 0.3) < 1e-3
+    ref, count, _ = handle.reference_states(tab[1:2], ext[1:2], got[1:2], 200)
+    assert count[0] == len(K.build_reference_from_spline(cs[1]["sx"], cs[1]["sy"], float(got[1])))
+
+
 def test_bspline_resampling_of_the_input_points(handle):
     """pqp_bspline_resample against the restatement of ReferencePathSmoother::bSpline (all three degrees, ragged point counts, a
     scenario with too few points), then on into pqp_spline_fit -> pqp_segment_raw_reference as ReferencePathSmoother::solve chains them."""
