@@ -24,6 +24,7 @@
  *                                     src/data_struct/reference_path.cpp:61, reference_path_impl.cpp:177-312    pqp_corridor_bounds
  *   ReferencePathImpl::buildReferenceFromSpline  reference_path_impl.cpp:314-338, PathOptimizer::processInitState path_optimizer.cpp:73-85
  *                                                                                                         pqp_reference_states
+ *   ReferencePathSmoother::postSmooth (tail)    reference_path_smoother.cpp:559-573                         pqp_offsets_to_points
  *   PathOptimizer::setReferencePathLength       path_optimizer.cpp:87-104                                   pqp_reference_length
  *   ReferencePathSmoother::bSpline              reference_path_smoother.cpp:490-521                         pqp_bspline_resample
  *   ReferencePathSmoother::segmentRawReference  reference_path_smoother.cpp:48-85                           pqp_segment_raw_reference
@@ -304,6 +305,17 @@ int pqp_reference_states_device(pqp_handle* h, int batch, int n_max, int m, cons
 int pqp_reference_states(pqp_handle* h, int batch, int n_max, int m, const double* spline, const double* spline_ext, const double* max_s,
                          const double* start, double ds_small, double ds_large, int dynamic, double* ref, int32_t* count,
                          double* init_err);
+
+/* ---- lateral offsets on a line -> points with chord-length abscissae -----------------------------------------------------------
+ * The tail of ReferencePathSmoother::postSmooth  src/reference_path_smoother/reference_path_smoother.cpp:559-573: x_list(i) =
+ * x_s(s_i) + l_i cos(heading(s_i) + pi/2), y_list likewise, s_list = accumulated chord length - the knots of the final reference
+ * line (pqp_spline_fit, :574-576; s_list.back() is its length).
+ * spline [batch][9][m_spline], spline_ext [batch][4]: the smoothed line; at_s, l [batch][m] = layers_s_list_ and pqp_post_smooth's
+ * out_l; m_of [batch] = points per scenario (pqp_dp_corridor's count) or NULL  ->  x, y, s [batch][m] (rows beyond m_of[q] untouched). */
+int pqp_offsets_to_points_device(pqp_handle* h, int batch, int m_spline, int m, const double* spline, const double* spline_ext, const double* at_s,
+                                 const double* l, const int32_t* m_of, double* x, double* y, double* s);
+int pqp_offsets_to_points(pqp_handle* h, int batch, int m_spline, int m, const double* spline, const double* spline_ext, const double* at_s,
+                          const double* l, const int32_t* m_of, double* x, double* y, double* s);
 
 /* ---- length of the reference line up to the target state ----------------------------------------------------------------------
  * PathOptimizer::setReferencePathLength  src/path_optimizer.cpp:87-104 (called in processReferencePath, :117, before

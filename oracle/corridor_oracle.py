@@ -526,6 +526,22 @@ def projection(sx, sy, tx, ty, max_s, start_s=0.0):                           # 
     return projection_newton(sx, sy, tx, ty, max_s, min_dis_s)
 
 
+def offsets_to_points(sx, sy, at_s, l):
+    """The tail of ReferencePathSmoother::postSmooth (reference_path_smoother.cpp:559-573): offsets l_i at abscissae s_i of the
+    smoothed line -> x_list, y_list and the accumulated chord length s_list."""
+    xs, ys, ss = [], [], []
+    s = 0.0
+    for i in range(len(at_s)):
+        ref_s = at_s[i]
+        ref_dir = math.atan2(spline_deriv(sy, 1, ref_s), spline_deriv(sx, 1, ref_s))           # getHeading tools.cpp:32-36
+        xs.append(spline_eval(sx, ref_s) + l[i] * math.cos(ref_dir + math.pi / 2))
+        ys.append(spline_eval(sy, ref_s) + l[i] * math.sin(ref_dir + math.pi / 2))
+        if i > 0:
+            s += math.sqrt(math.pow(xs[i] - xs[i - 1], 2) + math.pow(ys[i] - ys[i - 1], 2))
+        ss.append(s)
+    return np.array(xs), np.array(ys), np.array(ss)
+
+
 def reference_length(sx, sy, length, tx, ty):
     """PathOptimizer::setReferencePathLength (path_optimizer.cpp:87-104): the line's length, or the abscissa of the target state's
     projection when the target lies behind the line's end (x <= 0 in the end state's frame)."""

@@ -58,7 +58,7 @@ EXPORTS = [
     "pqp_last_kernel_ms", "pqp_kernel_ms_history", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
     "pqp_post_smooth", "pqp_post_smooth_device", "pqp_corridor_default_params", "pqp_corridor_bounds", "pqp_corridor_bounds_device",
     "pqp_reference_states", "pqp_reference_states_device", "pqp_spline_fit", "pqp_spline_fit_device", "pqp_dp_default_params",
-    "pqp_dp_corridor", "pqp_dp_corridor_device", "pqp_segment_raw_reference", "pqp_segment_raw_reference_device", "pqp_bspline_resample", "pqp_bspline_resample_device", "pqp_reference_length", "pqp_reference_length_device",
+    "pqp_dp_corridor", "pqp_dp_corridor_device", "pqp_segment_raw_reference", "pqp_segment_raw_reference_device", "pqp_bspline_resample", "pqp_bspline_resample_device", "pqp_reference_length", "pqp_reference_length_device", "pqp_offsets_to_points", "pqp_offsets_to_points_device",
 ]
 
 _lib = None
@@ -109,6 +109,8 @@ def load_library(path=None):
                                         C.POINTER(PqpCorridorParams), vp, vp]
     for name in ("pqp_reference_states", "pqp_reference_states_device"):
         getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, vp]
+    for name in ("pqp_offsets_to_points", "pqp_offsets_to_points_device"):
+        getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     for name in ("pqp_reference_length", "pqp_reference_length_device"):
         getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     for name in ("pqp_bspline_resample", "pqp_bspline_resample_device"):
@@ -245,6 +247,16 @@ class Handle:
         self._check(self.lib.pqp_reference_states(self._h, B, n_max, m, _ptr(spline), _ptr(spline_ext), _ptr(max_s), _ptr(st), ds_small,
                                                   ds_large, 1 if dynamic else 0, _ptr(ref), _ptr(count), _ptr(err)))
         return ref, count, err
+
+    def offsets_to_points(self, spline, spline_ext, at_s, l, m_of=None):
+        """pqp_offsets_to_points (host arrays): spline [B][9][m_spline], at_s, l [B][m], m_of [B] or None -> (x, y, s) [B][m]."""
+        spline = np.ascontiguousarray(spline, dtype=np.float64); spline_ext = np.ascontiguousarray(spline_ext, dtype=np.float64)
+        at_s = np.ascontiguousarray(at_s, dtype=np.float64); l = np.ascontiguousarray(l, dtype=np.float64)
+        mo = None if m_of is None else np.ascontiguousarray(m_of, dtype=np.int32)
+        B, ms, m = spline.shape[0], spline.shape[2], at_s.shape[1]
+        x = np.zeros((B, m)); y = np.zeros((B, m)); s = np.zeros((B, m))
+        self._check(self.lib.pqp_offsets_to_points(self._h, B, ms, m, _ptr(spline), _ptr(spline_ext), _ptr(at_s), _ptr(l), _ptr(mo), _ptr(x), _ptr(y), _ptr(s)))
+        return x, y, s
 
     def reference_length(self, spline, spline_ext, length, target):
         """pqp_reference_length (host arrays): spline [B][9][m], spline_ext [B][4], length [B], target [B][3] -> length_out [B]."""

@@ -1198,6 +1198,54 @@ int pqp_reference_states(pqp_handle* h, int batch, int n_max, int m, const doubl
     return PQP_OK;
 }
 
+// ---- lateral offsets on a line -> points with chord-length abscissae (tail of ReferencePathSmoother::postSmooth) ---------------------
+int pqp_offsets_to_points_device(pqp_handle* h, int batch, int m_spline, int m, const double* spline, const double* spline_ext, const double* at_s,
+                                 const double* l, const int32_t* m_of, double* x, double* y, double* s) {
+    if (!h || !spline || !spline_ext || !at_s || !l || !x || !y || !s || batch < 1 || m_spline < 3 || m < 1)
+        return fail(PQP_ERR_INVALID, "pqp_offsets_to_points: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    pqp::OffsetsArgs a;
+    a.batch = batch; a.m_spl = m_spline; a.m = m; a.spl = spline; a.spl_ext = spline_ext; a.at_s = at_s; a.l = l; a.m_of = m_of;
+    a.x = x; a.y = y; a.s = s;
+    const size_t lds = ((size_t)9 * m_spline + 2 * (size_t)m) * 8;
+    if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_offsets_to_points: 9 m_spline + 2 m doubles exceed one CU's LDS");
+    if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::offsets_to_points_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->next_event_pair();
+    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(pqp::offsets_to_points_kernel, dim3(batch), dim3(64), lds, h->stream, a);
+    PQP_HIP(hipGetLastError());
+    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return PQP_OK;
+}
+
+int pqp_offsets_to_points(pqp_handle* h, int batch, int m_spline, int m, const double* spline, const double* spline_ext, const double* at_s,
+                          const double* l, const int32_t* m_of, double* x, double* y, double* s) {
+    if (!h || !spline || !spline_ext || !at_s || !l || !x || !y || !s || batch < 1 || m_spline < 3 || m < 1)
+        return fail(PQP_ERR_INVALID, "pqp_offsets_to_points: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    const size_t b_spl = (size_t)batch * 9 * m_spline * 8, b_ext = (size_t)batch * 4 * 8, b_list = (size_t)batch * m * 8, b_n = (size_t)batch * 4;
+    const size_t sizes[6] = {3 * b_list, b_spl, b_ext, b_list, b_list, b_n};
+    int rc;
+    for (int j = 0; j < 6; ++j) if ((rc = h->c_buf[j].ensure(sizes[j]))) return rc;
+    PQP_HIP(hipMemcpyAsync(h->c_buf[1].p, spline, b_spl, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[2].p, spline_ext, b_ext, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[3].p, at_s, b_list, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemcpyAsync(h->c_buf[4].p, l, b_list, hipMemcpyHostToDevice, h->stream));
+    if (m_of) PQP_HIP(hipMemcpyAsync(h->c_buf[5].p, m_of, b_n, hipMemcpyHostToDevice, h->stream));
+    PQP_HIP(hipMemsetAsync(h->c_buf[0].p, 0, 3 * b_list, h->stream));
+    double* o = h->c_buf[0].as<double>();
+    const size_t bn = (size_t)batch * m;
+    if ((rc = pqp_offsets_to_points_device(h, batch, m_spline, m, h->c_buf[1].as<double>(), h->c_buf[2].as<double>(), h->c_buf[3].as<double>(),
+                                           h->c_buf[4].as<double>(), m_of ? h->c_buf[5].as<int32_t>() : nullptr, o, o + bn, o + 2 * bn)))
+        return rc;
+    PQP_HIP(hipMemcpyAsync(x, o, b_list, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(y, o + bn, b_list, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipMemcpyAsync(s, o + 2 * bn, b_list, hipMemcpyDeviceToHost, h->stream));
+    PQP_HIP(hipStreamSynchronize(h->stream));
+    return PQP_OK;
+}
+
 // ---- length of the reference line up to the target state (PathOptimizer::setReferencePathLength) ---------------------------------
 int pqp_reference_length_device(pqp_handle* h, int batch, int m, const double* spline, const double* spline_ext, const double* length,
                                 const double* target, double* length_out) {

@@ -131,6 +131,16 @@ def test_reference_state_sampling():
     assert np.allclose(np.diff(fixed[:, 0]), 0.3)
 
 
+def test_offsets_to_points():
+    """postSmooth's tail: on a straight line along x the points are (s_i, l_i) and the new abscissa is their chord length."""
+    s = np.linspace(0.0, 40.0, 41)
+    sx = K.spline_fit(s, s.copy()); sy = K.spline_fit(s, np.zeros_like(s))
+    at = np.array([0.0, 3.0, 6.0, 10.0]); l = np.array([0.5, -1.0, 0.0, 2.0])
+    x, y, ss = K.offsets_to_points(sx, sy, at, l)
+    assert np.abs(x - at).max() < 1e-12 and np.abs(y - l).max() < 1e-12
+    assert np.abs(ss - np.concatenate([[0.0], np.cumsum(np.hypot(np.diff(at), np.diff(l)))])).max() < 1e-12
+
+
 def test_reference_length_up_to_the_target():
     """setReferencePathLength: a target beyond the end of the line leaves the length alone, a target beside the line cuts it at
     the target's projection (on a straight line: the target's own abscissa)."""

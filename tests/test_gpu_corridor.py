@@ -302,6 +302,18 @@ def test_dp_corridor_feeds_post_smooth(handle):
     assert res["status"][0] == 1
     l = res["l"][0]
     assert abs(l[0] - vl[0]) < 1e-3 and np.all(l[1:] >= lb[0, 1:k] - 1e-3) and np.all(l[1:] <= ub[0, 1:k] + 1e-3)
+    # the tail of postSmooth (:559-576): offsets -> points with chord-length abscissae -> the final reference line's splines
+    full_l = np.zeros_like(ls); full_l[0, :k] = l
+    x, y, s = handle.offsets_to_points(c["tab"][None], c["ext"][None], ls, full_l, m_of=count)
+    wx, wy, ws = K.offsets_to_points(c["sx"], c["sy"], ls[0, :k], l)
+    np.testing.assert_allclose(x[0, :k], wx, rtol=0, atol=1e-11)           # atan2 / sin / cos: ocml vs libm
+    np.testing.assert_allclose(y[0, :k], wy, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(s[0, :k], ws, rtol=0, atol=1e-10)
+    assert np.all(x[0, k:] == 0.0) and np.all(s[0, k:] == 0.0)
+    tab, ext = handle.spline_fit(s[:, :k].copy(), x[:, :k].copy(), y[:, :k].copy())
+    np.testing.assert_array_equal(tab[0], K.pack_spline(K.spline_fit(s[0, :k], x[0, :k]), K.spline_fit(s[0, :k], y[0, :k]))[0])
+    ref, cnt, _ = handle.reference_states(tab, ext, s[:, k - 1].copy(), 200)      # and on to the path QP's reference states
+    assert cnt[0] == len(K.build_reference_from_spline(K.spline_fit(s[0, :k], x[0, :k]), K.spline_fit(s[0, :k], y[0, :k]), float(s[0, k - 1])))
 
 
 @pytest.mark.parametrize("name", ["scene_a", "scene_b"])
