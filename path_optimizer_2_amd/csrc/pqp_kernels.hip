@@ -491,7 +491,7 @@ struct pqp_handle {
     DevBuf s_ref, s_lin, s_bounds, s_scal;      // staging for the host-pointer entry points
     DevBuf s_out, s_status, s_iters, s_info, s_a, s_p, s_l, s_u, s_idx;
     // smoother QPs: banded problem data + shared sparsity (cached per type and size) + staging
-    DevBuf b_pband, b_q, b_aval, b_lo, b_up, b_x, b_y, b_acol, b_trow, b_tslot, b_in[5], b_out[3], c_buf[12], sp_work;
+    DevBuf b_pband, b_q, b_aval, b_lo, b_up, b_x, b_y, b_acol, b_trow, b_tslot, b_in[5], b_out[3], c_buf[12];
     int b_struct_type = -1, b_struct_n = -1;
 };
 
@@ -537,7 +537,7 @@ int pqp_destroy(pqp_handle* h) {
                       &h->b_lo, &h->b_up, &h->b_x, &h->b_y, &h->b_acol, &h->b_trow, &h->b_tslot, &h->b_in[0], &h->b_in[1], &h->b_in[2],
                       &h->b_in[3], &h->b_in[4], &h->b_out[0], &h->b_out[1], &h->b_out[2], &h->c_buf[0], &h->c_buf[1], &h->c_buf[2],
                       &h->c_buf[3], &h->c_buf[4], &h->c_buf[5], &h->c_buf[6], &h->c_buf[7], &h->c_buf[8], &h->c_buf[9], &h->c_buf[10],
-                      &h->c_buf[11], &h->sp_work})
+                      &h->c_buf[11]})
         b->release();
     for (int k = 0; k < pqp_handle::kEvRing; ++k) { if (h->evs0[k]) (void)hipEventDestroy(h->evs0[k]); if (h->evs1[k]) (void)hipEventDestroy(h->evs1[k]); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1338,13 +1338,14 @@ int pqp_spline_fit_device(pqp_handle* h, int batch, int m, const double* s, cons
     if (!h || !s || !x || !y || !spline || !spline_ext || batch < 1 || m < 3)
         return fail(PQP_ERR_INVALID, "pqp_spline_fit: bad argument (m >= 3: spline.cpp:164)");
     PQP_HIP(hipSetDevice(h->device));
-    int rc;
-    if ((rc = h->sp_work.ensure((size_t)batch * 4 * m * 8))) return rc;
     pqp::SplineFitArgs a;
-    a.batch = batch; a.m = m; a.s = s; a.vx = x; a.vy = y; a.spl = spline; a.spl_ext = spline_ext; a.work = h->sp_work.as<double>();
+    a.batch = batch; a.m = m; a.s = s; a.vx = x; a.vy = y; a.spl = spline; a.spl_ext = spline_ext;
+    const size_t lds = (size_t)7 * m * 8;
+    if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_spline_fit: 7 m doubles exceed one CU's LDS");
+    if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::spline_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     h->next_event_pair();
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(pqp::spline_fit_kernel, dim3((2 * batch + 63) / 64), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL(pqp::spline_fit_kernel, dim3(2 * batch), dim3(64), lds, h->stream, a);
     PQP_HIP(hipGetLastError());
     PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
