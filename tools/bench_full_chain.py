@@ -83,13 +83,16 @@ def chain():
     res = h.solve_var(nv, ref, bounds, scal, passes=1); stage("path QP (2 passes)")
     solved = (res["status"] == 1) & ok & (nv >= 2)
 
-    return B, n0, n1, k, count, nv, solved
+    return B, n0, n1, k, count, nv, solved, res
 
 
 chain()                                  # first pass: module load, buffer growth
-B, n0, n1, k, count, nv, solved = chain()
+B, n0, n1, k, count, nv, solved, res = chain()
 print(f"full chain: {batch} scenarios over {n_maps} maps, {P} input points each; {B} with the majority shapes (raw line {n0} points, "
       f"{n1} samples, {k} layers, {int(count.min())}..{int(count.max())} states); paths solved {int(solved.sum())}/{B}, blocked {int((nv < count).sum())}")
+kk, it = res["info"][:, 5], res["iters"]
+print(f"  path QP: ADMM iterations median {np.median(it):.0f} p99 {np.percentile(it, 99):.0f} max {it.max()}; reduced solves mean {kk.mean():.1f} "
+      f"p99 {np.percentile(kk, 99):.0f} max {kk.max():.0f}; polished passes {np.bincount(res['info'][:, 4].astype(int)).tolist()}")
 tot = 0.0
 for name, ms in times:
     tot += ms
