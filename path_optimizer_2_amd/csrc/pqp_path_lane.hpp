@@ -1672,7 +1672,9 @@ struct PathQp {
                         // have passed through a smaller violation on their way out)
                         if (stall >= 3 && !conservative) { conservative = true; best = viol; stall = 0; }
                         round += 1;
-                        give_up = (conservative && stall >= 8) || round >= max_rounds;
+                        // (the attempts after a pass's first periodic one start from a better ADMM iterate: when 5 rounds are not enough
+                        // for them the rounds are cycling, and every further one is wasted)
+                        give_up = (conservative && stall >= 8) || round >= ((prm.polish_every > 0 && it > prm.polish_every) ? 5 : max_rounds);
                     }
                     if (give_up) {
                         polish_mode = false;
