@@ -1672,9 +1672,10 @@ struct PathQp {
                         // have passed through a smaller violation on their way out)
                         if (stall >= 3 && !conservative) { conservative = true; best = viol; stall = 0; }
                         round += 1;
-                        // (the attempts after a pass's first periodic one start from a better ADMM iterate: when 5 rounds are not enough
-                        // for them the rounds are cycling, and every further one is wasted)
-                        give_up = (conservative && stall >= 8) || round >= ((prm.polish_every > 0 && it > prm.polish_every) ? 5 : max_rounds);
+                        // (the attempts after a pass's first periodic one start from a better ADMM iterate and get half the rounds:
+                        // when those are not enough the rounds are usually cycling, and every further one is wasted.  A quarter
+                        // is too few: long paths with contact segments then fail attempts they would have completed)
+                        give_up = (conservative && stall >= 8) || round >= ((prm.polish_every > 0 && it > prm.polish_every) ? max_rounds / 2 : max_rounds);
                     }
                     if (give_up) {
                         polish_mode = false;
