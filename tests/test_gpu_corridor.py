@@ -359,3 +359,19 @@ def test_argument_errors(handle):
     # a batch of one and a line shorter than one step are fine
     ref, count, _ = handle.reference_states(c["tab"][None], c["ext"][None], np.array([0.1]), 8)
     assert count[0] == 1 and ref[0, 0, 0] == 0.0
+    # the entry points added around the smoother QPs
+    with pytest.raises(capi.PqpError):
+        handle.bspline_resample(np.zeros((1, 3, 2)), np.array([3]), 32)                             # p_max < 4 (reference_path_smoother.cpp:33)
+    with pytest.raises(capi.PqpError):
+        handle.segment_raw_reference(c["tab"][None], c["ext"][None], np.array([10.0]), 32, delta_s=0.0)
+    with pytest.raises(capi.PqpError):
+        handle.offsets_to_points(c["tab"][None, :, :2], c["ext"][None], np.zeros((1, 4)), np.zeros((1, 4)))   # a 2-knot spline
+    with pytest.raises(capi.PqpError):
+        handle.bspline_resample(np.zeros((1, 8, 2)), np.array([8]), 8192)                           # 3 x 8192 samples do not fit one CU's LDS
+    # a degenerate input polygon (all points equal): length 0, one sample at t = 0 and the one at t = 1
+    r = handle.bspline_resample(np.ones((1, 6, 2)), np.array([6]), 16)
+    assert r["count"][0] == 2 and np.all(r["x"][0, :2] == 1.0) and np.all(r["s"][0, :2] == 0.0)
+    # a target exactly at the line's end leaves the length alone or cuts it at the end: the same number either way
+    L = float(c["tab"][0, -1])
+    end = [K.spline_eval(c["sx"], L), K.spline_eval(c["sy"], L), 0.0]
+    assert handle.reference_length(c["tab"][None], c["ext"][None], np.array([L]), np.array([end]))[0] == pytest.approx(L, abs=1e-9)
