@@ -65,7 +65,31 @@ def make_scene_fixture(name, seed, length):
     print(name, "states", len(ref), "usable", n_valid, "dp layers", len(dp["layers_s"]))
 
 
+def make_line_fixture(name, seed):
+    """The head of ReferencePathSmoother::solve: input points -> bSpline -> spline -> segmentRawReference, the tail of postSmooth
+    (offsets -> points) on that spline, and setReferencePathLength for a target beside the line."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import corridor_oracle as K
+    rng = np.random.default_rng(seed)
+    n = 9
+    pts = np.cumsum(np.column_stack([np.full(n, 3.7), rng.uniform(-1.2, 1.2, n)]), axis=0)
+    x, y, s = K.bspline_resample(pts)
+    sx, sy = K.spline_fit(s, x), K.spline_fit(s, y)
+    tab, ext = K.pack_spline(sx, sy)
+    seg = K.segment_raw_reference(sx, sy, float(s[-1]))
+    at_s = np.linspace(0.5, float(s[-1]) - 0.5, 12)
+    off = rng.uniform(-1.0, 1.0, 12)
+    op = K.offsets_to_points(sx, sy, at_s, off)
+    tx, ty = K.spline_eval(sx, 17.0) + 0.4, K.spline_eval(sy, 17.0) - 0.9
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), points=pts, raw_x=x, raw_y=y, raw_s=s, spline=tab, spline_ext=ext,
+                        seg_x=seg[0], seg_y=seg[1], seg_s=seg[2], seg_angle=seg[3], seg_k=seg[4], at_s=at_s, offsets=off,
+                        off_x=op[0], off_y=op[1], off_s=op[2], target=np.array([tx, ty, 0.0]),
+                        cut_length=K.reference_length(sx, sy, float(s[-1]), tx, ty))
+    print(name, "raw points", len(x), "samples", len(seg[2]))
+
+
 if __name__ == "__main__":
+    make_line_fixture("line_a", 3)
     make("path_n8", 8, 4, "varied")
     make("path_n80", 80, 4, "uniform")
     make_scene_fixture("scene_a", 0, 24.0)

@@ -245,3 +245,19 @@ def test_scene_fixtures_are_reproduced(name):
     assert n_valid == int(f["n_valid"]) and np.array_equal(bounds, f["bounds"])
     dp = K.graph_search_dp(sx, sy, float(f["length"]), tuple(f["start"]), f["dist"], g)
     assert np.array_equal(dp["layers_s"], f["dp_layers_s"]) and np.array_equal(dp["lb"], f["dp_lb"]) and np.array_equal(dp["ub"], f["dp_ub"])
+
+
+def test_line_fixture_is_reproduced():
+    """tests/golden/line_a.npz pins the head of ReferencePathSmoother::solve (bSpline -> spline -> segmentRawReference), the tail
+    of postSmooth and setReferencePathLength against silent changes of the restatement."""
+    f = np.load(os.path.join(ROOT, "tests", "golden", "line_a.npz"))
+    x, y, s = K.bspline_resample(f["points"])
+    assert np.array_equal(x, f["raw_x"]) and np.array_equal(y, f["raw_y"]) and np.array_equal(s, f["raw_s"])
+    sx, sy = K.spline_fit(s, x), K.spline_fit(s, y)
+    assert np.array_equal(K.pack_spline(sx, sy)[0], f["spline"])
+    seg = K.segment_raw_reference(sx, sy, float(s[-1]))
+    for got, key in zip(seg, ("seg_x", "seg_y", "seg_s", "seg_angle", "seg_k")):
+        assert np.array_equal(got, f[key])
+    op = K.offsets_to_points(sx, sy, f["at_s"], f["offsets"])
+    assert np.array_equal(op[0], f["off_x"]) and np.array_equal(op[2], f["off_s"])
+    assert K.reference_length(sx, sy, float(s[-1]), f["target"][0], f["target"][1]) == float(f["cut_length"])

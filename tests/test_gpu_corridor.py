@@ -342,6 +342,31 @@ def test_golden_scene_fixtures_through_the_hip_chain(handle, name):
     assert vl[0] == pytest.approx(float(f["dp_vehicle_l"]), abs=1e-12)
 
 
+def test_golden_line_fixture_through_the_hip_chain(handle):
+    """tests/golden/line_a.npz: input points -> pqp_bspline_resample -> pqp_spline_fit -> pqp_segment_raw_reference, plus
+    pqp_offsets_to_points and pqp_reference_length on that spline, against the committed vectors."""
+    import os
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "line_a.npz"))
+    pts = f["points"]
+    r = handle.bspline_resample(pts[None], np.array([len(pts)]), 64)
+    n = len(f["raw_x"])
+    assert r["count"][0] == n
+    np.testing.assert_allclose(r["x"][0, :n], f["raw_x"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(r["s"][0, :n], f["raw_s"], rtol=0, atol=1e-11)
+    tab, ext = handle.spline_fit(f["raw_s"][None], f["raw_x"][None], f["raw_y"][None])
+    np.testing.assert_array_equal(tab[0], f["spline"]); np.testing.assert_array_equal(ext[0], f["spline_ext"])
+    seg = handle.segment_raw_reference(tab, ext, f["raw_s"][-1:].copy(), 64)
+    m = len(f["seg_s"])
+    assert seg["count"][0] == m
+    np.testing.assert_array_equal(seg["s"][0, :m], f["seg_s"])
+    for key, name in (("x", "seg_x"), ("y", "seg_y"), ("angle", "seg_angle"), ("k", "seg_k")):
+        np.testing.assert_allclose(seg[key][0, :m], f[name], rtol=0, atol=1e-11)
+    x, y, s = handle.offsets_to_points(tab, ext, f["at_s"][None], f["offsets"][None])
+    np.testing.assert_allclose(x[0], f["off_x"], rtol=0, atol=1e-11); np.testing.assert_allclose(s[0], f["off_s"], rtol=0, atol=1e-10)
+    cut = handle.reference_length(tab, ext, f["raw_s"][-1:].copy(), f["target"][None])
+    assert cut[0] == pytest.approx(float(f["cut_length"]), abs=1e-9)
+
+
 def test_argument_errors(handle):
     """bad arguments come back as PQP_ERR_INVALID / PQP_ERR_CAPACITY (no exception crosses the ABI, nothing is launched)"""
     c = U.build(seed=0, n=8)
