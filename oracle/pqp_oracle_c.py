@@ -86,6 +86,7 @@ def timed_baseline(make_sample, n, eps, budget_s=15.0, rho_interval=100):
     dt = time.perf_counter() - t0
     return {"value": k / dt, "unit": "paths/s", "cores": cores, "kind": "port",
             "sample": f"{k} paths of the bench distribution (N={n}) in {dt:.1f} s, OSQP-paper restatement in C (oracle/pqp_oracle.c), "
-                      f"eps {eps:g}, no polish, one path per OpenMP task over {cores} threads; mean ADMM iterations "
+                      f"eps {eps:g}, no polish, direct O(N) assembly (the reference's dense cons x vars fill + scan, O(N^2), is not timed), "
+                      f"one path per OpenMP task over {cores} threads; mean ADMM iterations "
                       f"{float(r['iters'].mean()):.0f}; solved {r['solved']}/{k}",
             "per_core": k / dt / cores}
