@@ -71,6 +71,8 @@ inline void production_params(pqp_params* p) {
     p->polish_max_rounds = 0;                       // auto: max(24, n/5 - 8)
     p->polish_reseed = 1;
     p->adaptive_rho_tolerance = 2.0;                // re-balance rho sooner: the few slow QPs of a batch need 175 instead of 350 iterations
+    p->max_iter = 1000;                             // per pass (OSQP's 4000 in the defaults): every feasible QP of the sweeps ends within 500; an
+                                                    // infeasible one, which this setting cannot certify, then holds its batch up for 4 ms, not 15
     p->polish_patience = 5;                         // a QP whose polish cannot be verified (e.g. infeasible by 1e-5) ends like OSQP's,
                                                     // after attempts at 15, 45, 105, 225, 465 iterations
     p->eps_prim_inf = 0.0;                          // the kernel variant without OSQP's infeasibility certificate: 12 % faster

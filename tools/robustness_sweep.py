@@ -1,5 +1,5 @@
 """Solve many seeded batches with the production setting and report what did not end in an accepted polish, and the slowest QPs.
-Usage: python tools/robustness_sweep.py [seeds=16] [batch=8192]   (run on the GPU box)"""
+Usage: python tools/robustness_sweep.py [seeds=16] [batch=8192] [first_seed=1000]   (run on the GPU box)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,6 +7,7 @@ from path_optimizer_2_amd import capi
 from path_optimizer_2_amd.synth import make_batch
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+base = int(sys.argv[3]) if len(sys.argv) > 3 else 1000          # first seed
 for n, profile in ((80, "uniform"), (80, "varied"), (120, "varied"), (200, "uniform"), (37, "varied"), (300, "varied")):
     b = batch if n <= 120 else batch // 4
     h = capi.Handle(capi.production_params(), device=0, max_batch=b, max_n=n)
@@ -14,14 +15,14 @@ for n, profile in ((80, "uniform"), (80, "varied"), (120, "varied"), (200, "unif
     worst = []
     kk = []
     for s in range(seeds):
-        host = make_batch(b, n, profile, seed=1000 + s)
+        host = make_batch(b, n, profile, seed=base + s)
         r = h.solve(host["ref"], host["bounds"], host["scal"], passes=1)
         ok = (r["status"] == 1) & (r["info"][:, 4] == 2)
         tot += b; bad += int((~ok).sum())
         for q in np.nonzero(~ok)[0][:3]:
-            print(f"    n {n} {profile} seed {1000 + s} qp {q}: status {r['status'][q]} iters {r['iters'][q]} polished passes {r['info'][q, 4]:.0f}")
+            print(f"    n {n} {profile} seed {base + s} qp {q}: status {r['status'][q]} iters {r['iters'][q]} polished passes {r['info'][q, 4]:.0f}")
         k = r["info"][:, 5]; kk.append(k)
-        q = int(np.argmax(k)); worst.append((float(k[q]), 1000 + s, q))
+        q = int(np.argmax(k)); worst.append((float(k[q]), base + s, q))
     kk = np.concatenate(kk)
     worst.sort(reverse=True)
     print(f"n {n:3d} {profile:8s}: {tot} QPs, {bad} not solved+polished; reduced solves mean {kk.mean():.1f} p99 {np.percentile(kk, 99):.0f} "
