@@ -26,7 +26,7 @@ What each function follows (file:line relative to /root/reference):
                        tension_smoother.cpp:102-177, reference_path_smoother.cpp:582-636
 """
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import numpy as np
 import scipy.sparse as sp

@@ -1,6 +1,6 @@
 """Throughput of the corridor-bounds step on one GPU: `batch` scenarios of n waypoints over `n_maps` distinct distance maps
 (device-resident inputs, HIP-event kernel time).  Usage: python tools/bench_corridor.py [batch] [n] [n_maps]"""
-import os, sys, time
+import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))

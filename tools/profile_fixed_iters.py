@@ -1,6 +1,5 @@
 """One launch pattern for rocprofv3: batch QPs, fixed number of ADMM iterations (no early exit), 3 launches."""
 import os, sys
-import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from path_optimizer_2_amd import capi

@@ -3,7 +3,6 @@ Usage: python tools/stragglers.py [batch] [n] [profile] [key=value ...]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
 from path_optimizer_2_amd import capi
 from path_optimizer_2_amd.synth import make_batch
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
