@@ -5,20 +5,29 @@ A "step" = one pass of the hot path over one batch of synthetic scenarios: for e
     assemble -> cold ADMM solve -> unpack -> re-linearise -> warm re-solve -> unpack
 (PathOptimizer::optimizePath, reference src/path_optimizer.cpp:124-161), inputs already resident in HBM.
 
-Default workload = BASELINE.json configs[1]: batch 1024 QPs, N = 80, one GPU, solved to the engine's production
-setting: ADMM to eps_abs = eps_rel = 1e-4 with the KKT-verified polish (every returned path is the exact QP optimum,
-i.e. inside the 1e-4 parity bar; tests/test_gpu_parity.py).  `--no-polish` runs the plain OSQP termination instead.
+Workloads = BASELINE.json configs (`--config`; explicit --batch / --n / --profile override a preset's shape):
+    1  batch 1024, N = 80, shared sparsity, synthetic obstacle bounds, one GPU                  (default at --gpus 1)
+    2  batch 8192, N = 120, varied start / goal / curvature limits, one GPU
+    3  batch 65 536, N = 80 over 8 GPUs = 8192 QPs per GPU                                        (default at --gpus > 1)
+    4  batch 4096, N = 200 over 8 GPUs = 512 per GPU: TensionSmoother2 QP + path QP on two HIP streams (pipeline.py)
+Solver setting: the engine's production setting (pqp_production_params: ADMM to eps 1e-4 + KKT-verified polish — every returned path
+is the exact optimum of its QP, inside the 1e-4 parity bar).  The literal metric ("ADMM iters to 1e-4", plain OSQP termination, no
+polish) and the reference's own setting (eps 2e-3) are timed in the same run and reported under "secondary".
 
-With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank generates and solves its own
-contiguous shard of `--batch` QPs (weak scaling: per-GPU work fixed).  The QPs are independent, so the timed region has
-no data-path collective: barrier + synchronize on both sides, MAX over ranks of the elapsed time.  After the timing one
-RCCL all_gather of the result slabs (path_optimizer_2_amd/shard.py) checks the gather a caller would use.  Rank 0 prints
-ONE JSON line.
+With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank generates and solves its own contiguous shard (weak
+scaling: per-GPU work fixed).  The QPs are independent, so the timed region has no data-path collective: barrier + synchronize on both
+sides, MAX over ranks of the elapsed time.  After the timing one RCCL all_gather of the result slabs (shard.py) checks the gather a
+caller would use.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,22 +36,33 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
+SIMDS = 256 * 4            # 256 CUs x 4 SIMDs
+FP64_CYCLES_PER_VALU = 4   # a wave64 fp64 VALU instruction occupies its SIMD for 4 cycles (78.6 TFLOP/s fp64 vector peak / 2 flop /
+                           # 1024 SIMDs / 2.4 GHz = 16 lanes per cycle); SQ_ACTIVE_INST_* count quad-cycles (MICROARCH guide)
+
+CONFIGS = {
+    1: dict(batch=1024, n=80, profile="uniform", what="configs[1]: batch=1024 QPs, N=80, shared sparsity, synthetic obstacle bounds, 1 GPU"),
+    2: dict(batch=8192, n=120, profile="varied", what="configs[2]: batch=8192 QPs, N=120, varied start/goal + curvature limits, 1 GPU"),
+    3: dict(batch=8192, n=80, profile="uniform", what="configs[3]: batch=65536 QPs, N=80, sharded over 8 GPUs = 8192 QPs per GPU"),
+    4: dict(batch=512, n=200, profile="uniform", what="configs[4]: batch=4096, N=200 over 8 GPUs = 512 scenarios per GPU, TensionSmoother2 QP "
+                                                      "+ path QP pipelined on two HIP streams"),
+}
 
 
-def algorithmic_bytes(n, kkt_solves, factors, setups):
+def algorithmic_bytes(n, kkt_solves, admm_iters, factors, setups):
     """Streaming-model bytes of SURVEY.md §8(d), fp64, default flags:
          B_io   = 152 N + 40   per solve   (read 12 doubles/waypoint + 5 scalars, write 7 doubles/waypoint)
          B_asm  = 656 N        per solve   (assembled P, A, l, u, q written once and read once)
          B_iter = 1040 N       per reduced-KKT solve (band factor 48, A values 2x17, x/z/y 18 + 18, l/u 12 doubles/waypoint)
-       plus the two terms §8(d) leaves out because OSQP refactors at most ~3 times but the polish refactors every
-       active-set round:
-         B_fac  = 752 N        per factorisation (read A 17, rho 6, sigma 6, P 6; write the band 48, rho 11 doubles/waypoint)
-         B_ruiz = 3440 N       per setup   (10 equilibration passes x (read A 17, P 6, D 6, E 6; write D 6, E 2) doubles/waypoint)
-    """
+       Returned: (bytes charging every reduced-KKT solve = ADMM iterations + polish refinement solves, bytes charging ADMM iterations
+       only - §8(d)'s literal wording -, bytes with factorisations and Ruiz passes added:
+         B_fac  = 752 N per factorisation, B_ruiz = 3440 N per setup)."""
     b_io, b_asm, b_iter, b_fac, b_ruiz = 152 * n + 40, 656 * n, 1040 * n, 752 * n, 3440 * n
-    base = float(np.sum(setups * (b_io + b_asm) + np.asarray(kkt_solves, dtype=np.float64) * b_iter))
-    ext = base + float(np.sum(np.asarray(factors, dtype=np.float64) * b_fac + setups * b_ruiz))
-    return base, ext
+    fixed = float(np.sum(setups * (b_io + b_asm)))
+    with_kkt = fixed + float(np.sum(np.asarray(kkt_solves, dtype=np.float64) * b_iter))
+    admm_only = fixed + float(np.sum(np.asarray(admm_iters, dtype=np.float64) * b_iter))
+    ext = with_kkt + float(np.sum(np.asarray(factors, dtype=np.float64) * b_fac + setups * b_ruiz))
+    return with_kkt, admm_only, ext
 
 
 def cpu_baseline(make_sample, n, eps, budget_s):
@@ -53,15 +73,47 @@ def cpu_baseline(make_sample, n, eps, budget_s):
     return OC.timed_baseline(make_sample, n, eps, budget_s)
 
 
+def pmc_child(argv_core, kernel_substr, timeout_s):
+    """Hardware counters of THIS command's dominant kernel, measured now: three rocprofv3 --pmc passes (SQ counters; the TCC byte counters
+    FETCH_SIZE / WRITE_SIZE in a pass each: they do not fit one) of a short child run of bench.py, --kernel-trace only
+    beside --pmc (MI355X_MICROARCH.md, rocprofv3 PMC section).  Returns per-launch averages or None (never raises)."""
+    passes = ["SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU",
+              "FETCH_SIZE GRBM_GUI_ACTIVE", "WRITE_SIZE SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU"]
+    acc, cnt = {}, {}
+    try:
+        for pmc in passes:
+            with tempfile.TemporaryDirectory(dir="/tmp") as d:
+                cmd = ["rocprofv3", "--kernel-trace", "--pmc", *pmc.split(), "-f", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                       *argv_core, "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-secondary", "--pmc", "off", "--sustain", "0"]
+                env = dict(os.environ, TMPDIR="/tmp")
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if kernel_substr in row["Kernel_Name"]:
+                            c = row["Counter_Name"]
+                            acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"])
+                            cnt[c] = cnt.get(c, 0) + 1
+        if not acc:
+            return None
+        res = {c: acc[c] / cnt[c] for c in acc}
+        res["_launches"] = min(cnt.values())
+        return res
+    except Exception as e:      # rocprofv3 missing, counters unavailable, time-out: the bench line simply carries nulls
+        sys.stderr.write(f"[bench] pmc pass skipped: {type(e).__name__}: {e}\n")
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="QPs per GPU")
-    ap.add_argument("--n", type=int, default=80, help="waypoints per path")
+    ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4], help="BASELINE.json configs[k] (default: 1 at --gpus 1, else 3)")
+    ap.add_argument("--batch", type=int, default=None, help="QPs per GPU (default: the config's)")
+    ap.add_argument("--n", type=int, default=None, help="waypoints per path (default: the config's)")
+    ap.add_argument("--profile", default=None, choices=["uniform", "varied"])
     ap.add_argument("--eps", type=float, default=1e-4, help="eps_abs = eps_rel of the ADMM termination test")
-    ap.add_argument("--no-polish", action="store_true", help="plain OSQP termination (the reference setting), no polish")
+    ap.add_argument("--no-polish", action="store_true", help="plain OSQP termination, no polish")
     ap.add_argument("--rho-interval", type=int, default=15, help="adaptive_rho_interval (iterations)")
     ap.add_argument("--polish-every", type=int, default=15, help="also try the KKT-verified polish every k ADMM iterations")
     ap.add_argument("--polish-refine", type=int, default=2, help="refinement solves per active-set round of the polish")
@@ -70,13 +122,18 @@ def main():
     ap.add_argument("--rho-tolerance", type=float, default=2.0, help="adaptive_rho_tolerance")
     ap.add_argument("--polish-warm-set", type=int, default=2, help="1: pass 2 starts with a polish on pass 1's active set; 2: and keeps its equilibration")
     ap.add_argument("--check-termination", type=int, default=15, help="residual check interval (iterations)")
-    ap.add_argument("--inflight", type=int, default=1, help="batches in flight: k > 1 runs consecutive steps on k handles / HIP streams "
-                    "(what a server does with independent batches; the next batch fills the slots the slow tail of this one leaves idle)")
-    ap.add_argument("--profile", default="uniform", choices=["uniform", "varied"])
+    ap.add_argument("--inflight", type=int, default=1, help="batches in flight: k > 1 runs consecutive steps on k handles / HIP streams")
+    ap.add_argument("--no-cost-order", action="store_true", help="start the QPs of a batch in index order instead of most-expensive-first by "
+                    "their cost in the previous step (PQP_OPT_ORDER_BY_COST)")
     ap.add_argument("--reference-setting", action="store_true", help="the reference's solver setting instead of the production one: "
                     "pqp_default_params (OSQP defaults, no polish, infeasibility certificate on) at --eps (the reference runs 2e-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the plain-ADMM (literal metric) and index-order measurements")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of host CPU work for the cpu_baseline sample")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "off"], help="auto (1 GPU only): hardware counters of the dominant kernel from "
+                    "rocprofv3 --pmc child runs of this command, after the timed region")
+    ap.add_argument("--pmc-timeout", type=float, default=150.0)
+    ap.add_argument("--sustain", type=float, default=0.6, help="seconds of back-to-back steps timed after the K steps (reported as `sustained`; 0: skip)")
     args = ap.parse_args()
 
     import torch
@@ -98,37 +155,71 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
-    batch, n = args.batch, args.n
+    cfg_id = args.config if args.config is not None else (1 if max(world, args.gpus) == 1 else 3)
+    cfg = CONFIGS[cfg_id]
+    batch = args.batch if args.batch is not None else cfg["batch"]
+    n = args.n if args.n is not None else cfg["n"]
+    profile = args.profile or cfg["profile"]
+    preset_shape = (batch, n, profile) == (cfg["batch"], cfg["n"], cfg["profile"])
     total = batch * world
-    host = make_batch(batch, n, args.profile, seed=args.seed, first_qp=rank * batch)          # this rank's shard of the global batch
-    ref = torch.from_numpy(host["ref"]).to(dev)
-    bounds = torch.from_numpy(host["bounds"]).to(dev)
-    scal = torch.from_numpy(host["scal"]).to(dev)
-    out = torch.zeros((batch, n, 7), dtype=torch.float64, device=dev)
-    status = torch.zeros(batch, dtype=torch.int32, device=dev)
-    iters = torch.zeros(batch, dtype=torch.int32, device=dev)
-    info = torch.zeros((batch, 8), dtype=torch.float64, device=dev)
-
     polish = not args.no_polish and not args.reference_setting
-    prm = capi.default_params(eps_abs=args.eps, eps_rel=args.eps) if args.reference_setting else capi.production_params(eps_abs=args.eps, eps_rel=args.eps, polish=1 if polish else 0, polish_every=args.polish_every,
-                              adaptive_rho_interval=args.rho_interval, polish_warm_set=args.polish_warm_set if polish else 0, check_termination=args.check_termination, polish_refine_iter=args.polish_refine,
-                              polish_max_rounds=args.polish_max_rounds, adaptive_rho_tolerance=args.rho_tolerance)
-    h = capi.Handle(prm, device=local_rank, max_batch=batch, max_n=n)
-    # --inflight k: k - 1 more handles (own stream, own warm state, own outputs) used round-robin
-    extra = [(capi.Handle(prm, device=local_rank, max_batch=batch, max_n=n), torch.zeros_like(out), torch.zeros_like(status),
-              torch.zeros_like(iters), torch.zeros_like(info)) for _ in range(max(args.inflight, 1) - 1)]
-    lanes = [(h, out, status, iters, info)] + extra
-    counter = [0]
+    cost_order = not args.no_cost_order
 
-    def step():
-        hh, o, st, it, inf = lanes[counter[0] % len(lanes)]
-        counter[0] += 1
-        hh.solve_device(batch, n, ref, bounds, scal, o, passes=1, status=st, iters=it, info=inf)
+    def production(**over):
+        kw = dict(eps_abs=args.eps, eps_rel=args.eps, polish=1 if polish else 0, polish_every=args.polish_every, adaptive_rho_interval=args.rho_interval,
+                  polish_warm_set=args.polish_warm_set if polish else 0, check_termination=args.check_termination, polish_refine_iter=args.polish_refine,
+                  polish_max_rounds=args.polish_max_rounds, adaptive_rho_tolerance=args.rho_tolerance)
+        kw.update(over)
+        return capi.production_params(**kw)
 
-    def sync_all():
-        for hh, *_ in lanes:
-            hh.sync()
+    prm = capi.default_params(eps_abs=args.eps, eps_rel=args.eps) if args.reference_setting else production()
 
+    # ---------------------------------------------------------------------------------------------------------------------------
+    # the workload: `step()` enqueues one pass of the hot path over one batch; `sync_all()` waits for everything enqueued
+    # ---------------------------------------------------------------------------------------------------------------------------
+    pipe = None
+    if cfg_id == 4:
+        from path_optimizer_2_amd.pipeline import SmootherPathPipeline
+        pipe = SmootherPathPipeline(batch, n, device=local_rank, seed=rank, path_params=prm)
+        if cost_order:
+            pipe.hp.set_option(capi.OPT_ORDER_BY_COST, 1)
+        counter = [0]
+
+        def step():
+            pipe.step_pipelined(counter[0])
+            counter[0] += 1
+
+        sync_all = pipe.sync
+        main_handles = [pipe.hp]
+        out = pipe.buf[0]["out"]
+    else:
+        host = make_batch(batch, n, profile, seed=args.seed, first_qp=rank * batch)          # this rank's shard of the global batch
+        ref = torch.from_numpy(host["ref"]).to(dev)
+        bounds = torch.from_numpy(host["bounds"]).to(dev)
+        scal = torch.from_numpy(host["scal"]).to(dev)
+
+        def make_lane(p, order):
+            h = capi.Handle(p, device=local_rank, max_batch=batch, max_n=n)
+            h.set_option(capi.OPT_STORE_WARM, 0)          # every step is a complete optimizePath: nobody reads the warm state
+            h.set_option(capi.OPT_ORDER_BY_COST, 1 if order else 0)
+            return (h, torch.zeros((batch, n, 7), dtype=torch.float64, device=dev), torch.zeros(batch, dtype=torch.int32, device=dev),
+                    torch.zeros(batch, dtype=torch.int32, device=dev), torch.zeros((batch, 8), dtype=torch.float64, device=dev))
+
+        lanes = [make_lane(prm, cost_order) for _ in range(max(args.inflight, 1))]       # --inflight k: k handles used round-robin
+        main_handles = [ln[0] for ln in lanes]
+        out, status, iters, info = lanes[0][1:]
+        counter = [0]
+
+        def step():
+            hh, o, st, it, inf = lanes[counter[0] % len(lanes)]
+            counter[0] += 1
+            hh.solve_device(batch, n, ref, bounds, scal, o, passes=1, status=st, iters=it, info=inf)
+
+        def sync_all():
+            for hh, *_ in lanes:
+                hh.sync()
+
+    torch.cuda.synchronize()          # the inputs were produced on torch's stream; the handles launch on their own (non-blocking) streams
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -154,62 +245,157 @@ def main():
     # per-launch duration of the dominant kernel over the timed region: HIP events the handle recorded around every launch on the
     # stream it launched on, read back now (nothing was synchronised between the launches)
     ev_ms = []
-    for li, (hh, *_) in enumerate(lanes):
-        k = min(sum(1 for i in range(args.steps) if (args.warmup + i) % len(lanes) == li), 256)      # timed launches of this handle
+    for li, hh in enumerate(main_handles):
+        k = min(sum(1 for i in range(args.steps) if (args.warmup + i) % len(main_handles) == li), 256)      # timed launches of this handle
         if k > 0:
             ev_ms.extend(hh.kernel_ms_history(k).tolist())
-
-    it_np = iters.cpu().numpy()
-    st_np = status.cpu().numpy()
-    info_np = info.cpu().numpy()
-    kkt_np, fac_np = info_np[:, 5], info_np[:, 6]
-    setups = 2.0
     avg_kernel_s = float(np.mean(ev_ms)) * 1e-3
-    abytes, abytes_ext = algorithmic_bytes(n, kkt_np, fac_np, setups)
-    achieved = abytes / avg_kernel_s / 1e9
-    # measured HBM bytes per launch come from separate rocprofv3 --pmc passes of THIS command (FETCH_SIZE, WRITE_SIZE; the
-    # gfx950 x2 correction of FETCH_SIZE for wide reads applied; MI355X_MICROARCH.md HBM section), committed under profiles/
-    traffic, issue = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_bench_n1_pmc_per_launch.json")
-    if world == 1 and batch == 1024 and n == 80 and polish and os.path.exists(pmc_file):
-        try:
-            pmc = json.load(open(pmc_file))
+
+    # longer back-to-back run of the same step (the K steps above are what `value` is; a 20-step region lasts ~15 ms)
+    sustained = None
+    if args.sustain > 0:
+        k_long = int(max(args.steps, min(20000, args.sustain / max(dt / args.steps, 1e-6))))
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(k_long):
+            step()
+        sync_all()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt_long = time.perf_counter() - t1
+        if dist is not None:
+            tl = torch.tensor([dt_long], dtype=torch.float64, device=dev)
+            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+            dt_long = float(tl.item())
+        sustained = {"value": total * k_long / dt_long, "unit": "paths/s", "steps": k_long, "seconds": dt_long}
+
+    if pipe is not None:
+        res = pipe.result((counter[0] - 1))
+        it_np, st_np = res["it"], res["st"]
+        info_np = None
+        kkt_np = fac_np = None
+        sm_solved = int((res["sm_st"] == 1).sum())
+    else:
+        it_np, st_np, info_np = iters.cpu().numpy(), status.cpu().numpy(), info.cpu().numpy()
+        kkt_np, fac_np = info_np[:, 5], info_np[:, 6]
+    out_sha = hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:16]
+
+    # ---------------------------------------------------------------------------------------------------------------------------
+    # secondary measurements on the same inputs (N = 1, path-QP configs): index order, the literal metric, the reference's setting
+    # ---------------------------------------------------------------------------------------------------------------------------
+    secondary = None
+    if not args.no_secondary and world == 1 and pipe is None and not args.reference_setting and polish:
+        def timed(p, order, steps, warm=3):
+            ln = make_lane(p, order)
+            hh, o, st, it, inf = ln
+            for _ in range(warm):
+                hh.solve_device(batch, n, ref, bounds, scal, o, passes=1, status=st, iters=it, info=inf)
+            hh.sync()
+            ta = time.perf_counter()
+            for _ in range(steps):
+                hh.solve_device(batch, n, ref, bounds, scal, o, passes=1, status=st, iters=it, info=inf)
+            hh.sync()
+            tb = time.perf_counter() - ta
+            itn, stn = it.cpu().numpy(), st.cpu().numpy()
+            r = {"value": batch * steps / tb, "unit": "paths/s", "steps": steps, "ms_per_step": tb / steps * 1e3,
+                 "kernel_ms": float(np.mean(hh.kernel_ms_history(min(steps, 256)))), "solved": int((stn == 1).sum()),
+                 "admm_iters": {"min": int(itn.min()), "median": float(np.median(itn)), "p99": float(np.percentile(itn, 99)), "max": int(itn.max()),
+                                "mean": float(itn.mean())}, "out_sha1": hashlib.sha1(o.cpu().numpy().tobytes()).hexdigest()[:16]}
+            hh.close()
+            return r
+        secondary = {
+            "index_order": dict(timed(prm, not cost_order, args.steps), setting="the headline setting with the QPs started in index order"
+                                if cost_order else "the headline setting with the QPs started most-expensive-first (previous step's cost)"),
+            "plain_admm_eps_1e-4": dict(timed(capi.default_params(eps_abs=1e-4, eps_rel=1e-4), False, max(3, args.steps // 8)),
+                                        setting="the literal metric: OSQP termination at eps_abs = eps_rel = 1e-4, OSQP defaults, no polish "
+                                                "(pqp_default_params); paths 1e-5..2e-3 from the optimum"),
+            "reference_setting_eps_2e-3": dict(timed(capi.default_params(), False, max(3, args.steps // 4)),
+                                               setting="what base_solver.cpp:61-62 runs: eps 2e-3, OSQP defaults, no polish; paths 2e-4..2e-2 from the optimum"),
+        }
+
+    # ---------------------------------------------------------------------------------------------------------------------------
+    # roofline of the dominant kernel
+    # ---------------------------------------------------------------------------------------------------------------------------
+    roofline, roofline_issue = None, None
+    if pipe is None:
+        setups = 2.0
+        abytes, abytes_admm, abytes_ext = algorithmic_bytes(n, kkt_np, it_np, fac_np, setups)
+        achieved = abytes / avg_kernel_s / 1e9
+        pmc = None
+        if args.pmc == "auto" and world == 1 and rank == 0:
+            core = ["--config", str(cfg_id), "--batch", str(batch), "--n", str(n), "--profile", profile, "--eps", str(args.eps), "--seed", str(args.seed)]
+            core += ["--no-cost-order"] if not cost_order else []
+            core += ["--no-polish"] if args.no_polish else []
+            core += ["--reference-setting"] if args.reference_setting else []
+            pmc = pmc_child(core, "path_solve_kernel", args.pmc_timeout)
+        traffic = None
+        if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 tallies a wide read at half its bytes (MICROARCH guide, HBM): x2 on the reads
             traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
-            # what does bound the kernel (SURVEY.md 8d "secondary ceilings"): share of the wave cycles spent issuing fp64 VALU /
-            # LDS instructions and waiting, from the same PMC passes
+        true_io = 2.0 * batch * (152 * n + 40)
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic, "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command, after the timed region, "
+                                                           f"{pmc['_launches']} launches averaged; FETCH_SIZE x 2 (gfx950 wide-read tally)") if traffic else None,
+                    "kernel": "path_solve_kernel", "kernel_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_launch": abytes,
+                    "frac_admm_iterations_only": abytes_admm / avg_kernel_s / 1e9 / HBM_PEAK_GBS,
+                    "achieved_incl_factor_and_scaling": abytes_ext / avg_kernel_s / 1e9,
+                    "true_io_bytes_per_launch": true_io, "traffic_over_true_io": (traffic / true_io) if traffic else None,
+                    "note": "achieved / frac are SURVEY.md 8(d)'s STREAMING MODEL (bytes an HBM-streaming ADMM would move: 1040 N per reduced-KKT "
+                            "solve, polish refinement solves included; frac_admm_iterations_only charges ADMM iterations only) divided by the "
+                            "measured kernel time - a model, not traffic: the iterates are register/LDS resident and the kernel is bound by fp64 "
+                            "VALU issue + LDS latency (roofline_issue), `traffic` is what HBM really moved"}
+        if pmc and "SQ_ACTIVE_INST_VALU" in pmc and "SQ_WAVE_CYCLES" in pmc:
             wc = pmc["SQ_WAVE_CYCLES"]
-            issue = {"valu_active_frac": pmc["SQ_ACTIVE_INST_VALU"] / wc, "lds_active_frac": pmc["SQ_ACTIVE_INST_LDS"] / wc,
-                     "any_active_frac": pmc["SQ_ACTIVE_INST_ANY"] / wc, "wait_frac": pmc["SQ_WAIT_ANY"] / wc, "waves_per_simd": 1}
-        except Exception:
-            traffic = None
+            gui = pmc.get("GRBM_GUI_ACTIVE")                                      # summed over the 8 XCDs
+            kernel_cycles = gui / 8.0 if gui else avg_kernel_s * 2.4e9
+            valu_cycles = pmc["SQ_ACTIVE_INST_VALU"] * 4.0                       # quad-cycles -> cycles
+            roofline_issue = {"bound": "fp64_valu_issue", "achieved": valu_cycles / (SIMDS * kernel_cycles), "peak": 1.0, "unit": "fraction of the "
+                              "chip's VALU issue cycles (VALU-active cycles / (1024 SIMDs x kernel cycles))", "frac": valu_cycles / (SIMDS * kernel_cycles),
+                              "valu_active_frac_of_wave_cycles": pmc["SQ_ACTIVE_INST_VALU"] / wc, "lds_active_frac": pmc.get("SQ_ACTIVE_INST_LDS", 0.0) / wc,
+                              "scalar_active_frac": pmc.get("SQ_ACTIVE_INST_SCA", 0.0) / wc, "any_active_frac": pmc.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
+                              "wait_frac": pmc.get("SQ_WAIT_ANY", 0.0) / wc, "valu_instructions_per_launch": pmc.get("SQ_INSTS_VALU"),
+                              "waves_per_launch": pmc.get("SQ_WAVES"), "kernel_cycles": kernel_cycles,
+                              "source": f"rocprofv3 --pmc child pass of this command, {pmc['_launches']} launches averaged"}
+
     if rank == 0:
+        setting = "reference (pqp_default_params)" if args.reference_setting else "production (pqp_production_params)"
+        workload = cfg["what"] if preset_shape else f"custom shape on {cfg['what'].split(':')[0]}: batch={batch} per GPU, N={n}, {profile} profile"
         line = {
             "metric": "paths/sec (QP solves/sec) at N=80 waypoints; ADMM iters to 1e-4",
             "value": total * args.steps / dt, "unit": "paths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[1]: batch={batch} QPs per GPU, N={n}, shared sparsity, synthetic obstacle bounds ({args.profile} profile)",
-                       "batch_per_gpu": batch, "n_waypoints": n, "eps_abs": args.eps, "eps_rel": args.eps, "polish": polish,
-                       "setting": "reference (pqp_default_params)" if args.reference_setting else "production (pqp_production_params)",
+            "config": {"workload": workload, "config_id": cfg_id, "batch_per_gpu": batch, "n_waypoints": n, "profile": profile,
+                       "eps_abs": args.eps, "eps_rel": args.eps, "polish": polish, "setting": setting,
+                       "solver": "ADMM to eps 1e-4 + KKT-verified active-set polish (every path is the exact QP optimum)" if polish else "plain OSQP termination",
                        "polish_every": args.polish_every if polish else 0, "adaptive_rho_interval": 100 if args.reference_setting else args.rho_interval,
                        "polish_refine_iter": args.polish_refine, "polish_max_rounds": args.polish_max_rounds, "polish_warm_set": args.polish_warm_set,
                        "passes": "cold solve + 1 re-linearised warm re-solve (PathOptimizer::optimizePath)",
+                       "qp_start_order": "most expensive first by the previous step's cost (PQP_OPT_ORDER_BY_COST)" if cost_order else "index order",
                        "parallelism": f"{world} independent shard(s), no collective in the timed region", "batches_in_flight": max(args.inflight, 1)},
             "admm_iters": {"min": int(it_np.min()), "median": float(np.median(it_np)), "p99": float(np.percentile(it_np, 99)),
                            "max": int(it_np.max()), "mean": float(it_np.mean())},
-            "kkt_solves": {"mean": float(kkt_np.mean()), "p99": float(np.percentile(kkt_np, 99)), "max": float(kkt_np.max())},
-            "factorisations": {"mean": float(fac_np.mean()), "max": float(fac_np.max())},
-            "gather_check": gathered_ok, "solved": int((st_np == 1).sum()), "polished": int((info_np[:, 4] >= 2).sum()), "batch": batch,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "path_solve_kernel", "kernel_ms": avg_kernel_s * 1e3,
-                         "algorithmic_bytes_per_launch": abytes, "issue": issue,
-                         "achieved_incl_factor_and_scaling": abytes_ext / avg_kernel_s / 1e9,
-                         "note": "SURVEY.md 8(d) streaming-model bytes; the iterates are register/LDS resident, so measured HBM "
-                                 "traffic is far below this (profiles/, DESIGN.md 5)"},
+            "out_sha1": out_sha, "gather_check": gathered_ok, "solved": int((st_np == 1).sum()), "batch": batch,
+            "sustained": sustained, "secondary": secondary, "roofline": roofline, "roofline_issue": roofline_issue,
         }
-        if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(lambda k: make_batch(k, n, args.profile, seed=args.seed), n, args.eps, args.cpu_budget)
+        if info_np is not None:
+            line["kkt_solves"] = {"mean": float(kkt_np.mean()), "p99": float(np.percentile(kkt_np, 99)), "max": float(kkt_np.max())}
+            line["factorisations"] = {"mean": float(fac_np.mean()), "max": float(fac_np.max())}
+            line["polished"] = int((info_np[:, 4] >= 2).sum())
+        if pipe is not None:
+            line["unit"] = "paths/s"
+            line["smoother_solved"] = sm_solved
+            line["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                                "kernel": "path_solve_kernel (behind banded_solve_kernel on the other stream)", "kernel_ms": avg_kernel_s * 1e3,
+                                "note": "two kernels overlap on two streams; the streaming-model figure is reported for the path-QP configs"}
+        if not args.no_cpu_baseline and world == 1 and pipe is None:          # reported at N = 1 only
+            line["cpu_baseline"] = cpu_baseline(lambda k: make_batch(k, n, profile, seed=args.seed), n, args.eps, args.cpu_budget)
         print(json.dumps(line))
+    if pipe is not None:
+        pipe.close()
     if dist is not None:
         dist.destroy_process_group()
 

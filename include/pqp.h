@@ -167,7 +167,27 @@ const char* pqp_version(void);
 int pqp_create(pqp_handle** h, const pqp_params* params, int device, int max_batch, int max_n);
 int pqp_destroy(pqp_handle* h);
 int pqp_set_params(pqp_handle* h, const pqp_params* params);
+/* Handle options (not solver settings: results never depend on them).
+ *   PQP_OPT_STORE_WARM (default 1)     keep the final primal/dual iterate of every solve on the handle: what warm == 1 and
+ *                                      pqp_path_get_solution read (BaseSolver keeps its OSQP workspace the same way,
+ *                                      base_solver.hpp:62).  0 saves the write when every call is a complete optimizePath.
+ *   PQP_OPT_ORDER_BY_COST (default 0)  start the QPs of a batch most-expensive-first, by the reduced-KKT solves and
+ *                                      factorisations each QP needed in the handle's previous solve of the same batch and n
+ *                                      (a planner re-solves nearly the same scenarios every cycle).  The first solve of a shape
+ *                                      runs in index order. */
+typedef enum pqp_option { PQP_OPT_STORE_WARM = 1, PQP_OPT_ORDER_BY_COST = 2 } pqp_option;
+int pqp_set_option(pqp_handle* h, int option, int value);
 int pqp_get_stream(pqp_handle* h, void** hip_stream);   /* hipStream_t */
+/* The handle's stream is created non-blocking: work the caller enqueued on ANOTHER stream (the inputs of a *_device call produced by
+ * its own kernels or copies; NULL = the default stream) is not ordered before the handle's launches unless the caller says so:
+ * pqp_stream_wait makes everything enqueued on the handle from now on wait for what is enqueued on `hip_stream` up to now. */
+int pqp_stream_wait(pqp_handle* h, void* hip_stream);
+/* Ordering between two handles (= two streams) without the host waiting - BASELINE configs[4]: the smoother QP of scenario batch k on
+ * one handle, the path QP of batch k on another, the smoother of batch k + 1 overlapping the path QP of batch k.  pqp_mark records
+ * the handle's event `slot` (0..7) behind everything enqueued on it so far; pqp_wait_mark makes everything enqueued on `h` from
+ * now on wait for `other`'s mark `slot` as it was recorded last. */
+int pqp_mark(pqp_handle* h, int slot);
+int pqp_wait_mark(pqp_handle* h, pqp_handle* other, int slot);
 int pqp_sync(pqp_handle* h);
 
 /* BaseSolver ctor (base_solver.cpp:15-39): problem sizes.  `s` = the n arclengths of the path

@@ -151,6 +151,43 @@ static void assemble(const pqo_params* prm, int n, const double* ref, const doub
 #undef PUT
 }
 
+/* The reference's own way of building the same matrices (base_solver.cpp:122,145 and :159,210): a dense vars x vars zero matrix for P
+ * and a dense cons x vars zero matrix for A are allocated, filled entry by entry and turned into sparse matrices by
+ * Eigen's sparseView(), which scans EVERY entry column by column and keeps the non-zero ones - O(N^2) memory traffic per assembly,
+ * twice per path.  This restates that work (allocation, fill from the structural triplets, full column-major scan into a CSC triple)
+ * so that the CPU baseline can be timed in the reference-faithful mode; the values the solver then uses are the scanned ones,
+ * written back over the structural triplets (tests/test_oracle_c.py checks both modes give the same QP and the same solution). */
+static int g_dense_assembly = 0;
+void pqo_set_dense_assembly(int on) { g_dense_assembly = on; }
+
+static long assemble_dense_scan(pqo_qp* q) {
+    const size_t nv = (size_t)q->nv, nc = (size_t)q->nc;
+    double* H = (double*)calloc(nv * nv, sizeof(double));          /* Eigen::MatrixXd::Constant(vars, vars, 0)   :122 */
+    double* A = (double*)calloc(nc * nv, sizeof(double));          /* Eigen::MatrixXd::Zero(cons, vars)          :159 */
+    for (size_t j = 0; j < nv; ++j) H[j * nv + j] = q->pd[j];      /* column-major, as Eigen stores it */
+    for (int e = 0; e < q->nnz; ++e) A[(size_t)q->ci[e] * nc + q->ri[e]] = q->av[e];
+    /* hessian.sparseView() :145 */
+    long kept = 0;
+    for (size_t j = 0; j < nv; ++j)
+        for (size_t i = 0; i < nv; ++i)
+            if (H[j * nv + i] != 0.0) { if (i == j) q->pd[j] = H[j * nv + i]; ++kept; }
+    /* matrix_constraints.sparseView() :210 : the scan finds every structural entry again (an exactly-zero value would be dropped by
+       Eigen; the triplet then keeps its zero, which is the same matrix) */
+    double* val = (double*)malloc(sizeof(double) * (size_t)q->nnz);
+    int* rr = (int*)malloc(sizeof(int) * (size_t)q->nnz); int* cc = (int*)malloc(sizeof(int) * (size_t)q->nnz);
+    int m = 0;
+    for (size_t j = 0; j < nv; ++j)
+        for (size_t i = 0; i < nc; ++i) {
+            const double v = A[j * nc + i];
+            if (v != 0.0 && m < q->nnz) { rr[m] = (int)i; cc[m] = (int)j; val[m] = v; ++m; }
+        }
+    kept += m;
+    /* scanned values back onto the structural triplets */
+    for (int e = 0; e < q->nnz; ++e) q->av[e] = A[(size_t)q->ci[e] * nc + q->ri[e]];
+    free(val); free(rr); free(cc); free(H); free(A);
+    return kept;
+}
+
 /* interleave permutation: reference variable -> position in the banded ordering
  * per waypoint i: [l, psi, k, u_i, sf, sr] (last waypoint has no u) */
 static void interleave_perm(int n, int* pos) {
@@ -426,6 +463,7 @@ int pqo_solve_path(const pqo_params* prm, int n, const double* ref, const double
     int ok = 1;
     for (int p = 0; p <= passes; ++p) {
         assemble(prm, n, ref, lin, bounds, scal, q);
+        if (g_dense_assembly) (void)assemble_dense_scan(q);
         if (!w) w = work_alloc(q, pos);
         osqp_solve(prm, q, w, p ? x : NULL, p ? y : NULL, p ? info.rho : -1.0, x, y, &info);
         unpack(n, x, ref, out);

@@ -71,22 +71,35 @@ def solve_batch(prm, ref, bounds, scal, passes=1, threads=0):
 def timed_baseline(make_sample, n, eps, budget_s=15.0, rho_interval=100):
     """bench.py's cpu_baseline: the C restatement of the OSQP-paper algorithm (no polish: that is what the reference
     runs) with one path per task over all host cores, on a bounded sample of the SAME workload:
-    make_sample(k) returns k scenarios of the bench's distribution; k is sized to ~budget_s seconds of wall time."""
+    make_sample(k) returns k scenarios of the bench's distribution; k is sized to ~budget_s seconds of wall time.
+    Both assembly modes of SURVEY.md 8(d): direct O(N) structural fill (`value`) and the reference's dense cons x vars fill +
+    sparseView scan, O(N^2) (`reference_faithful_assembly`), each on half the budget."""
     lib = load()
     cores = lib.pqo_num_threads()
     prm = params(eps_abs=eps, eps_rel=eps, adaptive_rho_interval=rho_interval)
-    probe = make_sample(4 * cores)
-    t0 = time.perf_counter()
-    solve_batch(prm, probe["ref"], probe["bounds"], probe["scal"])
-    per = (time.perf_counter() - t0) / (4 * cores)
-    k = int(min(262144, max(4 * cores, budget_s / max(per, 1e-7))))
-    b = make_sample(k)
-    t0 = time.perf_counter()
-    r = solve_batch(prm, b["ref"], b["bounds"], b["scal"])
-    dt = time.perf_counter() - t0
+
+    def run(dense, budget):
+        lib.pqo_set_dense_assembly(1 if dense else 0)
+        try:
+            probe = make_sample(4 * cores)
+            t0 = time.perf_counter()
+            solve_batch(prm, probe["ref"], probe["bounds"], probe["scal"])
+            per = (time.perf_counter() - t0) / (4 * cores)
+            k = int(min(262144, max(4 * cores, budget / max(per, 1e-7))))
+            b = make_sample(k)
+            t0 = time.perf_counter()
+            r = solve_batch(prm, b["ref"], b["bounds"], b["scal"])
+            return k, time.perf_counter() - t0, r
+        finally:
+            lib.pqo_set_dense_assembly(0)
+
+    k, dt, r = run(False, 0.5 * budget_s)
+    kd, dtd, rd = run(True, 0.5 * budget_s)
     return {"value": k / dt, "unit": "paths/s", "cores": cores, "kind": "port",
             "sample": f"{k} paths of the bench distribution (N={n}) in {dt:.1f} s, OSQP-paper restatement in C (oracle/pqp_oracle.c), "
-                      f"eps {eps:g}, no polish, direct O(N) assembly (the reference's dense cons x vars fill + scan, O(N^2), is not timed), "
-                      f"one path per OpenMP task over {cores} threads; mean ADMM iterations "
+                      f"eps {eps:g}, no polish, direct O(N) assembly, one path per OpenMP task over {cores} threads; mean ADMM iterations "
                       f"{float(r['iters'].mean()):.0f}; solved {r['solved']}/{k}",
-            "per_core": k / dt / cores}
+            "per_core": k / dt / cores,
+            "reference_faithful_assembly": {"value": kd / dtd, "unit": "paths/s", "per_core": kd / dtd / cores,
+                                            "sample": f"{kd} paths in {dtd:.1f} s with the reference's dense (6N+2) x (6N-1) fill + sparseView scan "
+                                                      f"twice per path (base_solver.cpp:122,145,159,210); solved {rd['solved']}/{kd}"}}

@@ -52,8 +52,8 @@ class PqpSizes(C.Structure):
 
 
 EXPORTS = [
-    "pqp_default_params", "pqp_production_params", "pqp_last_error", "pqp_version", "pqp_create", "pqp_destroy", "pqp_set_params",
-    "pqp_get_stream", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
+    "pqp_default_params", "pqp_production_params", "pqp_last_error", "pqp_version", "pqp_create", "pqp_destroy", "pqp_set_params", "pqp_set_option",
+    "pqp_stream_wait", "pqp_mark", "pqp_wait_mark", "pqp_get_stream", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
     "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_solve_var_device", "pqp_path_solve_var", "pqp_path_get_solution",
     "pqp_last_kernel_ms", "pqp_kernel_ms_history", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
     "pqp_post_smooth", "pqp_post_smooth_device", "pqp_corridor_default_params", "pqp_corridor_bounds", "pqp_corridor_bounds_device",
@@ -84,6 +84,10 @@ def load_library(path=None):
     lib.pqp_create.argtypes = [C.POINTER(vp), C.POINTER(PqpParams), C.c_int, C.c_int, C.c_int]
     lib.pqp_destroy.argtypes = [vp]
     lib.pqp_set_params.argtypes = [vp, C.POINTER(PqpParams)]
+    lib.pqp_set_option.argtypes = [vp, C.c_int, C.c_int]
+    lib.pqp_stream_wait.argtypes = [vp, vp]
+    lib.pqp_mark.argtypes = [vp, C.c_int]
+    lib.pqp_wait_mark.argtypes = [vp, vp, C.c_int]
     lib.pqp_get_stream.argtypes = [vp, C.POINTER(vp)]
     lib.pqp_sync.argtypes = [vp]
     lib.pqp_path_sizes.argtypes = [C.POINTER(PqpParams), C.c_int, vp, C.POINTER(PqpSizes)]
@@ -160,6 +164,9 @@ def _ptr(a):
     return C.c_void_p(int(a))      # raw device pointer (e.g. torch.Tensor.data_ptr())
 
 
+OPT_STORE_WARM, OPT_ORDER_BY_COST = 1, 2
+
+
 class PqpError(RuntimeError):
     pass
 
@@ -194,6 +201,22 @@ class Handle:
 
     def sync(self):
         self._check(self.lib.pqp_sync(self._h))
+
+    def set_option(self, option, value):
+        """PQP_OPT_STORE_WARM = 1, PQP_OPT_ORDER_BY_COST = 2 (include/pqp.h)."""
+        self._check(self.lib.pqp_set_option(self._h, int(option), int(value)))
+
+    def mark(self, slot):
+        self._check(self.lib.pqp_mark(self._h, slot))
+
+    def wait_mark(self, other, slot):
+        """Everything enqueued on this handle from now on waits for `other`'s mark `slot` (pqp_wait_mark)."""
+        self._check(self.lib.pqp_wait_mark(self._h, other._h, slot))
+
+    def wait_stream(self, hip_stream=None):
+        """Order the handle's coming launches after what is enqueued on `hip_stream` now (None: the default stream; for torch tensors
+        pass torch.cuda.current_stream().cuda_stream)."""
+        self._check(self.lib.pqp_stream_wait(self._h, C.c_void_p(hip_stream or 0)))
 
     def stream(self):
         s = C.c_void_p()

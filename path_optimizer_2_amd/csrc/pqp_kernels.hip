@@ -1,9 +1,11 @@
 // pqp_kernels.hip — gfx950 (MI355X / CDNA4) kernels and the C ABI of include/pqp.h.
 //
-//   path_solve_kernel     one workgroup (64*NW lanes, 2 waypoints per lane) per QP: assemble -> Ruiz metrics
-//                         -> block-cyclic-reduction factor -> ADMM loop -> unpack -> re-linearise -> warm
-//                         re-solve, everything in VGPRs + ~24 KB of LDS; HBM is read once (scenario) and
-//                         written once (path).  Algorithm: pqp_path_lane.hpp.
+//   path_solve_kernel     persistent workgroups (64*NW lanes, one waypoint per lane) draw QPs from a ticket counter,
+//                         most expensive first when the handle knows the QPs' previous cost: assemble -> Ruiz
+//                         metrics -> block-cyclic-reduction factor -> ADMM loop + KKT-verified polish -> unpack ->
+//                         re-linearise -> warm re-solve, everything in VGPRs + ~28 KB of LDS (T = 128); HBM is read
+//                         once (scenario) and written once (path).  Algorithm: pqp_path_lane.hpp.
+//   path_order_kernel     ticket -> QP map of the next launch from the cost bins the last launch recorded.
 //   path_assemble_kernel  BaseSolver::setCost/setConstraints in the REFERENCE numbering: CSC values of A,
 //                         diagonal of P, l, u; staged through LDS and written with contiguous, coalesced
 //                         stores (base_solver.cpp:119-261).
@@ -200,19 +202,42 @@ struct DevCtx {
     }
 };
 
+// PQP_SOLVE_OCC: wavefronts per SIMD the solve kernel is compiled for (the register budget per lane is 512 / PQP_SOLVE_OCC)
+#ifndef PQP_SOLVE_OCC
+#define PQP_SOLVE_OCC 1
+#endif
 template <int NW, bool CERT>
-__global__ void __launch_bounds__(64 * NW) path_solve_kernel(const PathSolveArgs args) {
+__global__ void __launch_bounds__(64 * NW, (NW <= 2) ? PQP_SOLVE_OCC : 1) path_solve_kernel(const PathSolveArgs args) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int s_ticket;
 #ifndef PQP_MONOLITH
     Lane memlane;
 #endif
-    for (int qp = blockIdx.x; qp < args.batch; qp += gridDim.x) {
+    // Persistent workgroups: every workgroup draws tickets until the batch is used up (each workgroup ends on one ticket beyond
+    // it, so a launch consumes exactly batch + gridDim.x tickets and the host knows the next launch's base without a reset).
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = (int)(atomicAdd(args.ticket, 1ull) - args.ticket_base);
+        __syncthreads();
+        const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+        __syncthreads();
+        if (ticket >= args.batch) break;
+        const int qp = args.order ? args.order[ticket] : ticket;
         // (written out rather than through PathQp::count_of: with the call here the register allocator spills 170 VGPRs of the loop)
         if ((args.n_of ? args.n_of[qp] : args.n) < 2) {
+            // nothing to optimise: defined outputs for everything a later call may read (status, counters, warm state)
             if (threadIdx.x == 0) {
                 if (args.status) args.status[qp] = PQP_STATUS_UNSOLVED;
                 if (args.iters) args.iters[qp] = 0;
+                if (args.info) for (int k = 0; k < PQP_INFO_STRIDE; ++k) args.info[(size_t)qp * PQP_INFO_STRIDE + k] = 0.0;
+                args.wrho[qp] = args.prm.rho;
+                args.wye[2 * (size_t)qp] = 0.0; args.wye[2 * (size_t)qp + 1] = 0.0;
+                if (args.cost_key) record_cost(args, qp, 0);
             }
+            if (args.store_warm)
+                for (int k = threadIdx.x; k < args.n * 6; k += blockDim.x) {
+                    args.wx[(size_t)qp * args.n * 6 + k] = 0.0;
+                    args.wy[(size_t)qp * args.n * 6 + k] = 0.0;
+                }
             continue;
         }
         DevCtx<NW> ctx;
@@ -223,10 +248,39 @@ __global__ void __launch_bounds__(64 * NW) path_solve_kernel(const PathSolveArgs
 #endif
         ctx.shp = smem;
         ctx.args = &args;
-        PathQp<DevCtx<NW>, CERT> solver(ctx, args, qp);
+        PathQp<DevCtx<NW>, CERT> solver(ctx, args, qp, (int)blockIdx.x);
         solver.run();
         __syncthreads();
     }
+}
+
+// ticket -> QP of the next launch, most expensive first: cost bins in descending order, within a bin the order in which the
+// QPs finished last time.  key[batch] = bin << 24 | rank, hist[kCostBins] = QPs per bin (both written by the last solve);
+// hist_next is zeroed for the solve that follows.  One thread per QP, 256 threads per block.
+__global__ void __launch_bounds__(256) path_order_kernel(int batch, const int32_t* __restrict__ key, const int32_t* __restrict__ hist,
+                                                         int32_t* __restrict__ hist_next, int32_t* __restrict__ order) {
+    __shared__ int start[kCostBins];
+    const int b = threadIdx.x;
+    const int mine = hist[b];
+    start[b] = mine;
+    __syncthreads();
+    for (int off = 1; off < kCostBins; off <<= 1) {        // inclusive suffix sum
+        const int add = (b + off < kCostBins) ? start[b + off] : 0;
+        __syncthreads();
+        start[b] += add;
+        __syncthreads();
+    }
+    const int first = start[b] - mine;                     // QPs in more expensive bins
+    __syncthreads();
+    start[b] = first;
+    __syncthreads();
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q < batch) {
+        const int k = key[q];
+        const int pos = start[(k >> 24) & 0xff] + (k & 0xffffff);
+        if (pos < batch) order[pos] = q;
+    }
+    if (blockIdx.x == 0) hist_next[b] = 0;
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -467,6 +521,7 @@ struct DevBuf {
         p = nullptr; bytes = 0;
         PQP_HIP(hipMalloc(&p, need));
         bytes = need;
+        PQP_HIP(hipMemset(p, 0, need));        // no call ever reads uninitialised device memory (warm state of skipped QPs, info rows)
         return PQP_OK;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
@@ -485,9 +540,21 @@ struct pqp_handle {
     long long ev_count = 0;          // launches recorded so far
     hipEvent_t ev0 = nullptr, ev1 = nullptr;      // the pair of the launch being recorded
     bool timed = false;
+    static constexpr int kMarks = 8;
+    hipEvent_t marks[kMarks] = {};             // pqp_mark / pqp_wait_mark: ordering between the streams of two handles
     void next_event_pair() { ev0 = evs0[ev_count % kEvRing]; ev1 = evs1[ev_count % kEvRing]; ev_count += 1; }
     int warm_batch = 0, warm_n = 0;
-    DevBuf wx, wy, wye, wrho, wsave;            // warm state (lane layout) + polish save area
+    bool warm_stored = false;                   // the last solve wrote its final iterate to wx / wy / wye
+    DevBuf wx, wy, wye, wrho, wsave;            // warm state (lane layout) + polish save area (per workgroup slot)
+    // work distribution of the solve kernel: ticket counter (never reset: a launch uses batch + grid tickets), cost bins of the
+    // last solve and the ticket -> QP order derived from them
+    DevBuf ticket, cost_key, cost_hist, order;
+    unsigned long long ticket_next = 0;
+    long long solves = 0;                       // solve launches so far (parity selects the cost histogram being filled)
+    int hist_batch = 0, hist_n = 0;             // shape of the solve whose costs cost_key / cost_hist hold (0: none)
+    int opt_store_warm = 1, opt_order_by_cost = 0;
+    int num_cu = 0;
+    int blocks_per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // occupancy of the solve kernel variants [log2(nw)][cert]
     DevBuf s_ref, s_lin, s_bounds, s_scal;      // staging for the host-pointer entry points
     DevBuf s_out, s_status, s_iters, s_info, s_a, s_p, s_l, s_u, s_idx;
     // smoother QPs: banded problem data + shared sparsity (cached per type and size) + staging
@@ -514,16 +581,24 @@ int pqp_create(pqp_handle** out, const pqp_params* params, int device, int max_b
     if (!h) return fail(PQP_ERR_INVALID, "pqp_create: out of host memory");
     h->device = device;
     if (params) h->prm = *params; else pqp::default_params(&h->prm);
-    PQP_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    for (int k = 0; k < pqp_handle::kEvRing; ++k) { PQP_HIP(hipEventCreate(&h->evs0[k])); PQP_HIP(hipEventCreate(&h->evs1[k])); }
-    if (max_batch > 0 && max_n > 0) {
-        const size_t bn = (size_t)max_batch * max_n;
+    // (a failure below destroys what was built so far: pqp_destroy tolerates a partially built handle)
+    auto build = [&]() -> int {
+        PQP_HIP(hipDeviceGetAttribute(&h->num_cu, hipDeviceAttributeMultiprocessorCount, device));
+        PQP_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        for (int k = 0; k < pqp_handle::kEvRing; ++k) { PQP_HIP(hipEventCreate(&h->evs0[k])); PQP_HIP(hipEventCreate(&h->evs1[k])); }
+        for (int k = 0; k < pqp_handle::kMarks; ++k) PQP_HIP(hipEventCreateWithFlags(&h->marks[k], hipEventDisableTiming));
         int rc;
-        if ((rc = h->wx.ensure(bn * 6 * 8))) return rc;
-        if ((rc = h->wy.ensure(bn * 6 * 8))) return rc;
-        if ((rc = h->wye.ensure((size_t)max_batch * 2 * 8))) return rc;
-        if ((rc = h->wrho.ensure((size_t)max_batch * 8))) return rc;
-    }
+        if ((rc = h->ticket.ensure(8)) || (rc = h->cost_hist.ensure(2 * pqp::kCostBins * 4))) return rc;
+        if (max_batch > 0 && max_n > 0) {
+            const size_t bn = (size_t)max_batch * max_n;
+            if ((rc = h->wx.ensure(bn * 6 * 8)) || (rc = h->wy.ensure(bn * 6 * 8)) || (rc = h->wye.ensure((size_t)max_batch * 2 * 8)) ||
+                (rc = h->wrho.ensure((size_t)max_batch * 8)))
+                return rc;
+        }
+        return PQP_OK;
+    };
+    const int rc = build();
+    if (rc != PQP_OK) { (void)pqp_destroy(h); return rc; }
     *out = h;
     return PQP_OK;
 }
@@ -532,7 +607,7 @@ int pqp_destroy(pqp_handle* h) {
     if (!h) return PQP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (DevBuf* b : {&h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
+    for (DevBuf* b : {&h->ticket, &h->cost_key, &h->cost_hist, &h->order, &h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
                       &h->s_status, &h->s_iters, &h->s_info, &h->s_a, &h->s_p, &h->s_l, &h->s_u, &h->s_idx, &h->b_pband, &h->b_q, &h->b_aval,
                       &h->b_lo, &h->b_up, &h->b_x, &h->b_y, &h->b_acol, &h->b_trow, &h->b_tslot, &h->b_in[0], &h->b_in[1], &h->b_in[2],
                       &h->b_in[3], &h->b_in[4], &h->b_out[0], &h->b_out[1], &h->b_out[2], &h->c_buf[0], &h->c_buf[1], &h->c_buf[2],
@@ -540,6 +615,7 @@ int pqp_destroy(pqp_handle* h) {
                       &h->c_buf[11]})
         b->release();
     for (int k = 0; k < pqp_handle::kEvRing; ++k) { if (h->evs0[k]) (void)hipEventDestroy(h->evs0[k]); if (h->evs1[k]) (void)hipEventDestroy(h->evs1[k]); }
+    for (int k = 0; k < pqp_handle::kMarks; ++k) if (h->marks[k]) (void)hipEventDestroy(h->marks[k]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PQP_OK;
@@ -551,9 +627,44 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params) {
     return PQP_OK;
 }
 
+int pqp_set_option(pqp_handle* h, int option, int value) {
+    if (!h) return fail(PQP_ERR_INVALID, "pqp_set_option: null handle");
+    switch (option) {
+        case PQP_OPT_STORE_WARM: h->opt_store_warm = value ? 1 : 0; return PQP_OK;
+        case PQP_OPT_ORDER_BY_COST: h->opt_order_by_cost = value ? 1 : 0; h->hist_batch = 0; return PQP_OK;
+        default: return fail(PQP_ERR_INVALID, "pqp_set_option: unknown option");
+    }
+}
+
 int pqp_get_stream(pqp_handle* h, void** s) {
     if (!h || !s) return fail(PQP_ERR_INVALID, "pqp_get_stream: null argument");
     *s = (void*)h->stream;
+    return PQP_OK;
+}
+
+int pqp_stream_wait(pqp_handle* h, void* other_stream) {
+    if (!h) return fail(PQP_ERR_INVALID, "pqp_stream_wait: null handle");
+    PQP_HIP(hipSetDevice(h->device));
+    hipEvent_t ev;
+    PQP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)other_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, ev, 0);
+    (void)hipEventDestroy(ev);                 // released once the wait has completed
+    if (e != hipSuccess) return fail(PQP_ERR_HIP, std::string("pqp_stream_wait: ") + hipGetErrorString(e));
+    return PQP_OK;
+}
+
+int pqp_mark(pqp_handle* h, int slot) {
+    if (!h || slot < 0 || slot >= pqp_handle::kMarks) return fail(PQP_ERR_INVALID, "pqp_mark: bad handle or slot (0..7)");
+    PQP_HIP(hipSetDevice(h->device));
+    PQP_HIP(hipEventRecord(h->marks[slot], h->stream));
+    return PQP_OK;
+}
+
+int pqp_wait_mark(pqp_handle* h, pqp_handle* other, int slot) {
+    if (!h || !other || slot < 0 || slot >= pqp_handle::kMarks) return fail(PQP_ERR_INVALID, "pqp_wait_mark: bad handle or slot (0..7)");
+    PQP_HIP(hipSetDevice(h->device));
+    PQP_HIP(hipStreamWaitEvent(h->stream, other->marks[slot], 0));       // (a mark never recorded counts as complete)
     return PQP_OK;
 }
 
@@ -659,8 +770,8 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
         return fail(PQP_ERR_INVALID, "pqp_path_solve: bad argument");
     if (n > 512) return fail(PQP_ERR_CAPACITY, "pqp_path_solve: more than 512 waypoints per path (one lane per waypoint, 26 T + 160 doubles of LDS per QP)");
     PQP_HIP(hipSetDevice(h->device));
-    if (warm && (h->warm_batch != batch || h->warm_n != n))
-        return fail(PQP_ERR_INVALID, "pqp_path_solve: warm == 1 needs a previous solve with the same batch and n");
+    if (warm && (h->warm_batch != batch || h->warm_n != n || !h->warm_stored))
+        return fail(PQP_ERR_INVALID, "pqp_path_solve: warm == 1 needs a previous solve with the same batch and n (with PQP_OPT_STORE_WARM on)");
     const size_t bn = (size_t)batch * n;
     int rc;
     if (!warm) {
@@ -675,13 +786,9 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     a.status = status; a.iters = iters; a.info = info;
     a.wx = h->wx.as<double>(); a.wy = h->wy.as<double>(); a.wye = h->wye.as<double>(); a.wrho = h->wrho.as<double>();
     a.prm = h->prm;
-    int nw = 1;
-    while (64 * nw < n) nw *= 2;           // one waypoint per lane: T = 64 * nw >= n threads per QP
-    if ((rc = h->wsave.ensure((size_t)batch * 64 * nw * PQP_SAVE_STRIDE * 8))) return rc;
-    a.wsave = h->wsave.as<double>();
+    int nw = 1, lg = 0;
+    while (64 * nw < n) { nw *= 2; lg += 1; }           // one waypoint per lane: T = 64 * nw >= n threads per QP
     const size_t lds = (size_t)pqp::ShLayout{64 * nw}.total() * 8;
-    h->next_event_pair();
-    PQP_HIP(hipEventRecord(h->ev0, h->stream));
     // two variants of every kernel: with and without OSQP's primal infeasibility certificate (prm.eps_prim_inf > 0)
     const bool cert = h->prm.eps_prim_inf > 0.0;
     const void* fn = nullptr;
@@ -692,12 +799,49 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
         default: fn = cert ? (const void*)pqp::path_solve_kernel<8, true> : (const void*)pqp::path_solve_kernel<8, false>; break;
     }
     if (lds > 64 * 1024) PQP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // persistent workgroups: as many as the chip holds at once (a surplus one would only wait for a free slot), each with its own
+    // save area; they draw the QPs from the ticket counter
+    int& per_cu = h->blocks_per_cu[2 * lg + (cert ? 1 : 0)];
+    if (per_cu == 0) {
+        PQP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * nw, lds));
+        if (per_cu < 1) per_cu = 1;
+    }
+    const long long resident = (long long)per_cu * h->num_cu;
+    const int grid = (int)(batch < resident ? batch : resident);
+    if ((rc = h->wsave.ensure((size_t)grid * 64 * nw * PQP_SAVE_STRIDE * 8))) return rc;
+    a.wsave = h->wsave.as<double>();
+    a.store_warm = h->opt_store_warm;
+    a.ticket = h->ticket.as<unsigned long long>();
+    a.ticket_base = h->ticket_next;
+    h->ticket_next += (unsigned long long)batch + (unsigned long long)grid;
+    if (h->opt_order_by_cost) {
+        // most expensive QPs first, by what they cost in this handle's previous solve of the same shape (a planner re-solves
+        // nearly the same scenarios cycle after cycle); results do not depend on the order
+        if ((rc = h->cost_key.ensure((size_t)batch * 4)) || (rc = h->order.ensure((size_t)batch * 4))) return rc;
+        int32_t* hist_now = h->cost_hist.as<int32_t>() + (h->solves & 1) * pqp::kCostBins;
+        int32_t* hist_prev = h->cost_hist.as<int32_t>() + ((h->solves + 1) & 1) * pqp::kCostBins;
+        if (h->hist_batch == batch && h->hist_n == n) {
+            hipLaunchKernelGGL(pqp::path_order_kernel, dim3((batch + 255) / 256), dim3(256), 0, h->stream, batch, h->cost_key.as<int32_t>(),
+                               hist_prev, hist_now, h->order.as<int32_t>());
+            PQP_HIP(hipGetLastError());
+            a.order = h->order.as<int32_t>();
+        } else {
+            PQP_HIP(hipMemsetAsync(hist_now, 0, pqp::kCostBins * 4, h->stream));
+        }
+        a.cost_key = h->cost_key.as<int32_t>();
+        a.cost_hist = hist_now;
+        h->hist_batch = batch; h->hist_n = n;
+    }
+    h->solves += 1;
+    h->next_event_pair();
+    PQP_HIP(hipEventRecord(h->ev0, h->stream));
     void* kargs[] = {(void*)&a};
-    PQP_HIP(hipLaunchKernel(fn, dim3(batch), dim3(64 * nw), kargs, lds, h->stream));
+    PQP_HIP(hipLaunchKernel(fn, dim3(grid), dim3(64 * nw), kargs, lds, h->stream));
     PQP_HIP(hipGetLastError());
     PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     h->warm_batch = batch; h->warm_n = n;
+    h->warm_stored = h->opt_store_warm != 0;
     return PQP_OK;
 }
 
@@ -714,18 +858,30 @@ int pqp_path_solve_var_device(pqp_handle* h, int batch, int n_max, const int32_t
     return path_solve_impl(h, batch, n_max, n_of, ref, lin, bounds, scal, passes, warm, out, status, iters, info);
 }
 
+static int path_solve_host_body(pqp_handle* h, int batch, int n, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
+                                const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters, double* info,
+                                std::vector<int32_t>& counts);
+
 static int path_solve_host(pqp_handle* h, int batch, int n, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
                            const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters, double* info) {
     if (!h || !ref || !bounds || !scal || !out || batch < 1 || n < 2 || passes < 0)
         return fail(PQP_ERR_INVALID, "pqp_path_solve: bad argument");
     PQP_HIP(hipSetDevice(h->device));
+    std::vector<int32_t> counts;            // outlives every copy enqueued from it: an early error return synchronises first
+    const int rc = path_solve_host_body(h, batch, n, n_of, ref, lin, bounds, scal, passes, warm, out, status, iters, info, counts);
+    if (rc != PQP_OK) (void)hipStreamSynchronize(h->stream);
+    return rc;
+}
+
+static int path_solve_host_body(pqp_handle* h, int batch, int n, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
+                                const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters, double* info,
+                                std::vector<int32_t>& counts) {
     const size_t bn = (size_t)batch * n;
     int rc;
     // A box with lower > upper bound: OSQP refuses such data at setup (OsqpEigen's initSolver() fails and BaseSolver::solve returns
     // false, base_solver.cpp:76-80).  The host-pointer entry points see the data anyway: such a QP is not launched (waypoint count 0)
     // and comes back PQP_STATUS_PRIMAL_INFEASIBLE.  (The device-pointer entry points do not validate: there the row would be
     // pinned to its upper bound.)
-    std::vector<int32_t> counts;
     bool any_invalid = false;
     for (int q = 0; q < batch; ++q) {
         const int cnt = n_of ? n_of[q] : n;
@@ -784,7 +940,8 @@ int pqp_path_solve_var(pqp_handle* h, int batch, int n_max, const int32_t* n_of,
 
 int pqp_path_get_solution(pqp_handle* h, int batch, int n, int precise, double* x, double* y) {
     if (!h || batch < 1 || n < 2 || precise < 0 || precise > n) return fail(PQP_ERR_INVALID, "pqp_path_get_solution: bad argument");
-    if (h->warm_batch != batch || h->warm_n != n) return fail(PQP_ERR_INVALID, "pqp_path_get_solution: no solve of that shape on this handle");
+    if (h->warm_batch != batch || h->warm_n != n || !h->warm_stored)
+        return fail(PQP_ERR_INVALID, "pqp_path_get_solution: no solve of that shape on this handle (or PQP_OPT_STORE_WARM is off)");
     PQP_HIP(hipSetDevice(h->device));
     pqp::RefIndex R{n, precise};
     int rc;

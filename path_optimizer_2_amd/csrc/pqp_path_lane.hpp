@@ -1,11 +1,11 @@
 // pqp_path_lane.hpp — the per-waypoint ("lane") formulation of the batched path-QP ADMM solve.
 //
-// One workgroup owns one QP and one thread owns one waypoint (T = 64 * NW >= N threads, NW = 2 waves for the
-// N = 80 / 120 configurations).  All iterates, the problem data, the penalty metrics and the factorisation of a
-// QP live in registers (86 fp64 per waypoint -> the whole solver fits in 256 VGPRs, two waves per SIMD, no
-// scratch), neighbouring waypoints talk through ~27 KB of LDS, and HBM is touched only to read the scenario
-// and to write the result.  (Round-1 history: a 2-waypoints-per-lane layout needed > 512 VGPRs at the
-// factorisation and spilled 2 GB per launch; see DESIGN.md.)
+// One workgroup owns one QP at a time and one thread owns one waypoint (T = 64 * NW >= N threads, NW = 2 waves for
+// the N = 80 / 120 configurations).  All iterates, the problem data, the penalty metrics and the factorisation of a
+// QP live in registers (86 fp64 per waypoint; with the setup-time state and temporaries the kernel takes the whole
+// 512-register budget of a lane, i.e. ONE wave per SIMD, scratch-free), neighbouring waypoints talk through ~28 KB
+// of LDS, and HBM is touched only to read the scenario and to write the result.  (Round-1 history: a
+// 2-waypoints-per-lane layout needed > 512 VGPRs at the factorisation and spilled 2 GB per launch; see DESIGN.md.)
 //
 // What is computed (reference file:line relative to LiJiangnanBit/path_optimizer_2):
 //   * assemble   — BaseSolver::setCost / setConstraints / getSoftBounds
@@ -75,9 +75,19 @@ struct PathSolveArgs {
     double* wy;             // [batch][n][6]  (yT[3], yK, yF, yR)
     double* wye;            // [batch][2]
     double* wrho;           // [batch]
-    double* wsave;          // [batch][T][kSaveStride] save area: the ADMM state while a polish is tried + the best polished point
+    double* wsave;          // [slots][T][kSaveStride] save area of the workgroup slot that runs the QP: the ADMM state while a
+                            // polish is tried + the best polished point.  Per SLOT, not per QP: the few MB stay in L2
+    int store_warm;         // 0: the final iterate is not written to wx / wy / wye (nobody will ask for it)
+    // work distribution: persistent workgroups draw QP indices from a ticket counter; `order` (or nullptr) maps the i-th ticket to
+    // a QP - most expensive first, by the cost the QPs had in the handle's previous solve (pqp_path_order_kernel)
+    unsigned long long* ticket;
+    unsigned long long ticket_base;
+    const int32_t* order;   // [batch] or nullptr
+    int32_t* cost_key;      // [batch] or nullptr: bin << 24 | rank within the bin, written at the end of every QP
+    int32_t* cost_hist;     // [256] QPs per cost bin (atomically counted)
     pqp_params prm;
 };
+enum { kCostBins = 256 };
 
 // ---- scalar helpers ----------------------------------------------------------------------------------------
 // reciprocal and reciprocal square root: on the device the hardware seed + two Newton steps (~1 ulp) instead of the
@@ -402,6 +412,19 @@ PQP_HD bool primal_certificate(LC& c, double* sh, int T, double front_length, do
     return cscale * nm[0] > eps && lhs[0] < -eps * nm[0] && nm[1] < eps * nm[0];
 }
 
+// What a QP cost (about microseconds: 4 per reduced-KKT solve, 13 per factorisation), binned for the next launch's
+// most-expensive-first order: key = bin << 24 | rank of the QP within its bin (the order in which the QPs of a bin finished)
+PQP_HD void record_cost(const PathSolveArgs& a, int qp, int cost) {
+    int bin = cost >> 3;
+    bin = bin < kCostBins - 1 ? bin : kCostBins - 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int rank = atomicAdd(a.cost_hist + bin, 1);
+#else
+    const int rank = a.cost_hist[bin]++;
+#endif
+    a.cost_key[qp] = (bin << 24) | (rank & 0xffffff);
+}
+
 // uniform (per-QP) solver scalars; handed by value across the hot / cold boundary
 struct Uni {
     double rho, cscale, kap, alpha;
@@ -437,6 +460,7 @@ struct PathQp {
     Ctx& ctx;
     const PathSolveArgs& A;
     const int qp;
+    const int slot;           // workgroup slot (index of the save area)
     const int stride;         // waypoints per QP in the batch arrays
     const int n;              // waypoints of THIS QP
     const int T;
@@ -449,8 +473,8 @@ struct PathQp {
     int kkt_solves_;          // iterate() executions: ADMM iterations + polish refinement solves
     int factors_;             // factor() executions
 
-    PQP_HD PathQp(Ctx& c, const PathSolveArgs& a, int q)
-        : ctx(c), A(a), qp(q), stride(a.n), n(count_of(a, q)), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false), cert_(false), kkt_solves_(0), factors_(0) {}
+    PQP_HD PathQp(Ctx& c, const PathSolveArgs& a, int q, int slot_ = -1)
+        : ctx(c), A(a), qp(q), slot(slot_ < 0 ? q : slot_), stride(a.n), n(count_of(a, q)), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false), cert_(false), kkt_solves_(0), factors_(0) {}
 
     // waypoints of QP q; fewer than 2: nothing to optimise (a road blocked at the first waypoints; the reference does not get
     // this far) - the caller skips the QP with status PQP_STATUS_UNSOLVED instead of constructing a solver
@@ -727,7 +751,7 @@ struct PathQp {
     static constexpr int kSaveStride = PQP_SAVE_STRIDE;   // x6 yT3 yI3 zI3 rhoI3 (+2 pad) | best polished point: x6 yT3 yI3
     static constexpr int kPolishRounds = 40; // active-set correction rounds per polish attempt
 
-    PQP_HD double* save_slot(int t) const { return A.wsave + ((size_t)qp * T + t) * kSaveStride; }
+    PQP_HD double* save_slot(int t) const { return A.wsave + ((size_t)slot * T + t) * kSaveStride; }
 
     // how badly inequality row k fails the KKT test at the polished point: violation of its true box when it is
     // treated as inactive, wrong-signed multiplier when it is treated as active (0 for rows that do not exist)
@@ -757,8 +781,10 @@ struct PathQp {
         ctx.phase([&](int t, Lane& ln) {
             Slot& S = ln.s;
             double* w = save_slot(t);
-            _Pragma("unroll") for (int k = 0; k < 6; ++k) w[k] = S.x[k];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) { w[6 + k] = S.yT[k]; w[9 + k] = S.yI[k]; w[12 + k] = S.zI[k]; w[15 + k] = S.rhoI[k]; }
+            if (S.flags & F_REAL) {      // (padding lanes never read their slot back)
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) w[k] = S.x[k];
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) { w[6 + k] = S.yT[k]; w[9 + k] = S.yI[k]; w[12 + k] = S.zI[k]; w[15 + k] = S.rhoI[k]; }
+            }
             int fl = S.flags & ~((7 * F_ACTLO0) | (7 * F_ACTUP0));
             _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] *= tgain;
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
@@ -927,8 +953,10 @@ struct PathQp {
         ctx.phase([&](int t, Lane& ln) {
             const Slot& S = ln.s;
             double* w = save_slot(t) + 20;
-            _Pragma("unroll") for (int k = 0; k < 6; ++k) w[k] = S.x[k];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) { w[6 + k] = S.yT[k]; w[9 + k] = S.yI[k]; }
+            if (S.flags & F_REAL) {
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) w[k] = S.x[k];
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) { w[6 + k] = S.yT[k]; w[9 + k] = S.yI[k]; }
+            }
             if (S.flags & F_LAST) { end_rows()->by[0] = end_rows()->y[0]; end_rows()->by[1] = end_rows()->y[1]; }
         });
     }
@@ -1506,7 +1534,7 @@ struct PathQp {
             }
             unpack();
         } else {
-            store_warm();
+            if (A.store_warm) store_warm();
         }
     }
 
@@ -1580,7 +1608,8 @@ struct PathQp {
                 if (!polish_mode) {
                     it += 1;
                     if (it == 1) finish_first_iteration();
-                    check = prm.check_termination > 0 && (it % prm.check_termination) == 0;
+                    // (OSQP also tests the residuals when it stops at max_iter: a pass that converges between two checks is SOLVED)
+                    check = prm.check_termination > 0 && ((it % prm.check_termination) == 0 || it >= prm.max_iter);
                     adapt = prm.adaptive_rho && prm.adaptive_rho_interval > 0 && (it % prm.adaptive_rho_interval) == 0;
                     want_res = check || adapt;
                 } else {
@@ -1693,6 +1722,7 @@ struct PathQp {
         const int kkt_total = kkt_solves_, fac_total = factors_;
         ctx.phase([&](int t, Lane&) {
             if (t == 0) {
+                if (A.cost_key) record_cost(A, qp, 4 * kkt_total + 13 * fac_total);
                 A.wrho[qp] = rho_final;
                 if (A.status) A.status[qp] = status;
                 if (A.iters) A.iters[qp] = total_iters;

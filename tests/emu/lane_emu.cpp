@@ -80,6 +80,7 @@ extern "C" int pqp_emu_path_solve(const pqp_params* prm, int batch, int n, const
     a.wx = wx; a.wy = wy; a.wye = wye; a.wrho = wrho;
     std::vector<double> wsave((size_t)batch * T * PQP_SAVE_STRIDE, 0.0);
     a.wsave = wsave.data();
+    a.store_warm = 1;
     a.prm = *prm;
     a.n_of = g_n_of;
     for (int q = 0; q < batch; ++q) {
