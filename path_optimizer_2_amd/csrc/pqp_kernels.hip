@@ -86,10 +86,20 @@ __device__ __noinline__ bool dev_certificate(double* sh, double fl, double rl, d
     return primal_certificate(c, sh, 64 * NW, fl, rl, kap, eps, cscale);
 }
 
+// PQP_CST_LDS / PQP_PARK_SCALE: the register diet of pqp_path_lane.hpp (12 pass constants per waypoint in LDS, Ruiz vectors parked in
+// memory between the passes)
+#ifndef PQP_CST_LDS
+#define PQP_CST_LDS 0
+#endif
+#ifndef PQP_PARK_SCALE
+#define PQP_PARK_SCALE 1       // measured: +2 % (profiles/r02b_variants.txt); PQP_CST_LDS: no gain at one wave per SIMD
+#endif
+
 // Context whose lane state is a local struct (SROA -> registers).  A phase is the code between two workgroup
 // barriers (for a one-wave workgroup the barrier is only a wait on outstanding LDS traffic).
 template <int NW>
 struct RegCtx {
+    static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0;
     Lane lane;
     double* shp;
     __device__ __forceinline__ int T() const { return 64 * NW; }
@@ -144,6 +154,7 @@ __device__ __noinline__ Uni cold_entry(const PathSolveArgs* args, int qp, double
 // workgroup barriers (for a one-wave workgroup the barrier is only a wait on outstanding LDS traffic).
 template <int NW>
 struct DevCtx {
+    static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0;
     Lane lane;
     Lane* mem;
     double* shp;
@@ -545,7 +556,7 @@ struct pqp_handle {
     void next_event_pair() { ev0 = evs0[ev_count % kEvRing]; ev1 = evs1[ev_count % kEvRing]; ev_count += 1; }
     int warm_batch = 0, warm_n = 0;
     bool warm_stored = false;                   // the last solve wrote its final iterate to wx / wy / wye
-    DevBuf wx, wy, wye, wrho, wsave;            // warm state (lane layout) + polish save area (per workgroup slot)
+    DevBuf wx, wy, wye, wrho, wsave, wscale;    // warm state (lane layout) + polish save area, parked Ruiz vectors (per workgroup slot)
     // work distribution of the solve kernel: ticket counter (never reset: a launch uses batch + grid tickets), cost bins of the
     // last solve and the ticket -> QP order derived from them
     DevBuf ticket, cost_key, cost_hist, order;
@@ -607,7 +618,7 @@ int pqp_destroy(pqp_handle* h) {
     if (!h) return PQP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (DevBuf* b : {&h->ticket, &h->cost_key, &h->cost_hist, &h->order, &h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
+    for (DevBuf* b : {&h->wscale, &h->ticket, &h->cost_key, &h->cost_hist, &h->order, &h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
                       &h->s_status, &h->s_iters, &h->s_info, &h->s_a, &h->s_p, &h->s_l, &h->s_u, &h->s_idx, &h->b_pband, &h->b_q, &h->b_aval,
                       &h->b_lo, &h->b_up, &h->b_x, &h->b_y, &h->b_acol, &h->b_trow, &h->b_tslot, &h->b_in[0], &h->b_in[1], &h->b_in[2],
                       &h->b_in[3], &h->b_in[4], &h->b_out[0], &h->b_out[1], &h->b_out[2], &h->c_buf[0], &h->c_buf[1], &h->c_buf[2],
@@ -810,6 +821,8 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     const int grid = (int)(batch < resident ? batch : resident);
     if ((rc = h->wsave.ensure((size_t)grid * 64 * nw * PQP_SAVE_STRIDE * 8))) return rc;
     a.wsave = h->wsave.as<double>();
+    if ((rc = h->wscale.ensure((size_t)grid * 64 * nw * 12 * 8))) return rc;
+    a.wscale = h->wscale.as<double>();
     a.store_warm = h->opt_store_warm;
     a.ticket = h->ticket.as<unsigned long long>();
     a.ticket_base = h->ticket_next;

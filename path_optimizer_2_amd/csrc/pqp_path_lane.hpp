@@ -75,6 +75,7 @@ struct PathSolveArgs {
     double* wy;             // [batch][n][6]  (yT[3], yK, yF, yR)
     double* wye;            // [batch][2]
     double* wrho;           // [batch]
+    double* wscale;         // [slots][T][12] Ruiz D(6), E(6) parked between the passes of a QP (contexts with kParkScale)
     double* wsave;          // [slots][T][kSaveStride] save area of the workgroup slot that runs the QP: the ADMM state while a
                             // polish is tried + the best polished point.  Per SLOT, not per QP: the few MB stay in L2
     int store_warm;         // 0: the final iterate is not written to wx / wy / wye (nobody will ask for it)
@@ -305,7 +306,13 @@ struct ShLayout {
     PQP_HD int sk() const { return 24 * T; }                // [T][2] s, k_ref
     PQP_HD int end() const { return 26 * T; }               // EndRows (32 doubles)
     PQP_HD int red() const { return 26 * T + 32; }          // reduction scratch [8][16]
-    PQP_HD int total() const { return 26 * T + 32 + 128; }
+    // per-waypoint pass constants that are read once per iteration (kCstLds contexts keep them here instead of in registers):
+    // [12][T] sig(6) lo(2) up(2) idsf idsr, one array per constant (unit stride over the lanes: conflict-free)
+    // 24 zeros (written once per workgroup): where a lane has no neighbour its read is redirected here, so the reads of a phase
+    // need no exec-mask change and no select (a conditional LDS read costs two scalar instructions around every ds_read)
+    PQP_HD int zero() const { return 26 * T + 32 + 128; }
+    PQP_HD int cst() const { return 26 * T + 32 + 128 + 24; }
+    PQP_HD int total() const { return 38 * T + 32 + 128 + 24; }
     // y_k - y_{k-1} of the last iteration, [T][6] (infeasibility certificate): lives in the part of the factor-time buffer
     // the iteration does not use; every iteration rewrites it, and a check never follows a factorisation directly
     PQP_HD int yprev() const { return 12 * T; }
@@ -451,6 +458,8 @@ enum RefactorKind : int { RF_RESCALE = 0 /* d0 = ratio */, RF_POLISH_BEGIN = 1, 
 //   template<F> void phase_w(F f)         the same, but only the lanes of one wavefront need to see each other's LDS writes
 //   template<int K,F> void reduce_max/sum(double (&out)[K], F f)   f(t, Lane&, double (&v)[K])
 //   void cold(PathQp&, op, i0, i1, d0)    run do_cold() (possibly out of line)
+//   static constexpr bool kCstLds         12 per-waypoint pass constants live in LDS (ShLayout::cst) instead of in Slot fields
+//   static constexpr bool kParkScale      the Ruiz vectors D, E are parked in PathSolveArgs::wscale between the passes
 // =======================================================================================================
 // CERT: compile the primal infeasibility certificate in.  It is a template parameter because its mere presence in the kernel
 // (one more cold operation + six LDS stores per iteration) costs the ADMM iteration 12 % through register allocation;
@@ -472,6 +481,12 @@ struct PathQp {
     bool cert_;               // result of the last COLD_CERT
     int kkt_solves_;          // iterate() executions: ADMM iterations + polish refinement solves
     int factors_;             // factor() executions
+#ifdef PQP_TIMING
+    long long tsub_[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // debug build: ticks inside the cold operations (tools/kernel_timeline.py)
+#define PQP_SUB(k, stmt) do { const long long t0_ = ctx.clock(); stmt; tsub_[k] += ctx.clock() - t0_; } while (0)
+#else
+#define PQP_SUB(k, stmt) do { stmt; } while (0)
+#endif
 
     PQP_HD PathQp(Ctx& c, const PathSolveArgs& a, int q, int slot_ = -1)
         : ctx(c), A(a), qp(q), slot(slot_ < 0 ? q : slot_), stride(a.n), n(count_of(a, q)), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false), cert_(false), kkt_solves_(0), factors_(0) {}
@@ -481,6 +496,8 @@ struct PathQp {
     PQP_HD static int count_of(const PathSolveArgs& a, int q) { return a.n_of ? (a.n_of[q] < a.n ? a.n_of[q] : a.n) : a.n; }
 
     PQP_HD EndRows* end_rows() const { return reinterpret_cast<EndRows*>(sh + L.end()); }
+    // row `other` of an exchange buffer, or the zero block when that neighbour does not exist
+    PQP_HD const double* nb(bool ok, int base, int stride, int other) const { return sh + (ok ? base + stride * other : L.zero()); }
 
     // NOTE on style: per-lane state must stay in registers, which needs every Lane field to be written through
     // one unconditional store (values chosen with selects) or under a single branch without an else-store; only
@@ -495,6 +512,7 @@ struct PathQp {
         ctx.phase([&](int t, Lane& ln) {
             Slot& S = ln.s;
             const int i = t;
+            if (t < 24) sh[L.zero() + t] = 0.0;
             const bool real = i < n;
             const int ic = real ? i : n - 1;
             const double* r = A.ref + ((size_t)qp * stride + ic) * PQP_REF_STRIDE;
@@ -546,8 +564,9 @@ struct PathQp {
             double flo, fup, rlo, rup;
             soft_bounds(f_lb, f_ub, prm.expected_safety_margin, prm.min_clearance, flo, fup);
             soft_bounds(b[2], b[3], prm.expected_safety_margin, prm.min_clearance, rlo, rup);
-            S.lo[0] = real ? flo : 0.0; S.up[0] = real ? fup : 0.0;
-            S.lo[1] = (real && precise) ? rlo : 0.0; S.up[1] = (real && precise) ? rup : 0.0;
+            const double lo0 = real ? flo : 0.0, up0 = real ? fup : 0.0, lo1 = (real && precise) ? rlo : 0.0, up1 = (real && precise) ? rup : 0.0;
+            if constexpr (kCst) { cst_set(t, C_LO, lo0); cst_set(t, C_LO + 1, lo1); cst_set(t, C_UP, up0); cst_set(t, C_UP + 1, up1); }
+            else { S.lo[0] = lo0; S.up[0] = up0; S.lo[1] = lo1; S.up[1] = up1; }
             if (S.flags & F_LAST) {                                         // :250-259
                 EndRows* er = end_rows();
                 double elo = -kInfty, eup = kInfty;
@@ -566,16 +585,28 @@ struct PathQp {
     }
 
     // the box of inequality row k (0: curvature, 1: front, 2: rear) as assembled ...
-    PQP_HD double raw_lo(const Slot& S, int k) const { return k == 0 ? ((S.flags & F_REAL) ? -kap : 0.0) : S.lo[k - 1]; }
-    PQP_HD double raw_up(const Slot& S, int k) const { return k == 0 ? ((S.flags & F_REAL) ? kap : 0.0) : S.up[k - 1]; }
+    // Pass constants of a waypoint that the iteration reads once: in registers (Slot fields) or, in contexts with kCstLds, in LDS -
+    // 24 registers less in the ADMM loop, which is what lets two wavefronts share a SIMD.
+    static constexpr bool kCst = Ctx::kCstLds;
+    enum : int { C_SIG = 0, C_LO = 6, C_UP = 8, C_IDSF = 10, C_IDSR = 11 };
+    PQP_HD double cst_get(int t, int c) const { return sh[L.cst() + c * T + t]; }
+    PQP_HD void cst_set(int t, int c, double v) const { sh[L.cst() + c * T + t] = v; }
+    PQP_HD double sig_of(const Slot& S, int t, int k) const { if constexpr (kCst) return cst_get(t, C_SIG + k); else return S.sig[k]; }
+    PQP_HD void set_sig(Slot& S, int t, int k, double v) const { if constexpr (kCst) cst_set(t, C_SIG + k, v); else S.sig[k] = v; }
+    PQP_HD double idsf_of(const Slot& S, int t) const { if constexpr (kCst) return cst_get(t, C_IDSF); else return S.idsf; }
+    PQP_HD double idsr_of(const Slot& S, int t) const { if constexpr (kCst) return cst_get(t, C_IDSR); else return S.idsr; }
+    PQP_HD double lo_of(const Slot& S, int t, int j) const { if constexpr (kCst) return cst_get(t, C_LO + j); else return S.lo[j]; }
+    PQP_HD double up_of(const Slot& S, int t, int j) const { if constexpr (kCst) return cst_get(t, C_UP + j); else return S.up[j]; }
+    PQP_HD double raw_lo(const Slot& S, int t, int k) const { return k == 0 ? ((S.flags & F_REAL) ? -kap : 0.0) : lo_of(S, t, k - 1); }
+    PQP_HD double raw_up(const Slot& S, int t, int k) const { return k == 0 ? ((S.flags & F_REAL) ? kap : 0.0) : up_of(S, t, k - 1); }
     // ... and as the iteration sees it: while polishing, an active row is pinned to its bound, an inactive row is free
-    PQP_HD double box_lo(const Slot& S, int k) const {
-        const double lo = raw_lo(S, k), up = raw_up(S, k);
+    PQP_HD double box_lo(const Slot& S, int t, int k) const {
+        const double lo = raw_lo(S, t, k), up = raw_up(S, t, k);
         if (!polishing_) return lo;
         return (S.flags & (F_ACTLO0 << k)) ? lo : ((S.flags & (F_ACTUP0 << k)) ? up : -kInfty);
     }
-    PQP_HD double box_up(const Slot& S, int k) const {
-        const double lo = raw_lo(S, k), up = raw_up(S, k);
+    PQP_HD double box_up(const Slot& S, int t, int k) const {
+        const double lo = raw_lo(S, t, k), up = raw_up(S, t, k);
         if (!polishing_) return up;
         return (S.flags & (F_ACTLO0 << k)) ? lo : ((S.flags & (F_ACTUP0 << k)) ? up : kInfty);
     }
@@ -595,6 +626,17 @@ struct PathQp {
     // only rebuilds the metrics; any positive diagonal scaling is a valid metric, OSQP's own update path re-equilibrates
     PQP_HD void ruiz(bool reuse = false) {
         if (!reuse) ruiz_equilibrate();
+        // kParkScale: D, E are only read here, once per pass - between the passes they live in the workgroup slot's memory instead
+        // of in 24 registers of the ADMM loop
+        if constexpr (Ctx::kParkScale) {
+            ctx.phase([&](int t, Lane& ln) {
+                double* w = A.wscale + ((size_t)slot * T + t) * 12;
+                if (!reuse) { _Pragma("unroll") for (int k = 0; k < 6; ++k) { w[k] = ln.w.D[k]; w[6 + k] = ln.w.E[k]; } }
+                double d[6], e[6];
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) { d[k] = reuse ? w[k] : ln.w.D[k]; e[k] = reuse ? w[6 + k] : ln.w.E[k]; }
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) { ln.w.D[k] = d[k]; ln.w.E[k] = e[k]; }
+            });
+        }
         ruiz_metrics();
     }
     PQP_HD void ruiz_equilibrate() {
@@ -626,8 +668,8 @@ struct PathQp {
                 const Slot& S = ln.s;
                 SlotSetup& W = ln.w;
                 double Dp[3], mn[3];
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) Dp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) mn[k] = (t + 1 < T) ? sh[L.bufG() + 3 * (t + 1) + k] : 0.0;
+                { const double* dp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Dp[k] = dp_[k]; }
+                { const double* mn_ = nb(t + 1 < T, L.bufG(), 3, t + 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) mn[k] = mn_[k]; }
                 const bool real = S.flags & F_REAL, last = S.flags & F_LAST, precise = S.flags & F_PRECISE, prev = S.flags & F_PREV;
                 EndRows* er = end_rows();
                 const double ee0 = last ? er->E[0] : 0.0, ee1 = last ? er->E[1] : 0.0;
@@ -678,17 +720,17 @@ struct PathQp {
         const pqp_params& prm = A.prm;
         const double c = cscale, rho_now = rho;
         const double ic = 1.0 / c;
-        ctx.phase([&](int, Lane& ln) {
+        ctx.phase([&](int t, Lane& ln) {
             Slot& S = ln.s;
             const SlotSetup& W = ln.w;
             const bool real = S.flags & F_REAL, precise = S.flags & F_PRECISE;
-            _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] = prm.sigma * rcp(c * W.D[k] * W.D[k]);
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) set_sig(S, t, k, prm.sigma * rcp(c * W.D[k] * W.D[k]));
             _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] = real ? rho_now * kRhoEqFactor * W.E[k] * W.E[k] * ic : 0.0;
             int fl = S.flags & ~((7 * F_FREE0) | (7 * F_EQ0));      // the active-set bits of a previous polish survive
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                 const bool rowreal = real && (k < 2 || precise);
                 const double e = W.E[3 + k], e2 = e * e * ic;
-                const double sl = e * raw_lo(S, k), su = e * raw_up(S, k);
+                const double sl = e * raw_lo(S, t, k), su = e * raw_up(S, t, k);
                 const bool free_row = sl < -kInfty * kMinScaling && su > kInfty * kMinScaling;
                 const bool eq_row = !free_row && (su - sl < kRhoTol);
                 const double r = !rowreal ? 0.0 : (free_row ? kRhoMin * e2 : (eq_row ? rho_now * kRhoEqFactor * e2 : rho_now * e2));
@@ -755,10 +797,10 @@ struct PathQp {
 
     // how badly inequality row k fails the KKT test at the polished point: violation of its true box when it is
     // treated as inactive, wrong-signed multiplier when it is treated as active (0 for rows that do not exist)
-    PQP_HD double row_violation(const Slot& S, int k, double ax) const {
+    PQP_HD double row_violation(const Slot& S, int t, int k, double ax) const {
         const bool rowreal = (S.flags & F_REAL) && (k < 2 || (S.flags & F_PRECISE)) && !(S.flags & (F_FREE0 << k));
         const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
-        const double pv = fmax(raw_lo(S, k) - ax, ax - raw_up(S, k));
+        const double pv = fmax(raw_lo(S, t, k) - ax, ax - raw_up(S, t, k));
         const double dv = alo ? S.yI[k] : (aup ? -S.yI[k] : 0.0);
         return rowreal ? fmax(fmax(pv, dv), 0.0) : 0.0;
     }
@@ -791,13 +833,13 @@ struct PathQp {
                 const bool fr = S.flags & (F_FREE0 << k), eq = S.flags & (F_EQ0 << k);
                 const double e2 = S.rhoI[k] * (eq ? irho_eq : irho);     // E^2 / c of the row
                 const bool can = !fr && S.rhoI[k] > 0.0;
-                const bool act_lo = can && ((S.zI[k] - raw_lo(S, k)) * e2 < -S.yI[k]);
-                const bool act_up = can && !act_lo && ((raw_up(S, k) - S.zI[k]) * e2 < S.yI[k]);
+                const bool act_lo = can && ((S.zI[k] - raw_lo(S, t, k)) * e2 < -S.yI[k]);
+                const bool act_up = can && !act_lo && ((raw_up(S, t, k) - S.zI[k]) * e2 < S.yI[k]);
                 if (act_lo) fl |= (F_ACTLO0 << k);
                 if (act_up) fl |= (F_ACTUP0 << k);
             }
             S.flags = keep_set ? S.flags : fl;      // keep_set: start from the active set of the previous pass
-            _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] *= sgain;
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) set_sig(S, t, k, sig_of(S, t, k) * sgain);
             if (S.flags & F_LAST) {
                 EndRows* er = end_rows();
                 for (int k = 0; k < 2; ++k) {
@@ -830,7 +872,7 @@ struct PathQp {
                 const double r = act ? gain * e2 : 0.0;
                 // (read every candidate into a value first: a select between two lane FIELDS becomes an address select,
                 //  i.e. dynamic indexing of the lane struct, which would push the whole struct into scratch memory)
-                const double lo_k = raw_lo(S, k), up_k = raw_up(S, k), z_k = S.zI[k], y_k = S.yI[k];
+                const double lo_k = raw_lo(S, t, k), up_k = raw_up(S, t, k), z_k = S.zI[k], y_k = S.yI[k];
                 S.rhoI[k] = r;
                 S.rinvI[k] = act ? rcp(r) : 0.0;
                 S.yI[k] = act ? y_k : 0.0;
@@ -856,10 +898,10 @@ struct PathQp {
         ctx.template reduce_max<1>(viol, [&](int t, Lane& ln, double (&v)[1]) {
             const Slot& S = ln.s;
             double Xp[3], aT[3], aI[3];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
+            { const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
             rows_of(S, Xp, S.x, aT, aI);
             double w = 0.0;
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) w = fmax(w, row_violation(S, k, aI[k]));
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) w = fmax(w, row_violation(S, t, k, aI[k]));
             if (S.flags & F_LAST) {
                 const EndRows* er = end_rows();
                 for (int k = 0; k < 2; ++k) w = fmax(w, end_violation(er, k, S.x[k]));
@@ -877,11 +919,11 @@ struct PathQp {
         ctx.phase([&](int t, Lane& ln) {
             const Slot& S = ln.s;
             double Xp[3], aT[3], aI[3];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
+            { const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
             rows_of(S, Xp, S.x, aT, aI);
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                 const bool inactive = !(S.flags & ((F_ACTLO0 << k) | (F_ACTUP0 << k)));
-                const double v = row_violation(S, k, aI[k]);
+                const double v = row_violation(S, t, k, aI[k]);
                 sh[L.bufQ() + 3 * t + k] = (inactive && v > thr) ? v : 0.0;
             }
             if (S.flags & F_LAST) {
@@ -915,18 +957,18 @@ struct PathQp {
         ctx.phase([&](int t, Lane& ln) {
             Slot& S = ln.s;
             double Xp[3], aT[3], aI[3];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
+            { const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
             rows_of(S, Xp, S.x, aT, aI);
             int fl = S.flags;
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                 const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
-                const double w = row_violation(S, k, aI[k]);
+                const double w = row_violation(S, t, k, aI[k]);
                 const bool move = w > thr && (alo || aup || polish_is_peak(t, k, w, S.flags & F_LAST));
-                const bool add_lo = move && !alo && !aup && (raw_lo(S, k) - aI[k] > aI[k] - raw_up(S, k));
+                const bool add_lo = move && !alo && !aup && (raw_lo(S, t, k) - aI[k] > aI[k] - raw_up(S, t, k));
                 const bool add_up = move && !alo && !aup && !add_lo;
 #ifdef PQP_EMU_DEBUG
                 if (move) printf("      row t=%d k=%d %s viol %.3e (ax %.5f lo %.5f up %.5f y %.4e)\n", t, k, (alo || aup) ? "RELEASE" : (add_lo ? "ADD_LO" : "ADD_UP"),
-                                 row_violation(S, k, aI[k]), aI[k], raw_lo(S, k), raw_up(S, k), S.yI[k]);
+                                 row_violation(S, t, k, aI[k]), aI[k], raw_lo(S, t, k), raw_up(S, t, k), S.yI[k]);
 #endif
                 if (move && (alo || aup)) fl &= ~((F_ACTLO0 << k) | (F_ACTUP0 << k));
                 if (add_lo) fl |= (F_ACTLO0 << k);
@@ -987,7 +1029,7 @@ struct PathQp {
                 S.rinvI[k] = r > 0.0 ? rcp(r) : 0.0;
                 S.rhoT[k] *= itgain;
             }
-            _Pragma("unroll") for (int k = 0; k < 6; ++k) S.sig[k] *= isgain;
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) set_sig(S, t, k, sig_of(S, t, k) * isgain);
             if (S.flags & F_LAST) {
                 EndRows* er = end_rows();
                 for (int k = 0; k < 2; ++k) {
@@ -1003,11 +1045,11 @@ struct PathQp {
             ctx.phase([&](int t, Lane& ln) {
                 Slot& S = ln.s;
                 double Xp[3], aT[3], aI[3];
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
+                { const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
                 rows_of(S, Xp, S.x, aT, aI);
                 const bool real = S.flags & F_REAL;
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                    const double lo_k = raw_lo(S, k), up_k = raw_up(S, k);
+                    const double lo_k = raw_lo(S, t, k), up_k = raw_up(S, t, k);
                     S.zI[k] = real ? fmin(fmax(aI[k], lo_k), up_k) : 0.0;
                 }
                 if (S.flags & F_LAST) {
@@ -1031,23 +1073,24 @@ struct PathQp {
             double re0 = 0.0, re1 = 0.0;
             if (S.flags & F_LAST) { re0 = end_rows()->rho[0]; re1 = end_rows()->rho[1]; }
             const double rK = S.rhoI[0], rF = S.rhoI[1], rR = S.rhoI[2];
-            const double dsf = cost_diag(prm, S.flags, 4) + S.sig[4] + rF, dsr = cost_diag(prm, S.flags, 5) + S.sig[5] + rR;
-            S.idsf = rcp(dsf); S.idsr = rcp(dsr);
-            S.cF = rF * S.idsf; S.cR = rR * S.idsr;
+            const double dsf = cost_diag(prm, S.flags, 4) + sig_of(S, t, 4) + rF, dsr = cost_diag(prm, S.flags, 5) + sig_of(S, t, 5) + rR;
+            const double idsf = rcp(dsf), idsr = rcp(dsr);
+            if constexpr (kCst) { cst_set(t, C_IDSF, idsf); cst_set(t, C_IDSR, idsr); } else { S.idsf = idsf; S.idsr = idsr; }
+            S.cF = rF * idsf; S.cR = rR * idsr;
             const double gf = rF - rF * S.cF, gr = rR - rR * S.cR;
             const double ds = S.a[5];
             S.tu = S.rhoT[2] * ds;
-            const double du = cost_diag(prm, S.flags, 3) + S.sig[3] + S.tu * ds;
+            const double du = cost_diag(prm, S.flags, 3) + sig_of(S, t, 3) + S.tu * ds;
             S.idu = rcp(du);
             S.tudc = S.tu * S.idu;
             const double gu = S.rhoT[2] - S.tu * S.tudc;
             const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
-            W.Dg[0] = cost_diag(prm, S.flags, 0) + S.sig[0] + S.rhoT[0] + gf + gr + re0;
+            W.Dg[0] = cost_diag(prm, S.flags, 0) + sig_of(S, t, 0) + S.rhoT[0] + gf + gr + re0;
             W.Dg[1] = gf * cf + gr * cr;
             W.Dg[2] = 0.0;
-            W.Dg[3] = cost_diag(prm, S.flags, 1) + S.sig[1] + S.rhoT[1] + gf * cf * cf + gr * cr * cr + re1;
+            W.Dg[3] = cost_diag(prm, S.flags, 1) + sig_of(S, t, 1) + S.rhoT[1] + gf * cf * cf + gr * cr * cr + re1;
             W.Dg[4] = 0.0;
-            W.Dg[5] = cost_diag(prm, S.flags, 2) + S.sig[2] + gu + rK;
+            W.Dg[5] = cost_diag(prm, S.flags, 2) + sig_of(S, t, 2) + gu + rK;
             const double r0 = S.rhoT[0], r1 = S.rhoT[1];
             const double a00 = S.a[0], a01 = S.a[1], a10 = S.a[2], a11 = S.a[3], a12 = S.a[4];
             const double gup = (S.flags & F_PREV) ? gu : 0.0;
@@ -1068,10 +1111,9 @@ struct PathQp {
         // F2: receive from the next waypoint
         ctx.phase([&](int t, Lane& ln) {
             SlotSetup& W = ln.w;
-            const bool has = t + 1 < T;
-            const double* f = sh + L.fbuf() + 15 * (has ? t + 1 : t);
-            _Pragma("unroll") for (int k = 0; k < 6; ++k) W.Dg[k] += has ? f[k] : 0.0;
-            _Pragma("unroll") for (int k = 0; k < 9; ++k) W.Rc[k] = has ? f[6 + k] : 0.0;
+            const double* f = nb(t + 1 < T, L.fbuf(), 15, t + 1);
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) W.Dg[k] += f[k];
+            _Pragma("unroll") for (int k = 0; k < 9; ++k) W.Rc[k] = f[6 + k];
         });
         // Cyclic-reduction tree over tp = t + 1 in [1, T]: level h eliminates tp = h (mod 2h), the root is tp = T (the last
         // thread).  With this numbering the only node of a wavefront that talks to the next wavefront during the levels
@@ -1086,13 +1128,11 @@ struct PathQp {
                     const int hp = h >> 1;   // stride of the level just eliminated
                     const bool surv = (tp & (h - 1)) == 0;
                     const bool hr = surv && (t + hp < T), hl = surv && (t - hp >= 0);
-                    const double* fr = sh + L.fbuf() + 21 * (hr ? t + hp : t);
-                    const double* fl = sh + L.fbuf() + 21 * (hl ? t - hp : t);
-                    _Pragma("unroll") for (int k = 0; k < 6; ++k) W.Dg[k] -= (hr ? fr[k] : 0.0) + (hl ? fl[6 + k] : 0.0);
-                    _Pragma("unroll") for (int k = 0; k < 9; ++k) {
-                        W.Rc[k] = surv ? (hr ? fr[12 + k] : 0.0) : W.Rc[k];
-                        W.Lc[k] = hl ? fl[12 + k] : (surv ? 0.0 : W.Lc[k]);
-                    }
+                    const double* fr = nb(hr, L.fbuf(), 21, t + hp);       // (no neighbour: 21 zeros)
+                    const double* fl = nb(hl, L.fbuf(), 21, t - hp);
+                    _Pragma("unroll") for (int k = 0; k < 6; ++k) W.Dg[k] -= fr[k] + fl[6 + k];
+                    // (ONE branch around all eighteen loads: written as selects, every load gets its own exec-mask change)
+                    if (surv) { _Pragma("unroll") for (int k = 0; k < 9; ++k) { W.Rc[k] = fr[12 + k]; W.Lc[k] = fl[12 + k]; } }
                 }
                 const bool elim = (h < T) ? ((tp & (2 * h - 1)) == h) : (tp == T);
                 if (elim) {      // every thread is eliminated at exactly one level (the last thread: the root)
@@ -1151,17 +1191,17 @@ struct PathQp {
                 we0 = er->rho[0] * er->z[0] - er->y[0];
                 we1 = er->rho[1] * er->z[1] - er->y[1];
             }
-            S.rv = S.sig[3] * S.x[3] + S.a[5] * wT[2];
-            S.rsf = S.sig[4] * S.x[4] + wI[1];
-            S.rsr = S.sig[5] * S.x[5] + wI[2];
+            S.rv = sig_of(S, t, 3) * S.x[3] + S.a[5] * wT[2];
+            S.rsf = sig_of(S, t, 4) * S.x[4] + wI[1];
+            S.rsr = sig_of(S, t, 5) * S.x[5] + wI[2];
             const double tud = S.tudc * S.rv;
             double g[3];
             back_msg(S, wT, g);
             g[2] -= tud;
             const double eF = S.cF * S.rsf, eR = S.cR * S.rsr;
-            S.r[0] = S.sig[0] * S.x[0] - wT[0] + wI[1] + wI[2] + we0 - eF - eR;
-            S.r[1] = S.sig[1] * S.x[1] - wT[1] + cf * wI[1] + cr * wI[2] + we1 - cf * eF - cr * eR;
-            S.r[2] = S.sig[2] * S.x[2] - wT[2] + wI[0] + tud;
+            S.r[0] = sig_of(S, t, 0) * S.x[0] - wT[0] + wI[1] + wI[2] + we0 - eF - eR;
+            S.r[1] = sig_of(S, t, 1) * S.x[1] - wT[1] + cf * wI[1] + cr * wI[2] + we1 - cf * eF - cr * eR;
+            S.r[2] = sig_of(S, t, 2) * S.x[2] - wT[2] + wI[0] + tud;
             _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufG() + 3 * t + k] = g[k];
         });
         // Forward pass.  Levels h < 64 stay inside a wavefront (wave-local phases: no workgroup barrier); a wave's last lane
@@ -1176,13 +1216,15 @@ struct PathQp {
                 const bool edge = (tp & 63) == 0;            // last lane of its wavefront
                 if (h == 1) {
                     const bool has = (t + 1 < T) && !edge;
-                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += has ? sh[L.bufG() + 3 * (t + 1) + k] : 0.0;
+                    const double* g_ = nb(has, L.bufG(), 3, t + 1);
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += g_[k];
                 } else {
                     const int hp = h >> 1;
                     const bool surv = (tp & (h - 1)) == 0;
                     const bool hr = surv && (t + hp < T) && !edge, hl = surv && (t - hp >= 0);
-                    _Pragma("unroll") for (int k = 0; k < 3; ++k)
-                        S.r[k] -= (hr ? sh[L.bufQ() + 3 * (t + hp) + k] : 0.0) + (hl ? sh[L.bufP() + 3 * (t - hp) + k] : 0.0);
+                    const double* q_ = nb(hr, L.bufQ(), 3, t + hp);
+                    const double* p_ = nb(hl, L.bufP(), 3, t - hp);
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] -= q_[k] + p_[k];
                 }
                 if ((tp & (2 * h - 1)) == h) {
                     double p[3];
@@ -1210,8 +1252,9 @@ struct PathQp {
                     const int hp = h >> 1;
                     const bool surv = (tp & (h - 1)) == 0;
                     const bool hr = surv && (t + hp < T), hl = surv && (t - hp >= 0);
-                    _Pragma("unroll") for (int k = 0; k < 3; ++k)
-                        S.r[k] -= (hr ? sh[L.bufQ() + 3 * (t + hp) + k] : 0.0) + (hl ? sh[L.bufP() + 3 * (t - hp) + k] : 0.0);
+                    const double* q_ = nb(hr, L.bufQ(), 3, t + hp);
+                    const double* p_ = nb(hl, L.bufP(), 3, t - hp);
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] -= q_[k] + p_[k];
                 } else if (t + 1 < T && !edge) {     // T == 1 only
                     _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += sh[L.bufG() + 3 * (t + 1) + k];
                 }
@@ -1239,14 +1282,14 @@ struct PathQp {
                 const int tp = t + 1;
                 const bool act = (tp & (2 * h - 1)) == h;
                 const bool hl = act && (t - h >= 0), hr = act && (t + h < T);
-                const double* xl = sh + L.xbuf() + 3 * (hl ? t - h : t);
-                const double* xr = sh + L.xbuf() + 3 * (hr ? t + h : t);
+                const double* xl = nb(hl, L.xbuf(), 3, t - h);         // no neighbour: x = 0 from the zero block
+                const double* xr = nb(hr, L.xbuf(), 3, t + h);
                 double x3[3], p[3], pr[3];
                 sym3_vec(S.Dinv, S.r, x3);
                 mat3t_vec(S.GL, xl, p);
                 mat3t_vec(S.GR, xr, pr);
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                    const double v = x3[k] - (hl ? p[k] : 0.0) - (hr ? pr[k] : 0.0);
+                    const double v = x3[k] - p[k] - pr[k];
                     S.xt[k] = act ? v : S.xt[k];
                     if (act) sh[L.xbuf() + 3 * t + k] = v;
                 }
@@ -1260,13 +1303,13 @@ struct PathQp {
         ctx.phase_w([&](int t, Lane& ln) {
             Slot& S = ln.s;
             double Xp[3];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
+            { const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
             const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
             double xt[6];
             xt[0] = S.xt[0]; xt[1] = S.xt[1]; xt[2] = S.xt[2];
             xt[3] = (S.rv - S.tu * (((S.flags & F_PREV) ? Xp[2] : 0.0) - xt[2])) * S.idu;
-            xt[4] = (S.rsf - S.rhoI[1] * (xt[0] + cf * xt[1])) * S.idsf;
-            xt[5] = (S.rsr - S.rhoI[2] * (xt[0] + cr * xt[1])) * S.idsr;
+            xt[4] = (S.rsf - S.rhoI[1] * (xt[0] + cf * xt[1])) * idsf_of(S, t);
+            xt[5] = (S.rsr - S.rhoI[2] * (xt[0] + cr * xt[1])) * idsr_of(S, t);
             double zT[3], zI[3];
             rows_of(S, Xp, xt, zT, zI);
             _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = alpha * xt[k] + (1.0 - alpha) * S.x[k];
@@ -1279,7 +1322,7 @@ struct PathQp {
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                 const double zh = alpha * zI[k] + (1.0 - alpha) * S.zI[k];
                 const double v = zh + S.yI[k] * S.rinvI[k];
-                const double zn = fmin(fmax(v, box_lo(S, k)), box_up(S, k));
+                const double zn = fmin(fmax(v, box_lo(S, t, k)), box_up(S, t, k));
                 const double d = S.rhoI[k] * (zh - zn);
                 S.yI[k] += d;
                 if (CERT) dyp[3 + k] = d;
@@ -1323,8 +1366,8 @@ struct PathQp {
         ctx.template reduce_max<5>(res, [&](int t, Lane& ln, double (&v)[5]) {
             const Slot& S = ln.s;
             double Xp[3], gn[3];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) gn[k] = (t + 1 < T) ? sh[L.bufG() + 3 * (t + 1) + k] : 0.0;
+            { const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
+            { const double* gn_ = nb(t + 1 < T, L.bufG(), 3, t + 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) gn[k] = gn_[k]; }
             const bool real = S.flags & F_REAL;
             const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
             double aT[3], aI[3];
@@ -1382,8 +1425,8 @@ struct PathQp {
             double* pc = sh + L.stageC() + 3 * t;
             _Pragma("unroll") for (int k = 0; k < 6; ++k) pa[k] = S.a[k];
             _Pragma("unroll") for (int k = 0; k < 3; ++k) pa[6 + k] = S.bT[k];
-            pb[0] = (double)S.flags; pb[1] = S.lo[0]; pb[2] = S.lo[1];
-            pc[0] = S.up[0]; pc[1] = S.up[1]; pc[2] = 0.0;
+            pb[0] = (double)S.flags; pb[1] = lo_of(S, t, 0); pb[2] = lo_of(S, t, 1);
+            pc[0] = up_of(S, t, 0); pc[1] = up_of(S, t, 1); pc[2] = 0.0;
         });
         return ctx.certificate(sh, T, A.prm.front_length, A.prm.rear_length, kap, A.prm.eps_prim_inf, cscale);
     }
@@ -1402,7 +1445,7 @@ struct PathQp {
         ctx.phase([&](int t, Lane& ln) {
             Slot& S = ln.s;
             double Xp[3], aT[3], aI[3];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = (t > 0) ? sh[L.xbuf() + 3 * (t - 1) + k] : 0.0;
+            { const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
             rows_of(S, Xp, S.x, aT, aI);
             const bool real = S.flags & F_REAL;
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
@@ -1490,7 +1533,7 @@ struct PathQp {
         if (op == COLD_BEGIN_PASS) {
             const bool have_warm = (i1 & 1) != 0;
             if (i0 == 0) {
-                load();
+                PQP_SUB(0, load());
                 rho = prm.rho;
                 if (A.warm) {
                     load_warm();
@@ -1501,30 +1544,30 @@ struct PathQp {
                     });
                 }
             }
-            assemble();
-            ruiz(/*reuse=*/(i1 & 2) != 0 && prm.polish_warm_set >= 2);
-            start_transition_rows(have_warm);
+            PQP_SUB(1, assemble());
+            PQP_SUB(2, ruiz(/*reuse=*/(i1 & 2) != 0 && prm.polish_warm_set >= 2));
+            PQP_SUB(3, start_transition_rows(have_warm));
             if (i1 & 2) {      // warm re-solve: go straight to a polish on the active set the previous pass ended with
-                polish_begin(true);
+                PQP_SUB(4, polish_begin(true));
                 polishing_ = true; alpha_ = 1.0;
-                polish_apply_set();
+                PQP_SUB(4, polish_apply_set());
             }
-            factor();
+            PQP_SUB(5, factor());
         } else if (op == COLD_REFACTOR) {
             if (i0 == RF_RESCALE) {
                 rescale_rho(d0);
             } else if (i0 == RF_POLISH_BEGIN) {
-                polish_begin(false);
+                PQP_SUB(4, polish_begin(false));
                 polishing_ = true; alpha_ = 1.0;
-                polish_apply_set();
+                PQP_SUB(4, polish_apply_set());
             } else if (i0 == RF_POLISH_UPDATE) {
-                polish_update_set(d0);
-                polish_apply_set();
+                PQP_SUB(6, polish_update_set(d0));
+                PQP_SUB(4, polish_apply_set());
             } else {   // RF_POLISH_REJECT
-                polish_end(false, d0 != 0.0);
+                PQP_SUB(7, polish_end(false, d0 != 0.0));
                 polishing_ = false; alpha_ = prm.alpha;
             }
-            factor();
+            PQP_SUB(5, factor());
         } else if (op == COLD_CERT) {
             if (CERT) cert_ = primal_infeasible();
         } else if (op == COLD_END_PASS) {
@@ -1733,6 +1776,7 @@ struct PathQp {
 #ifdef PQP_TIMING
                     tacc[7] = ctx.clock() - t_begin;
                     for (int k = 0; k < 8; ++k) f[k] = (double)tacc[k];
+                    for (int k = 0; k < 8; ++k) A.out[(size_t)qp * stride * PQP_OUT_STRIDE + k] = (double)tsub_[k];     // debug build only
 #endif
                 }
             }

@@ -14,7 +14,11 @@ extern "C" void pqp_emu_set_counts(const int32_t* n_of) { g_n_of = n_of; }
 extern "C" void pqp_emu_set_wave_order(int o) { g_wave_order = o; }
 
 namespace {
+#ifndef PQP_EMU_DIET
+#define PQP_EMU_DIET 0
+#endif
 struct HostCtx {
+    static constexpr bool kCstLds = PQP_EMU_DIET != 0, kParkScale = PQP_EMU_DIET != 0;
     int T_;
     std::vector<pqp::Lane> lanes;
     std::vector<double> shm;
@@ -80,6 +84,8 @@ extern "C" int pqp_emu_path_solve(const pqp_params* prm, int batch, int n, const
     a.wx = wx; a.wy = wy; a.wye = wye; a.wrho = wrho;
     std::vector<double> wsave((size_t)batch * T * PQP_SAVE_STRIDE, 0.0);
     a.wsave = wsave.data();
+    std::vector<double> wscale((size_t)batch * T * 12, 0.0);
+    a.wscale = wscale.data();
     a.store_warm = 1;
     a.prm = *prm;
     a.n_of = g_n_of;
@@ -107,6 +113,8 @@ extern "C" int pqp_emu_probe(const pqp_params* prm, int n, const double* ref, co
     a.batch = 1; a.n = n; a.ref = ref; a.bounds = bounds; a.scal = scal; a.prm = *prm;
     std::vector<double> wsave((size_t)T * PQP_SAVE_STRIDE, 0.0);
     a.wsave = wsave.data();
+    std::vector<double> wscale((size_t)T * 12, 0.0);
+    a.wscale = wscale.data();
     HostCtx ctx(T);
     pqp::PathQp<HostCtx> s(ctx, a, 0);
     s.load();
@@ -124,8 +132,8 @@ extern "C" int pqp_emu_probe(const pqp_params* prm, int n, const double* ref, co
         int o = 0;
         for (int k = 0; k < 6; ++k) d[o++] = S.a[k];
         for (int k = 0; k < 3; ++k) d[o++] = S.bT[k];
-        for (int k = 0; k < 3; ++k) d[o++] = s.box_lo(S, k);
-        for (int k = 0; k < 3; ++k) d[o++] = s.box_up(S, k);
+        for (int k = 0; k < 3; ++k) d[o++] = s.box_lo(S, i, k);
+        for (int k = 0; k < 3; ++k) d[o++] = s.box_up(S, i, k);
         for (int k = 0; k < 6; ++k) d[o++] = W.D[k];
         for (int k = 0; k < 6; ++k) d[o++] = W.E[k];
         for (int k = 0; k < 6; ++k) d[o++] = S.sig[k];

@@ -10,7 +10,9 @@ from path_optimizer_2_amd.capi import PqpParams
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "emu", "lane_emu.cpp")
-LIB = os.path.join(HERE, "emu", "liblane_emu.so")
+# PQP_EMU_DIET=1: the emulation of the register-diet contexts (pass constants in the shared-memory array, Ruiz vectors parked)
+DIET = os.environ.get("PQP_EMU_DIET", "0") == "1"
+LIB = os.path.join(HERE, "emu", "liblane_emu_diet.so" if DIET else "liblane_emu.so")
 _DEPS = [SRC, os.path.join(ROOT, "path_optimizer_2_amd", "csrc", "pqp_path_lane.hpp"),
          os.path.join(ROOT, "path_optimizer_2_amd", "csrc", "pqp_defaults.hpp"), os.path.join(ROOT, "include", "pqp.h")]
 _lib = None
@@ -21,7 +23,7 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in _DEPS):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC], check=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", f"-DPQP_EMU_DIET={1 if DIET else 0}", "-o", LIB, SRC], check=True)
     _lib = C.CDLL(LIB)
     return _lib
 

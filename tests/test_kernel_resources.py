@@ -41,7 +41,8 @@ def _find(kernels, *parts):
 @pytest.mark.parametrize("cert", [0, 1])
 def test_path_solve_kernel_keeps_its_lane_state_in_registers(kernels, nw, cert):
     r = _find(kernels, "path_solve_kernel", f"ILi{nw}ELb{cert}E")
-    assert r["ScratchSize"] <= 64, r          # 32 B today: a few SGPR-spill slots; the lane struct would be 1 KB
+    assert r["ScratchSize"] <= 256, r         # 32-128 B today: a few spill slots of the cold code (none in the ADMM loop); the lane
+                                              # struct in scratch would be 1 KB
     assert r["Occupancy"] >= 1
 
 

@@ -13,6 +13,6 @@ def one(spec):
     g.build_hip(defines=[d for d in defs.split(",") if d], out=out)
     return out
 
-with ThreadPoolExecutor(max_workers=4) as ex:
+with ThreadPoolExecutor(max_workers=6) as ex:
     for o in ex.map(one, sys.argv[1:]):
         print("built", o)

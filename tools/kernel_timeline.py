@@ -47,3 +47,6 @@ if __name__ == "__main__":
     for k, nm in enumerate(names):
         print(f"  {nm:36s} mean {t[:, k].mean():8.1f} us   p99 {np.percentile(t[:, k], 99):8.1f}   max {t[:, k].max():8.1f}")
     print(f"  sum of means (0..6) {t[:, :7].sum(1).mean():.1f} us")
+    sub = out.cpu().numpy().reshape(batch, -1)[:, :8] / 100.0      # the timing build writes the cold operations' sub-times over out[qp][0][0..7]
+    for k, nm in enumerate(["load", "assemble", "ruiz", "start_transition_rows", "polish begin / apply set", "factor", "polish update set", "polish end (reject)"]):
+        print(f"    cold: {nm:28s} mean {sub[:, k].mean():8.1f} us   max {sub[:, k].max():8.1f}")
