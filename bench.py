@@ -343,6 +343,7 @@ def main():
                     "frac_admm_iterations_only": abytes_admm / avg_kernel_s / 1e9 / HBM_PEAK_GBS,
                     "achieved_incl_factor_and_scaling": abytes_ext / avg_kernel_s / 1e9,
                     "true_io_bytes_per_launch": true_io, "traffic_over_true_io": (traffic / true_io) if traffic else None,
+                    "fetch_size_kib": pmc.get("FETCH_SIZE") if pmc else None, "write_size_kib": pmc.get("WRITE_SIZE") if pmc else None,
                     "note": "achieved / frac are SURVEY.md 8(d)'s STREAMING MODEL (bytes an HBM-streaming ADMM would move: 1040 N per reduced-KKT "
                             "solve, polish refinement solves included; frac_admm_iterations_only charges ADMM iterations only) divided by the "
                             "measured kernel time - a model, not traffic: the iterates are register/LDS resident and the kernel is bound by fp64 "

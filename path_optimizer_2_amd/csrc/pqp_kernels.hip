@@ -99,7 +99,7 @@ __device__ __noinline__ bool dev_certificate(double* sh, double fl, double rl, d
 // barriers (for a one-wave workgroup the barrier is only a wait on outstanding LDS traffic).
 template <int NW>
 struct RegCtx {
-    static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0;
+    static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0, kSaveLds = NW <= 4;
     Lane lane;
     double* shp;
     __device__ __forceinline__ int T() const { return 64 * NW; }
@@ -154,7 +154,8 @@ __device__ __noinline__ Uni cold_entry(const PathSolveArgs* args, int qp, double
 // workgroup barriers (for a one-wave workgroup the barrier is only a wait on outstanding LDS traffic).
 template <int NW>
 struct DevCtx {
-    static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0;
+    // kSaveLds: up to 256 lanes the polish save area fits beside the exchange buffers (72 KB per QP at T = 128, two QPs per CU)
+    static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0, kSaveLds = NW <= 4;
     Lane lane;
     Lane* mem;
     double* shp;
@@ -799,7 +800,8 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     a.prm = h->prm;
     int nw = 1, lg = 0;
     while (64 * nw < n) { nw *= 2; lg += 1; }           // one waypoint per lane: T = 64 * nw >= n threads per QP
-    const size_t lds = (size_t)pqp::ShLayout{64 * nw}.total() * 8;
+    const bool save_lds = nw <= 4;
+    const size_t lds = (size_t)pqp::ShLayout{64 * nw}.total(save_lds) * 8;
     // two variants of every kernel: with and without OSQP's primal infeasibility certificate (prm.eps_prim_inf > 0)
     const bool cert = h->prm.eps_prim_inf > 0.0;
     const void* fn = nullptr;
@@ -819,9 +821,11 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     }
     const long long resident = (long long)per_cu * h->num_cu;
     const int grid = (int)(batch < resident ? batch : resident);
-    if ((rc = h->wsave.ensure((size_t)grid * 64 * nw * PQP_SAVE_STRIDE * 8))) return rc;
+    if (!save_lds) {          // more than 256 lanes per QP: the save area and the parked Ruiz vectors live in the workgroup slot's global memory
+        if ((rc = h->wsave.ensure((size_t)grid * 64 * nw * PQP_SAVE_STRIDE * 8))) return rc;
+        if ((rc = h->wscale.ensure((size_t)grid * 64 * nw * 12 * 8))) return rc;
+    }
     a.wsave = h->wsave.as<double>();
-    if ((rc = h->wscale.ensure((size_t)grid * 64 * nw * 12 * 8))) return rc;
     a.wscale = h->wscale.as<double>();
     a.store_warm = h->opt_store_warm;
     a.ticket = h->ticket.as<unsigned long long>();

@@ -312,7 +312,9 @@ struct ShLayout {
     // need no exec-mask change and no select (a conditional LDS read costs two scalar instructions around every ds_read)
     PQP_HD int zero() const { return 26 * T + 32 + 128; }
     PQP_HD int cst() const { return 26 * T + 32 + 128 + 24; }
-    PQP_HD int total() const { return 38 * T + 32 + 128 + 24; }
+    // contexts with kSaveLds (T <= 256) keep the polish save area here instead of in global memory: [T][PQP_SAVE_STRIDE]
+    PQP_HD int save() const { return 38 * T + 32 + 128 + 24; }
+    PQP_HD int total(bool save_in_lds = false) const { return (save_in_lds ? 38 + PQP_SAVE_STRIDE : 38) * T + 32 + 128 + 24; }
     // y_k - y_{k-1} of the last iteration, [T][6] (infeasibility certificate): lives in the part of the factor-time buffer
     // the iteration does not use; every iteration rewrites it, and a check never follows a factorisation directly
     PQP_HD int yprev() const { return 12 * T; }
@@ -459,7 +461,8 @@ enum RefactorKind : int { RF_RESCALE = 0 /* d0 = ratio */, RF_POLISH_BEGIN = 1, 
 //   template<int K,F> void reduce_max/sum(double (&out)[K], F f)   f(t, Lane&, double (&v)[K])
 //   void cold(PathQp&, op, i0, i1, d0)    run do_cold() (possibly out of line)
 //   static constexpr bool kCstLds         12 per-waypoint pass constants live in LDS (ShLayout::cst) instead of in Slot fields
-//   static constexpr bool kParkScale      the Ruiz vectors D, E are parked in PathSolveArgs::wscale between the passes
+//   static constexpr bool kParkScale      the Ruiz vectors D, E are parked (LDS or PathSolveArgs::wscale) between the passes
+//   static constexpr bool kSaveLds        the polish save area (and the parked D, E) live in LDS: ShLayout::total(true) doubles
 // =======================================================================================================
 // CERT: compile the primal infeasibility certificate in.  It is a template parameter because its mere presence in the kernel
 // (one more cold operation + six LDS stores per iteration) costs the ADMM iteration 12 % through register allocation;
@@ -496,6 +499,11 @@ struct PathQp {
     PQP_HD static int count_of(const PathSolveArgs& a, int q) { return a.n_of ? (a.n_of[q] < a.n ? a.n_of[q] : a.n) : a.n; }
 
     PQP_HD EndRows* end_rows() const { return reinterpret_cast<EndRows*>(sh + L.end()); }
+    // With n < T the root of the cyclic-reduction tree (tp = T, the last lane) is a padding node, and so is everything between the last
+    // waypoint and it: the couplings across the first padding lane are exact zeros, hence node T/2 hands the root nothing and needs
+    // nothing from it - node T/2 IS the root of the real tree.  For T >= 128 the factorisation and the solves then stop one level
+    // earlier: one cross-wavefront level with its workgroup barrier less per solve (two barriers instead of four at T = 128).
+    PQP_HD bool root_is_padding() const { return T >= 128 && n < T; }
     // row `other` of an exchange buffer, or the zero block when that neighbour does not exist
     PQP_HD const double* nb(bool ok, int base, int stride, int other) const { return sh + (ok ? base + stride * other : L.zero()); }
 
@@ -630,10 +638,11 @@ struct PathQp {
         // of in 24 registers of the ADMM loop
         if constexpr (Ctx::kParkScale) {
             ctx.phase([&](int t, Lane& ln) {
-                double* w = A.wscale + ((size_t)slot * T + t) * 12;
-                if (!reuse) { _Pragma("unroll") for (int k = 0; k < 6; ++k) { w[k] = ln.w.D[k]; w[6 + k] = ln.w.E[k]; } }
+                double* w = scale_slot(t);
+                const int ws = scale_stride();
+                if (!reuse) { _Pragma("unroll") for (int k = 0; k < 6; ++k) { w[k * ws] = ln.w.D[k]; w[(6 + k) * ws] = ln.w.E[k]; } }
                 double d[6], e[6];
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) { d[k] = reuse ? w[k] : ln.w.D[k]; e[k] = reuse ? w[6 + k] : ln.w.E[k]; }
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) { d[k] = reuse ? w[k * ws] : ln.w.D[k]; e[k] = reuse ? w[(6 + k) * ws] : ln.w.E[k]; }
                 _Pragma("unroll") for (int k = 0; k < 6; ++k) { ln.w.D[k] = d[k]; ln.w.E[k] = e[k]; }
             });
         }
@@ -793,7 +802,17 @@ struct PathQp {
     static constexpr int kSaveStride = PQP_SAVE_STRIDE;   // x6 yT3 yI3 zI3 rhoI3 (+2 pad) | best polished point: x6 yT3 yI3
     static constexpr int kPolishRounds = 40; // active-set correction rounds per polish attempt
 
-    PQP_HD double* save_slot(int t) const { return A.wsave + ((size_t)slot * T + t) * kSaveStride; }
+    PQP_HD double* save_slot(int t) const {
+        if constexpr (Ctx::kSaveLds) return sh + L.save() + t * kSaveStride;
+        else return A.wsave + ((size_t)slot * T + t) * kSaveStride;
+    }
+    // parked Ruiz vectors of lane t, D(6) E(6): element k at scale_slot(t)[k * scale_stride()] - the (otherwise unused) constants region
+    // of the LDS layout, one array per element, or the workgroup slot's global memory
+    PQP_HD double* scale_slot(int t) const {
+        if constexpr (Ctx::kSaveLds && !Ctx::kCstLds) return sh + L.cst() + t;
+        else return A.wscale + ((size_t)slot * T + t) * 12;
+    }
+    PQP_HD int scale_stride() const { return (Ctx::kSaveLds && !Ctx::kCstLds) ? T : 1; }
 
     // how badly inequality row k fails the KKT test at the polished point: violation of its true box when it is
     // treated as inactive, wrong-signed multiplier when it is treated as active (0 for rows that do not exist)
@@ -1119,7 +1138,9 @@ struct PathQp {
         // thread).  With this numbering the only node of a wavefront that talks to the next wavefront during the levels
         // h < 64 is its LAST lane (tp = 64m), and that node only RECEIVES until its own elimination at a level >= 64 — which
         // is what lets iterate() run the 6 in-wave levels without workgroup barriers.
-        _Pragma("nounroll") for (int h = 1; h <= T; h <<= 1) {
+        // (root_is_padding(): the tree ends one level earlier, see iterate())
+        const int h_last = root_is_padding() ? (T >> 1) : T;
+        _Pragma("nounroll") for (int h = 1; h <= h_last; h <<= 1) {
             ctx.phase([&](int t, Lane& ln) {
                 Slot& S = ln.s;
                 SlotSetup& W = ln.w;
@@ -1236,7 +1257,10 @@ struct PathQp {
             });
         }
         ctx.phase([&](int, Lane&) {});      // the one barrier between the in-wave levels and the cross-wave part
+        const bool short_tree = root_is_padding();
         for (int h = hw; h <= T; h <<= 1) {
+            if (short_tree && h == T) break;
+            const bool root_here = h == T || (short_tree && h == (T >> 1));       // (h is a compile-time value once the loop is unrolled)
             ctx.phase([&](int t, Lane& ln) {
                 Slot& S = ln.s;
                 const int tp = t + 1;
@@ -1258,7 +1282,7 @@ struct PathQp {
                 } else if (t + 1 < T && !edge) {     // T == 1 only
                     _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += sh[L.bufG() + 3 * (t + 1) + k];
                 }
-                if (h < T) {
+                if (!root_here) {
                     if ((tp & (2 * h - 1)) == h) {
                         double p[3];
                         mat3_vec(S.GL, S.r, p);
@@ -1269,14 +1293,17 @@ struct PathQp {
                 } else {
                     double x3[3];
                     sym3_vec(S.Dinv, S.r, x3);
-                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.xt[k] = x3[k];      // only the root's value survives
-                    if (tp == T) { _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xbuf() + 3 * t + k] = x3[k]; }
+                    // only the root's value survives (every other node is overwritten at its backward level); with the short tree the
+                    // padding root tp = T has no backward level and no factor: its x~ is 0
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.xt[k] = (h != T && tp == T) ? 0.0 : x3[k];
+                    if (tp == h) { _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xbuf() + 3 * t + k] = x3[k]; }
                 }
             });
         }
         // Backward pass: cross-wave levels with barriers, then the in-wave levels wave-locally (what they read from another
         // wavefront - the x of its last lane - was written before the last barrier).
         for (int h = T >> 1; h >= 1; h >>= 1) {
+            if (short_tree && h == (T >> 1)) continue;          // that node was the root
             auto body = [&](int t, Lane& ln) {
                 Slot& S = ln.s;
                 const int tp = t + 1;

@@ -18,11 +18,13 @@ namespace {
 #define PQP_EMU_DIET 0
 #endif
 struct HostCtx {
-    static constexpr bool kCstLds = PQP_EMU_DIET != 0, kParkScale = PQP_EMU_DIET != 0;
+    // default: the device contexts' setting (Ruiz vectors parked, save area in the shared array up to 256 lanes); PQP_EMU_DIET: pass
+    // constants in the shared array too, everything parked in global memory
+    static constexpr bool kCstLds = PQP_EMU_DIET != 0, kParkScale = true, kSaveLds = PQP_EMU_DIET == 0;
     int T_;
     std::vector<pqp::Lane> lanes;
     std::vector<double> shm;
-    explicit HostCtx(int T) : T_(T), lanes(T), shm(pqp::ShLayout{T}.total(), 0.0) {}
+    explicit HostCtx(int T) : T_(T), lanes(T), shm(pqp::ShLayout{T}.total(true), 0.0) {}
     int T() const { return T_; }
     double* sh() { return shm.data(); }
     template <class F> void phase(F f) { for (int t = 0; t < T_; ++t) f(t, lanes[t]); }
