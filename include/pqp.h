@@ -141,7 +141,11 @@ typedef struct pqp_params {
                                          residual test and the gap between polish attempts has doubled k times without an accepted
                                          polish, the ADMM point is returned as PQP_STATUS_SOLVED without polish - OSQP's behaviour when
                                          its polish fails (info[4] counts the polished passes).  With polish_every = 0: at once. */
-    int32_t reserved0;                /* padding, 0 */
+    int32_t prim_inf_after;           /* 0: OSQP's certificate on y_k - y_{k-1} at every termination check (the kernel variant with the
+                                         certificate in its loop, ~12 % slower iterations).  k > 0: the lean kernel; from iteration k on every
+                                         termination check that neither converged nor started a polish evaluates the SAME certificate on
+                                         dy = y_now - y_at_the_previous_such_check (any dy that passes it proves infeasibility): nothing in
+                                         the ADMM loop, an infeasible QP stops about two checks after iteration k */
     /* smoother QP weights (src/config/planning_flags.cpp:51-61) */
     double tension2_deviation_weight;        /* 0.005 */
     double tension2_curvature_weight;        /* 1     */

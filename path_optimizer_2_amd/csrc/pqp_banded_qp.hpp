@@ -565,7 +565,9 @@ struct BandedQp {
         double eps_scale = 1.0;
         int polish_gap = prm.polish_every, next_polish = prm.polish_every;
         for (it = 1; it <= prm.max_iter; ++it) {
-            if (prm.eps_prim_inf > 0.0 && prm.check_termination > 0 && (it % prm.check_termination) == 0)
+            // (prim_inf_after > 0: the certificate only from that iteration on - the production setting's feasible QPs never get there)
+            const bool cert_now = prm.eps_prim_inf > 0.0 && it >= prm.prim_inf_after;
+            if (cert_now && prm.check_termination > 0 && (it % prm.check_termination) == 0)
                 rows([&](int r) { sh[L.yp() + r] = sh[L.y() + r]; });
             iterate();
             const bool check = prm.check_termination > 0 && (it % prm.check_termination) == 0;
@@ -581,7 +583,7 @@ struct BandedQp {
                 if (converged) {
                     if (!prm.polish || eps_scale * fmax(prm.eps_abs, prm.eps_rel) < 1e-10) { status = PQP_STATUS_SOLVED; break; }
                     start_polish = true;
-                } else if (prm.eps_prim_inf > 0.0 && it > 1 && primal_infeasible()) {
+                } else if (cert_now && it > 1 && primal_infeasible()) {
                     status = PQP_STATUS_PRIMAL_INFEASIBLE; break;
                 } else if (prm.polish && prm.polish_every > 0 && it >= next_polish) {
                     start_polish = true;

@@ -41,7 +41,7 @@ inline void default_params(pqp_params* p) {
     p->polish_reseed_factor = 1.0;
     p->eps_prim_inf = 1e-4;
     p->polish_patience = 0;
-    p->reserved0 = 0;
+    p->prim_inf_after = 0;                          // OSQP: the certificate at every check
     p->polish_delta = 1e-6;
     p->polish_tol = 1e-7;
     p->tension2_deviation_weight = 0.005;           // planning_flags.cpp:57
@@ -55,8 +55,8 @@ inline void default_params(pqp_params* p) {
 // The engine's production setting on top of the defaults: ADMM to 1e-4, KKT-verified polish (a returned path is the exact
 // optimum of its QP), residual check / rho adaptation / polish attempt every 15 iterations, 2 refinement solves per active-set
 // round, at most max(24, n/5 - 8) rounds per attempt, pass 2 starts from pass 1's active set and equilibration, an attempt that
-// gives up re-seeds ADMM with its best point, a QP whose polish cannot be verified ends like OSQP's (ADMM point, unpolished), no
-// infeasibility certificate (set eps_prim_inf = 1e-4 to get OSQP's behaviour back).  Tuned on MI355X (DESIGN.md sections 2, 5);
+// gives up re-seeds ADMM with its best point, a QP whose polish cannot be verified ends like OSQP's (ADMM point, unpolished), the
+// infeasibility certificate evaluated outside the ADMM loop from iteration 100 on (prim_inf_after = 0 gives OSQP's every-check test back).  Tuned on MI355X (DESIGN.md sections 2, 5);
 // bench.py, smoke() and the parity tests run this setting.
 inline void production_params(pqp_params* p) {
     default_params(p);
@@ -75,7 +75,9 @@ inline void production_params(pqp_params* p) {
                                                     // infeasible one, which this setting cannot certify, then holds its batch up for 4 ms, not 15
     p->polish_patience = 5;                         // a QP whose polish cannot be verified (e.g. infeasible by 1e-5) ends like OSQP's,
                                                     // after attempts at 15, 45, 105, 225, 465 iterations
-    p->eps_prim_inf = 0.0;                          // the kernel variant without OSQP's infeasibility certificate: 12 % faster
-                                                    // iterations; an infeasible QP then ends with PQP_STATUS_MAX_ITER
+    p->prim_inf_after = 100;                        // the lean kernel (no certificate work inside the ADMM loop: 12 % faster iterations); from
+                                                    // iteration 100 on the certificate is evaluated between checks on y_now - y_previous_check,
+                                                    // so an infeasible QP ends PRIMAL_INFEASIBLE after ~130 iterations instead of holding its
+                                                    // batch up until max_iter (every feasible QP of the sweeps is long done by then)
 }
 }  // namespace pqp

@@ -95,6 +95,13 @@ __device__ __noinline__ bool dev_certificate(double* sh, double fl, double rl, d
 #define PQP_PARK_SCALE 1       // measured: +2 % (profiles/r02b_variants.txt); PQP_CST_LDS: no gain at one wave per SIMD
 #endif
 
+template <int NW>
+__device__ __noinline__ bool dev_late_certificate(double* sh, int t, double* snap, bool have, LateCertIn in, double fl, double rl, double kap, double eps,
+                                                  double cscale) {
+    LaneLessCtx<NW> c{sh};
+    return late_certificate(c, sh, 64 * NW, t, snap, have, in, fl, rl, kap, eps, cscale);
+}
+
 // Context whose lane state is a local struct (SROA -> registers).  A phase is the code between two workgroup
 // barriers (for a one-wave workgroup the barrier is only a wait on outstanding LDS traffic).
 template <int NW>
@@ -112,6 +119,10 @@ struct RegCtx {
     __device__ __forceinline__ long long clock() const { return (long long)wall_clock64(); }     // 100 MHz
     __device__ __forceinline__ bool certificate(double* sh, int, double fl, double rl, double kap, double eps, double cscale) {
         return dev_certificate<NW>(sh, fl, rl, kap, eps, cscale);
+    }
+    __device__ __forceinline__ bool late_certificate(double* sh, int t, double* snap, bool have, const LateCertIn& in, double fl, double rl, double kap,
+                                                     double eps, double cscale) {
+        return dev_late_certificate<NW>(sh, t, snap, have, in, fl, rl, kap, eps, cscale);
     }
     // wave-local phase: LDS operations of one wavefront execute in program order, so lanes of the same wavefront see each
     // other's writes without a workgroup barrier; the fence only stops the compiler from moving LDS accesses across it
@@ -163,6 +174,10 @@ struct DevCtx {
     __device__ __forceinline__ long long clock() const { return (long long)wall_clock64(); }     // 100 MHz
     __device__ __forceinline__ bool certificate(double* sh, int, double fl, double rl, double kap, double eps, double cscale) {
         return dev_certificate<NW>(sh, fl, rl, kap, eps, cscale);
+    }
+    __device__ __forceinline__ bool late_certificate(double* sh, int t, double* snap, bool have, const LateCertIn& in, double fl, double rl, double kap,
+                                                     double eps, double cscale) {
+        return dev_late_certificate<NW>(sh, t, snap, have, in, fl, rl, kap, eps, cscale);
     }
     __device__ __forceinline__ int T() const { return 64 * NW; }
     __device__ __forceinline__ double* sh() { return shp; }
@@ -533,7 +548,12 @@ struct DevBuf {
         p = nullptr; bytes = 0;
         PQP_HIP(hipMalloc(&p, need));
         bytes = need;
-        PQP_HIP(hipMemset(p, 0, need));        // no call ever reads uninitialised device memory (warm state of skipped QPs, info rows)
+        // No call ever reads uninitialised device memory (warm state of skipped QPs, info rows).  hipMemset runs on the NULL stream and
+        // may return before the fill has executed; the handles' streams are non-blocking, i.e. NOT ordered behind the NULL stream, so a
+        // fill still queued there could land on the buffer milliseconds later, after kernels of the handle have written it (seen: a
+        // whole smoother batch solved on zeroed problem data).  Allocation is rare: wait for the fill.
+        PQP_HIP(hipMemset(p, 0, need));
+        PQP_HIP(hipStreamSynchronize(nullptr));
         return PQP_OK;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
@@ -803,7 +823,7 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     const bool save_lds = nw <= 4;
     const size_t lds = (size_t)pqp::ShLayout{64 * nw}.total(save_lds) * 8;
     // two variants of every kernel: with and without OSQP's primal infeasibility certificate (prm.eps_prim_inf > 0)
-    const bool cert = h->prm.eps_prim_inf > 0.0;
+    const bool cert = h->prm.eps_prim_inf > 0.0 && h->prm.prim_inf_after <= 0;
     const void* fn = nullptr;
     switch (nw) {
         case 1: fn = cert ? (const void*)pqp::path_solve_kernel<1, true> : (const void*)pqp::path_solve_kernel<1, false>; break;
@@ -823,7 +843,7 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     const int grid = (int)(batch < resident ? batch : resident);
     if (!save_lds) {          // more than 256 lanes per QP: the save area and the parked Ruiz vectors live in the workgroup slot's global memory
         if ((rc = h->wsave.ensure((size_t)grid * 64 * nw * PQP_SAVE_STRIDE * 8))) return rc;
-        if ((rc = h->wscale.ensure((size_t)grid * 64 * nw * 12 * 8))) return rc;
+        if ((rc = h->wscale.ensure((size_t)grid * 64 * nw * 18 * 8))) return rc;
     }
     a.wsave = h->wsave.as<double>();
     a.wscale = h->wscale.as<double>();

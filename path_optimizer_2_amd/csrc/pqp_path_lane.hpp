@@ -75,7 +75,7 @@ struct PathSolveArgs {
     double* wy;             // [batch][n][6]  (yT[3], yK, yF, yR)
     double* wye;            // [batch][2]
     double* wrho;           // [batch]
-    double* wscale;         // [slots][T][12] Ruiz D(6), E(6) parked between the passes of a QP (contexts with kParkScale)
+    double* wscale;         // [slots][T][18] contexts without kSaveLds: Ruiz D(6), E(6) parked between the passes of a QP, dual snapshot(6)
     double* wsave;          // [slots][T][kSaveStride] save area of the workgroup slot that runs the QP: the ADMM state while a
                             // polish is tried + the best polished point.  Per SLOT, not per QP: the few MB stay in L2
     int store_warm;         // 0: the final iterate is not written to wx / wy / wye (nobody will ask for it)
@@ -287,7 +287,8 @@ struct EndRows {
     double sz[2], sy[2];    // ADMM state parked while a polish is tried
     double by[2];           // multipliers of the best polished point of the current attempt
     double yp[2];           // y_k - y_{k-1} of the last iteration (infeasibility certificate)
-    double pad[6];
+    double pad[6];          // [0..1] polish: violations of the end rows published for the local-maximum rule; [2..3] end-row duals at the
+                            // previous late infeasibility check
 };
 
 // shared-memory layout in doubles, T = threads per QP = padded number of waypoints.  The per-iteration exchange
@@ -314,7 +315,9 @@ struct ShLayout {
     PQP_HD int cst() const { return 26 * T + 32 + 128 + 24; }
     // contexts with kSaveLds (T <= 256) keep the polish save area here instead of in global memory: [T][PQP_SAVE_STRIDE]
     PQP_HD int save() const { return 38 * T + 32 + 128 + 24; }
-    PQP_HD int total(bool save_in_lds = false) const { return (save_in_lds ? 38 + PQP_SAVE_STRIDE : 38) * T + 32 + 128 + 24; }
+    // ... and the dual iterate of the previous late infeasibility check, [T][6] (prim_inf_after)
+    PQP_HD int ysnap() const { return (38 + PQP_SAVE_STRIDE) * T + 32 + 128 + 24; }
+    PQP_HD int total(bool save_in_lds = false) const { return (save_in_lds ? 44 + PQP_SAVE_STRIDE : 38) * T + 32 + 128 + 24; }
     // y_k - y_{k-1} of the last iteration, [T][6] (infeasibility certificate): lives in the part of the factor-time buffer
     // the iteration does not use; every iteration rewrites it, and a check never follows a factorisation directly
     PQP_HD int yprev() const { return 12 * T; }
@@ -421,6 +424,34 @@ PQP_HD bool primal_certificate(LC& c, double* sh, int T, double front_length, do
     return cscale * nm[0] > eps && lhs[0] < -eps * nm[0] && nm[1] < eps * nm[0];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The late form of the certificate (pqp_params::prim_inf_after): dy = y_now - y_at_the_previous_late_check.  One call per lane with
+// the lane's values by value; LC as for primal_certificate.  Writes dy and the staged pass constants to LDS, refreshes the snapshot,
+// evaluates the test (when a snapshot of this pass existed).
+// ---------------------------------------------------------------------------------------------------------
+struct LateCertIn {
+    double y[6], a[6], b[3], lo0, lo1, up0, up1;
+    int flags;
+};
+template <class LC>
+PQP_HD bool late_certificate(LC& c, double* sh, int T, int t, double* snap, bool have, const LateCertIn& in, double front_length, double rear_length,
+                             double kap, double eps, double cscale) {
+    const ShLayout L{T};
+    EndRows* er = reinterpret_cast<EndRows*>(sh + L.end());
+    double* dyp = sh + L.yprev() + 6 * t;
+    double* pa = sh + L.stageA() + 9 * t;
+    double* pb = sh + L.stageB() + 3 * t;
+    double* pc = sh + L.stageC() + 3 * t;
+    for (int k = 0; k < 6; ++k) { dyp[k] = in.y[k] - snap[k]; snap[k] = in.y[k]; pa[k] = in.a[k]; }
+    for (int k = 0; k < 3; ++k) pa[6 + k] = in.b[k];
+    pb[0] = (double)in.flags; pb[1] = in.lo0; pb[2] = in.lo1;
+    pc[0] = in.up0; pc[1] = in.up1; pc[2] = 0.0;
+    if (in.flags & F_LAST)
+        for (int k = 0; k < 2; ++k) { er->yp[k] = er->y[k] - er->pad[2 + k]; er->pad[2 + k] = er->y[k]; }
+    c.phase([](int) {});          // every lane has staged its values
+    return have ? primal_certificate(c, sh, T, front_length, rear_length, kap, eps, cscale) : false;
+}
+
 // What a QP cost (about microseconds: 4 per reduced-KKT solve, 13 per factorisation), binned for the next launch's
 // most-expensive-first order: key = bin << 24 | rank of the QP within its bin (the order in which the QPs of a bin finished)
 PQP_HD void record_cost(const PathSolveArgs& a, int qp, int cost) {
@@ -482,6 +513,7 @@ struct PathQp {
     double rho, cscale, kap, alpha_;
     bool polishing_;
     bool cert_;               // result of the last COLD_CERT
+    bool snap_valid_;         // late certificate: a dual snapshot of this pass exists
     int kkt_solves_;          // iterate() executions: ADMM iterations + polish refinement solves
     int factors_;             // factor() executions
 #ifdef PQP_TIMING
@@ -492,7 +524,7 @@ struct PathQp {
 #endif
 
     PQP_HD PathQp(Ctx& c, const PathSolveArgs& a, int q, int slot_ = -1)
-        : ctx(c), A(a), qp(q), slot(slot_ < 0 ? q : slot_), stride(a.n), n(count_of(a, q)), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false), cert_(false), kkt_solves_(0), factors_(0) {}
+        : ctx(c), A(a), qp(q), slot(slot_ < 0 ? q : slot_), stride(a.n), n(count_of(a, q)), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false), cert_(false), snap_valid_(false), kkt_solves_(0), factors_(0) {}
 
     // waypoints of QP q; fewer than 2: nothing to optimise (a road blocked at the first waypoints; the reference does not get
     // this far) - the caller skips the QP with status PQP_STATUS_UNSOLVED instead of constructing a solver
@@ -810,7 +842,7 @@ struct PathQp {
     // of the LDS layout, one array per element, or the workgroup slot's global memory
     PQP_HD double* scale_slot(int t) const {
         if constexpr (Ctx::kSaveLds && !Ctx::kCstLds) return sh + L.cst() + t;
-        else return A.wscale + ((size_t)slot * T + t) * 12;
+        else return A.wscale + ((size_t)slot * T + t) * 18;
     }
     PQP_HD int scale_stride() const { return (Ctx::kSaveLds && !Ctx::kCstLds) ? T : 1; }
 
@@ -1444,6 +1476,29 @@ struct PathQp {
     // The certificate itself is evaluated by primal_certificate() below from LDS only: the lanes first stage the pass
     // constants it needs.  Keeping the lane struct out of that code (on the device it is an out-of-line function) keeps its
     // register needs out of the ADMM loop - inline, it cost the loop 100 spilled VGPRs and 40 % of its speed.
+    // The late form (prim_inf_after, lean kernel): dy = y_now - y_at_the_previous_late_check instead of y_k - y_{k-1}.  The test itself
+    // is a Farkas certificate - whatever dy passes it proves the QP infeasible to the tolerance - so it needs no consecutive
+    // iterates, and nothing has to be stored inside the ADMM loop.  The first call of a pass only takes the snapshot.
+    PQP_HD double* snap_slot(int t) const {
+        if constexpr (Ctx::kSaveLds) return sh + L.ysnap() + 6 * t;
+        else return A.wscale + ((size_t)slot * T + t) * 18 + 12;
+    }
+    PQP_HD bool primal_infeasible_late() {
+        const bool have = snap_valid_;
+        snap_valid_ = true;
+        // (everything happens in the context's function - out of line on the device - from values handed over by value: the lane struct
+        // never has its address taken, and the register needs of the test stay out of this kernel's allocation)
+        bool res = false;
+        ctx.phase([&](int t, Lane& ln) {
+            const Slot& S = ln.s;
+            LateCertIn in;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { in.y[k] = S.yT[k]; in.y[3 + k] = S.yI[k]; in.b[k] = S.bT[k]; }
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) in.a[k] = S.a[k];
+            in.flags = S.flags; in.lo0 = lo_of(S, t, 0); in.lo1 = lo_of(S, t, 1); in.up0 = up_of(S, t, 0); in.up1 = up_of(S, t, 1);
+            res = ctx.late_certificate(sh, t, snap_slot(t), have, in, A.prm.front_length, A.prm.rear_length, kap, A.prm.eps_prim_inf, cscale);
+        });
+        return res;
+    }
     PQP_HD bool primal_infeasible() {
         ctx.phase([&](int t, Lane& ln) {
             const Slot& S = ln.s;
@@ -1550,8 +1605,8 @@ struct PathQp {
         });
     }
 
-    PQP_HD Uni get_uni() const { return Uni{rho, cscale, kap, alpha_, kkt_solves_, factors_, polishing_ ? 1 : 0, cert_ ? 1 : 0}; }
-    PQP_HD void set_uni(const Uni& u) { rho = u.rho; cscale = u.cscale; kap = u.kap; alpha_ = u.alpha; kkt_solves_ = u.kkt_solves; factors_ = u.factors; polishing_ = u.polishing != 0; cert_ = u.cert != 0; }
+    PQP_HD Uni get_uni() const { return Uni{rho, cscale, kap, alpha_, kkt_solves_, factors_, polishing_ ? 1 : 0, (cert_ ? 1 : 0) | (snap_valid_ ? 2 : 0)}; }
+    PQP_HD void set_uni(const Uni& u) { rho = u.rho; cscale = u.cscale; kap = u.kap; alpha_ = u.alpha; kkt_solves_ = u.kkt_solves; factors_ = u.factors; polishing_ = u.polishing != 0; cert_ = (u.cert & 1) != 0; snap_valid_ = (u.cert & 2) != 0; }
 
     // The cold side of the solver.  On the device this runs inside a __noinline__ function on a copy of the lane
     // state that lives in memory (DevCtx::cold), so its register needs never leak into the ADMM loop.
@@ -1597,6 +1652,7 @@ struct PathQp {
             PQP_SUB(5, factor());
         } else if (op == COLD_CERT) {
             if (CERT) cert_ = primal_infeasible();
+            else cert_ = primal_infeasible_late();
         } else if (op == COLD_END_PASS) {
             if (i0) {
                 polish_end(true);
@@ -1649,7 +1705,7 @@ struct PathQp {
                 PQP_TOC(op == COLD_BEGIN_PASS ? 0 : op == COLD_REFACTOR ? (i0 == RF_RESCALE ? 1 : 2) : op == COLD_CERT ? 5 : 3);
             }
             if (op == COLD_FINISH) break;
-            if (CERT && op == COLD_CERT && cert_) { status = PQP_STATUS_PRIMAL_INFEASIBLE; op = COLD_END_PASS; i0 = 0; continue; }
+            if (op == COLD_CERT && cert_) { status = PQP_STATUS_PRIMAL_INFEASIBLE; op = COLD_END_PASS; i0 = 0; continue; }
             if (op == COLD_END_PASS) {
                 last_iters = it;
                 total_iters += it;
@@ -1661,6 +1717,7 @@ struct PathQp {
             }
             if (op == COLD_BEGIN_PASS) {
                 status = PQP_STATUS_MAX_ITER;
+                snap_valid_ = false;
                 polish_mode = false; conservative = false; end_after_reject = false;
                 eps_scale = 1.0; best = 1e300;
                 it = 0; refine_left = 0; round = 0; stall = 0;
@@ -1743,6 +1800,8 @@ struct PathQp {
                     // not converged, nothing else due at this check: is the problem infeasible?  (a cold operation: evaluated
                     // inside this loop the test costs the ADMM iteration 14 % through register pressure alone)
                     if (CERT && check && prm.eps_prim_inf > 0.0 && it > 1) { op = COLD_CERT; break; }
+                    // the lean kernel: the same certificate between two late checks (see primal_infeasible_late)
+                    if (!CERT && check && prm.prim_inf_after > 0 && prm.eps_prim_inf > 0.0 && it >= prm.prim_inf_after) { op = COLD_CERT; break; }
                 } else {
                     // KKT acceptance test of the polished point (OSQP paper 4.2 + verification)
                     const double tol = prm.polish_tol;

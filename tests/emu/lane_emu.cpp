@@ -1,13 +1,26 @@
 // lane_emu.cpp — TEST INFRASTRUCTURE: runs the device algorithm source (pqp_path_lane.hpp) on the host,
 // phase by phase, lane by lane, so the algorithm can be checked against the oracle without a GPU.
 // Built only by tests/ (tests/test_lane_emulation.py); never linked into libpqp_hip.so, never timed.
+#include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <vector>
 
 #include "../../path_optimizer_2_amd/csrc/pqp_path_lane.hpp"
 #include "../../path_optimizer_2_amd/csrc/pqp_defaults.hpp"
 #include "../../path_optimizer_2_amd/csrc/pqp_banded_qp.hpp"
 
+// PQP_EMU_POISON=1 in the environment: shared arrays and lane registers start as NaN instead of zero, so that anything the algorithm
+// reads before it wrote it (LDS and registers are NOT cleared between the QPs of a persistent workgroup) shows up in the results
+static double poison_value() {
+    static const bool on = std::getenv("PQP_EMU_POISON") && std::getenv("PQP_EMU_POISON")[0] == '1';
+    return on ? std::numeric_limits<double>::quiet_NaN() : 0.0;
+}
+template <class LaneT>
+static void poison_lanes(std::vector<LaneT>& lanes) {
+    if (poison_value() == 0.0) return;
+    for (auto& l : lanes) std::memset(static_cast<void*>(&l), 0xff, sizeof(LaneT));      // all-ones doubles are NaN, ints are -1
+}
 static int g_wave_order = 1;
 static const int32_t* g_n_of = nullptr;      // per-QP waypoint counts of the next pqp_emu_path_solve call (nullptr: all n)
 extern "C" void pqp_emu_set_counts(const int32_t* n_of) { g_n_of = n_of; }
@@ -24,7 +37,7 @@ struct HostCtx {
     int T_;
     std::vector<pqp::Lane> lanes;
     std::vector<double> shm;
-    explicit HostCtx(int T) : T_(T), lanes(T), shm(pqp::ShLayout{T}.total(true), 0.0) {}
+    explicit HostCtx(int T) : T_(T), lanes(T), shm(pqp::ShLayout{T}.total(true), poison_value()) { poison_lanes(lanes); }
     int T() const { return T_; }
     double* sh() { return shm.data(); }
     template <class F> void phase(F f) { for (int t = 0; t < T_; ++t) f(t, lanes[t]); }
@@ -58,6 +71,23 @@ struct HostCtx {
         LaneLess c{T};
         return pqp::primal_certificate(c, sh, T, fl, rl, kap, eps, cscale);
     }
+    // The device calls this once per lane and the lanes meet at the barrier inside; lane by lane on the host: every lane stages its
+    // values (the phase inside is then a no-op), the LAST lane's call evaluates the test on the complete data
+    struct StageOnly {
+        int T_;
+        int T() const { return T_; }
+        template <class F> void phase(F) {}
+        template <int K, class F> void reduce_max(double (&out)[K], F) { for (int k = 0; k < K; ++k) out[k] = 0.0; }
+        template <int K, class F> void reduce_sum(double (&out)[K], F) { for (int k = 0; k < K; ++k) out[k] = 0.0; }
+    };
+    bool late_certificate(double* sh, int t, double* snap, bool have, const pqp::LateCertIn& in, double fl, double rl, double kap, double eps,
+                          double cscale) {
+        StageOnly st{T_};
+        (void)pqp::late_certificate(st, sh, T_, t, snap, false, in, fl, rl, kap, eps, cscale);
+        if (t != T_ - 1 || !have) return false;
+        LaneLess c{T_};
+        return pqp::primal_certificate(c, sh, T_, fl, rl, kap, eps, cscale);
+    }
     template <int K, class F> void reduce_max(double (&out)[K], F f) {
         for (int k = 0; k < K; ++k) out[k] = 0.0;
         for (int t = 0; t < T_; ++t) { double v[K]; f(t, lanes[t], v); for (int k = 0; k < K; ++k) out[k] = out[k] > v[k] ? out[k] : v[k]; }
@@ -86,7 +116,7 @@ extern "C" int pqp_emu_path_solve(const pqp_params* prm, int batch, int n, const
     a.wx = wx; a.wy = wy; a.wye = wye; a.wrho = wrho;
     std::vector<double> wsave((size_t)batch * T * PQP_SAVE_STRIDE, 0.0);
     a.wsave = wsave.data();
-    std::vector<double> wscale((size_t)batch * T * 12, 0.0);
+    std::vector<double> wscale((size_t)batch * T * 18, 0.0);
     a.wscale = wscale.data();
     a.store_warm = 1;
     a.prm = *prm;
@@ -98,7 +128,7 @@ extern "C" int pqp_emu_path_solve(const pqp_params* prm, int batch, int n, const
             continue;
         }
         HostCtx ctx(T);
-        if (prm->eps_prim_inf > 0.0) { pqp::PathQp<HostCtx, true> s(ctx, a, q); s.run(); }       // the two variants the launcher picks from
+        if (prm->eps_prim_inf > 0.0 && prm->prim_inf_after <= 0) { pqp::PathQp<HostCtx, true> s(ctx, a, q); s.run(); }       // the two variants the launcher picks from
         else { pqp::PathQp<HostCtx, false> s(ctx, a, q); s.run(); }
     }
     return 0;
@@ -115,7 +145,7 @@ extern "C" int pqp_emu_probe(const pqp_params* prm, int n, const double* ref, co
     a.batch = 1; a.n = n; a.ref = ref; a.bounds = bounds; a.scal = scal; a.prm = *prm;
     std::vector<double> wsave((size_t)T * PQP_SAVE_STRIDE, 0.0);
     a.wsave = wsave.data();
-    std::vector<double> wscale((size_t)T * 12, 0.0);
+    std::vector<double> wscale((size_t)T * 18, 0.0);
     a.wscale = wscale.data();
     HostCtx ctx(T);
     pqp::PathQp<HostCtx> s(ctx, a, 0);
@@ -155,7 +185,7 @@ struct BqHostCtx {
     int T_;
     std::vector<double> shm;
     std::vector<pqp::BqLane<B>> lanes;
-    BqHostCtx(int T, int doubles) : T_(T), shm(doubles, 0.0), lanes(T) {}
+    BqHostCtx(int T, int doubles) : T_(T), shm(doubles, poison_value()), lanes(T) { poison_lanes(lanes); }
     int T() const { return T_; }
     double* sh() { return shm.data(); }
     template <class F> void phase(F f) { for (int t = 0; t < T_; ++t) f(t, lanes[t]); }

@@ -252,7 +252,7 @@ def test_error_paths(hip_lib):
 def test_primal_infeasibility_certificate_on_the_gpu(hip_lib):
     """OSQP's certificate (kernel variant with eps_prim_inf > 0, the default parameters): a start curvature outside the
     curvature box ends with PQP_STATUS_PRIMAL_INFEASIBLE at the same termination check as the restatement; the production
-    variant (no certificate) runs the same QP to max_iter; feasible neighbours are not affected."""
+    setting ends it after ~130 iterations through the late form of the certificate; feasible neighbours are not affected."""
     b = make_batch(4, 80)
     b["scal"][2, 2] = 0.5
     h = capi.Handle(capi.default_params(hip_lib), max_batch=4, max_n=80)
@@ -261,10 +261,17 @@ def test_primal_infeasibility_certificate_on_the_gpu(hip_lib):
     ref = O.solve_path(b["ref"][2], b["bounds"][2], b["scal"][2])
     assert [x["status"] for x in ref] == ["primal_infeasible"] and r["iters"][2] == ref[0]["iters"]
     h.close()
-    h2 = capi.Handle(capi.production_params(max_iter=300), max_batch=4, max_n=80)
+    # the production setting: the lean kernel evaluates the certificate between two checks from iteration 100 on ...
+    h2 = capi.Handle(capi.production_params(), max_batch=4, max_n=80)
     r2 = h2.solve(b["ref"], b["bounds"], b["scal"], passes=1)
-    assert list(r2["status"]) == [1, 1, 2, 1]
+    assert list(r2["status"]) == [1, 1, 4, 1] and 100 <= r2["iters"][2] <= 250
     h2.close()
+    # ... and without any certificate the same QP runs to max_iter; the feasible neighbours get bit for bit the same paths
+    h3 = capi.Handle(capi.production_params(max_iter=300, eps_prim_inf=0.0), max_batch=4, max_n=80)
+    r3 = h3.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    assert list(r3["status"]) == [1, 1, 2, 1]
+    np.testing.assert_array_equal(r3["out"][[0, 1, 3]], r2["out"][[0, 1, 3]])
+    h3.close()
 
 
 @pytest.mark.parametrize("n,batch", [(80, 1024), (200, 256), (300, 64)])

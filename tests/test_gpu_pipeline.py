@@ -34,8 +34,11 @@ def test_two_stream_pipeline_equals_the_serial_run(hip_lib):
         got[k] = pipe.result(k)
     pipe.close()
     for k, g in got.items():
-        for key in ("ref", "scal", "out", "st", "it"):
-            np.testing.assert_array_equal(g[key], want[k][key], err_msg=f"batch {k} {key}")
+        for key in ("sx", "ref", "scal", "out", "st", "it"):
+            same_as = [j for j in range(steps) if np.array_equal(g[key], want[j][key])]
+            rows = np.where((g[key] != want[k][key]).reshape(B, -1).any(axis=1))[0]
+            np.testing.assert_array_equal(g[key], want[k][key], err_msg=f"batch {k} {key} (equal to the serial run's batches {same_as}; {len(rows)} scenarios "
+                                          f"differ, first {rows[:8]}; smoother solved {int((g['sm_st'] == 1).sum())}/{B}; nan {int(np.isnan(g[key]).sum())})")
     # the path QP's answer is the optimum of the QP its reference states define (a sample against the converged oracle)
     g = got[steps - 1]
     bounds = make_batch(B, n, seed=20260926)["bounds"]

@@ -108,9 +108,14 @@ def test_primal_infeasibility_certificate():
     OSQP's certificate on y_k - y_{k-1} fires at the same termination check as in the restatement, instead of 4000 iterations."""
     b = make_batch(3, 80)
     b["scal"][1, 2] = 0.5                       # |k0| > tan(35 deg) / 2.5
-    for prm in (E.params(), E.production(eps_prim_inf=1e-4)):       # (the production setting ships without the certificate)
+    # default parameters: OSQP's every-check test; production with prim_inf_after = 0: the same; production as shipped: the late form
+    # (the certificate between two checks from iteration 100 on, nothing in the ADMM loop)
+    for prm, late in ((E.params(), False), (E.production(prim_inf_after=0), False), (E.production(), True)):
         r = E.solve(prm, b["ref"], b["bounds"], b["scal"], passes=1)
         assert list(r["status"]) == [1, 4, 1]
+        if late:
+            assert 100 <= r["iters"][1] <= 250, r["iters"]      # (165: attempts, checks and the first snapshot come first)
+            np.testing.assert_array_equal(r["out"][[0, 2]], E.solve(E.production(eps_prim_inf=0.0), b["ref"][[0, 2]], b["bounds"][[0, 2]], b["scal"][[0, 2]], passes=1)["out"])
     ref = O.solve_path(b["ref"][1], b["bounds"][1], b["scal"][1])
     assert [x["status"] for x in ref] == ["primal_infeasible"]
     assert E.solve(E.params(), b["ref"], b["bounds"], b["scal"])["iters"][1] == ref[0]["iters"]
