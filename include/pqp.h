@@ -250,6 +250,23 @@ int pqp_path_solve_var(pqp_handle* h, int batch, int n_max, const int32_t* n_of,
  * getSolution(), base_solver.cpp:89,112): x [batch][vars], y [batch][cons].  HOST buffers; either may be NULL. */
 int pqp_path_get_solution(pqp_handle* h, int batch, int n, int precise, double* x, double* y);
 
+/* ---- one node, several GPUs -----------------------------------------------------------------------------------
+ * The QPs of a batch are independent: the batch is cut into contiguous shards (pqp_shard_range: the first total % world shards get one
+ * QP more), every shard has its own handle - GPU, stream, workspaces - and its own host thread; pqp_multi_path_solve moves each
+ * shard's slice of the caller's HOST arrays to its GPU, solves it there (pqp_path_solve / pqp_path_solve_var when n_of is given) and
+ * brings the paths back.  No collective: with the consumer on the host, per-GPU copies beat a device-side gather.  devices[n_shards]
+ * = the device ordinal of every shard (NULL: 0, 1, ...; the same ordinal may appear twice: two handles on one GPU).  The reference
+ * has no counterpart (it solves one path per call, base_solver.cpp:56-95). */
+typedef struct pqp_multi pqp_multi;
+void pqp_shard_range(int total, int world, int rank, int* first, int* count);
+int pqp_multi_create(pqp_multi** m, const pqp_params* params, int n_shards, const int* devices, int max_batch_per_shard, int max_n);
+int pqp_multi_destroy(pqp_multi* m);
+int pqp_multi_shards(const pqp_multi* m);
+pqp_handle* pqp_multi_handle(pqp_multi* m, int shard);       /* a shard's own handle (device-resident use, options, timing) */
+int pqp_multi_set_option(pqp_multi* m, int option, int value);
+int pqp_multi_path_solve(pqp_multi* m, int batch, int n, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
+                         const double* scal, int passes, double* out, int32_t* status, int32_t* iters, double* info);
+
 /* ---- reference-line smoothing QPs; the solver settings of the handle apply (the reference runs
  *      them at OSQP's default eps 1e-3: tension_smoother_2.cpp:32-36, tension_smoother.cpp:61-65, reference_path_smoother.cpp:533-537).
  *      All lists are [batch][n] fp64; out_s is the cumulative chord length of the smoothed points. ------------------------- */

@@ -53,7 +53,8 @@ class PqpSizes(C.Structure):
 
 EXPORTS = [
     "pqp_default_params", "pqp_production_params", "pqp_last_error", "pqp_version", "pqp_create", "pqp_destroy", "pqp_set_params", "pqp_set_option",
-    "pqp_stream_wait", "pqp_mark", "pqp_wait_mark", "pqp_get_stream", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
+    "pqp_stream_wait", "pqp_mark", "pqp_wait_mark", "pqp_get_stream",
+    "pqp_shard_range", "pqp_multi_create", "pqp_multi_destroy", "pqp_multi_shards", "pqp_multi_handle", "pqp_multi_set_option", "pqp_multi_path_solve", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
     "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_solve_var_device", "pqp_path_solve_var", "pqp_path_get_solution",
     "pqp_last_kernel_ms", "pqp_kernel_ms_history", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
     "pqp_post_smooth", "pqp_post_smooth_device", "pqp_corridor_default_params", "pqp_corridor_bounds", "pqp_corridor_bounds_device",
@@ -89,6 +90,15 @@ def load_library(path=None):
     lib.pqp_mark.argtypes = [vp, C.c_int]
     lib.pqp_wait_mark.argtypes = [vp, vp, C.c_int]
     lib.pqp_get_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.pqp_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
+    lib.pqp_shard_range.restype = None
+    lib.pqp_multi_create.argtypes = [C.POINTER(vp), C.POINTER(PqpParams), C.c_int, ip, C.c_int, C.c_int]
+    lib.pqp_multi_destroy.argtypes = [vp]
+    lib.pqp_multi_shards.argtypes = [vp]
+    lib.pqp_multi_handle.argtypes = [vp, C.c_int]
+    lib.pqp_multi_handle.restype = vp
+    lib.pqp_multi_set_option.argtypes = [vp, C.c_int, C.c_int]
+    lib.pqp_multi_path_solve.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
     lib.pqp_sync.argtypes = [vp]
     lib.pqp_path_sizes.argtypes = [C.POINTER(PqpParams), C.c_int, vp, C.POINTER(PqpSizes)]
     lib.pqp_path_pattern.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
@@ -165,6 +175,47 @@ def _ptr(a):
 
 
 OPT_STORE_WARM, OPT_ORDER_BY_COST = 1, 2
+
+
+class MultiHandle:
+    """pqp_multi: one handle + one host thread per shard of the batch (several GPUs of one node; devices may repeat)."""
+
+    def __init__(self, params=None, devices=(0,), max_batch_per_shard=1024, max_n=128):
+        self.lib = load_library()
+        self.params = params or default_params(self.lib)
+        self._m = C.c_void_p()
+        devs = (C.c_int32 * len(devices))(*devices)
+        rc = self.lib.pqp_multi_create(C.byref(self._m), C.byref(self.params), len(devices), devs, max_batch_per_shard, max_n)
+        if rc != 0:
+            raise PqpError(f"pqp error {rc}: {self.lib.pqp_last_error().decode()}")
+
+    def close(self):
+        if self._m:
+            self.lib.pqp_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, option, value):
+        if self.lib.pqp_multi_set_option(self._m, int(option), int(value)) != 0:
+            raise PqpError(self.lib.pqp_last_error().decode())
+
+    def solve(self, ref, bounds, scal, lin=None, passes=1, n_of=None):
+        ref = np.ascontiguousarray(ref, dtype=np.float64); bounds = np.ascontiguousarray(bounds, dtype=np.float64)
+        scal = np.ascontiguousarray(scal, dtype=np.float64)
+        lin = None if lin is None else np.ascontiguousarray(lin, dtype=np.float64)
+        counts = None if n_of is None else np.ascontiguousarray(n_of, dtype=np.int32)
+        batch, n = ref.shape[0], ref.shape[1]
+        out = np.zeros((batch, n, 7)); status = np.zeros(batch, dtype=np.int32); iters = np.zeros(batch, dtype=np.int32); info = np.zeros((batch, 8))
+        rc = self.lib.pqp_multi_path_solve(self._m, batch, n, _ptr(counts), _ptr(ref), _ptr(lin), _ptr(bounds), _ptr(scal), passes, _ptr(out),
+                                           _ptr(status), _ptr(iters), _ptr(info))
+        if rc != 0:
+            raise PqpError(f"pqp error {rc}: {self.lib.pqp_last_error().decode()}")
+        return dict(out=out, status=status, iters=iters, info=info)
 
 
 class PqpError(RuntimeError):

@@ -599,6 +599,7 @@ extern "C" {
 void pqp_default_params(pqp_params* p) { if (p) pqp::default_params(p); }
 void pqp_production_params(pqp_params* p) { if (p) pqp::production_params(p); }
 const char* pqp_last_error(void) { return g_last_error.c_str(); }
+void pqp_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }      // for the other translation units of the library
 const char* pqp_version(void) { return "pqp-hip 0.1 (gfx950)"; }
 
 int pqp_create(pqp_handle** out, const pqp_params* params, int device, int max_batch, int max_n) {

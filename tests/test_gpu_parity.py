@@ -43,6 +43,49 @@ def test_pattern_bit_exact(handle, n, precise):
     np.testing.assert_array_equal(pcols, opcols)
 
 
+def test_n3_hand_derived_map_through_the_hip_kernels(handle):
+    """the (row, col) list of the N = 3 path QP written out by hand from base_solver.cpp:154-209 and the value
+    recipe of every entry - against path_pattern_kernel and path_assemble_kernel themselves (not via the oracle)."""
+    rows, colptr, pcols = handle.pattern(3, 3)
+    cols = np.repeat(np.arange(17), np.diff(colptr))
+    got = sorted(zip(rows.tolist(), cols.tolist()))
+    exp = [(r, r) for r in range(9)]
+    exp += [(3, 0), (3, 1), (4, 0), (4, 1), (4, 2), (5, 2), (5, 9), (6, 3), (6, 4), (7, 3), (7, 4), (7, 5), (8, 5), (8, 10)]
+    exp += [(9, 2), (10, 5), (11, 8)]
+    exp += [(12, 0), (12, 1), (12, 11), (13, 0), (13, 1), (13, 12), (14, 3), (14, 4), (14, 13), (15, 3), (15, 4), (15, 14),
+            (16, 6), (16, 7), (16, 15), (17, 6), (17, 7), (17, 16)]
+    exp += [(18, 6), (19, 7)]
+    assert got == sorted(exp) and len(got) == 46
+    np.testing.assert_array_equal(pcols, [2, 5, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+    # values: one scenario, a linearisation point with l, psi, k all non-zero
+    ref = np.array([[[0.0, 0.02, 0.1, 1.0, 2.0], [0.3, 0.03, 0.106, 1.3, 2.03], [0.55, 0.01, 0.113, 1.55, 2.06]]])
+    lin = np.array([[[0.2, 0.05, 0.03], [0.25, -0.04, 0.02], [0.1, 0.02, 0.015]]])
+    bounds = np.array([[[-1.0, 1.5, -1.2, 1.4, -1.1, 1.3]] * 3])
+    scal = np.array([[0.1, -0.02, 0.025, 0.2, 0.0, 35.0 * np.pi / 180.0]])
+    a_val, p_val, lo, up = handle.assemble(ref, lin, bounds, scal)
+    A = sp.csc_matrix((a_val[0], rows, colptr), shape=(20, 17)).toarray()
+    for i in range(2):
+        l, psi, k = lin[0, i]
+        ds = ref[0, i + 1, 0] - ref[0, i, 0]
+        r = 3 * (i + 1)
+        np.testing.assert_allclose(A[r, 3 * i:3 * i + 2], [1 + ds * (-k * np.tan(psi)), ds * (1 - k * l) / np.cos(psi) ** 2], rtol=1e-14)
+        np.testing.assert_allclose(A[r + 1, 3 * i:3 * i + 3], [ds * (-k * k / np.cos(psi)), 1 + ds * (1 - k * l) * k * np.tan(psi) / np.cos(psi),
+                                                               ds * (1 - k * l) / np.cos(psi)], rtol=1e-14)
+        assert A[r + 2, 3 * i + 2] == 1.0 and A[r + 2, 9 + i] == ds and A[r, r] == A[r + 1, r + 1] == A[r + 2, r + 2] == -1.0
+    for i in range(3):
+        assert A[9 + i, 3 * i + 2] == 1.0
+        np.testing.assert_array_equal(A[12 + 2 * i, [3 * i, 3 * i + 1, 11 + 2 * i]], [1.0, 3.9, 1.0])
+        np.testing.assert_array_equal(A[13 + 2 * i, [3 * i, 3 * i + 1, 12 + 2 * i]], [1.0, -1.0, 1.0])
+    assert A[18, 6] == 1.0 and A[19, 7] == 1.0
+    np.testing.assert_array_equal(p_val[0], [20, 20, 20, 100, 100, 10, 10, 10, 10, 10, 10])
+    np.testing.assert_array_equal(lo[0, :3], -scal[0, :3]); np.testing.assert_array_equal(up[0, :3], -scal[0, :3])
+    kap = np.tan(35.0 * np.pi / 180.0) / 2.5
+    np.testing.assert_allclose(lo[0, 9:12], -kap, rtol=1e-15); np.testing.assert_allclose(up[0, 9:12], kap, rtol=1e-15)
+    # getSoftBounds(lb, ub, 0.6): clearance 2.5 -> remain 1.3 -> shrink 0.6
+    np.testing.assert_allclose([lo[0, 12], up[0, 12]], [-1.0 + 0.6, 1.5 - 0.6], rtol=1e-15)
+    assert (lo[0, 18], up[0, 18]) == (-1.0, 1.0)
+
+
 @pytest.mark.parametrize("n,profile", [(8, "uniform"), (80, "uniform"), (120, "varied"), (200, "varied")])
 def test_assemble_matches_oracle(handle, n, profile):
     b = make_batch(6, n, profile)
@@ -335,4 +378,23 @@ def test_inverted_box_is_refused_by_the_host_entry_points(hip_lib):
     assert list(r["status"]) == [1, 4, 1] and r["iters"][1] == 0 and not r["out"][1].any()
     ok = capi.Handle(_polished(), max_batch=3, max_n=40).solve(b["ref"][[0, 2]], b["bounds"][[0, 2]], b["scal"][[0, 2]], passes=1)
     np.testing.assert_array_equal(r["out"][[0, 2]], ok["out"])
+    h.close()
+
+
+def test_hip_solution_against_the_direct_active_set_solve(hip_lib):
+    """A third, solver-free pin: the primal / dual the HIP kernel returns for a single solve (production setting) is fed
+    to a direct sparse-LU solve of the KKT system on its active set; that point passes the KKT conditions by itself and the kernel's x
+    equals it - no ADMM of any oracle is involved."""
+    from test_oracle import direct_active_set_solve
+    n = 80
+    b = make_batch(6, n, "varied")
+    h = capi.Handle(_polished(), max_batch=6, max_n=n)
+    r = h.solve(b["ref"], b["bounds"], b["scal"], passes=0)
+    assert (r["status"] == 1).all()
+    x, y = h.get_solution(6, n)
+    for q in range(6):
+        Pd, A, lo, up, sz = O.assemble_path_qp(b["ref"][q], O.first_linearization(b["ref"][q]), b["bounds"][q], b["scal"][q])
+        xd, yd, kkt = direct_active_set_solve(Pd, A, lo, up, x[q], y[q])
+        assert kkt < 1e-8, kkt
+        assert np.abs(x[q][:3 * n] - xd[:3 * n]).max() < 1e-6
     h.close()

@@ -1,0 +1,112 @@
+"""The multi-GPU driver of the C ABI (pqp_multi_*: one handle + host thread per shard) and the batched C++ surface
+(include/pqp_batched_solver.hpp).  CPU: the sharding rule, symbols, clean failure without a GPU.  GPU: two shards on ONE device
+(two handles, two host threads) against the single-handle solve; BatchedPathSolver with ragged scenarios against the C ABI."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from path_optimizer_2_amd import capi
+from path_optimizer_2_amd.shard import shard_range
+from path_optimizer_2_amd.synth import make_batch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "path_optimizer_2_amd", "csrc")
+EXE = os.path.join(ROOT, "tests", "cpp", "batched_demo")
+
+
+def test_shard_range_is_the_contiguous_split_of_the_python_side(hip_lib):
+    first, count = C.c_int32(), C.c_int32()
+    for total, world in [(65536, 8), (4096, 8), (1024, 3), (7, 8), (1, 1), (1000, 7)]:
+        covered = 0
+        for rank in range(world):
+            hip_lib.pqp_shard_range(total, world, rank, C.byref(first), C.byref(count))
+            assert (first.value, count.value) == shard_range(total, world, rank)
+            assert first.value == covered
+            covered += count.value
+        assert covered == total
+
+
+def test_multi_create_fails_loudly_without_a_device(hip_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.PqpError, match="no HIP device"):
+        capi.MultiHandle(devices=(0, 1))
+
+
+@pytest.fixture(scope="module")
+def batched_exe(hip_lib):
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", EXE, os.path.join(ROOT, "tests", "cpp", "batched_demo.cpp"), "-L" + CSRC, "-lpqp_hip",
+                    "-Wl,-rpath," + CSRC], check=True)
+    return EXE
+
+
+def _scenarios_text(b, counts):
+    lines = [str(len(counts))]
+    for q, n in enumerate(counts):
+        lines.append(str(n))
+        for i in range(n):
+            lines.append(" ".join(repr(float(v)) for v in list(b["ref"][q, i]) + list(b["bounds"][q, i])))
+        lines.append(" ".join(repr(float(v)) for v in b["scal"][q]))
+    return "\n".join(lines) + "\n"
+
+
+def test_batched_solver_builds_and_fails_cleanly_without_gpu(batched_exe):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    b = make_batch(2, 20)
+    r = subprocess.run([batched_exe], input=_scenarios_text(b, [20, 12]), capture_output=True, text=True)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr and "Solving failed" in r.stderr
+
+
+@pytest.mark.gpu
+def test_two_shards_on_one_device_equal_the_single_handle_solve(hip_lib):
+    """pqp_multi_path_solve with two handles (two host threads) on device 0: bit for bit what one handle gives for the whole batch,
+    with and without a waypoint count per QP, odd batch (shards of 129 and 128)."""
+    b = make_batch(257, 80)
+    prm = capi.production_params()
+    one = capi.Handle(prm, max_batch=257, max_n=80)
+    want = one.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    two = capi.MultiHandle(prm, devices=(0, 0), max_batch_per_shard=129, max_n=80)
+    got = two.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    for k in ("out", "status", "iters"):
+        np.testing.assert_array_equal(got[k], want[k])
+    assert (got["status"] == 1).all()
+    counts = np.full(257, 80, dtype=np.int32)
+    counts[::5] = 61
+    counts[3] = 1                                   # a road blocked at its first waypoint: skipped, UNSOLVED
+    want_v = one.solve_var(counts, b["ref"], b["bounds"], b["scal"], passes=1)
+    got_v = two.solve(b["ref"], b["bounds"], b["scal"], passes=1, n_of=counts)
+    for k in ("out", "status", "iters"):
+        np.testing.assert_array_equal(got_v[k], want_v[k])
+    assert got_v["status"][3] == 0 and (np.delete(got_v["status"], 3) == 1).all()
+    two.close(); one.close()
+
+
+@pytest.mark.gpu
+def test_batched_cpp_solver_against_the_c_abi(batched_exe, hip_lib):
+    """BatchedPathSolver (production setting) on three scenarios of different length, one and two shards: the paths the C++ vectors
+    carry are the C ABI's solve_var result digit for digit."""
+    b = make_batch(3, 80)
+    counts = [80, 57, 33]
+    h = capi.Handle(capi.production_params(), max_batch=3, max_n=80)
+    want = h.solve_var(np.array(counts, dtype=np.int32), b["ref"], b["bounds"], b["scal"], passes=1)
+    h.close()
+    for shards in ("1", "2"):
+        env = dict(os.environ)
+        r = subprocess.run([batched_exe, shards], input=_scenarios_text(b, counts), capture_output=True, text=True, env=env)
+        if shards == "2" and r.returncode != 0 and "bad device ordinal" in r.stderr:
+            continue                                 # a one-GPU box: the second shard's device does not exist (refused loudly)
+        assert r.returncode == 0, r.stderr
+        rows = r.stdout.strip().splitlines()
+        pos = 0
+        for q, n in enumerate(counts):
+            ok, m = (int(v) for v in rows[pos].split())
+            assert ok == 1 and m == n
+            got = np.array([[float(v) for v in ln.split()] for ln in rows[pos + 1:pos + 1 + m]])
+            np.testing.assert_array_equal(got, want["out"][q, :n])
+            pos += 1 + m

@@ -63,3 +63,19 @@ def test_batch_driver_matches_single():
     for q in range(6):
         s = OC.solve_path(prm, b["ref"][q], b["bounds"][q], b["scal"][q])
         np.testing.assert_array_equal(r["out"][q], s["out"])
+
+
+def test_dense_assembly_mode_gives_the_same_qp_and_solution():
+    """The reference-faithful assembly of the CPU baseline (dense cons x vars fill + full scan, base_solver.cpp:122,145,159,210) is the
+    same QP as the direct structural fill: identical paths and iteration counts."""
+    b = make_batch(6, 40, "varied")
+    prm = OC.params(eps_abs=1e-5, eps_rel=1e-5)
+    direct = OC.solve_batch(prm, b["ref"], b["bounds"], b["scal"])
+    OC.load().pqo_set_dense_assembly(1)
+    try:
+        dense = OC.solve_batch(prm, b["ref"], b["bounds"], b["scal"])
+    finally:
+        OC.load().pqo_set_dense_assembly(0)
+    np.testing.assert_array_equal(dense["out"], direct["out"])
+    np.testing.assert_array_equal(dense["iters"], direct["iters"])
+    assert dense["solved"] == direct["solved"] == 6
