@@ -426,6 +426,64 @@ int pqp_dp_corridor(pqp_handle* h, int batch, int m, int max_layers, const doubl
                     const double* start, const float* dist, int n_maps, const int32_t* map_of, const pqp_grid_geometry* geom,
                     const pqp_dp_params* prm, double* layers_s, double* lb, double* ub, int32_t* count, double* vehicle_l);
 
+/* ---- the whole of PathOptimizer::solve as one device-resident call -----------------------------------------------------------------
+ * PathOptimizer::solve  src/path_optimizer.cpp:34-71  =  ReferencePathSmoother::solve (reference_path_smoother.cpp:31-45: bSpline,
+ * TensionSmoother2 QP, graphSearchDp, postSmooth QP) + processReferencePath (:106-122) + optimizePath (:124-161), for a batch of
+ * scenarios that differ in every count (input points, raw-line points, smoother samples, DP layers, waypoints).  All pointers are DEVICE
+ * pointers; nothing is copied to the host between the steps; the call returns when everything is enqueued (pqp_sync(h) waits).
+ *   h  : the handle whose parameters the path QP uses (pqp_production_params or the reference's pqp_default_params);
+ *   hs : the handle the two smoother QPs run on - the reference solves them at OSQP's default eps 1e-3 (tension_smoother_2.cpp:32-36),
+ *        i.e. pqp_default_params with eps_abs = eps_rel = 1e-3 - or NULL: h's own parameters.  The two handles are ordered by marks 6, 7.
+ *   points [batch][p_max][2], n_points [batch]  PathOptimizer::solve's reference_points (fewer than 4: "Few reference points")
+ *   start, target [batch][3]                    x, y, heading of the vehicle's start and target state (the PathOptimizer constructor)
+ *   start_k [batch] or NULL                     curvature of the start state (NULL: 0, State's default)
+ *   dist / map_of / geom                        the obstacle distance layer(s), as for pqp_corridor_bounds
+ *   out [batch][n_max][7], n_out [batch]        the path (the SlState fields getOptimizedPath fills) and its waypoint count
+ *   status [batch]                              pqp_status of the path QP (PQP_STATUS_UNSOLVED when the scenario never got there)
+ *   stage [batch] or NULL                       where a scenario stopped: the reference's `return false` sites
+ *   iters [batch] or NULL                       ADMM iterations of the path QP */
+typedef enum pqp_chain_stage {
+    PQP_CHAIN_OK = 0,
+    PQP_CHAIN_FEW_POINTS = 1,            /* reference_path_smoother.cpp:33-36 */
+    PQP_CHAIN_SMOOTHER_FAILED = 2,       /* tension_smoother.cpp:32-35 */
+    PQP_CHAIN_SEARCH_FAILED = 3,         /* graphSearchDp returned false (:164-167, no reachable node) */
+    PQP_CHAIN_SHORT_REFERENCE = 4,       /* postSmooth: fewer than 4 layers (:528-531) */
+    PQP_CHAIN_POST_SMOOTH_FAILED = 5,    /* :555-558 */
+    PQP_CHAIN_HEADING = 6,               /* initial heading error above 75 degrees (path_optimizer.cpp:113-116) */
+    PQP_CHAIN_BLOCKED = 7,               /* the road is blocked before the second waypoint */
+    PQP_CHAIN_PATH_QP_FAILED = 8,        /* "Solving failed!" (path_optimizer.cpp:143-156); status says why */
+    PQP_CHAIN_CAPACITY = 9               /* a line needs more points / samples / layers / waypoints than pqp_chain_config allows */
+} pqp_chain_stage;
+typedef struct pqp_chain_config {
+    int32_t raw_max, sample_max, layer_max, n_max;   /* capacities per scenario: raw-line points (bSpline, about one per metre), 1 m samples of
+                                                        the smoother QP (<= 256), DP layers (1.5 m, <= 341), waypoints of the path (<= 512) */
+    double output_spacing;               /* 0.3   FLAGS_output_spacing, planning_flags.cpp:106 */
+    int32_t dynamic_segmentation;        /* 1     FLAGS_enable_dynamic_segmentation, :110 */
+    double max_steering_angle;           /* 35 degrees, :22 */
+    double smoothed_length_margin;       /* 3.0   tension_smoother.cpp:40: the smoothed line is declared 3 m longer than its last point */
+    pqp_corridor_params corridor;
+    pqp_dp_params dp;
+} pqp_chain_config;
+void pqp_chain_default_config(pqp_chain_config* c);
+int pqp_optimize_path_device(pqp_handle* h, pqp_handle* hs, const pqp_chain_config* cfg, int batch, int p_max, const double* points,
+                             const int32_t* n_points, const double* start, const double* target, const float* dist, const int32_t* map_of,
+                             const pqp_grid_geometry* geom, const double* start_k, double* out, int32_t* n_out, int32_t* status, int32_t* stage,
+                             int32_t* iters);
+/* Map::getObstacleDistance (src/tools/Map.cpp:16-22) at the points x_list, y_list [batch][n]: the `clearance` input of pqp_smooth_tension
+ * (tension_smoother.cpp:168), gathered on the device from the same distance layer(s) pqp_corridor_bounds takes */
+int pqp_clearance_device(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const float* dist, const int32_t* map_of,
+                         const pqp_grid_geometry* geom, double* clearance);
+/* the three steps of the chain that share one size per launch elsewhere, with a count per scenario (device pointers): a scenario with
+ * fewer points is the same QP padded with decoupled dummies (same optimum); the spline table is padded with knots far beyond the line,
+ * whose cubic coefficient is zero - term by term tk::spline's right-hand extrapolation */
+int pqp_smooth_tension2_var_device(pqp_handle* h, int batch, int n_max, const int32_t* n_of, const double* x_list, const double* y_list,
+                                   const double* angle_list, const double* k_list, const double* s_list, double* out_x, double* out_y,
+                                   double* out_s, int32_t* status, int32_t* iters, double* info);
+int pqp_post_smooth_var_device(pqp_handle* h, int batch, int m_max, const int32_t* m_of, const double* layers_s, const double* lb, const double* ub,
+                               const double* vehicle_l, double* out_l, int32_t* status, int32_t* iters, double* info);
+int pqp_spline_fit_var_device(pqp_handle* h, int batch, int m_max, const int32_t* m_of, const double* s, const double* x, const double* y,
+                              double* spline, double* spline_ext);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,12 @@ class PqpDpParams(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("lateral_range", "longitudinal_spacing", "lateral_spacing", "car_width")]
 
 
+class PqpChainConfig(C.Structure):
+    _fields_ = [("raw_max", C.c_int32), ("sample_max", C.c_int32), ("layer_max", C.c_int32), ("n_max", C.c_int32), ("output_spacing", C.c_double),
+                ("dynamic_segmentation", C.c_int32), ("max_steering_angle", C.c_double), ("smoothed_length_margin", C.c_double),
+                ("corridor", PqpCorridorParams), ("dp", PqpDpParams)]
+
+
 class PqpSizes(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("n", "state", "control", "precise", "slack", "vars", "cons", "nnz_a", "nnz_p")]
 
@@ -54,6 +60,7 @@ class PqpSizes(C.Structure):
 EXPORTS = [
     "pqp_default_params", "pqp_production_params", "pqp_last_error", "pqp_version", "pqp_create", "pqp_destroy", "pqp_set_params", "pqp_set_option",
     "pqp_stream_wait", "pqp_mark", "pqp_wait_mark", "pqp_get_stream",
+    "pqp_chain_default_config", "pqp_optimize_path_device", "pqp_clearance_device", "pqp_smooth_tension2_var_device", "pqp_post_smooth_var_device", "pqp_spline_fit_var_device",
     "pqp_shard_range", "pqp_multi_create", "pqp_multi_destroy", "pqp_multi_shards", "pqp_multi_handle", "pqp_multi_set_option", "pqp_multi_path_solve", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
     "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_solve_var_device", "pqp_path_solve_var", "pqp_path_get_solution",
     "pqp_last_kernel_ms", "pqp_kernel_ms_history", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
@@ -90,6 +97,14 @@ def load_library(path=None):
     lib.pqp_mark.argtypes = [vp, C.c_int]
     lib.pqp_wait_mark.argtypes = [vp, vp, C.c_int]
     lib.pqp_get_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.pqp_chain_default_config.argtypes = [C.POINTER(PqpChainConfig)]
+    lib.pqp_chain_default_config.restype = None
+    lib.pqp_optimize_path_device.argtypes = [vp, vp, C.POINTER(PqpChainConfig), C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(PqpGridGeometry),
+                                             vp, vp, vp, vp, vp, vp]
+    lib.pqp_clearance_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.POINTER(PqpGridGeometry), vp]
+    lib.pqp_smooth_tension2_var_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 12
+    lib.pqp_post_smooth_var_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 9
+    lib.pqp_spline_fit_var_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 6
     lib.pqp_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
     lib.pqp_shard_range.restype = None
     lib.pqp_multi_create.argtypes = [C.POINTER(vp), C.POINTER(PqpParams), C.c_int, ip, C.c_int, C.c_int]
@@ -273,6 +288,40 @@ class Handle:
         s = C.c_void_p()
         self._check(self.lib.pqp_get_stream(self._h, C.byref(s)))
         return s.value
+
+    def chain_config(self, **over):
+        c = PqpChainConfig()
+        self.lib.pqp_chain_default_config(C.byref(c))
+        for k, v in over.items():
+            setattr(c, k, v)
+        return c
+
+    def optimize_path(self, points, n_points, start, target, dist, geom, map_of=None, smoother=None, cfg=None, start_k=None):
+        """pqp_optimize_path_device with torch as the memory plumbing: host arrays in, device-resident chain, host arrays out.
+        points [B][p_max][2], n_points [B], start / target [B][3], dist [n_maps][rows][cols] float32.  smoother: the handle the two
+        smoother QPs run on (None: this one).  Returns dict(out [B][n_max][7], n_out, status, stage, iters)."""
+        import torch
+        dev = torch.device("cuda", 0)
+        cfg = cfg or self.chain_config()
+        t = lambda a, dt: None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+        dist = np.asarray(dist, dtype=np.float32)
+        if dist.ndim == 2:
+            dist = dist[None]
+        d_dist = t(np.transpose(dist, (0, 2, 1)), np.float32)              # the ABI's column-major layer
+        B, p_max = points.shape[0], points.shape[1]
+        d_pts, d_np, d_st, d_tg = t(points, np.float64), t(n_points, np.int32), t(start, np.float64), t(target, np.float64)
+        d_map, d_k = t(map_of, np.int32), t(start_k, np.float64)
+        out = torch.zeros((B, cfg.n_max, 7), dtype=torch.float64, device=dev)
+        ints = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(4)]
+        torch.cuda.synchronize()
+        p = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+        self._check(self.lib.pqp_optimize_path_device(self._h, smoother._h if smoother is not None else None, C.byref(cfg), B, p_max, p(d_pts), p(d_np),
+                                                      p(d_st), p(d_tg), p(d_dist), p(d_map), C.byref(geom), p(d_k), p(out), p(ints[0]), p(ints[1]),
+                                                      p(ints[2]), p(ints[3])))
+        self.sync()
+        if smoother is not None:
+            smoother.sync()
+        return dict(out=out.cpu().numpy(), n_out=ints[0].cpu().numpy(), status=ints[1].cpu().numpy(), stage=ints[2].cpu().numpy(), iters=ints[3].cpu().numpy())
 
     def corridor_params(self, **over):
         p = PqpCorridorParams()

@@ -581,6 +581,7 @@ struct pqp_handle {
     // work distribution of the solve kernel: ticket counter (never reset: a launch uses batch + grid tickets), cost bins of the
     // last solve and the ticket -> QP order derived from them
     DevBuf ticket, cost_key, cost_hist, order;
+    DevBuf chain_d, chain_i;                    // workspace of pqp_optimize_path_device
     unsigned long long ticket_next = 0;
     long long solves = 0;                       // solve launches so far (parity selects the cost histogram being filled)
     int hist_batch = 0, hist_n = 0;             // shape of the solve whose costs cost_key / cost_hist hold (0: none)
@@ -640,7 +641,7 @@ int pqp_destroy(pqp_handle* h) {
     if (!h) return PQP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (DevBuf* b : {&h->wscale, &h->ticket, &h->cost_key, &h->cost_hist, &h->order, &h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
+    for (DevBuf* b : {&h->chain_d, &h->chain_i, &h->wscale, &h->ticket, &h->cost_key, &h->cost_hist, &h->order, &h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
                       &h->s_status, &h->s_iters, &h->s_info, &h->s_a, &h->s_p, &h->s_l, &h->s_u, &h->s_idx, &h->b_pband, &h->b_q, &h->b_aval,
                       &h->b_lo, &h->b_up, &h->b_x, &h->b_y, &h->b_acol, &h->b_trow, &h->b_tslot, &h->b_in[0], &h->b_in[1], &h->b_in[2],
                       &h->b_in[3], &h->b_in[4], &h->b_out[0], &h->b_out[1], &h->b_out[2], &h->c_buf[0], &h->c_buf[1], &h->c_buf[2],
@@ -1114,24 +1115,37 @@ int sm_alloc(pqp_handle* h, int type, int batch, int n) {
 }
 }  // namespace
 
-// TensionSmoother2::osqpSmooth (tension_smoother_2.cpp:20-72), device pointers, all lists [batch][n]
-int pqp_smooth_tension2_device(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list,
-                               const double* k_list, const double* s_list, double* out_x, double* out_y, double* out_s, int32_t* status,
-                               int32_t* iters, double* info) {
+// TensionSmoother2::osqpSmooth (tension_smoother_2.cpp:20-72), device pointers, all lists [batch][n]; n_of [batch] (device) or nullptr
+static int smooth_tension2_impl(pqp_handle* h, int batch, int n, const int32_t* n_of, const double* x_list, const double* y_list,
+                                const double* angle_list, const double* k_list, const double* s_list, double* out_x, double* out_y, double* out_s,
+                                int32_t* status, int32_t* iters, double* info) {
     if (!h || !x_list || !y_list || !angle_list || !k_list || !s_list || !out_x || !out_y || !out_s || batch < 1 || n < 3)
         return fail(PQP_ERR_INVALID, "pqp_smooth_tension2: bad argument");
     PQP_HIP(hipSetDevice(h->device));
     int rc;
     if ((rc = sm_alloc(h, SM_TENSION2, batch, n))) return rc;
     const int total = batch * n;
-    hipLaunchKernelGGL(pqp::tension2_assemble_kernel, dim3((total + 255) / 256), dim3(256), 0, h->stream, batch, n, x_list, y_list, angle_list,
+    hipLaunchKernelGGL(pqp::tension2_assemble_kernel, dim3((total + 255) / 256), dim3(256), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list,
                        k_list, s_list, h->prm.tension2_deviation_weight, h->prm.tension2_curvature_weight, h->prm.tension2_curvature_rate_weight,
                        h->b_pband.as<double>(), h->b_q.as<double>(), h->b_aval.as<double>(), h->b_lo.as<double>(), h->b_up.as<double>());
     PQP_HIP(hipGetLastError());
     if ((rc = sm_solve(h, SM_TENSION2, batch, n, status, iters, info))) return rc;
-    hipLaunchKernelGGL(pqp::tension_finish_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, batch, n, 4 * n - 1, 4, h->b_x.as<double>(), out_x, out_y, out_s);
+    hipLaunchKernelGGL(pqp::tension_finish_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, batch, n, n_of, 4 * n - 1, 4, h->b_x.as<double>(), out_x, out_y, out_s);
     PQP_HIP(hipGetLastError());
     return PQP_OK;
+}
+
+int pqp_smooth_tension2_device(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list,
+                               const double* k_list, const double* s_list, double* out_x, double* out_y, double* out_s, int32_t* status,
+                               int32_t* iters, double* info) {
+    return smooth_tension2_impl(h, batch, n, nullptr, x_list, y_list, angle_list, k_list, s_list, out_x, out_y, out_s, status, iters, info);
+}
+
+int pqp_smooth_tension2_var_device(pqp_handle* h, int batch, int n_max, const int32_t* n_of, const double* x_list, const double* y_list,
+                                   const double* angle_list, const double* k_list, const double* s_list, double* out_x, double* out_y,
+                                   double* out_s, int32_t* status, int32_t* iters, double* info) {
+    if (!n_of) return fail(PQP_ERR_INVALID, "pqp_smooth_tension2_var: n_of is null");
+    return smooth_tension2_impl(h, batch, n_max, n_of, x_list, y_list, angle_list, k_list, s_list, out_x, out_y, out_s, status, iters, info);
 }
 
 // TensionSmoother::osqpSmooth (tension_smoother.cpp:49-100); clearance[batch][n] = Map::getObstacleDistance at each point
@@ -1148,26 +1162,37 @@ int pqp_smooth_tension_device(pqp_handle* h, int batch, int n, const double* x_l
                        h->b_pband.as<double>(), h->b_q.as<double>(), h->b_aval.as<double>(), h->b_lo.as<double>(), h->b_up.as<double>());
     PQP_HIP(hipGetLastError());
     if ((rc = sm_solve(h, SM_TENSION, batch, n, status, iters, info))) return rc;
-    hipLaunchKernelGGL(pqp::tension_finish_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, batch, n, 3 * n, 3, h->b_x.as<double>(), out_x, out_y, out_s);
+    hipLaunchKernelGGL(pqp::tension_finish_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, batch, n, (const int32_t*)nullptr, 3 * n, 3, h->b_x.as<double>(), out_x, out_y, out_s);
     PQP_HIP(hipGetLastError());
     return PQP_OK;
 }
 
 // ReferencePathSmoother::postSmooth QP (reference_path_smoother.cpp:526-558): out_l[batch][m] = the lateral offsets l_i
-int pqp_post_smooth_device(pqp_handle* h, int batch, int m, const double* layers_s, const double* lb, const double* ub, const double* vehicle_l,
-                           double* out_l, int32_t* status, int32_t* iters, double* info) {
+static int post_smooth_impl(pqp_handle* h, int batch, int m, const int32_t* m_of, const double* layers_s, const double* lb, const double* ub,
+                            const double* vehicle_l, double* out_l, int32_t* status, int32_t* iters, double* info) {
     if (!h || !layers_s || !lb || !ub || !vehicle_l || !out_l || batch < 1 || m < 4) return fail(PQP_ERR_INVALID, "pqp_post_smooth: bad argument (m >= 4, reference_path_smoother.cpp:528)");
     PQP_HIP(hipSetDevice(h->device));
     int rc;
     if ((rc = sm_alloc(h, SM_POST, batch, m))) return rc;
     const int total = batch * m;
-    hipLaunchKernelGGL(pqp::post_assemble_kernel, dim3((total + 255) / 256), dim3(256), 0, h->stream, batch, m, layers_s, lb, ub, vehicle_l,
+    hipLaunchKernelGGL(pqp::post_assemble_kernel, dim3((total + 255) / 256), dim3(256), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l,
                        h->b_pband.as<double>(), h->b_q.as<double>(), h->b_aval.as<double>(), h->b_lo.as<double>(), h->b_up.as<double>());
     PQP_HIP(hipGetLastError());
     if ((rc = sm_solve(h, SM_POST, batch, m, status, iters, info))) return rc;
     hipLaunchKernelGGL(pqp::post_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, h->stream, batch, m, h->b_x.as<double>(), out_l);
     PQP_HIP(hipGetLastError());
     return PQP_OK;
+}
+
+int pqp_post_smooth_device(pqp_handle* h, int batch, int m, const double* layers_s, const double* lb, const double* ub, const double* vehicle_l,
+                           double* out_l, int32_t* status, int32_t* iters, double* info) {
+    return post_smooth_impl(h, batch, m, nullptr, layers_s, lb, ub, vehicle_l, out_l, status, iters, info);
+}
+
+int pqp_post_smooth_var_device(pqp_handle* h, int batch, int m_max, const int32_t* m_of, const double* layers_s, const double* lb, const double* ub,
+                               const double* vehicle_l, double* out_l, int32_t* status, int32_t* iters, double* info) {
+    if (!m_of) return fail(PQP_ERR_INVALID, "pqp_post_smooth_var: m_of is null");
+    return post_smooth_impl(h, batch, m_max, m_of, layers_s, lb, ub, vehicle_l, out_l, status, iters, info);
 }
 
 // host-pointer conveniences: nin input lists of [batch][n] (+ optional [batch] scalar list), nout output lists
@@ -1528,12 +1553,13 @@ int pqp_bspline_resample(pqp_handle* h, int batch, int p_max, int n_max, const d
 }
 
 // ---- spline fit ---------------------------------------------------------------------------------------
-int pqp_spline_fit_device(pqp_handle* h, int batch, int m, const double* s, const double* x, const double* y, double* spline,
-                          double* spline_ext) {
+static int spline_fit_impl(pqp_handle* h, int batch, int m, const int32_t* m_of, const double* s, const double* x, const double* y, double* spline,
+                           double* spline_ext) {
     if (!h || !s || !x || !y || !spline || !spline_ext || batch < 1 || m < 3)
         return fail(PQP_ERR_INVALID, "pqp_spline_fit: bad argument (m >= 3: spline.cpp:164)");
     PQP_HIP(hipSetDevice(h->device));
     pqp::SplineFitArgs a;
+    a.m_of = m_of;
     a.batch = batch; a.m = m; a.s = s; a.vx = x; a.vy = y; a.spl = spline; a.spl_ext = spline_ext;
     const size_t lds = (size_t)7 * m * 8;
     if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_spline_fit: 7 m doubles exceed one CU's LDS");
@@ -1545,6 +1571,17 @@ int pqp_spline_fit_device(pqp_handle* h, int batch, int m, const double* s, cons
     PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return PQP_OK;
+}
+
+int pqp_spline_fit_device(pqp_handle* h, int batch, int m, const double* s, const double* x, const double* y, double* spline,
+                          double* spline_ext) {
+    return spline_fit_impl(h, batch, m, nullptr, s, x, y, spline, spline_ext);
+}
+
+int pqp_spline_fit_var_device(pqp_handle* h, int batch, int m_max, const int32_t* m_of, const double* s, const double* x, const double* y,
+                              double* spline, double* spline_ext) {
+    if (!m_of) return fail(PQP_ERR_INVALID, "pqp_spline_fit_var: m_of is null");
+    return spline_fit_impl(h, batch, m_max, m_of, s, x, y, spline, spline_ext);
 }
 
 int pqp_spline_fit(pqp_handle* h, int batch, int m, const double* s, const double* x, const double* y, double* spline, double* spline_ext) {
@@ -1630,3 +1667,5 @@ int pqp_dp_corridor(pqp_handle* h, int batch, int m, int max_layers, const doubl
 }
 
 }  // extern "C"
+
+#include "pqp_chain.inc"

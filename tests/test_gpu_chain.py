@@ -1,0 +1,138 @@
+"""pqp_optimize_path_device: the whole of PathOptimizer::solve (reference src/path_optimizer.cpp:34-71) for a ragged batch as one
+device-resident call, against the same twelve steps run one scenario at a time through the per-step entry points (each of which is
+checked against its oracle in test_gpu_corridor.py / test_gpu_smoothers.py / test_gpu_parity.py), and the reference's `return false`
+sites as stages.  Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+
+from path_optimizer_2_amd import capi
+from path_optimizer_2_amd.synth import make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _smoother_params():
+    # the reference's smoother setting (OSQP default eps 1e-3) + the KKT-verified polish, so that both sides return the QP's optimum
+    return capi.default_params(eps_abs=1e-3, eps_rel=1e-3, polish=1, polish_every=25, adaptive_rho_interval=25)
+
+
+def _scenarios(B, n_maps=4, seed=5):
+    cs = [make_scene(seed=s, n=40, n_obstacles=25, knots_every=3.05) for s in range(n_maps)]
+    rng = np.random.default_rng(seed)
+    p_max = len(cs[0]["knots_x"])
+    pts = np.zeros((B, p_max, 2)); n_pts = np.zeros(B, dtype=np.int32); map_of = (np.arange(B) % n_maps).astype(np.int32)
+    start = np.zeros((B, 3)); target = np.zeros((B, 3))
+    for b in range(B):
+        c = cs[b % n_maps]
+        P = int(rng.integers(7, p_max + 1))                       # polygons of different length: every count downstream differs
+        n_pts[b] = P
+        pts[b, :P, 0] = c["knots_x"][:P]; pts[b, :P, 1] = c["knots_y"][:P] + rng.normal(scale=0.15, size=P)
+        h0 = np.arctan2(pts[b, 1, 1] - pts[b, 0, 1], pts[b, 1, 0] - pts[b, 0, 0])
+        start[b] = (pts[b, 0, 0] + 0.1, pts[b, 0, 1] + 0.1, h0 + 0.03)
+        h1 = np.arctan2(pts[b, P - 1, 1] - pts[b, P - 2, 1], pts[b, P - 1, 0] - pts[b, P - 2, 0])
+        target[b] = (pts[b, P - 1, 0], pts[b, P - 1, 1], h1)
+    c0 = cs[0]
+    geom = capi.PqpGridGeometry(c0["rows"], c0["cols"], c0["resolution"], c0["length"][0], c0["length"][1], c0["pos"][0], c0["pos"][1])
+    return dict(pts=pts, n_pts=n_pts, map_of=map_of, start=start, target=target, dist=np.stack([c["dist"] for c in cs]), geom=geom)
+
+
+def _one_by_one(h, hs, sc, b, cfg):
+    """The chain for scenario b alone, exact sizes, through the per-step host-pointer entry points."""
+    P = int(sc["n_pts"][b])
+    mo = sc["map_of"][b:b + 1]
+    st, tg = sc["start"][b:b + 1], sc["target"][b:b + 1]
+    r = h.bspline_resample(sc["pts"][b:b + 1, :P], np.array([P], dtype=np.int32), cfg.raw_max)
+    n0 = int(r["count"][0])
+    x0, y0, s0 = (r[k][:, :n0] for k in ("x", "y", "s"))
+    tab, ext = h.spline_fit(s0, x0, y0)
+    seg = h.segment_raw_reference(tab, ext, s0[:, -1].copy(), cfg.sample_max)
+    n1 = int(seg["count"][0])
+    sm = hs.smooth_tension2(*(seg[k][:, :n1] for k in ("x", "y", "angle", "k", "s")))
+    assert sm["status"][0] == 1
+    tab, ext = h.spline_fit(sm["s"], sm["x"], sm["y"])
+    ls, lb, ub, cnt, vl = h.dp_corridor(tab, ext, sm["s"][:, -1] + cfg.smoothed_length_margin, st, sc["dist"], sc["geom"], max_layers=cfg.layer_max, map_of=mo)
+    k = int(cnt[0])
+    assert k >= 4
+    ps = hs.post_smooth(ls[:, :k].copy(), lb[:, :k].copy(), ub[:, :k].copy(), vl)
+    assert ps["status"][0] == 1
+    x2, y2, s2 = h.offsets_to_points(tab, ext, ls[:, :k].copy(), ps["l"])
+    tab, ext = h.spline_fit(s2, x2, y2)
+    max_s = h.reference_length(tab, ext, s2[:, -1].copy(), tg)
+    ref, count, err = h.reference_states(tab, ext, max_s, cfg.n_max, start=st, ds_small=cfg.output_spacing / 2, ds_large=cfg.output_spacing, dynamic=True)
+    bounds, nv = h.corridor_bounds(ref, tab, ext, sc["dist"], sc["geom"], map_of=mo, n_of=count)
+    scal = np.array([[err[0, 0], err[0, 1], 0.0, tg[0, 2], 1.0 if nv[0] < count[0] else 0.0, cfg.max_steering_angle]])
+    res = h.solve_var(nv, ref, bounds, scal, passes=1)
+    return dict(n0=n0, n1=n1, layers=k, count=int(count[0]), nv=int(nv[0]), out=res["out"][0], status=int(res["status"][0]))
+
+
+def test_ragged_batch_equals_the_steps_run_one_scenario_at_a_time(hip_lib):
+    B = 24
+    sc = _scenarios(B)
+    h = capi.Handle(capi.production_params(), max_batch=B, max_n=256)
+    hs = capi.Handle(_smoother_params(), max_batch=B, max_n=128)
+    cfg = h.chain_config()
+    got = h.optimize_path(sc["pts"], sc["n_pts"], sc["start"], sc["target"], sc["dist"], sc["geom"], map_of=sc["map_of"], smoother=hs, cfg=cfg)
+    assert (got["stage"] == 0).sum() >= B - 2, got["stage"]
+    seen = set()
+    for b in range(B):
+        if got["stage"][b] != 0:
+            continue
+        want = _one_by_one(h, hs, sc, b, cfg)
+        seen.add((want["n0"], want["n1"], want["layers"], want["nv"]))
+        assert got["n_out"][b] == want["nv"] and got["status"][b] == want["status"] == 1
+        nv = want["nv"]
+        # both sides solve their QPs to the optimum (polish); the padded smoother QPs and the exact-size ones agree to the polish
+        # tolerance, and so does everything downstream
+        assert np.abs(got["out"][b, :nv] - want["out"][:nv]).max() < 2e-5, (b, np.abs(got["out"][b, :nv] - want["out"][:nv]).max())
+        assert np.all(got["out"][b, nv:] == 0.0)
+    assert len(seen) >= 6                          # the batch really was ragged
+    h.close(); hs.close()
+
+
+def test_stages_are_the_reference_s_return_false_sites(hip_lib):
+    sc = _scenarios(6, seed=9)
+    sc["n_pts"][1] = 3                                               # "Few reference points" (reference_path_smoother.cpp:33-36)
+    sc["start"][2, :2] += np.array([-np.sin(sc["start"][2, 2]), np.cos(sc["start"][2, 2])]) * 14.0      # 14 m beside the line: graphSearchDp quits
+    sc["start"][3, 2] += 1.6                                         # 92 degrees off the line's heading: path_optimizer.cpp:113-116
+    h = capi.Handle(capi.production_params(), max_batch=6, max_n=256)
+    hs = capi.Handle(_smoother_params(), max_batch=6, max_n=128)
+    got = h.optimize_path(sc["pts"], sc["n_pts"], sc["start"], sc["target"], sc["dist"], sc["geom"], map_of=sc["map_of"], smoother=hs)
+    assert got["stage"][1] == 1 and got["stage"][2] == 3 and got["stage"][3] == 6, got["stage"]
+    for b in (1, 2, 3):
+        assert got["status"][b] == 0 and got["n_out"][b] == 0
+    for b in (0, 4, 5):
+        assert got["stage"][b] == 0 and got["status"][b] == 1 and got["n_out"][b] >= 2 and np.isfinite(got["out"][b]).all()
+    # one handle for everything (smoother QPs at the path QP's setting) works too
+    alone = h.optimize_path(sc["pts"], sc["n_pts"], sc["start"], sc["target"], sc["dist"], sc["geom"], map_of=sc["map_of"])
+    assert list(alone["stage"]) == list(got["stage"])
+    h.close(); hs.close()
+
+
+def test_clearance_lookup_on_the_device(hip_lib):
+    """pqp_clearance_device = Map::getObstacleDistance at the raw line's points (tension_smoother.cpp:168), against the restatement of
+    grid_map's bilinear lookup in the corridor oracle; its output feeds pqp_smooth_tension."""
+    import torch
+    import corridor_oracle as K
+    sc = _scenarios(3, n_maps=3, seed=2)
+    h = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3), max_batch=3, max_n=64)
+    rng = np.random.default_rng(0)
+    n = 40
+    x = rng.uniform(-30, 30, size=(3, n)); y = rng.uniform(-18, 18, size=(3, n))
+    x[0, 0], y[0, 0] = 1e3, 0.0                                   # outside the map: 0 (Map.cpp:17-21)
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt=np.float64: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    d_dist = t(np.transpose(sc["dist"], (0, 2, 1)), np.float32)
+    d_x, d_y, d_map = t(x), t(y), t(np.arange(3), np.int32)
+    out = torch.zeros((3, n), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    p = lambda a: capi.C.c_void_p(a.data_ptr())
+    assert h.lib.pqp_clearance_device(h._h, 3, n, p(d_x), p(d_y), p(d_dist), p(d_map), capi.C.byref(sc["geom"]), p(out)) == 0
+    h.sync()
+    got = out.cpu().numpy()
+    for b in range(3):
+        for i in range(n):
+            assert got[b, i] == K.obstacle_distance(sc["dist"][b], sc["geom"], x[b, i], y[b, i])
+    assert got[0, 0] == 0.0
+    r = h.smooth_tension(np.cumsum(np.ones((3, n)), axis=1), np.zeros((3, n)), np.zeros((3, n)), got)
+    assert (r["status"] == 1).all()
+    h.close()
