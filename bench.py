@@ -10,6 +10,8 @@ Workloads = BASELINE.json configs (`--config`; explicit --batch / --n / --profil
     2  batch 8192, N = 120, varied start / goal / curvature limits, one GPU
     3  batch 65 536, N = 80 over 8 GPUs = 8192 QPs per GPU                                        (default at --gpus > 1)
     4  batch 4096, N = 200 over 8 GPUs = 512 per GPU: TensionSmoother2 QP + path QP on two HIP streams (pipeline.py)
+Two batches are kept in flight by default (--inflight 2: consecutive steps alternate between two handles / HIP streams; every step is
+still one pass over one whole batch, and K steps are timed); --inflight 1 and its figure in "secondary" = one launch strictly after the other.
 Solver setting: the engine's production setting (pqp_production_params: ADMM to eps 1e-4 + KKT-verified polish — every returned path
 is the exact optimum of its QP, inside the 1e-4 parity bar).  The literal metric ("ADMM iters to 1e-4", plain OSQP termination, no
 polish) and the reference's own setting (eps 2e-3) are timed in the same run and reported under "secondary".
@@ -84,7 +86,8 @@ def pmc_child(argv_core, kernel_substr, timeout_s):
         for pmc in passes:
             with tempfile.TemporaryDirectory(dir="/tmp") as d:
                 cmd = ["rocprofv3", "--kernel-trace", "--pmc", *pmc.split(), "-f", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
-                       *argv_core, "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-secondary", "--pmc", "off", "--sustain", "0"]
+                       *argv_core, "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-secondary", "--pmc", "off", "--sustain", "0",
+                       "--inflight", "1"]          # (one kernel at a time: the counters of a launch are its own)
                 env = dict(os.environ, TMPDIR="/tmp")
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
                 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -122,7 +125,9 @@ def main():
     ap.add_argument("--rho-tolerance", type=float, default=2.0, help="adaptive_rho_tolerance")
     ap.add_argument("--polish-warm-set", type=int, default=2, help="1: pass 2 starts with a polish on pass 1's active set; 2: and keeps its equilibration")
     ap.add_argument("--check-termination", type=int, default=15, help="residual check interval (iterations)")
-    ap.add_argument("--inflight", type=int, default=1, help="batches in flight: k > 1 runs consecutive steps on k handles / HIP streams")
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight: consecutive steps (independent batches) go round-robin to k handles / HIP "
+                    "streams, as a planning server keeps independent batches in flight: the next batch's QPs fill the slots the slow tail of "
+                    "this one leaves idle.  1 = strictly one launch after the other (reported under secondary.one_batch_at_a_time)")
     ap.add_argument("--no-cost-order", action="store_true", help="start the QPs of a batch in index order instead of most-expensive-first by "
                     "their cost in the previous step (PQP_OPT_ORDER_BY_COST)")
     ap.add_argument("--reference-setting", action="store_true", help="the reference's solver setting instead of the production one: "
@@ -307,6 +312,8 @@ def main():
             hh.close()
             return r
         secondary = {
+            "one_batch_at_a_time": dict(timed(prm, cost_order, args.steps), setting="the headline setting, one launch strictly after the other (--inflight 1)")
+            if len(lanes) > 1 else None,
             "index_order": dict(timed(prm, not cost_order, args.steps), setting="the headline setting with the QPs started in index order"
                                 if cost_order else "the headline setting with the QPs started most-expensive-first (previous step's cost)"),
             "plain_admm_eps_1e-4": dict(timed(capi.default_params(eps_abs=1e-4, eps_rel=1e-4), False, max(3, args.steps // 8)),
@@ -336,7 +343,10 @@ def main():
             # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 tallies a wide read at half its bytes (MICROARCH guide, HBM): x2 on the reads
             traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
         true_io = 2.0 * batch * (152 * n + 40)
+        # launches of different handles overlap: mean number of solve kernels running at a time over the timed region
+        concurrency = max(1.0, args.steps * avg_kernel_s / dt) if len(main_handles) > 1 else 1.0
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "kernels_running_at_a_time": concurrency, "frac_chip_wide": achieved * concurrency / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command, after the timed region, "
                                                            f"{pmc['_launches']} launches averaged; FETCH_SIZE x 2 (gfx950 wide-read tally)") if traffic else None,
                     "kernel": "path_solve_kernel", "kernel_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_launch": abytes,
@@ -344,7 +354,9 @@ def main():
                     "achieved_incl_factor_and_scaling": abytes_ext / avg_kernel_s / 1e9,
                     "true_io_bytes_per_launch": true_io, "traffic_over_true_io": (traffic / true_io) if traffic else None,
                     "fetch_size_kib": pmc.get("FETCH_SIZE") if pmc else None, "write_size_kib": pmc.get("WRITE_SIZE") if pmc else None,
-                    "note": "achieved / frac are SURVEY.md 8(d)'s STREAMING MODEL (bytes an HBM-streaming ADMM would move: 1040 N per reduced-KKT "
+                    "launches_in_flight": len(main_handles),
+                    "note": "achieved / frac are per LAUNCH (bytes of one launch / its own event-timed duration); with two launches in flight each "
+                            "one shares the chip and lasts longer, frac_chip_wide = frac x kernels running at a time. They are SURVEY.md 8(d)'s STREAMING MODEL (bytes an HBM-streaming ADMM would move: 1040 N per reduced-KKT "
                             "solve, polish refinement solves included; frac_admm_iterations_only charges ADMM iterations only) divided by the "
                             "measured kernel time - a model, not traffic: the iterates are register/LDS resident and the kernel is bound by fp64 "
                             "VALU issue + LDS latency (roofline_issue), `traffic` is what HBM really moved"}

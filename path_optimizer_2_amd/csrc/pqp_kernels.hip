@@ -5,7 +5,7 @@
 //                         metrics -> block-cyclic-reduction factor -> ADMM loop + KKT-verified polish -> unpack ->
 //                         re-linearise -> warm re-solve, everything in VGPRs + ~28 KB of LDS (T = 128); HBM is read
 //                         once (scenario) and written once (path).  Algorithm: pqp_path_lane.hpp.
-//   path_order_kernel     ticket -> QP map of the next launch from the cost bins the last launch recorded.
+//                         The last workgroup to finish a launch writes the ticket -> QP map of the next one (order_next_launch).
 //   path_assemble_kernel  BaseSolver::setCost/setConstraints in the REFERENCE numbering: CSC values of A,
 //                         diagonal of P, l, u; staged through LDS and written with contiguous, coalesced
 //                         stores (base_solver.cpp:119-261).
@@ -229,6 +229,33 @@ struct DevCtx {
     }
 };
 
+// ticket -> QP of the NEXT launch, most expensive first: cost bins in descending order, within a bin the order in which the QPs
+// finished.  Run by the last workgroup of a launch to leave its ticket loop (every workgroup counts itself out on hist[kCostBins]):
+// all keys and bin counts of the launch are complete then.  No separate kernel: with two launches in flight a tiny ordering kernel
+// waits for a free CU slot behind the other launch's persistent workgroups (measured: 266 us instead of 3).
+__device__ void order_next_launch(const PathSolveArgs& args) {
+    __shared__ int start[kCostBins];
+    __shared__ int s_last;
+    if (threadIdx.x == 0) s_last = atomicAdd(args.cost_hist + kCostBins, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    const int nt = blockDim.x;
+    for (int b = threadIdx.x; b < kCostBins; b += nt) start[b] = __hip_atomic_load(args.cost_hist + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) {                 // exclusive suffix sum over 256 bins: QPs in more expensive bins
+        int acc = 0;
+        for (int b = kCostBins - 1; b >= 0; --b) { const int c = start[b]; start[b] = acc; acc += c; }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < args.batch; q += nt) {
+        const int k = __hip_atomic_load(args.cost_key + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int pos = start[(k >> 24) & 0xff] + (k & 0xffffff);
+        if (pos < args.batch) args.order_next[pos] = q;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b <= kCostBins; b += nt) __hip_atomic_store(args.cost_hist + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+}
+
 // PQP_SOLVE_OCC: wavefronts per SIMD the solve kernel is compiled for (the register budget per lane is 512 / PQP_SOLVE_OCC)
 #ifndef PQP_SOLVE_OCC
 #define PQP_SOLVE_OCC 1
@@ -279,35 +306,7 @@ __global__ void __launch_bounds__(64 * NW, (NW <= 2) ? PQP_SOLVE_OCC : 1) path_s
         solver.run();
         __syncthreads();
     }
-}
-
-// ticket -> QP of the next launch, most expensive first: cost bins in descending order, within a bin the order in which the
-// QPs finished last time.  key[batch] = bin << 24 | rank, hist[kCostBins] = QPs per bin (both written by the last solve);
-// hist_next is zeroed for the solve that follows.  One thread per QP, 256 threads per block.
-__global__ void __launch_bounds__(256) path_order_kernel(int batch, const int32_t* __restrict__ key, const int32_t* __restrict__ hist,
-                                                         int32_t* __restrict__ hist_next, int32_t* __restrict__ order) {
-    __shared__ int start[kCostBins];
-    const int b = threadIdx.x;
-    const int mine = hist[b];
-    start[b] = mine;
-    __syncthreads();
-    for (int off = 1; off < kCostBins; off <<= 1) {        // inclusive suffix sum
-        const int add = (b + off < kCostBins) ? start[b + off] : 0;
-        __syncthreads();
-        start[b] += add;
-        __syncthreads();
-    }
-    const int first = start[b] - mine;                     // QPs in more expensive bins
-    __syncthreads();
-    start[b] = first;
-    __syncthreads();
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q < batch) {
-        const int k = key[q];
-        const int pos = start[(k >> 24) & 0xff] + (k & 0xffffff);
-        if (pos < batch) order[pos] = q;
-    }
-    if (blockIdx.x == 0) hist_next[b] = 0;
+    if (args.cost_key) order_next_launch(args);
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -856,19 +855,15 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     if (h->opt_order_by_cost) {
         // most expensive QPs first, by what they cost in this handle's previous solve of the same shape (a planner re-solves
         // nearly the same scenarios cycle after cycle); results do not depend on the order
-        if ((rc = h->cost_key.ensure((size_t)batch * 4)) || (rc = h->order.ensure((size_t)batch * 4))) return rc;
-        int32_t* hist_now = h->cost_hist.as<int32_t>() + (h->solves & 1) * pqp::kCostBins;
-        int32_t* hist_prev = h->cost_hist.as<int32_t>() + ((h->solves + 1) & 1) * pqp::kCostBins;
-        if (h->hist_batch == batch && h->hist_n == n) {
-            hipLaunchKernelGGL(pqp::path_order_kernel, dim3((batch + 255) / 256), dim3(256), 0, h->stream, batch, h->cost_key.as<int32_t>(),
-                               hist_prev, hist_now, h->order.as<int32_t>());
-            PQP_HIP(hipGetLastError());
-            a.order = h->order.as<int32_t>();
-        } else {
-            PQP_HIP(hipMemsetAsync(hist_now, 0, pqp::kCostBins * 4, h->stream));
-        }
+        if ((rc = h->cost_key.ensure((size_t)batch * 4)) || (rc = h->order.ensure((size_t)2 * batch * 4))) return rc;
+        // two order arrays: the one this launch reads (written by the previous launch's last workgroup) and the one it writes
+        int32_t* order_read = h->order.as<int32_t>() + (size_t)(h->solves & 1) * batch;
+        int32_t* order_write = h->order.as<int32_t>() + (size_t)((h->solves + 1) & 1) * batch;
+        if (h->hist_batch == batch && h->hist_n == n) a.order = order_read;
+        else PQP_HIP(hipMemsetAsync(h->cost_hist.p, 0, (pqp::kCostBins + 1) * 4, h->stream));      // (a shape change: stale counts)
         a.cost_key = h->cost_key.as<int32_t>();
-        a.cost_hist = hist_now;
+        a.cost_hist = h->cost_hist.as<int32_t>();
+        a.order_next = order_write;
         h->hist_batch = batch; h->hist_n = n;
     }
     h->solves += 1;

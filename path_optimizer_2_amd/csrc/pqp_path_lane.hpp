@@ -85,7 +85,8 @@ struct PathSolveArgs {
     unsigned long long ticket_base;
     const int32_t* order;   // [batch] or nullptr
     int32_t* cost_key;      // [batch] or nullptr: bin << 24 | rank within the bin, written at the end of every QP
-    int32_t* cost_hist;     // [256] QPs per cost bin (atomically counted)
+    int32_t* cost_hist;     // [256] QPs per cost bin (atomically counted) + [256] = workgroups that have finished this launch
+    int32_t* order_next;    // [batch] the ticket -> QP map of the NEXT launch, written by the last workgroup to finish this one
     pqp_params prm;
 };
 enum { kCostBins = 256 };
@@ -459,10 +460,12 @@ PQP_HD void record_cost(const PathSolveArgs& a, int qp, int cost) {
     bin = bin < kCostBins - 1 ? bin : kCostBins - 1;
 #if defined(__HIP_DEVICE_COMPILE__)
     const int rank = atomicAdd(a.cost_hist + bin, 1);
+    // (device-scope store: the last workgroup of the launch, on whatever XCD, reads it with a device-scope load)
+    __hip_atomic_store(a.cost_key + qp, (bin << 24) | (rank & 0xffffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
     const int rank = a.cost_hist[bin]++;
-#endif
     a.cost_key[qp] = (bin << 24) | (rank & 0xffffff);
+#endif
 }
 
 // uniform (per-QP) solver scalars; handed by value across the hot / cold boundary
