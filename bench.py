@@ -117,14 +117,15 @@ def main():
     ap.add_argument("--profile", default=None, choices=["uniform", "varied"])
     ap.add_argument("--eps", type=float, default=1e-4, help="eps_abs = eps_rel of the ADMM termination test")
     ap.add_argument("--no-polish", action="store_true", help="plain OSQP termination, no polish")
-    ap.add_argument("--rho-interval", type=int, default=15, help="adaptive_rho_interval (iterations)")
-    ap.add_argument("--polish-every", type=int, default=15, help="also try the KKT-verified polish every k ADMM iterations")
+    ap.add_argument("--rho-interval", type=int, default=None, help="adaptive_rho_interval (iterations; default: the production setting's 8)")
+    ap.add_argument("--polish-every", type=int, default=None, help="also try the KKT-verified polish every k ADMM iterations (default 8)")
     ap.add_argument("--polish-refine", type=int, default=2, help="refinement solves per active-set round of the polish")
     ap.add_argument("--polish-max-rounds", type=int, default=0, help="active-set rounds before a polish attempt gives up (0: max(24, n/5 - 8))")
+    ap.add_argument("--scaling", type=int, default=None, help="Ruiz equilibration passes (default: the production setting's)")
     ap.add_argument("--seed", type=int, default=None, help="seed of the synthetic scenarios (default: synth.BASE_SEED)")
     ap.add_argument("--rho-tolerance", type=float, default=2.0, help="adaptive_rho_tolerance")
     ap.add_argument("--polish-warm-set", type=int, default=2, help="1: pass 2 starts with a polish on pass 1's active set; 2: and keeps its equilibration")
-    ap.add_argument("--check-termination", type=int, default=15, help="residual check interval (iterations)")
+    ap.add_argument("--check-termination", type=int, default=None, help="residual check interval (iterations; default 8)")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight: consecutive steps (independent batches) go round-robin to k handles / HIP "
                     "streams, as a planning server keeps independent batches in flight: the next batch's QPs fill the slots the slow tail of "
                     "this one leaves idle.  1 = strictly one launch after the other (reported under secondary.one_batch_at_a_time)")
@@ -171,9 +172,14 @@ def main():
     cost_order = not args.no_cost_order
 
     def production(**over):
-        kw = dict(eps_abs=args.eps, eps_rel=args.eps, polish=1 if polish else 0, polish_every=args.polish_every, adaptive_rho_interval=args.rho_interval,
-                  polish_warm_set=args.polish_warm_set if polish else 0, check_termination=args.check_termination, polish_refine_iter=args.polish_refine,
-                  polish_max_rounds=args.polish_max_rounds, adaptive_rho_tolerance=args.rho_tolerance)
+        kw = dict(eps_abs=args.eps, eps_rel=args.eps, polish=1 if polish else 0, polish_warm_set=args.polish_warm_set if polish else 0,
+                  polish_refine_iter=args.polish_refine, polish_max_rounds=args.polish_max_rounds, adaptive_rho_tolerance=args.rho_tolerance)
+        for key, val in (("scaling", args.scaling), ("adaptive_rho_interval", args.rho_interval), ("polish_every", args.polish_every),
+                         ("check_termination", args.check_termination)):
+            if val is not None:
+                kw[key] = val
+        if not polish:
+            kw["polish_every"] = 0
         kw.update(over)
         return capi.production_params(**kw)
 
@@ -384,7 +390,8 @@ def main():
             "config": {"workload": workload, "config_id": cfg_id, "batch_per_gpu": batch, "n_waypoints": n, "profile": profile,
                        "eps_abs": args.eps, "eps_rel": args.eps, "polish": polish, "setting": setting,
                        "solver": "ADMM to eps 1e-4 + KKT-verified active-set polish (every path is the exact QP optimum)" if polish else "plain OSQP termination",
-                       "polish_every": args.polish_every if polish else 0, "adaptive_rho_interval": 100 if args.reference_setting else args.rho_interval,
+                       "polish_every": prm.polish_every, "adaptive_rho_interval": prm.adaptive_rho_interval, "check_termination": prm.check_termination,
+                       "ruiz_passes": prm.scaling,
                        "polish_refine_iter": args.polish_refine, "polish_max_rounds": args.polish_max_rounds, "polish_warm_set": args.polish_warm_set,
                        "passes": "cold solve + 1 re-linearised warm re-solve (PathOptimizer::optimizePath)",
                        "qp_start_order": "most expensive first by the previous step's cost (PQP_OPT_ORDER_BY_COST)" if cost_order else "index order",

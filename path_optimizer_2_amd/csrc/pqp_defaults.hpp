@@ -53,7 +53,7 @@ inline void default_params(pqp_params* p) {
 }
 
 // The engine's production setting on top of the defaults: ADMM to 1e-4, KKT-verified polish (a returned path is the exact
-// optimum of its QP), residual check / rho adaptation / polish attempt every 15 iterations, 2 refinement solves per active-set
+// optimum of its QP), 4 Ruiz passes, residual check / rho adaptation / polish attempt every 8 iterations, 2 refinement solves per active-set
 // round, at most max(24, n/5 - 8) rounds per attempt, pass 2 starts from pass 1's active set and equilibration, an attempt that
 // gives up re-seeds ADMM with its best point, a QP whose polish cannot be verified ends like OSQP's (ADMM point, unpolished), the
 // infeasibility certificate evaluated outside the ADMM loop from iteration 100 on (prim_inf_after = 0 gives OSQP's every-check test back).  Tuned on MI355X (DESIGN.md sections 2, 5);
@@ -62,11 +62,14 @@ inline void production_params(pqp_params* p) {
     default_params(p);
     p->eps_abs = 1e-4;
     p->eps_rel = 1e-4;
-    p->adaptive_rho_interval = 15;
-    p->check_termination = 15;
+    p->scaling = 4;                                 // 4 Ruiz passes instead of OSQP's 10: the polish returns the exact optimum whatever the
+                                                    // metric, the ADMM iterations before it only have to predict the active set (+0.5 % solves,
+                                                    // -6 passes of 2.5 us: +4.5 % paths/s, profiles/r02h_policy_sweep.txt)
+    p->adaptive_rho_interval = 8;
+    p->check_termination = 8;
     p->polish = 1;
     p->polish_refine_iter = 2;
-    p->polish_every = 15;
+    p->polish_every = 8;                            // (round 1: 15.  A factorisation now costs 2 solves, not 3.3: earlier, cheaper attempts win: +6 %)
     p->polish_warm_set = 2;
     p->polish_max_rounds = 0;                       // auto: max(24, n/5 - 8)
     p->polish_reseed = 1;
@@ -74,7 +77,7 @@ inline void production_params(pqp_params* p) {
     p->max_iter = 1000;                             // per pass (OSQP's 4000 in the defaults): every feasible QP of the sweeps ends within 500; an
                                                     // infeasible one, which this setting cannot certify, then holds its batch up for 4 ms, not 15
     p->polish_patience = 5;                         // a QP whose polish cannot be verified (e.g. infeasible by 1e-5) ends like OSQP's,
-                                                    // after attempts at 15, 45, 105, 225, 465 iterations
+                                                    // after attempts at 8, 24, 56, 120, 248 iterations
     p->prim_inf_after = 100;                        // the lean kernel (no certificate work inside the ADMM loop: 12 % faster iterations); from
                                                     // iteration 100 on the certificate is evaluated between checks on y_now - y_previous_check,
                                                     // so an infeasible QP ends PRIMAL_INFEASIBLE after ~130 iterations instead of holding its

@@ -11,8 +11,8 @@ LIB = os.path.join(CSRC, "libpqp_hip_timing.so")
 
 
 def build():
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DPQP_MONOLITH", "-DPQP_TIMING", "-fPIC", "-shared",
-                    "-o", LIB, os.path.join(CSRC, "pqp_kernels.hip")], check=True, cwd=CSRC)
+    import __graft_entry__ as g
+    g.build_hip(defines=["PQP_TIMING"], out=LIB)
 
 
 if __name__ == "__main__":
