@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--no-polish", action="store_true", help="plain OSQP termination, no polish")
     ap.add_argument("--rho-interval", type=int, default=None, help="adaptive_rho_interval (iterations; default: the production setting's 8)")
     ap.add_argument("--polish-every", type=int, default=None, help="also try the KKT-verified polish every k ADMM iterations (default 8)")
+    ap.add_argument("--polish-lazy", type=int, default=None, help="rounds of a polish attempt that move rows after one solve (default: the production setting's 5)")
     ap.add_argument("--polish-refine", type=int, default=2, help="refinement solves per active-set round of the polish")
     ap.add_argument("--polish-max-rounds", type=int, default=0, help="active-set rounds before a polish attempt gives up (0: max(24, n/5 - 8))")
     ap.add_argument("--scaling", type=int, default=None, help="Ruiz equilibration passes (default: the production setting's)")
@@ -175,7 +176,7 @@ def main():
         kw = dict(eps_abs=args.eps, eps_rel=args.eps, polish=1 if polish else 0, polish_warm_set=args.polish_warm_set if polish else 0,
                   polish_refine_iter=args.polish_refine, polish_max_rounds=args.polish_max_rounds, adaptive_rho_tolerance=args.rho_tolerance)
         for key, val in (("scaling", args.scaling), ("adaptive_rho_interval", args.rho_interval), ("polish_every", args.polish_every),
-                         ("check_termination", args.check_termination)):
+                         ("check_termination", args.check_termination), ("polish_lazy", args.polish_lazy)):
             if val is not None:
                 kw[key] = val
         if not polish:
@@ -391,7 +392,7 @@ def main():
                        "eps_abs": args.eps, "eps_rel": args.eps, "polish": polish, "setting": setting,
                        "solver": "ADMM to eps 1e-4 + KKT-verified active-set polish (every path is the exact QP optimum)" if polish else "plain OSQP termination",
                        "polish_every": prm.polish_every, "adaptive_rho_interval": prm.adaptive_rho_interval, "check_termination": prm.check_termination,
-                       "ruiz_passes": prm.scaling,
+                       "ruiz_passes": prm.scaling, "polish_lazy": prm.polish_lazy,
                        "polish_refine_iter": args.polish_refine, "polish_max_rounds": args.polish_max_rounds, "polish_warm_set": args.polish_warm_set,
                        "passes": "cold solve + 1 re-linearised warm re-solve (PathOptimizer::optimizePath)",
                        "qp_start_order": "most expensive first by the previous step's cost (PQP_OPT_ORDER_BY_COST)" if cost_order else "index order",

@@ -146,6 +146,12 @@ typedef struct pqp_params {
                                          termination check that neither converged nor started a polish evaluates the SAME certificate on
                                          dy = y_now - y_at_the_previous_such_check (any dy that passes it proves infeasibility): nothing in
                                          the ADMM loop, an infeasible QP stops about two checks after iteration k */
+    int32_t polish_lazy;              /* 0: every active-set round refines its point with polish_refine_iter solves before it is looked at.
+                                         k > 0: a round first looks after ONE solve; during the first k full rounds of an attempt rows that
+                                         fail the test by more than 10 x that solve's residual change sides at once, the remaining
+                                         refinement solves only run when nothing moves that far (they are what the KKT acceptance test
+                                         needs, not what the set update needs).  The accepted point is always a fully refined one. */
+    int32_t reserved1;                /* padding, 0 */
     /* smoother QP weights (src/config/planning_flags.cpp:51-61) */
     double tension2_deviation_weight;        /* 0.005 */
     double tension2_curvature_weight;        /* 1     */

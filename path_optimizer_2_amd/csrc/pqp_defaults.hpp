@@ -42,6 +42,8 @@ inline void default_params(pqp_params* p) {
     p->eps_prim_inf = 1e-4;
     p->polish_patience = 0;
     p->prim_inf_after = 0;                          // OSQP: the certificate at every check
+    p->polish_lazy = 0;
+    p->reserved1 = 0;
     p->polish_delta = 1e-6;
     p->polish_tol = 1e-7;
     p->tension2_deviation_weight = 0.005;           // planning_flags.cpp:57
@@ -54,7 +56,7 @@ inline void default_params(pqp_params* p) {
 
 // The engine's production setting on top of the defaults: ADMM to 1e-4, KKT-verified polish (a returned path is the exact
 // optimum of its QP), 4 Ruiz passes, residual check / rho adaptation / polish attempt every 8 iterations, 2 refinement solves per active-set
-// round, at most max(24, n/5 - 8) rounds per attempt, pass 2 starts from pass 1's active set and equilibration, an attempt that
+// round (the first 5 rounds of an attempt move their rows after the first of them), at most max(24, n/5 - 8) rounds per attempt, pass 2 starts from pass 1's active set and equilibration, an attempt that
 // gives up re-seeds ADMM with its best point, a QP whose polish cannot be verified ends like OSQP's (ADMM point, unpolished), the
 // infeasibility certificate evaluated outside the ADMM loop from iteration 100 on (prim_inf_after = 0 gives OSQP's every-check test back).  Tuned on MI355X (DESIGN.md sections 2, 5);
 // bench.py, smoke() and the parity tests run this setting.
@@ -78,6 +80,9 @@ inline void production_params(pqp_params* p) {
                                                     // infeasible one, which this setting cannot certify, then holds its batch up for 4 ms, not 15
     p->polish_patience = 5;                         // a QP whose polish cannot be verified (e.g. infeasible by 1e-5) ends like OSQP's,
                                                     // after attempts at 8, 24, 56, 120, 248 iterations
+    p->polish_lazy = 5;                             // the first 5 rounds of an attempt move rows after one solve: -11 % solve+factor cost on the
+                                                    // emulator sweeps with the tails unchanged (8 and more: the tails grow), +4..10 % paths/s
+                                                    // on MI355X (profiles/r02i_lazy_refinement.txt)
     p->prim_inf_after = 100;                        // the lean kernel (no certificate work inside the ADMM loop: 12 % faster iterations); from
                                                     // iteration 100 on the certificate is evaluated between checks on y_now - y_previous_check,
                                                     // so an infeasible QP ends PRIMAL_INFEASIBLE after ~130 iterations instead of holding its

@@ -1687,6 +1687,7 @@ struct PathQp {
         double eps_scale = 1.0, best = 1e300, best_any = 1e300, admm_merit = 1e300;
         int it = 0, refine_left = 0, round = 0, stall = 0, polish_gap = 0, next_polish = 0;
         int extra_refine = 0;            // extra pairs of refinement solves spent on the current polish round
+        bool lazy_look = false;          // polish_lazy: the next look at the polished point follows a single solve
         bool direct_polish = false, last_accepted = false;
         // the pending cold operation
         int op = COLD_BEGIN_PASS, i0 = 0, i1 = A.warm ? 1 : 0;
@@ -1726,7 +1727,7 @@ struct PathQp {
                 it = 0; refine_left = 0; round = 0; stall = 0;
                 polish_gap = prm.polish_every; next_polish = prm.polish_every;
                 last_accepted = false;
-                if (direct_polish) { polish_mode = true; refine_left = prm.polish_refine_iter; best_any = 1e300; admm_merit = 1e300; }
+                if (direct_polish) { polish_mode = true; refine_left = prm.polish_lazy ? 1 : prm.polish_refine_iter; lazy_look = prm.polish_lazy != 0; best_any = 1e300; admm_merit = 1e300; }
             } else if (end_after_reject) {       // a rejected polish at max_iter
                 op = COLD_END_PASS; i0 = 0;
                 continue;
@@ -1782,7 +1783,8 @@ struct PathQp {
                         printf("  START qp %d it %d ratio_p %.3e ratio_d %.3e\n", qp, it, res[0] / (prm.eps_abs + prm.eps_rel * res[2]), res[1] / (prm.eps_abs + prm.eps_rel * res[3]));
 #endif
                         polish_mode = true;
-                        refine_left = prm.polish_refine_iter; round = 0; stall = 0; best = 1e300; conservative = false;
+                        refine_left = prm.polish_lazy ? 1 : prm.polish_refine_iter; lazy_look = prm.polish_lazy != 0;
+                        round = 0; stall = 0; best = 1e300; conservative = false;
                         best_any = 1e300; admm_merit = fmax(res[0], res[1]);
                         op = COLD_REFACTOR; i0 = RF_POLISH_BEGIN; break;
                     }
@@ -1812,6 +1814,21 @@ struct PathQp {
                     { PQP_TIC; viol = polish_violation(); PQP_TOC(6); }
                     const bool solve_ok = res[4] == 0.0 && res[0] <= tol * (1.0 + res[2]) && res[1] <= tol * (1.0 + res[3]);
                     const bool ok = solve_ok && viol <= tol;
+                    // polish_lazy = k: the first look of a round comes after one solve.  Its point is not accurate enough for the acceptance
+                    // test, but rows that fail by far more than the solve's own residual fail at the refined point too: during the first
+                    // k full rounds of an attempt (where many rows move at once) they move now and the round is over; otherwise the
+                    // remaining refinement solves follow.  (Unbounded k: the late rounds, which move single rows, cycle on unrefined points.)
+                    if (lazy_look) {
+                        lazy_look = false;
+                        const double noise = 10.0 * fmax(res[0], res[1]);
+                        if (res[4] == 0.0 && !ok && viol > fmax(10.0 * tol, noise) && round + 1 < max_rounds && round < prm.polish_lazy && !conservative) {
+                            round += 1;
+                            refine_left = 1; lazy_look = true;
+                            op = COLD_REFACTOR; i0 = RF_POLISH_UPDATE; d0 = fmax(tol, noise); break;
+                        }
+                        // (nothing moves: the point is only looked at again, and only ever accepted, fully refined)
+                        refine_left = prm.polish_refine_iter > 1 ? prm.polish_refine_iter - 1 : 1; continue;
+                    }
                     // the refinement solves start from the ADMM iterate; from a distant one the budgeted number of them may leave the
                     // polished point short of the accuracy the KKT test needs: up to 3 more pairs of solves instead of throwing the
                     // attempt away
@@ -1845,7 +1862,7 @@ struct PathQp {
                         d0 = (prm.polish_reseed && best_any < prm.polish_reseed_factor * admm_merit) ? 1.0 : 0.0;
                         op = COLD_REFACTOR; i0 = RF_POLISH_REJECT; break;
                     }
-                    refine_left = prm.polish_refine_iter;
+                    refine_left = prm.polish_lazy ? 1 : prm.polish_refine_iter; lazy_look = prm.polish_lazy != 0;
                     op = COLD_REFACTOR; i0 = RF_POLISH_UPDATE; d0 = conservative ? fmax(tol, 0.9 * viol) : tol; break;
                 }
             }

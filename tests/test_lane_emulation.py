@@ -161,3 +161,18 @@ def test_a_polish_that_cannot_be_verified_ends_like_osqp():
     r0 = E.solve(E.production(polish_patience=0, max_iter=1500), b["ref"], b["bounds"], b["scal"], passes=1)
     assert r0["status"][0] == 2
 
+
+
+@pytest.mark.parametrize("n,profile", [(80, "uniform"), (120, "varied"), (200, "uniform")])
+def test_lazy_refinement_changes_the_cost_not_the_answer(n, profile):
+    """polish_lazy = k: the first k rounds of a polish attempt move their rows after ONE solve.  The accepted point is still a fully
+    refined one that passes the KKT test: the same optimum as with polish_lazy = 0, with fewer KKT solves on average."""
+    b = make_batch(64, n, profile, seed=77)
+    eager = E.solve(E.production(polish_lazy=0), b["ref"], b["bounds"], b["scal"], passes=1)
+    lazy = E.solve(E.production(), b["ref"], b["bounds"], b["scal"], passes=1)
+    assert E.production().polish_lazy > 0
+    for r in (eager, lazy):
+        assert (r["status"] == 1).all() and (r["info"][:, 4] == 2).all()
+    assert np.abs(eager["out"][:, :, 3:5] - lazy["out"][:, :, 3:5]).max() < 2e-6        # two KKT-verified (1e-7) points of one QP
+    assert lazy["info"][:, 5].mean() < 0.92 * eager["info"][:, 5].mean()                # KKT solves
+    assert lazy["info"][:, 5].max() <= 1.5 * eager["info"][:, 5].max()                  # and no new stragglers
