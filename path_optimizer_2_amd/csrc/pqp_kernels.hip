@@ -31,17 +31,50 @@ namespace pqp {
 // device execution context for PathQp: a phase is the code between two workgroup barriers
 // -------------------------------------------------------------------------------------------------------
 // wave / workgroup reductions shared by the hot and the cold context
+// One step of a wavefront max-reduction in the VALU (DPP: data-parallel primitives move a value between lanes inside the instruction,
+// no LDS round trip as with __shfl): x = max(x, x of the lane CTRL selects); lanes without a source keep their value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max_step(double x) {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return fmax(x, __hiloint2double(ohi, olo));
+}
+// max over the 64 lanes of a wavefront, the same value in every lane (and known to the compiler as wave-uniform)
+__device__ __forceinline__ double wave_max(double x) {
+    x = dpp_max_step<0x111, 0xf>(x);      // row_shr:1
+    x = dpp_max_step<0x112, 0xf>(x);      // row_shr:2
+    x = dpp_max_step<0x114, 0xf>(x);      // row_shr:4
+    x = dpp_max_step<0x118, 0xf>(x);      // row_shr:8      -> lane 15 of every row of 16: the row's max
+    x = dpp_max_step<0x142, 0xa>(x);      // row_bcast:15   -> lanes 31, 63: max of rows 0-1, 2-3
+    x = dpp_max_step<0x143, 0xc>(x);      // row_bcast:31   -> lane 63: max of the wavefront
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
+
+// the same for a sum (lanes without a source add 0)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_sum_step(double x) {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const int olo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    const int ohi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return x + __hiloint2double(ohi, olo);
+}
+__device__ __forceinline__ double wave_sum(double x) {
+    x = dpp_sum_step<0x111, 0xf>(x);
+    x = dpp_sum_step<0x112, 0xf>(x);
+    x = dpp_sum_step<0x114, 0xf>(x);
+    x = dpp_sum_step<0x118, 0xf>(x);
+    x = dpp_sum_step<0x142, 0xa>(x);
+    x = dpp_sum_step<0x143, 0xc>(x);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
+
 template <int NW, int K, bool MAX>
 __device__ __forceinline__ void wg_reduce(double (&v)[K], double* shp) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         double x = v[k];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double o = __shfl_xor(x, off, 64);
-            x = MAX ? fmax(x, o) : x + o;
-        }
-        v[k] = x;
+        v[k] = MAX ? wave_max(x) : wave_sum(x);
     }
     if (NW > 1) {
         double* red = shp + ShLayout{64 * NW}.red();
@@ -88,6 +121,9 @@ __device__ __noinline__ bool dev_certificate(double* sh, double fl, double rl, d
 
 // PQP_CST_LDS / PQP_PARK_SCALE: the register diet of pqp_path_lane.hpp (12 pass constants per waypoint in LDS, Ruiz vectors parked in
 // memory between the passes)
+#ifndef PQP_DPP
+#define PQP_DPP 1      // +x %: profiles/r02j
+#endif
 #ifndef PQP_CST_LDS
 #define PQP_CST_LDS 0
 #endif
@@ -107,6 +143,18 @@ __device__ __noinline__ bool dev_late_certificate(double* sh, int t, double* sna
 template <int NW>
 struct RegCtx {
     static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0, kSaveLds = NW <= 4;
+    // DPP moves (PQP_DPP): the value of the lane H below / above in the same row of 16 lanes, of the previous row's last lane; 0 where
+    // there is no such lane.  Must run with every lane enabled (a disabled source lane reads as "no lane").
+    static constexpr bool kDpp = PQP_DPP != 0;
+    template <int CTRL, int ROW_MASK>
+    __device__ __forceinline__ static double dpp0(double v) {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+        return __hiloint2double(hi, lo);
+    }
+    template <int H> __device__ __forceinline__ static double lane_below(double v) { return dpp0<0x110 + H, 0xf>(v); }     // row_shr:H
+    template <int H> __device__ __forceinline__ static double lane_above(double v) { return dpp0<0x100 + H, 0xf>(v); }     // row_shl:H
+    __device__ __forceinline__ static double prev_row_last(double v) { return dpp0<0x142, 0xe>(v); }                      // row_bcast:15
     Lane lane;
     double* shp;
     __device__ __forceinline__ int T() const { return 64 * NW; }
@@ -167,6 +215,18 @@ template <int NW>
 struct DevCtx {
     // kSaveLds: up to 256 lanes the polish save area fits beside the exchange buffers (72 KB per QP at T = 128, two QPs per CU)
     static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0, kSaveLds = NW <= 4;
+    // DPP moves (PQP_DPP): the value of the lane H below / above in the same row of 16 lanes, of the previous row's last lane; 0 where
+    // there is no such lane.  Must run with every lane enabled (a disabled source lane reads as "no lane").
+    static constexpr bool kDpp = PQP_DPP != 0;
+    template <int CTRL, int ROW_MASK>
+    __device__ __forceinline__ static double dpp0(double v) {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+        return __hiloint2double(hi, lo);
+    }
+    template <int H> __device__ __forceinline__ static double lane_below(double v) { return dpp0<0x110 + H, 0xf>(v); }     // row_shr:H
+    template <int H> __device__ __forceinline__ static double lane_above(double v) { return dpp0<0x100 + H, 0xf>(v); }     // row_shl:H
+    __device__ __forceinline__ static double prev_row_last(double v) { return dpp0<0x142, 0xe>(v); }                      // row_bcast:15
     Lane lane;
     Lane* mem;
     double* shp;
@@ -270,6 +330,9 @@ __global__ void __launch_bounds__(64 * NW, (NW <= 2) ? PQP_SOLVE_OCC : 1) path_s
     // Persistent workgroups: every workgroup draws tickets until the batch is used up (each workgroup ends on one ticket beyond
     // it, so a launch consumes exactly batch + gridDim.x tickets and the host knows the next launch's base without a reset).
     for (;;) {
+#ifdef PQP_TIMING
+        const long long t_ticket0 = (long long)wall_clock64();
+#endif
         if (threadIdx.x == 0) s_ticket = (int)(atomicAdd(args.ticket, 1ull) - args.ticket_base);
         __syncthreads();
         const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
@@ -303,8 +366,14 @@ __global__ void __launch_bounds__(64 * NW, (NW <= 2) ? PQP_SOLVE_OCC : 1) path_s
         ctx.shp = smem;
         ctx.args = &args;
         PathQp<DevCtx<NW>, CERT> solver(ctx, args, qp, (int)blockIdx.x);
+#ifdef PQP_TIMING
+        const long long t_ticket1 = (long long)wall_clock64();
+#endif
         solver.run();
         __syncthreads();
+#ifdef PQP_TIMING
+        if (threadIdx.x == 0) args.out[(size_t)qp * args.n * PQP_OUT_STRIDE + 8] = (double)(t_ticket1 - t_ticket0);     // debug build only
+#endif
     }
     if (args.cost_key) order_next_launch(args);
 }

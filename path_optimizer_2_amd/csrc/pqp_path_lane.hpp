@@ -521,7 +521,12 @@ struct PathQp {
     int factors_;             // factor() executions
 #ifdef PQP_TIMING
     long long tsub_[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // debug build: ticks inside the cold operations (tools/kernel_timeline.py)
-#define PQP_SUB(k, stmt) do { const long long t0_ = ctx.clock(); stmt; tsub_[k] += ctx.clock() - t0_; } while (0)
+// PQP_TIMING_MASK: bit k = category k of run() is timed, bit 8 + k = sub-time k of the cold operations (one category per build keeps the
+// clock reads from perturbing what they measure; the total, tacc[7], is always taken)
+#ifndef PQP_TIMING_MASK
+#define PQP_TIMING_MASK 0xffff
+#endif
+#define PQP_SUB(k, stmt) do { if ((PQP_TIMING_MASK >> (8 + (k))) & 1) { const long long t0_ = ctx.clock(); stmt; tsub_[k] += ctx.clock() - t0_; } else { stmt; } } while (0)
 #else
 #define PQP_SUB(k, stmt) do { stmt; } while (0)
 #endif
@@ -945,25 +950,8 @@ struct PathQp {
         });
     }
 
-    // --- polish piece 3: worst KKT failure of the polished point over all inequality rows
-    //     (needs sh[xbuf] = X of every waypoint, published by residuals())
-    PQP_HD double polish_violation() {
-        double viol[1];
-        ctx.template reduce_max<1>(viol, [&](int t, Lane& ln, double (&v)[1]) {
-            const Slot& S = ln.s;
-            double Xp[3], aT[3], aI[3];
-            { const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
-            rows_of(S, Xp, S.x, aT, aI);
-            double w = 0.0;
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) w = fmax(w, row_violation(S, t, k, aI[k]));
-            if (S.flags & F_LAST) {
-                const EndRows* er = end_rows();
-                for (int k = 0; k < 2; ++k) w = fmax(w, end_violation(er, k, S.x[k]));
-            }
-            v[0] = w;
-        });
-        return viol[0];
-    }
+    // --- polish piece 3: worst KKT failure of the polished point over all inequality rows: res[5] of residuals() (one reduction
+    //     for the solve's residuals and the KKT test)
 
     // --- polish piece 3b: the inactive rows that fail the test by more than thr, published per waypoint and row kind (0: none).
     //     A run of violated neighbouring rows of one kind is ONE bump of the path over its bound: pinning its peak removes it,
@@ -1229,10 +1217,55 @@ struct PathQp {
     // ---------------------------------------------------------------------------------------------
     // one ADMM iteration
     // ---------------------------------------------------------------------------------------------
+    // Contexts with kDpp (the device): the exchanges between lanes of one row of 16 - levels h <= 8 of both passes, the message of the
+    // next waypoint, the X~ of the previous one - move through DPP operands inside VALU instructions instead of an LDS write + read
+    // (9 of the 15 LDS round trips of an iteration, each ~100 exposed cycles at one wavefront per SIMD).  A row's last lane (tp = 16m)
+    // survives every level below 16 and only RECEIVES from the next row: it takes those messages from LDS at level 16, all at once -
+    // the same deferral the wavefront's last lane uses across the workgroup barrier.
+    template <int H>
+    PQP_HD void forward_level_dpp(double (&gm)[3], double (&qm)[3], double (&pm)[3]) {
+        ctx.phase_w([&](int t, Lane& ln) {
+            Slot& S = ln.s;
+            const int tp = t + 1;
+            if constexpr (H == 1) {
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += ctx.template lane_above<1>(gm[k]);
+            } else {
+                double qv[3], pv[3];
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) { qv[k] = ctx.template lane_above<(H >> 1)>(qm[k]); pv[k] = ctx.template lane_below<(H >> 1)>(pm[k]); }
+                if ((tp & (H - 1)) == 0) { _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] -= qv[k] + pv[k]; }
+            }
+            if ((tp & (2 * H - 1)) == H) {
+                mat3_vec(S.GL, S.r, qm);
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufQ() + 3 * t + k] = qm[k];       // (for the row's / wavefront's last lane)
+                mat3_vec(S.GR, S.r, pm);
+                if constexpr (H >= 8) { _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufP() + 3 * t + k] = pm[k]; }
+            }
+        });
+    }
+    template <int H>
+    PQP_HD void backward_level_dpp(const double (&xpv)[3]) {
+        ctx.phase_w([&](int t, Lane& ln) {
+            Slot& S = ln.s;
+            const int tp = t + 1;
+            double xl[3], xr[3];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { xl[k] = ctx.template lane_below<H>(S.xt[k]); xr[k] = ctx.template lane_above<H>(S.xt[k]); }
+            if ((t & 15) < H) { _Pragma("unroll") for (int k = 0; k < 3; ++k) xl[k] = xpv[k]; }       // t - H is the previous row's last lane
+            if ((tp & (2 * H - 1)) == H) {
+                double x3[3], p[3], pr[3];
+                sym3_vec(S.Dinv, S.r, x3);
+                mat3t_vec(S.GL, xl, p);
+                mat3t_vec(S.GR, xr, pr);
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.xt[k] = x3[k] - p[k] - pr[k];
+            }
+        });
+    }
+
     PQP_HD void iterate() {
         const pqp_params& prm = A.prm;
         kkt_solves_ += 1;
         const double alpha = alpha_;
+        constexpr bool D = Ctx::kDpp;
+        double gm[3] = {0.0, 0.0, 0.0}, qm[3] = {0.0, 0.0, 0.0}, pm[3] = {0.0, 0.0, 0.0}, xpv[3] = {0.0, 0.0, 0.0};    // kDpp: per-lane transients
         // I1: w = R z - y, reduced right-hand side pieces, message to the previous waypoint.  Wave-local: the message is read
         // by the previous lane (the last lane of a wavefront reads its neighbour's after the barrier below).
         ctx.phase_w([&](int t, Lane& ln) {
@@ -1259,13 +1292,42 @@ struct PathQp {
             S.r[1] = sig_of(S, t, 1) * S.x[1] - wT[1] + cf * wI[1] + cr * wI[2] + we1 - cf * eF - cr * eR;
             S.r[2] = sig_of(S, t, 2) * S.x[2] - wT[2] + wI[0] + tud;
             _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufG() + 3 * t + k] = g[k];
+            if constexpr (D) { _Pragma("unroll") for (int k = 0; k < 3; ++k) gm[k] = g[k]; }
         });
         // Forward pass.  Levels h < 64 stay inside a wavefront (wave-local phases: no workgroup barrier); a wave's last lane
         // (tp = 64m, a survivor of all of them) defers what it would receive from the next wavefront - the message g of
         // waypoint t+1 and the level messages of the nodes t + hp - and adds them after ONE barrier.  Levels h >= 64 and the
         // root use workgroup barriers.  (T = 64: no barrier at all.)
         const int hw = T < 64 ? T : 64;
-        for (int h = 1; h < hw; h <<= 1) {
+        if constexpr (D) {
+            forward_level_dpp<1>(gm, qm, pm);
+            forward_level_dpp<2>(gm, qm, pm);
+            forward_level_dpp<4>(gm, qm, pm);
+            forward_level_dpp<8>(gm, qm, pm);
+            // level 16: its survivors are the rows' last lanes; everything they have deferred arrives now (not the wavefront's last
+            // lane: it waits for the barrier below)
+            ctx.phase_w([&](int t, Lane& ln) {
+                Slot& S = ln.s;
+                const int tp = t + 1;
+                const bool surv = (tp & 15) == 0, wedge = (tp & 63) == 0;
+                const bool hr = surv && !wedge, hl = surv && (t - 8 >= 0);
+                const double* q_ = nb(hr, L.bufQ(), 3, t + 8);
+                const double* p_ = nb(hl, L.bufP(), 3, t - 8);
+                const double* g_ = nb(hr, L.bufG(), 3, t + 1);
+                const double* q1 = nb(hr, L.bufQ(), 3, t + 1);
+                const double* q2 = nb(hr, L.bufQ(), 3, t + 2);
+                const double* q4 = nb(hr, L.bufQ(), 3, t + 4);
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += g_[k] - (q1[k] + q2[k] + q4[k]) - (q_[k] + p_[k]);
+                if ((tp & 31) == 16) {
+                    double p[3];
+                    mat3_vec(S.GL, S.r, p);
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufQ() + 3 * t + k] = p[k];
+                    mat3_vec(S.GR, S.r, p);
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.bufP() + 3 * t + k] = p[k];
+                }
+            });
+        }
+        for (int h = D ? 32 : 1; h < hw; h <<= 1) {
             ctx.phase_w([&](int t, Lane& ln) {
                 Slot& S = ln.s;
                 const int tp = t + 1;
@@ -1337,7 +1399,7 @@ struct PathQp {
         }
         // Backward pass: cross-wave levels with barriers, then the in-wave levels wave-locally (what they read from another
         // wavefront - the x of its last lane - was written before the last barrier).
-        for (int h = T >> 1; h >= 1; h >>= 1) {
+        for (int h = T >> 1; h >= (D ? 16 : 1); h >>= 1) {
             if (short_tree && h == (T >> 1)) continue;          // that node was the root
             auto body = [&](int t, Lane& ln) {
                 Slot& S = ln.s;
@@ -1358,6 +1420,21 @@ struct PathQp {
             };
             if (h >= 64) ctx.phase(body); else ctx.phase_w(body);
         }
+        if constexpr (D) {
+            // X~ of the previous row's last lane (solved at a level >= 16): row_bcast inside the wavefront, LDS across wavefronts
+            ctx.phase_w([&](int t, Lane& ln) {
+                const int w0 = t & ~63;
+                const double* xw = nb(w0 > 0, L.xbuf(), 3, w0 - 1);
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) {
+                    const double b = ctx.prev_row_last(ln.s.xt[k]);
+                    xpv[k] = (t & 63) < 16 ? xw[k] : b;
+                }
+            });
+            backward_level_dpp<8>(xpv);
+            backward_level_dpp<4>(xpv);
+            backward_level_dpp<2>(xpv);
+            backward_level_dpp<1>(xpv);
+        }
         // I3: back-substitute v, sf, sr; z~ = A x~; relaxed updates, projection, dual update.  Wave-local: a lane reads the X~ of the
         // previous one; the first lane of a wavefront reads the last lane of the previous wavefront, which wrote its X~ before
         // the last workgroup barrier of the backward pass.  iterate() therefore ENDS WITHOUT A BARRIER: the next iterate() may
@@ -1365,7 +1442,11 @@ struct PathQp {
         ctx.phase_w([&](int t, Lane& ln) {
             Slot& S = ln.s;
             double Xp[3];
-            { const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
+            if constexpr (D) {
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) { const double b = ctx.template lane_below<1>(S.xt[k]); Xp[k] = (t & 15) ? b : xpv[k]; }
+            } else {
+                const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k];
+            }
             const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
             double xt[6];
             xt[0] = S.xt[0]; xt[1] = S.xt[1]; xt[2] = S.xt[2];
@@ -1417,15 +1498,16 @@ struct PathQp {
     // residuals (unscaled inf-norms, OSQP termination quantities):
     //   res[0] = ||Ax - z||, res[1] = ||Px + A^T y|| (q == 0), res[2] = max(||Ax||, ||z||), res[3] = max(||Px||, ||A^T y||)
     //   res[4] = 1 if an iterate is not finite
+    //   res[5] = worst KKT failure over the inequality rows for the current active set (only meaningful while polishing)
     // ---------------------------------------------------------------------------------------------
-    PQP_HD void residuals(double (&res)[5]) {
+    PQP_HD void residuals(double (&res)[6]) {
         const pqp_params& prm = A.prm;
         ctx.phase([&](int t, Lane& ln) {
             double g[3];
             back_msg(ln.s, ln.s.yT, g);
             _Pragma("unroll") for (int k = 0; k < 3; ++k) { sh[L.xbuf() + 3 * t + k] = ln.s.x[k]; sh[L.bufG() + 3 * t + k] = g[k]; }
         });
-        ctx.template reduce_max<5>(res, [&](int t, Lane& ln, double (&v)[5]) {
+        ctx.template reduce_max<6>(res, [&](int t, Lane& ln, double (&v)[6]) {
             const Slot& S = ln.s;
             double Xp[3], gn[3];
             { const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
@@ -1439,12 +1521,14 @@ struct PathQp {
                 pr = fmax(pr, fmax(fabs(aT[k] - S.bT[k]), fabs(aI[k] - S.zI[k])));
                 nz = fmax(nz, fmax(fmax(fabs(aT[k]), fabs(S.bT[k])), fmax(fabs(aI[k]), fabs(S.zI[k]))));
             }
-            double ye0 = 0.0, ye1 = 0.0;
+            double ye0 = 0.0, ye1 = 0.0, w = 0.0;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) w = fmax(w, row_violation(S, t, k, aI[k]));
             if (S.flags & F_LAST) {
                 const EndRows* er = end_rows();
                 pr = fmax(pr, fmax(fabs(S.x[0] - er->z[0]), fabs(S.x[1] - er->z[1])));
                 nz = fmax(nz, fmax(fmax(fabs(S.x[0]), fabs(er->z[0])), fmax(fabs(S.x[1]), fabs(er->z[1]))));
                 ye0 = er->y[0]; ye1 = er->y[1];
+                for (int k = 0; k < 2; ++k) w = fmax(w, end_violation(er, k, S.x[k]));
             }
             double aty[6];
             aty[0] = -S.yT[0] + gn[0] + S.yI[1] + S.yI[2] + ye0;
@@ -1466,6 +1550,7 @@ struct PathQp {
             v[2] = real ? nz : 0.0;
             v[3] = nd;
             v[4] = bad;
+            v[5] = w;
         });
     }
 
@@ -1580,7 +1665,16 @@ struct PathQp {
     // ---------------------------------------------------------------------------------------------
     // unpack (base_solver.cpp:263-288) and publish the next linearisation point
     // ---------------------------------------------------------------------------------------------
-    PQP_HD void unpack() {
+    // final = false (a re-linearised pass follows): only the linearisation point - the output record of this pass would be overwritten
+    // by the next one, and its sincos and seven stores per waypoint are 2 % of a QP's time
+    PQP_HD void unpack(bool final) {
+        if (!final) {
+            ctx.phase([&](int t, Lane& ln) {
+                const Slot& S = ln.s;
+                if (S.flags & F_REAL) { sh[L.lin() + 3 * t + 0] = S.x[0]; sh[L.lin() + 3 * t + 1] = S.x[1]; sh[L.lin() + 3 * t + 2] = S.x[2]; }
+            });
+            return;
+        }
         ctx.phase([&](int t, Lane& ln) {
             sh[L.xbuf() + t] = ln.s.x[3];    // v of waypoint t = u of waypoint t-1
         });
@@ -1661,7 +1755,7 @@ struct PathQp {
                 polish_end(true);
                 polishing_ = false; alpha_ = prm.alpha;
             }
-            unpack();
+            unpack(i1 != 0);
         } else {
             if (A.store_warm) store_warm();
         }
@@ -1680,7 +1774,7 @@ struct PathQp {
         // active-set rounds per polish attempt; <= 0: sized to the path (long paths need more rounds, short ones pay for them)
         const int auto_rounds = n / 5 - 8;
         const int max_rounds = prm.polish_max_rounds > 0 ? prm.polish_max_rounds : (auto_rounds > 24 ? auto_rounds : 24);
-        double res[5] = {0, 0, 0, 0, 0};
+        double res[6] = {0, 0, 0, 0, 0, 0};
         int pass = 0;
         // per-pass state of the hot loop
         bool polish_mode = false, conservative = false, end_after_reject = false;
@@ -1696,15 +1790,17 @@ struct PathQp {
         // debug build only (tools/kernel_timeline.py): wall-clock ticks per category, written over the info record
         long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const long long t_begin = ctx.clock();
-#define PQP_TIC const long long tic_ = ctx.clock()
-#define PQP_TOC(k) tacc[k] += ctx.clock() - tic_
+#define PQP_TIC(m) const long long tic_ = (PQP_TIMING_MASK & (m)) ? ctx.clock() : 0
+#define PQP_TOC(k) do { if ((PQP_TIMING_MASK >> (k)) & 1) tacc[k] += ctx.clock() - tic_; } while (0)
 #else
-#define PQP_TIC
+#define PQP_TIC(m)
 #define PQP_TOC(k)
 #endif
         for (;;) {
+            // (the last pass of the call - the reference stops after a solve that fails - writes the output record)
+            if (op == COLD_END_PASS) i1 = (status != PQP_STATUS_SOLVED || pass == A.passes) ? 1 : 0;
             {
-                PQP_TIC;
+                PQP_TIC(0x2f);
                 ctx.cold(*this, op, i0, i1, d0);
                 PQP_TOC(op == COLD_BEGIN_PASS ? 0 : op == COLD_REFACTOR ? (i0 == RF_RESCALE ? 1 : 2) : op == COLD_CERT ? 5 : 3);
             }
@@ -1734,7 +1830,7 @@ struct PathQp {
             }
             // ---- hot loop: runs until the next cold operation is due
             for (;;) {
-                { PQP_TIC; iterate(); PQP_TOC(4); }
+                { PQP_TIC(0x10); iterate(); PQP_TOC(4); }
                 bool want_res, check = false, adapt = false;
                 if (!polish_mode) {
                     it += 1;
@@ -1752,7 +1848,7 @@ struct PathQp {
                     continue;
                 }
                 sync_after_iterate();
-                { PQP_TIC; residuals(res); PQP_TOC(5); }
+                { PQP_TIC(0x20); residuals(res); PQP_TOC(5); }
                 if (!polish_mode) {
                     bool start_polish = false;
                     if (res[4] != 0.0) { status = PQP_STATUS_NUMERICAL; op = COLD_END_PASS; i0 = 0; break; }
@@ -1810,8 +1906,7 @@ struct PathQp {
                 } else {
                     // KKT acceptance test of the polished point (OSQP paper 4.2 + verification)
                     const double tol = prm.polish_tol;
-                    double viol;
-                    { PQP_TIC; viol = polish_violation(); PQP_TOC(6); }
+                    const double viol = res[5];
                     const bool solve_ok = res[4] == 0.0 && res[0] <= tol * (1.0 + res[2]) && res[1] <= tol * (1.0 + res[3]);
                     const bool ok = solve_ok && viol <= tol;
                     // polish_lazy = k: the first look of a round comes after one solve.  Its point is not accurate enough for the acceptance
@@ -1869,6 +1964,7 @@ struct PathQp {
         }
         const double rho_final = rho;
         const int kkt_total = kkt_solves_, fac_total = factors_;
+        PQP_TIC(0x40);
         ctx.phase([&](int t, Lane&) {
             if (t == 0) {
                 if (A.cost_key) record_cost(A, qp, 4 * kkt_total + 13 * fac_total);
@@ -1887,6 +1983,10 @@ struct PathQp {
                 }
             }
         });
+#ifdef PQP_TIMING
+        // the finish phase itself (category 6) and what the kernel's ticket loop spent before this QP (out[..][8], set by the kernel)
+        if ((PQP_TIMING_MASK >> 6) & 1) { const long long d_ = ctx.clock() - tic_; ctx.phase([&](int t, Lane&) { if (t == 0 && A.info) A.info[PQP_INFO_STRIDE * (size_t)qp + 6] = (double)d_; }); }
+#endif
     }
 };
 

@@ -7,12 +7,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "path_optimizer_2_amd", "csrc")
-LIB = os.path.join(CSRC, "libpqp_hip_timing.so")
+MASK = os.environ.get("PQP_TIMING_MASK")       # e.g. 0x10: only iterate() is timed (and the total): one category per build perturbs least
+LIB = os.path.join(CSRC, "libpqp_hip_timing.so" if MASK is None else f"libpqp_hip_timing_{MASK}.so")
 
 
 def build():
     import __graft_entry__ as g
-    g.build_hip(defines=["PQP_TIMING"], out=LIB)
+    g.build_hip(defines=["PQP_TIMING"] + ([] if MASK is None else [f"PQP_TIMING_MASK={MASK}"]), out=LIB)
 
 
 if __name__ == "__main__":
@@ -42,11 +43,13 @@ if __name__ == "__main__":
     h.sync()
     t = info.cpu().numpy() / 100.0          # ticks of 10 ns -> microseconds
     names = ["begin_pass(assemble+ruiz+factor)", "refactor(rho)", "refactor(polish set)", "end_pass(unpack)", "iterate", "residuals",
-             "polish_violation", "TOTAL"]
+             "finish phase (record, stores)", "TOTAL"]
     print(f"batch {batch} n {n} {over}: kernel {h.last_kernel_ms():.3f} ms")
     for k, nm in enumerate(names):
         print(f"  {nm:36s} mean {t[:, k].mean():8.1f} us   p99 {np.percentile(t[:, k], 99):8.1f}   max {t[:, k].max():8.1f}")
     print(f"  sum of means (0..6) {t[:, :7].sum(1).mean():.1f} us")
+    tk = out.cpu().numpy().reshape(batch, -1)[:, 8] / 100.0
+    print(f"    kernel loop: ticket -> QP known     mean {tk.mean():8.1f} us   max {tk.max():8.1f}")
     sub = out.cpu().numpy().reshape(batch, -1)[:, :8] / 100.0      # the timing build writes the cold operations' sub-times over out[qp][0][0..7]
     for k, nm in enumerate(["load", "assemble", "ruiz", "start_transition_rows", "polish begin / apply set", "factor", "polish update set", "polish end (reject)"]):
         print(f"    cold: {nm:28s} mean {sub[:, k].mean():8.1f} us   max {sub[:, k].max():8.1f}")
