@@ -367,6 +367,15 @@ def main():
                             "solve, polish refinement solves included; frac_admm_iterations_only charges ADMM iterations only) divided by the "
                             "measured kernel time - a model, not traffic: the iterates are register/LDS resident and the kernel is bound by fp64 "
                             "VALU issue + LDS latency (roofline_issue), `traffic` is what HBM really moved"}
+        if secondary and secondary.get("plain_admm_eps_1e-4"):
+            # what the model says about the solver the metric names: OSQP's plain ADMM streaming its data from HBM every iteration
+            its = secondary["plain_admm_eps_1e-4"]["admm_iters"]["mean"]
+            b_path = 2.0 * (152 * n + 40 + 656 * n) + its * 1040 * n
+            bound = HBM_PEAK_GBS * 1e9 / b_path
+            roofline["streaming_plain_admm"] = {"admm_iterations_per_path": its, "model_bytes_per_path": b_path, "hbm_bound_paths_per_s": bound,
+                                                "this_run_over_that_bound": batch * args.steps / dt / bound,
+                                                "note": "SURVEY.md 8(d)'s B_path for plain ADMM to eps 1e-4 (iterations measured in this run, `secondary`): the "
+                                                        "paths/s at which an HBM-streaming implementation of the metric's literal algorithm saturates 8 TB/s"}
         if pmc and "SQ_ACTIVE_INST_VALU" in pmc and "SQ_WAVE_CYCLES" in pmc:
             wc = pmc["SQ_WAVE_CYCLES"]
             gui = pmc.get("GRBM_GUI_ACTIVE")                                      # summed over the 8 XCDs

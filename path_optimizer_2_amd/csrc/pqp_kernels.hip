@@ -30,6 +30,26 @@ namespace pqp {
 // -------------------------------------------------------------------------------------------------------
 // device execution context for PathQp: a phase is the code between two workgroup barriers
 // -------------------------------------------------------------------------------------------------------
+#ifndef PQP_UNIFORM
+#define PQP_UNIFORM 1     // +4.4 %: profiles/r02l_uniform_control.txt
+#endif
+// A value that is the same in every lane, told to the compiler: what is derived from it - the control state of PathQp::run - then
+// branches with s_cbranch instead of exec-mask bookkeeping (v_cndmask per state variable per branch).
+__device__ __forceinline__ double uniform(double x) {
+#if PQP_UNIFORM
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+#else
+    return x;
+#endif
+}
+__device__ __forceinline__ bool uniform(bool x) {
+#if PQP_UNIFORM
+    return __builtin_amdgcn_readfirstlane((int)x) != 0;
+#else
+    return x;
+#endif
+}
+
 // wave / workgroup reductions shared by the hot and the cold context
 // One step of a wavefront max-reduction in the VALU (DPP: data-parallel primitives move a value between lanes inside the instruction,
 // no LDS round trip as with __shfl): x = max(x, x of the lane CTRL selects); lanes without a source keep their value.
@@ -85,7 +105,7 @@ __device__ __forceinline__ void wg_reduce(double (&v)[K], double* shp) {
         for (int k = 0; k < K; ++k) {
             double x = red[k * 16];
             for (int j = 1; j < NW; ++j) x = MAX ? fmax(x, red[k * 16 + j]) : x + red[k * 16 + j];
-            v[k] = x;
+            v[k] = uniform(x);
         }
     }
     __syncthreads();
@@ -155,6 +175,7 @@ struct RegCtx {
     template <int H> __device__ __forceinline__ static double lane_below(double v) { return dpp0<0x110 + H, 0xf>(v); }     // row_shr:H
     template <int H> __device__ __forceinline__ static double lane_above(double v) { return dpp0<0x100 + H, 0xf>(v); }     // row_shl:H
     __device__ __forceinline__ static double prev_row_last(double v) { return dpp0<0x142, 0xe>(v); }                      // row_bcast:15
+    __device__ __forceinline__ static double uni(double x) { return uniform(x); }      // a wave-uniform value that reaches control flow
     Lane lane;
     double* shp;
     __device__ __forceinline__ int T() const { return 64 * NW; }
@@ -166,11 +187,11 @@ struct RegCtx {
     }
     __device__ __forceinline__ long long clock() const { return (long long)wall_clock64(); }     // 100 MHz
     __device__ __forceinline__ bool certificate(double* sh, int, double fl, double rl, double kap, double eps, double cscale) {
-        return dev_certificate<NW>(sh, fl, rl, kap, eps, cscale);
+        return uniform(dev_certificate<NW>(sh, fl, rl, kap, eps, cscale));
     }
     __device__ __forceinline__ bool late_certificate(double* sh, int t, double* snap, bool have, const LateCertIn& in, double fl, double rl, double kap,
                                                      double eps, double cscale) {
-        return dev_late_certificate<NW>(sh, t, snap, have, in, fl, rl, kap, eps, cscale);
+        return uniform(dev_late_certificate<NW>(sh, t, snap, have, in, fl, rl, kap, eps, cscale));
     }
     // wave-local phase: LDS operations of one wavefront execute in program order, so lanes of the same wavefront see each
     // other's writes without a workgroup barrier; the fence only stops the compiler from moving LDS accesses across it
@@ -227,17 +248,18 @@ struct DevCtx {
     template <int H> __device__ __forceinline__ static double lane_below(double v) { return dpp0<0x110 + H, 0xf>(v); }     // row_shr:H
     template <int H> __device__ __forceinline__ static double lane_above(double v) { return dpp0<0x100 + H, 0xf>(v); }     // row_shl:H
     __device__ __forceinline__ static double prev_row_last(double v) { return dpp0<0x142, 0xe>(v); }                      // row_bcast:15
+    __device__ __forceinline__ static double uni(double x) { return uniform(x); }      // a wave-uniform value that reaches control flow
     Lane lane;
     Lane* mem;
     double* shp;
     const PathSolveArgs* args;
     __device__ __forceinline__ long long clock() const { return (long long)wall_clock64(); }     // 100 MHz
     __device__ __forceinline__ bool certificate(double* sh, int, double fl, double rl, double kap, double eps, double cscale) {
-        return dev_certificate<NW>(sh, fl, rl, kap, eps, cscale);
+        return uniform(dev_certificate<NW>(sh, fl, rl, kap, eps, cscale));
     }
     __device__ __forceinline__ bool late_certificate(double* sh, int t, double* snap, bool have, const LateCertIn& in, double fl, double rl, double kap,
                                                      double eps, double cscale) {
-        return dev_late_certificate<NW>(sh, t, snap, have, in, fl, rl, kap, eps, cscale);
+        return uniform(dev_late_certificate<NW>(sh, t, snap, have, in, fl, rl, kap, eps, cscale));
     }
     __device__ __forceinline__ int T() const { return 64 * NW; }
     __device__ __forceinline__ double* sh() { return shp; }

@@ -1716,7 +1716,7 @@ struct PathQp {
                 rho = prm.rho;
                 if (A.warm) {
                     load_warm();
-                    rho = A.wrho[qp];
+                    rho = ctx.uni(A.wrho[qp]);       // (a vector load: told to be the same in every lane, see DevCtx::uni)
                 } else {
                     ctx.phase([&](int, Lane& ln) {
                         if (ln.s.flags & F_LAST) { end_rows()->y[0] = 0.0; end_rows()->y[1] = 0.0; }
@@ -1800,9 +1800,9 @@ struct PathQp {
             // (the last pass of the call - the reference stops after a solve that fails - writes the output record)
             if (op == COLD_END_PASS) i1 = (status != PQP_STATUS_SOLVED || pass == A.passes) ? 1 : 0;
             {
-                PQP_TIC(0x2f);
+                PQP_TIC(0x2d);
                 ctx.cold(*this, op, i0, i1, d0);
-                PQP_TOC(op == COLD_BEGIN_PASS ? 0 : op == COLD_REFACTOR ? (i0 == RF_RESCALE ? 1 : 2) : op == COLD_CERT ? 5 : 3);
+                PQP_TOC(op == COLD_BEGIN_PASS ? 0 : op == COLD_REFACTOR ? 2 : op == COLD_CERT ? 5 : 3);
             }
             if (op == COLD_FINISH) break;
             if (op == COLD_CERT && cert_) { status = PQP_STATUS_PRIMAL_INFEASIBLE; op = COLD_END_PASS; i0 = 0; continue; }
@@ -1829,6 +1829,9 @@ struct PathQp {
                 continue;
             }
             // ---- hot loop: runs until the next cold operation is due
+#ifdef PQP_TIMING
+            const long long tic_hot_ = (PQP_TIMING_MASK & 0x02) ? ctx.clock() : 0;      // category 1: the whole hot loop (iterate + residuals + policy)
+#endif
             for (;;) {
                 { PQP_TIC(0x10); iterate(); PQP_TOC(4); }
                 bool want_res, check = false, adapt = false;
@@ -1961,6 +1964,9 @@ struct PathQp {
                     op = COLD_REFACTOR; i0 = RF_POLISH_UPDATE; d0 = conservative ? fmax(tol, 0.9 * viol) : tol; break;
                 }
             }
+#ifdef PQP_TIMING
+            if (PQP_TIMING_MASK & 0x02) tacc[1] += ctx.clock() - tic_hot_;
+#endif
         }
         const double rho_final = rho;
         const int kkt_total = kkt_solves_, fac_total = factors_;

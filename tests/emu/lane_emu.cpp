@@ -52,6 +52,7 @@ struct HostCtx {
             for (int t = 64 * w; t < 64 * (w + 1) && t < T_; ++t) f(t, lanes[t]);
         }
     }
+    static double uni(double x) { return x; }
     template <class PQ> void cold(PQ& pq, int op, int i0, int i1, double d0) { pq.do_cold(op, i0, i1, d0); }
     // lane-less context of the infeasibility certificate
     struct LaneLess {

@@ -42,7 +42,7 @@ if __name__ == "__main__":
         h.solve_device(batch, n, ref, bounds, scal, out, passes=1, info=info)
     h.sync()
     t = info.cpu().numpy() / 100.0          # ticks of 10 ns -> microseconds
-    names = ["begin_pass(assemble+ruiz+factor)", "refactor(rho)", "refactor(polish set)", "end_pass(unpack)", "iterate", "residuals",
+    names = ["begin_pass(assemble+ruiz+factor)", "hot loop (iterate+residuals+policy)", "refactor(polish set)", "end_pass(unpack)", "iterate", "residuals",
              "finish phase (record, stores)", "TOTAL"]
     print(f"batch {batch} n {n} {over}: kernel {h.last_kernel_ms():.3f} ms")
     for k, nm in enumerate(names):
