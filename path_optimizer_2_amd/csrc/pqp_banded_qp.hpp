@@ -41,6 +41,8 @@ struct BandedQpArgs {
     double* info;            // [batch][PQP_INFO_STRIDE] or nullptr
     pqp_params prm;
 };
+// Ctx::kStage: the row data of A, the index lists and q are copied to LDS once per QP (BqLayout::total(true) doubles of LDS); otherwise
+// they are read from global memory (L2) at every use - two dependent global round trips per ADMM iteration.
 
 // per-lane register state: the factor rows of variable t (valid at the elimination level of its block) and the
 // factorisation workspace
@@ -81,7 +83,10 @@ struct BqLayout {
     PQP_HD int ys() const { return zs() + nc; }                    // polish: saved y
     PQP_HD int yp() const { return ys() + nc; }                    // multipliers one iteration before a termination check
     PQP_HD int red() const { return yp() + nc; }                   // [5][16] reduction scratch
-    PQP_HD int total() const { return red() + 128; }
+    PQP_HD int sav() const { return red() + 128; }                 // staged: aval [nc][kRMax]
+    PQP_HD int sq() const { return sav() + nc * 4; }               // staged: q [nv]
+    PQP_HD int sidx() const { return sq() + nv; }                  // staged (int32): acol [nc][kRMax], trow [nv][kCMax], tslot [nv][kCMax]
+    PQP_HD int total(bool staged = false) const { return staged ? sidx() + (nc * 4 + nv * 12 + 1) / 2 : red() + 128; }
 };
 
 // Ctx: T(), sh(), phase(f(t, BqLane<B>&)), reduce_max/sum<K>(out, f(t, v[K]))
@@ -108,18 +113,38 @@ struct BandedQp {
     template <class F> PQP_HD void rows(F f) { ctx.phase([&](int t, Lane&) { for (int r = t; r < nc; r += T) f(r); }); }
     template <class F> PQP_HD void cols(F f) { ctx.phase([&](int t, Lane&) { for (int j = t; j < nv; j += T) f(j); }); }
 
+    // staged copies (LDS) of the per-QP row values, of q and of the batch's index lists
+    PQP_HD const double* s_aval() const { return sh + L.sav(); }
+    PQP_HD const int* s_acol() const { return reinterpret_cast<const int*>(sh + L.sidx()); }
+    PQP_HD const int* s_trow() const { return s_acol() + nc * kRMax; }
+    PQP_HD const int* s_tslot() const { return s_trow() + nv * kCMax; }
+    PQP_HD double q_of(int j) const { return Ctx::kStage ? sh[L.sq() + j] : A.q[(size_t)qp * nv + j]; }
+
     PQP_HD double row_dot(int r, const double* v) const {      // (A v)_r
-        const double* av = aval() + (size_t)r * kRMax;
-        const int* ac = A.acol + (size_t)r * kRMax;
         double s = 0.0;
-        for (int k = 0; k < kRMax; ++k) { const int c = ac[k]; if (c >= 0) s += av[k] * v[c]; }
+        if constexpr (Ctx::kStage) {
+            const double* av = s_aval() + r * kRMax;
+            const int* ac = s_acol() + r * kRMax;
+            for (int k = 0; k < kRMax; ++k) { const int c = ac[k]; if (c >= 0) s += av[k] * v[c]; }
+        } else {
+            const double* av = aval() + (size_t)r * kRMax;
+            const int* ac = A.acol + (size_t)r * kRMax;
+            for (int k = 0; k < kRMax; ++k) { const int c = ac[k]; if (c >= 0) s += av[k] * v[c]; }
+        }
         return s;
     }
     PQP_HD double col_dot(int j, const double* w) const {      // (A' w)_j
-        const int* tr = A.trow + (size_t)j * kCMax;
-        const int* ts = A.tslot + (size_t)j * kCMax;
         double s = 0.0;
-        for (int k = 0; k < kCMax; ++k) { const int r = tr[k]; if (r >= 0) s += aval()[(size_t)r * kRMax + ts[k]] * w[r]; }
+        if constexpr (Ctx::kStage) {
+            const int* tr = s_trow() + j * kCMax;
+            const int* ts = s_tslot() + j * kCMax;
+            const double* av = s_aval();
+            for (int k = 0; k < kCMax; ++k) { const int r = tr[k]; if (r >= 0) s += av[r * kRMax + ts[k]] * w[r]; }
+        } else {
+            const int* tr = A.trow + (size_t)j * kCMax;
+            const int* ts = A.tslot + (size_t)j * kCMax;
+            for (int k = 0; k < kCMax; ++k) { const int r = tr[k]; if (r >= 0) s += aval()[(size_t)r * kRMax + ts[k]] * w[r]; }
+        }
         return s;
     }
     PQP_HD double p_times(int j, const double* v) const {      // (P v)_j, symmetric band
@@ -141,6 +166,16 @@ struct BandedQp {
             sh[L.z() + r] = 0.0; sh[L.y() + r] = 0.0; sh[L.esc() + r] = 1.0; sh[L.act() + r] = 0.0;
         });
         cols([&](int j) { sh[L.x() + j] = 0.0; sh[L.dsc() + j] = 1.0; });
+        if constexpr (Ctx::kStage) {
+            ctx.phase([&](int t, Lane&) {
+                double* av = sh + L.sav();
+                int* ix = reinterpret_cast<int*>(sh + L.sidx());
+                const double* ga = aval();
+                for (int k = t; k < nc * kRMax; k += T) { av[k] = ga[k]; ix[k] = A.acol[k]; }
+                for (int k = t; k < nv * kCMax; k += T) { ix[nc * kRMax + k] = A.trow[k]; ix[nc * kRMax + nv * kCMax + k] = A.tslot[k]; }
+                for (int j = t; j < nv; j += T) sh[L.sq() + j] = A.q[(size_t)qp * nv + j];
+            });
+        }
     }
 
     PQP_HD void ruiz() {
@@ -399,7 +434,7 @@ struct BandedQp {
         double* zt = sh + L.zt(); double* xt = sh + L.xt();
         const double* rv = sh + L.rv();
         rows([&](int r) { zt[r] = rv[r] * z[r] - y[r]; });
-        ctx.phase([&](int t, Lane& ln) { ln.r = t < nv ? sh[L.sig() + t] * x[t] - qv[t] + col_dot(t, zt) : 0.0; ln.b0 = ln.r; ln.x0 = 0.0; });
+        ctx.phase([&](int t, Lane& ln) { ln.r = t < nv ? sh[L.sig() + t] * x[t] - q_of(t) + col_dot(t, zt) : 0.0; ln.b0 = ln.r; ln.x0 = 0.0; });
         band_solve();
         // While polishing (penalties 1/delta next to delta: condition ~1e12) the cyclic-reduction solve alone is not accurate
         // enough (S2: |b - S x| ~ 25); iterative refinement against the exactly applied S reaches the round-off floor

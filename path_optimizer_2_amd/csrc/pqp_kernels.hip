@@ -1165,13 +1165,17 @@ int sm_solve(pqp_handle* h, int type, int batch, int n, int32_t* status, int32_t
     a.pband = h->b_pband.as<double>(); a.q = h->b_q.as<double>(); a.acol = h->b_acol.as<int>(); a.aval = h->b_aval.as<double>();
     a.trow = h->b_trow.as<int>(); a.tslot = h->b_tslot.as<int>(); a.lo = h->b_lo.as<double>(); a.up = h->b_up.as<double>();
     a.x = h->b_x.as<double>(); a.y = h->b_y.as<double>(); a.status = status; a.iters = iters; a.info = info; a.prm = h->prm;
-    const size_t lds = (size_t)pqp::BqLayout{sh.nv, sh.nc, sh.bw}.total() * 8;
-    if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "smoother QP too large for one CU's LDS");
+    // the row data of A, the index lists and q staged in LDS once per QP (256-lane kernels: always - two of them still share a CU's LDS up
+    // to 80 KB each; 512-lane kernels: when it fits; 1024-lane kernels: never)
+    const size_t lds0 = (size_t)pqp::BqLayout{sh.nv, sh.nc, sh.bw}.total(false) * 8, lds1 = (size_t)pqp::BqLayout{sh.nv, sh.nc, sh.bw}.total(true) * 8;
+    if (lds0 > 160 * 1024) return fail(PQP_ERR_CAPACITY, "smoother QP too large for one CU's LDS");
     const int nbb = pqp::BqLayout{sh.nv, sh.nc, sh.bw}.nbb();
     const int threads = 64 * ((nbb + 63) / 64);        // one lane per (padded) variable
     if (threads > 1024) return fail(PQP_ERR_CAPACITY, "smoother QP has more than 1024 variables");
+    const bool stage = threads <= 512 && lds1 <= 160 * 1024;
+    const size_t lds = stage ? lds1 : lds0;
     const void* fn = nullptr;
-#define PQP_BQ_PICK(BB) fn = threads <= 256 ? (const void*)pqp::banded_solve_kernel<BB, 256> : threads <= 512 ? (const void*)pqp::banded_solve_kernel<BB, 512> : (const void*)pqp::banded_solve_kernel<BB, 1024>
+#define PQP_BQ_PICK(BB) fn = (threads <= 256 && stage) ? (const void*)pqp::banded_solve_kernel<BB, 256, true> : threads <= 512 ? (stage ? (const void*)pqp::banded_solve_kernel<BB, 512, true> : (const void*)pqp::banded_solve_kernel<BB, 512, false>) : (const void*)pqp::banded_solve_kernel<BB, 1024, false>
     switch (sh.bw) {
         case 3: PQP_BQ_PICK(3); break;
         case 4: PQP_BQ_PICK(4); break;

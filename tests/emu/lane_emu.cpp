@@ -183,6 +183,7 @@ extern "C" int pqp_emu_probe(const pqp_params* prm, int n, const double* ref, co
 namespace {
 template <int B>
 struct BqHostCtx {
+    static constexpr bool kStage = true;      // as the device's 256- and 512-lane kernels: row data, index lists and q in the shared array
     int T_;
     std::vector<double> shm;
     std::vector<pqp::BqLane<B>> lanes;
@@ -205,7 +206,7 @@ void bq_run(const pqp::BandedQpArgs& a) {
     const pqp::BqLayout L{a.nv, a.nc, a.bw};
     const int T = 64 * ((L.nbb() + 63) / 64);
     for (int qp = 0; qp < a.batch; ++qp) {
-        BqHostCtx<B> ctx(T, L.total());
+        BqHostCtx<B> ctx(T, L.total(true));
         pqp::BandedQp<BqHostCtx<B>, B> s(ctx, a, qp);
         s.run();
     }
