@@ -1711,12 +1711,12 @@ int pqp_dp_corridor_device(pqp_handle* h, int batch, int m, int max_layers, cons
     pqp::DpArgs a;
     a.batch = batch; a.m = m; a.max_layers = max_layers; a.spl = spline; a.spl_ext = spline_ext; a.length = length; a.start = start;
     a.dist = dist; a.map_of = map_of; a.g = *geom; a.p = *prm; a.layers_s = layers_s; a.lb = lb; a.ub = ub; a.count = count; a.vehicle_l = vehicle_l;
-    const size_t lds = pqp::DpLds{m, max_layers}.total_bytes();
-    if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_dp_corridor: 9 m + 17 max_layers doubles exceed one CU's LDS");
+    const size_t lds = pqp::DpLds{m, max_layers, pqp::dp_lateral_samples(prm->lateral_range, prm->lateral_spacing)}.total_bytes();
+    if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_dp_corridor: 9 m + 17 max_layers doubles (+ the edge table) exceed one CU's LDS");
     if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::dp_corridor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     h->next_event_pair();
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(pqp::dp_corridor_kernel, dim3(batch), dim3(64), lds, h->stream, a);
+    hipLaunchKernelGGL(pqp::dp_corridor_kernel, dim3(batch), dim3(pqp::kDpThreads), lds, h->stream, a);
     PQP_HIP(hipGetLastError());
     PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
