@@ -32,7 +32,10 @@ geom = capi.PqpGridGeometry(c0["rows"], c0["cols"], c0["resolution"], c0["length
 dist = np.stack([c["dist"] for c in cs])
 
 h = capi.Handle(capi.production_params(), device=0, max_batch=batch, max_n=256)                    # path QP: production setting
-hs = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3), device=0, max_batch=batch, max_n=128)   # smoother QPs: the reference's
+# smoother QPs: the reference's setting (OSQP defaults, eps 1e-3).  OSQP's default adaptive_rho_interval is time based - the iteration at which
+# 40 % of the setup time has passed, rounded to a multiple of check_termination = 25 and at least 25; here: 25 (--rho-interval-100: the
+# fixed 100 of pqp_default_params, with which the postSmooth QP needs 129 instead of 57 iterations)
+hs = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3, adaptive_rho_interval=100 if "--rho-interval-100" in sys.argv else 25), device=0, max_batch=batch, max_n=128)
 h.set_option(capi.OPT_STORE_WARM, 0); h.set_option(capi.OPT_ORDER_BY_COST, 1)
 # capacities sized to the workload (lines of 18..36 m): every smoother QP of the batch runs at the padded maximum size
 cfg = h.chain_config(raw_max=64, sample_max=48, layer_max=32, n_max=128) if "--default-capacities" not in sys.argv else h.chain_config()
