@@ -175,11 +175,11 @@ PQP_HD void mat3_mul_mat3_sym(const double* G, const double* M, double* S) {
     S[4] = G[3] * M[2] + G[4] * M[5] + G[5] * M[8];
     S[5] = G[6] * M[2] + G[7] * M[5] + G[8] * M[8];
 }
-// C = -(G * M)
-PQP_HD void mat3_mul_mat3_neg(const double* G, const double* M, double* C) {
+// C = G * M
+PQP_HD void mat3_mul_mat3(const double* G, const double* M, double* C) {
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c)
-            C[3 * r + c] = -(G[3 * r] * M[c] + G[3 * r + 1] * M[3 + c] + G[3 * r + 2] * M[6 + c]);
+            C[3 * r + c] = G[3 * r] * M[c] + G[3 * r + 1] * M[3 + c] + G[3 * r + 2] * M[6 + c];
 }
 PQP_HD void mat3_vec(const double* M, const double* v, double* o) {
     for (int r = 0; r < 3; ++r) o[r] = M[3 * r] * v[0] + M[3 * r + 1] * v[1] + M[3 * r + 2] * v[2];
@@ -1136,10 +1136,13 @@ struct PathQp {
             const double r0 = S.rhoT[0], r1 = S.rhoT[1];
             const double a00 = S.a[0], a01 = S.a[1], a10 = S.a[2], a11 = S.a[3], a12 = S.a[4];
             const double gup = (S.flags & F_PREV) ? gu : 0.0;
-            // coupling block: rows = previous waypoint's (l,psi,k), cols = own
-            W.Lc[0] = -r0 * a00; W.Lc[1] = -r1 * a10; W.Lc[2] = 0.0;
-            W.Lc[3] = -r0 * a01; W.Lc[4] = -r1 * a11; W.Lc[5] = 0.0;
-            W.Lc[6] = 0.0;       W.Lc[7] = -r1 * a12; W.Lc[8] = -gup;
+            // coupling block: rows = previous waypoint's (l,psi,k), cols = own.  The factorisation carries the NEGATED couplings C' = -C:
+            // the coupling a level creates between the two neighbours of an eliminated node, -(Lc D^-1) Rc, is then the plain product
+            // Lc' D^-1 Rc' (no negation of nine entries per level), the Schur updates Lc D^-1 Lc^T do not see the sign, and the solves
+            // add GL' r / GL'^T x where they subtracted GL r / GL^T x - the same values bit for bit.
+            W.Lc[0] = r0 * a00; W.Lc[1] = r1 * a10; W.Lc[2] = 0.0;
+            W.Lc[3] = r0 * a01; W.Lc[4] = r1 * a11; W.Lc[5] = 0.0;
+            W.Lc[6] = 0.0;      W.Lc[7] = r1 * a12; W.Lc[8] = gup;
             // contribution of this waypoint's T rows to the previous waypoint's diagonal block
             double* f = sh + L.fbuf() + 15 * t;
             f[0] = r0 * a00 * a00 + r1 * a10 * a10;
@@ -1187,7 +1190,7 @@ struct PathQp {
                         double* f = sh + L.fbuf() + 21 * t;
                         mat3_mul_mat3t_sym(S.GL, W.Lc, f);
                         mat3_mul_mat3_sym(S.GR, W.Rc, f + 6);
-                        mat3_mul_mat3_neg(S.GL, W.Rc, f + 12);
+                        mat3_mul_mat3(S.GL, W.Rc, f + 12);
                     }
                 }
             });
@@ -1232,7 +1235,7 @@ struct PathQp {
             } else {
                 double qv[3], pv[3];
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) { qv[k] = ctx.template lane_above<(H >> 1)>(qm[k]); pv[k] = ctx.template lane_below<(H >> 1)>(pm[k]); }
-                if ((tp & (H - 1)) == 0) { _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] -= qv[k] + pv[k]; }
+                if ((tp & (H - 1)) == 0) { _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += qv[k] + pv[k]; }
             }
             if ((tp & (2 * H - 1)) == H) {
                 mat3_vec(S.GL, S.r, qm);
@@ -1255,7 +1258,7 @@ struct PathQp {
                 sym3_vec(S.Dinv, S.r, x3);
                 mat3t_vec(S.GL, xl, p);
                 mat3t_vec(S.GR, xr, pr);
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.xt[k] = x3[k] - p[k] - pr[k];
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.xt[k] = x3[k] + p[k] + pr[k];
             }
         });
     }
@@ -1317,7 +1320,7 @@ struct PathQp {
                 const double* q1 = nb(hr, L.bufQ(), 3, t + 1);
                 const double* q2 = nb(hr, L.bufQ(), 3, t + 2);
                 const double* q4 = nb(hr, L.bufQ(), 3, t + 4);
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += g_[k] - (q1[k] + q2[k] + q4[k]) - (q_[k] + p_[k]);
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += g_[k] + (q1[k] + q2[k] + q4[k]) + (q_[k] + p_[k]);
                 if ((tp & 31) == 16) {
                     double p[3];
                     mat3_vec(S.GL, S.r, p);
@@ -1342,7 +1345,7 @@ struct PathQp {
                     const bool hr = surv && (t + hp < T) && !edge, hl = surv && (t - hp >= 0);
                     const double* q_ = nb(hr, L.bufQ(), 3, t + hp);
                     const double* p_ = nb(hl, L.bufP(), 3, t - hp);
-                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] -= q_[k] + p_[k];
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += q_[k] + p_[k];
                 }
                 if ((tp & (2 * h - 1)) == h) {
                     double p[3];
@@ -1366,7 +1369,7 @@ struct PathQp {
                     // deferred: message of waypoint t+1 and the right-hand level messages of all in-wave levels
                     if (t + 1 < T) { _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += sh[L.bufG() + 3 * (t + 1) + k]; }
                     for (int hp = 1; hp < (hw >> 1); hp <<= 1) {
-                        if (t + hp < T) { _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] -= sh[L.bufQ() + 3 * (t + hp) + k]; }
+                        if (t + hp < T) { _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += sh[L.bufQ() + 3 * (t + hp) + k]; }
                     }
                 }
                 if (h > 1) {
@@ -1375,7 +1378,7 @@ struct PathQp {
                     const bool hr = surv && (t + hp < T), hl = surv && (t - hp >= 0);
                     const double* q_ = nb(hr, L.bufQ(), 3, t + hp);
                     const double* p_ = nb(hl, L.bufP(), 3, t - hp);
-                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] -= q_[k] + p_[k];
+                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += q_[k] + p_[k];
                 } else if (t + 1 < T && !edge) {     // T == 1 only
                     _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += sh[L.bufG() + 3 * (t + 1) + k];
                 }
@@ -1413,7 +1416,7 @@ struct PathQp {
                 mat3t_vec(S.GL, xl, p);
                 mat3t_vec(S.GR, xr, pr);
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                    const double v = x3[k] - p[k] - pr[k];
+                    const double v = x3[k] + p[k] + pr[k];
                     S.xt[k] = act ? v : S.xt[k];
                     if (act) sh[L.xbuf() + 3 * t + k] = v;
                 }
