@@ -311,8 +311,8 @@ struct DevCtx {
     }
 };
 
-// ticket -> QP of the NEXT launch, most expensive first: cost bins in descending order, within a bin the order in which the QPs
-// finished.  Run by the last workgroup of a launch to leave its ticket loop (every workgroup counts itself out on hist[kCostBins]):
+// ticket -> QP of the NEXT launch, most expensive first: cost bins in descending order, within a bin in whatever order this workgroup's
+// lanes draw their ranks (results do not depend on the order).  Run by the last workgroup of a launch to leave its ticket loop (every workgroup counts itself out on hist[kCostBins]):
 // all keys and bin counts of the launch are complete then.  No separate kernel: with two launches in flight a tiny ordering kernel
 // waits for a free CU slot behind the other launch's persistent workgroups (measured: 266 us instead of 3).
 __device__ void order_next_launch(const PathSolveArgs& args) {
@@ -331,7 +331,7 @@ __device__ void order_next_launch(const PathSolveArgs& args) {
     __syncthreads();
     for (int q = threadIdx.x; q < args.batch; q += nt) {
         const int k = __hip_atomic_load(args.cost_key + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int pos = start[(k >> 24) & 0xff] + (k & 0xffffff);
+        const int pos = atomicAdd(&start[(k >> 24) & 0xff], 1);          // (LDS atomic: the rank of q within its bin)
         if (pos < args.batch) args.order_next[pos] = q;
     }
     __syncthreads();
@@ -351,6 +351,9 @@ __global__ void __launch_bounds__(64 * NW, (NW <= 2) ? PQP_SOLVE_OCC : 1) path_s
 #endif
     // Persistent workgroups: every workgroup draws tickets until the batch is used up (each workgroup ends on one ticket beyond
     // it, so a launch consumes exactly batch + gridDim.x tickets and the host knows the next launch's base without a reset).
+    // (Drawing the next ticket while the current QP is solved - to hide the ~2 us of the returning atomic - was measured and dropped: at
+    // batch 1024 on 512 slots every workgroup then reserves its second QP the moment it starts its first, the most expensive QPs of the
+    // first round pair up with the most expensive of the rest, and the launch takes 0.69 instead of 0.53 ms.)
     for (;;) {
 #ifdef PQP_TIMING
         const long long t_ticket0 = (long long)wall_clock64();

@@ -454,17 +454,19 @@ PQP_HD bool late_certificate(LC& c, double* sh, int T, int t, double* snap, bool
 }
 
 // What a QP cost (about microseconds: 4 per reduced-KKT solve, 13 per factorisation), binned for the next launch's
-// most-expensive-first order: key = bin << 24 | rank of the QP within its bin (the order in which the QPs of a bin finished)
+// most-expensive-first order: key = bin << 24.  Neither the counter update nor the store returns anything the QP waits for (a returning
+// atomic on device-scope memory is ~2 us of exposed latency at the end of every QP); the rank within a bin is handed out by the
+// workgroup that writes the next launch's order.
 PQP_HD void record_cost(const PathSolveArgs& a, int qp, int cost) {
     int bin = cost >> 3;
     bin = bin < kCostBins - 1 ? bin : kCostBins - 1;
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int rank = atomicAdd(a.cost_hist + bin, 1);
+    (void)__hip_atomic_fetch_add(a.cost_hist + bin, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // (device-scope store: the last workgroup of the launch, on whatever XCD, reads it with a device-scope load)
-    __hip_atomic_store(a.cost_key + qp, (bin << 24) | (rank & 0xffffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.cost_key + qp, bin << 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-    const int rank = a.cost_hist[bin]++;
-    a.cost_key[qp] = (bin << 24) | (rank & 0xffffff);
+    a.cost_hist[bin]++;
+    a.cost_key[qp] = bin << 24;
 #endif
 }
 
