@@ -3,8 +3,10 @@
 //   path_solve_kernel     persistent workgroups (64*NW lanes, one waypoint per lane) draw QPs from a ticket counter,
 //                         most expensive first when the handle knows the QPs' previous cost: assemble -> Ruiz
 //                         metrics -> block-cyclic-reduction factor -> ADMM loop + KKT-verified polish -> unpack ->
-//                         re-linearise -> warm re-solve, everything in VGPRs + ~28 KB of LDS (T = 128); HBM is read
-//                         once (scenario) and written once (path).  Algorithm: pqp_path_lane.hpp.
+//                         re-linearise -> warm re-solve, everything in VGPRs + 79 KB of LDS (T = 128: exchange buffers, polish save
+//                         area, parked Ruiz vectors; two QPs per CU); lanes of one row of 16 exchange through DPP operands, the
+//                         solver's control state is wave-uniform (scalar branches); HBM is read once (scenario) and written once
+//                         (path).  Algorithm: pqp_path_lane.hpp.
 //                         The last workgroup to finish a launch writes the ticket -> QP map of the next one (order_next_launch).
 //   path_assemble_kernel  BaseSolver::setCost/setConstraints in the REFERENCE numbering: CSC values of A,
 //                         diagonal of P, l, u; staged through LDS and written with contiguous, coalesced

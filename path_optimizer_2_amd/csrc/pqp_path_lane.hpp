@@ -3,8 +3,9 @@
 // One workgroup owns one QP at a time and one thread owns one waypoint (T = 64 * NW >= N threads, NW = 2 waves for
 // the N = 80 / 120 configurations).  All iterates, the problem data, the penalty metrics and the factorisation of a
 // QP live in registers (86 fp64 per waypoint; with the setup-time state and temporaries the kernel takes the whole
-// 512-register budget of a lane, i.e. ONE wave per SIMD, scratch-free), neighbouring waypoints talk through ~28 KB
-// of LDS, and HBM is touched only to read the scenario and to write the result.  (Round-1 history: a
+// 512-register budget of a lane, i.e. ONE wave per SIMD), neighbouring waypoints talk through LDS (exchange buffers 21 T doubles; with
+// the polish save area and the parked Ruiz vectors 79 KB per QP at T = 128) or, on the device, through DPP operands when they sit in the
+// same row of 16 lanes (Ctx::kDpp), and HBM is touched only to read the scenario and to write the result.  (Round-1 history: a
 // 2-waypoints-per-lane layout needed > 512 VGPRs at the factorisation and spilled 2 GB per launch; see DESIGN.md.)
 //
 // What is computed (reference file:line relative to LiJiangnanBit/path_optimizer_2):
