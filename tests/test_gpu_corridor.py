@@ -279,6 +279,29 @@ def test_dp_corridor_search(handle, seed, length):
     assert same.mean() > 0.95, (lb[0, :k], want["lb"], ub[0, :k], want["ub"])
 
 
+@pytest.mark.parametrize("rng,spacing,lon,length", [(10.0, 0.6, 1.5, 40.0),      # the reference's grid: 34 samples, window of 7 predecessors
+                                                    (3.0, 0.2, 1.5, 30.0),       # 31 samples, window of 17
+                                                    (1.5, 0.6, 1.5, 30.0),       # 6 samples: the window covers the whole layer
+                                                    (6.0, 1.0, 0.5, 40.0)])      # 80 layers: more than one chunk of 32 prepared layers
+def test_dp_corridor_search_on_other_grids(handle, rng, spacing, lon, length):
+    """The admissible-predecessor window, the chunked preparation of the layers' nodes and the parallel bound refinement must give what
+    the reference's serial loops give, whatever the lateral grid and the number of layers."""
+    c = U.build(seed=2, n=10)
+    start = np.array([[c["ref"][0, 3] + 0.1, c["ref"][0, 4] + 0.3, c["ref"][0, 2] + 0.02]])
+    prm = capi.PqpDpParams(rng, lon, spacing, 2.0)
+    ls, lb, ub, count, vl = handle.dp_corridor(c["tab"][None], c["ext"][None], np.array([length]), start, c["dist"], _geom(c["geom"]), prm=prm, max_layers=96)
+    want = K.graph_search_dp(c["sx"], c["sy"], length, tuple(start[0]), c["dist"], c["geom"],
+                             prm=K.DpParams(lateral_range=rng, longitudinal_spacing=lon, lateral_spacing=spacing))
+    if want is None:
+        assert count[0] == 0
+        return
+    assert count[0] == len(want["layers_s"])
+    k = int(count[0])
+    np.testing.assert_allclose(ls[0, :k], want["layers_s"], rtol=0, atol=1e-11)
+    same = (np.abs(lb[0, :k] - want["lb"]) < 1e-9) & (np.abs(ub[0, :k] - want["ub"]) < 1e-9)
+    assert same.mean() > 0.95, (lb[0, :k], want["lb"], ub[0, :k], want["ub"])
+
+
 def test_dp_corridor_edge_cases(handle):
     c = U.build(seed=3, n=10)
     g = _geom(c["geom"])
