@@ -31,41 +31,53 @@ c0 = cs[0]
 geom = capi.PqpGridGeometry(c0["rows"], c0["cols"], c0["resolution"], c0["length"][0], c0["length"][1], c0["pos"][0], c0["pos"][1])
 dist = np.stack([c["dist"] for c in cs])
 
-h = capi.Handle(capi.production_params(), device=0, max_batch=batch, max_n=256)                    # path QP: production setting
-# smoother QPs: the reference's setting (OSQP defaults, eps 1e-3).  OSQP's default adaptive_rho_interval is time based - the iteration at which
-# 40 % of the setup time has passed, rounded to a multiple of check_termination = 25 and at least 25; here: 25 (--rho-interval-100: the
-# fixed 100 of pqp_default_params, with which the postSmooth QP needs 129 instead of 57 iterations)
-hs = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3, adaptive_rho_interval=100 if "--rho-interval-100" in sys.argv else 25), device=0, max_batch=batch, max_n=128)
-h.set_option(capi.OPT_STORE_WARM, 0); h.set_option(capi.OPT_ORDER_BY_COST, 1)
-# capacities sized to the workload (lines of 18..36 m): every smoother QP of the batch runs at the padded maximum size
-cfg = h.chain_config(raw_max=64, sample_max=48, layer_max=32, n_max=128) if "--default-capacities" not in sys.argv else h.chain_config()
+inflight = 2 if "--inflight-2" in sys.argv else 1      # independent batches in flight (each on its own pair of handles / streams)
 dev = torch.device("cuda", 0)
 t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
 d_pts, d_np, d_st, d_tg, d_map = t(pts, np.float64), t(n_pts, np.int32), t(start, np.float64), t(target, np.float64), t(map_of, np.int32)
 d_dist = t(np.transpose(dist, (0, 2, 1)), np.float32)
-out = torch.zeros((batch, cfg.n_max, 7), dtype=torch.float64, device=dev)
-n_out, status, stage, iters = (torch.zeros(batch, dtype=torch.int32, device=dev) for _ in range(4))
-torch.cuda.synchronize()
 p = lambda x: capi.C.c_void_p(x.data_ptr())
+lanes = []
+for _ in range(inflight):
+    h = capi.Handle(capi.production_params(), device=0, max_batch=batch, max_n=256)                    # path QP: production setting
+    # smoother QPs: the reference's setting (OSQP defaults, eps 1e-3).  OSQP's default adaptive_rho_interval is time based - the iteration at which
+    # 40 % of the setup time has passed, rounded to a multiple of check_termination = 25 and at least 25; here: 25 (--rho-interval-100: the
+    # fixed 100 of pqp_default_params, with which the postSmooth QP needs 129 instead of 57 iterations)
+    hs = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3, adaptive_rho_interval=100 if "--rho-interval-100" in sys.argv else 25), device=0, max_batch=batch, max_n=128)
+    h.set_option(capi.OPT_STORE_WARM, 0); h.set_option(capi.OPT_ORDER_BY_COST, 1)
+    # capacities sized to the workload (lines of 18..36 m): every smoother QP of the batch runs at the padded maximum size
+    cfg = h.chain_config(raw_max=64, sample_max=48, layer_max=32, n_max=128) if "--default-capacities" not in sys.argv else h.chain_config()
+    out = torch.zeros((batch, cfg.n_max, 7), dtype=torch.float64, device=dev)
+    n_out, status, stage, iters = (torch.zeros(batch, dtype=torch.int32, device=dev) for _ in range(4))
+    lanes.append((h, hs, cfg, out, n_out, status, stage, iters))
+torch.cuda.synchronize()
 
 
-def run():
+def run(k):
+    h, hs, cfg, out, n_out, status, stage, iters = lanes[k % inflight]
     h._check(h.lib.pqp_optimize_path_device(h._h, hs._h, capi.C.byref(cfg), batch, p_max, p(d_pts), p(d_np), p(d_st), p(d_tg), p(d_dist), p(d_map),
                                             capi.C.byref(geom), None, p(out), p(n_out), p(status), p(stage), p(iters)))
 
 
-for _ in range(3):
-    run()
-h.sync(); hs.sync()
+def sync():
+    for h, hs, *_ in lanes:
+        h.sync(); hs.sync()
+
+
+for k in range(3 * inflight):
+    run(k)
+sync()
 t0 = time.perf_counter()
-for _ in range(reps):
-    run()
-h.sync(); hs.sync()
-dt = (time.perf_counter() - t0) / reps
+for k in range(reps * inflight):
+    run(k)
+sync()
+dt = (time.perf_counter() - t0) / (reps * inflight)
+h, hs, cfg, out, n_out, status, stage, iters = lanes[0]
 sg, no = stage.cpu().numpy(), n_out.cpu().numpy()
 names = ["ok", "few points", "smoother failed", "search failed", "short reference", "post smooth failed", "heading", "blocked", "path QP failed", "capacity"]
 print(f"pqp_optimize_path_device: {batch} ragged scenarios over {n_maps} maps ({int(n_pts.min())}..{int(n_pts.max())} input points): "
-      f"{dt * 1e3:.3f} ms per batch = {batch / dt:.0f} scenarios/s, input points -> optimised path, device resident")
+      f"{dt * 1e3:.3f} ms per batch = {batch / dt:.0f} scenarios/s, input points -> optimised path, device resident"
+      + (f", {inflight} batches in flight" if inflight > 1 else ""))
 print("  stages: " + ", ".join(f"{names[k]} {int((sg == k).sum())}" for k in range(10) if (sg == k).any()))
 ok = sg == 0
 print(f"  paths: {int(ok.sum())} solved, waypoints {int(no[ok].min())}..{int(no[ok].max())} (mean {no[ok].mean():.0f}); "
