@@ -192,7 +192,10 @@ def main():
     pipe = None
     if cfg_id == 4:
         from path_optimizer_2_amd.pipeline import SmootherPathPipeline
-        pipe = SmootherPathPipeline(batch, n, device=local_rank, seed=rank, path_params=prm)
+        # the smoother of the production setting: TensionSmoother2's QP has no inequality rows, so it is solved as ONE KKT system (polish = 2:
+        # the exact optimum, no ADMM iterations); --reference-setting: the reference's 25 ADMM iterations to eps 1e-3
+        sm_prm = capi.default_params(eps_abs=1e-3, eps_rel=1e-3) if args.reference_setting else capi.default_params(eps_abs=1e-3, eps_rel=1e-3, polish=2, scaling=0)
+        pipe = SmootherPathPipeline(batch, n, device=local_rank, seed=rank, path_params=prm, smoother_params=sm_prm)
         if cost_order:
             pipe.hp.set_option(capi.OPT_ORDER_BY_COST, 1)
         counter = [0]
@@ -405,7 +408,9 @@ def main():
                        "polish_refine_iter": args.polish_refine, "polish_max_rounds": args.polish_max_rounds, "polish_warm_set": args.polish_warm_set,
                        "passes": "cold solve + 1 re-linearised warm re-solve (PathOptimizer::optimizePath)",
                        "qp_start_order": "most expensive first by the previous step's cost (PQP_OPT_ORDER_BY_COST)" if cost_order else "index order",
-                       "parallelism": f"{world} independent shard(s), no collective in the timed region", "batches_in_flight": max(args.inflight, 1)},
+                       "parallelism": f"{world} independent shard(s), no collective in the timed region", "batches_in_flight": max(args.inflight, 1),
+                       **({"smoother": "TensionSmoother2 QP (equality rows only) " + ("as the reference runs it: ADMM to eps 1e-3" if args.reference_setting else
+                                       "solved as one KKT system (pqp_params.polish = 2, no equilibration: exact optimum, no ADMM iterations)")} if pipe is not None else {})},
             "admm_iters": {"min": int(it_np.min()), "median": float(np.median(it_np)), "p99": float(np.percentile(it_np, 99)),
                            "max": int(it_np.max()), "mean": float(it_np.mean())},
             "out_sha1": out_sha, "gather_check": gathered_ok, "solved": int((st_np == 1).sum()), "batch": batch,

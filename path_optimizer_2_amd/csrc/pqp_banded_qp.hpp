@@ -439,7 +439,7 @@ struct BandedQp {
         // While polishing (penalties 1/delta next to delta: condition ~1e12) the cyclic-reduction solve alone is not accurate
         // enough (S2: |b - S x| ~ 25); iterative refinement against the exactly applied S reaches the round-off floor
         // eps |S| |x| in one step, a second one is insurance.
-        for (int step = 0; step < (polishing_ ? 2 : 0); ++step) {
+        for (int step = 0; step < (polishing_ ? (B > 4 ? 2 : 1) : 0); ++step) {
             rows([&](int r) { zt[r] = rv[r] * row_dot(r, xt); });
             ctx.phase([&](int t, Lane& ln) {
                 ln.x0 += ln.r;
@@ -529,7 +529,8 @@ struct BandedQp {
             const bool fr = b < 0.0;
             const double e = sh[L.esc() + r], e2 = e * e / cscale;
             const double z = sh[L.z() + r], y = sh[L.y() + r];
-            const bool alo = !fr && ((z - sh[L.lo() + r]) * e2 < -y);
+            const bool eq = !fr && is_equality_row(r);           // an equality row is active whatever (z, y) say
+            const bool alo = !fr && (eq || (z - sh[L.lo() + r]) * e2 < -y);
             const bool aup = !fr && !alo && ((sh[L.up() + r] - z) * e2 < y);
             sh[L.act() + r] = alo ? -1.0 : (aup ? 1.0 : 0.0);
         });
@@ -546,11 +547,13 @@ struct BandedQp {
             else sh[L.z() + r] = a < 0.0 ? sh[L.lo() + r] : sh[L.up() + r];
         });
     }
+    PQP_HD bool is_equality_row(int r) const { return sh[L.up() + r] - sh[L.lo() + r] < kRhoTol; }
     PQP_HD double row_violation(int r, double ax) const {
         if (sh[L.e2() + r] < 0.0) return 0.0;
         const double a = sh[L.act() + r], y = sh[L.y() + r];
         const double pv = fmax(sh[L.lo() + r] - ax, ax - sh[L.up() + r]);
-        const double dv = a < 0.0 ? y : (a > 0.0 ? -y : 0.0);
+        // (the multiplier of an equality row may have either sign)
+        const double dv = is_equality_row(r) ? 0.0 : (a < 0.0 ? y : (a > 0.0 ? -y : 0.0));
         return fmax(fmax(pv, dv), 0.0);
     }
     PQP_HD double polish_violation() {
@@ -594,40 +597,57 @@ struct BandedQp {
             });
             set_rho();
         }
-        factor();
+        // polish != 0: a QP WITHOUT inequality rows (TensionSmoother2's: every row of tension_smoother_2.cpp:119-145 has l == u) is an
+        // equality-constrained QP - one KKT system.  It is solved as the polish solves it (all rows active, penalty 1/delta, proximal
+        // multiplier iterations as refinement, KKT test) at iteration 0: no ADMM iterations, `iters` = 0, the exact optimum where the
+        // reference's ADMM stops within eps of it.  QPs with inequality rows: polish == 1 ADMM + KKT-verified polish, == 2 the plain ADMM.
+        const bool polish_on = prm.polish == 1;
+        bool direct = false;
+        if (prm.polish != 0) {
+            double ineq[1];
+            ctx.template reduce_max<1>(ineq, [&](int t, double (&v)[1]) {
+                v[0] = 0.0;
+                for (int r = t; r < nc; r += T) v[0] = fmax(v[0], (sh[L.e2() + r] < 0.0 || is_equality_row(r)) ? 0.0 : 1.0);
+            });
+            direct = ineq[0] == 0.0;
+        }
+        if (!direct) factor();
         int status = PQP_STATUS_MAX_ITER, it = 0, polished = 0;
         double res[5] = {0, 0, 0, 0, 0};
         double eps_scale = 1.0;
         int polish_gap = prm.polish_every, next_polish = prm.polish_every;
-        for (it = 1; it <= prm.max_iter; ++it) {
+        for (it = direct ? 0 : 1; it <= prm.max_iter; ++it) {
             // (prim_inf_after > 0: the certificate only from that iteration on - the production setting's feasible QPs never get there)
             const bool cert_now = prm.eps_prim_inf > 0.0 && it >= prm.prim_inf_after;
+            bool start_polish = it == 0;
+            bool check = false, adapt = false;
+            if (it > 0) {
             if (cert_now && prm.check_termination > 0 && (it % prm.check_termination) == 0)
                 rows([&](int r) { sh[L.yp() + r] = sh[L.y() + r]; });
             iterate();
-            const bool check = prm.check_termination > 0 && (it % prm.check_termination) == 0;
-            const bool adapt = prm.adaptive_rho && prm.adaptive_rho_interval > 0 && (it % prm.adaptive_rho_interval) == 0;
+            check = prm.check_termination > 0 && (it % prm.check_termination) == 0;
+            adapt = prm.adaptive_rho && prm.adaptive_rho_interval > 0 && (it % prm.adaptive_rho_interval) == 0;
             if (!check && !adapt) continue;
             residuals(res);
             if (res[4] != 0.0) { status = PQP_STATUS_NUMERICAL; break; }
-            bool start_polish = false;
+            }
             if (check) {
                 const double eps_p = eps_scale * (prm.eps_abs + prm.eps_rel * res[2]);
                 const double eps_d = eps_scale * (prm.eps_abs + prm.eps_rel * res[3]);
                 const bool converged = res[0] <= eps_p && res[1] <= eps_d;
                 if (converged) {
-                    if (!prm.polish || eps_scale * fmax(prm.eps_abs, prm.eps_rel) < 1e-10) { status = PQP_STATUS_SOLVED; break; }
+                    if (!polish_on || eps_scale * fmax(prm.eps_abs, prm.eps_rel) < 1e-10) { status = PQP_STATUS_SOLVED; break; }
                     start_polish = true;
                 } else if (cert_now && it > 1 && primal_infeasible()) {
                     status = PQP_STATUS_PRIMAL_INFEASIBLE; break;
-                } else if (prm.polish && prm.polish_every > 0 && it >= next_polish) {
+                } else if (polish_on && prm.polish_every > 0 && it >= next_polish) {
                     start_polish = true;
                     polish_gap *= 2;
                     next_polish = it + polish_gap;
                 }
             }
             if (start_polish) {
-                const bool was_converged = res[0] <= eps_scale * (prm.eps_abs + prm.eps_rel * res[2]) && res[1] <= eps_scale * (prm.eps_abs + prm.eps_rel * res[3]);
+                const bool was_converged = it > 0 && res[0] <= eps_scale * (prm.eps_abs + prm.eps_rel * res[2]) && res[1] <= eps_scale * (prm.eps_abs + prm.eps_rel * res[3]);
                 polish_begin();
                 polishing_ = true; alpha_ = 1.0;
                 bool ok = false, conservative = false;

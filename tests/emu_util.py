@@ -13,7 +13,7 @@ SRC = os.path.join(HERE, "emu", "lane_emu.cpp")
 # PQP_EMU_DIET=1: the emulation of the register-diet contexts (pass constants in the shared-memory array, Ruiz vectors parked)
 DIET = os.environ.get("PQP_EMU_DIET", "0") == "1"
 LIB = os.path.join(HERE, "emu", "liblane_emu_diet.so" if DIET else "liblane_emu.so")
-_DEPS = [SRC, os.path.join(ROOT, "path_optimizer_2_amd", "csrc", "pqp_path_lane.hpp"),
+_DEPS = [SRC, os.path.join(ROOT, "path_optimizer_2_amd", "csrc", "pqp_path_lane.hpp"), os.path.join(ROOT, "path_optimizer_2_amd", "csrc", "pqp_banded_qp.hpp"),
          os.path.join(ROOT, "path_optimizer_2_amd", "csrc", "pqp_defaults.hpp"), os.path.join(ROOT, "include", "pqp.h")]
 _lib = None
 

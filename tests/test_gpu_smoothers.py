@@ -83,6 +83,6 @@ def test_post_smooth(hip_lib, m, batch):
         P, q, A, lo, up = O.assemble_post(s[b], list(zip(lb[b], ub[b])), l0[b])
         ref = O.osqp_admm(sp.csc_matrix(P), q, A, lo, up, TIGHT)
         assert np.abs(r["l"][b] - ref["x"][:m]).max() < 1e-5
-        assert abs(r["l"][b][0] - l0[b]) < 1e-9
+        assert abs(r["l"][b][0] - l0[b]) < 1e-7                   # the KKT acceptance tolerance (polish_tol)
         assert (r["l"][b][1:] >= lb[b][1:] - 1e-7).all() and (r["l"][b][1:] <= ub[b][1:] + 1e-7).all()
     h.close()

@@ -43,7 +43,12 @@ for _ in range(inflight):
     # smoother QPs: the reference's setting (OSQP defaults, eps 1e-3).  OSQP's default adaptive_rho_interval is time based - the iteration at which
     # 40 % of the setup time has passed, rounded to a multiple of check_termination = 25 and at least 25; here: 25 (--rho-interval-100: the
     # fixed 100 of pqp_default_params, with which the postSmooth QP needs 129 instead of 57 iterations)
-    hs = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3, adaptive_rho_interval=100 if "--rho-interval-100" in sys.argv else 25), device=0, max_batch=batch, max_n=128)
+    # --exact-smoothers (polish = 1, attempts every 25 iterations): TensionSmoother2's QP has no inequality rows - solved as one KKT system
+    # instead of 25 ADMM iterations -, postSmooth's ends in a KKT-verified polish after 25 iterations: both return the exact optimum.
+    # --exact-s1 (polish = 2): only the former; postSmooth runs the reference's plain ADMM
+    pol = 1 if "--exact-smoothers" in sys.argv else (2 if "--exact-s1" in sys.argv else 0)
+    hs = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3, adaptive_rho_interval=100 if "--rho-interval-100" in sys.argv else 25,
+                                         polish=pol, polish_every=25 if pol == 1 else 0), device=0, max_batch=batch, max_n=128)
     h.set_option(capi.OPT_STORE_WARM, 0); h.set_option(capi.OPT_ORDER_BY_COST, 1)
     # capacities sized to the workload (lines of 18..36 m): every smoother QP of the batch runs at the padded maximum size
     cfg = h.chain_config(raw_max=64, sample_max=48, layer_max=32, n_max=128) if "--default-capacities" not in sys.argv else h.chain_config()
