@@ -588,7 +588,25 @@ struct BandedQp {
     PQP_HD void run() {
         const pqp_params& prm = A.prm;
         load();
-        if (prm.scaling > 0) ruiz();
+        // polish != 0: a QP WITHOUT inequality rows (TensionSmoother2's: every row of tension_smoother_2.cpp:119-145 has l == u) is an
+        // equality-constrained QP - one KKT system.  It is solved as the polish solves it (all rows active, penalty 1/delta, proximal
+        // multiplier iterations as refinement, KKT test) at iteration 0: no equilibration, no ADMM iterations, `iters` = 0, the exact optimum
+        // where the reference's ADMM stops within eps of it.  QPs with inequality rows: polish == 1 ADMM + KKT-verified polish, == 2 the plain ADMM.
+        const bool polish_on = prm.polish == 1;
+        bool direct = false;
+        if (prm.polish != 0) {
+            double ineq[1];
+            ctx.template reduce_max<1>(ineq, [&](int t, double (&v)[1]) {
+                v[0] = 0.0;
+                for (int r = t; r < nc; r += T) {
+                    const double sl = sh[L.lo() + r], su = sh[L.up() + r];
+                    const bool free_row = sl < -kInfty * kMinScaling && su > kInfty * kMinScaling;
+                    v[0] = fmax(v[0], (free_row || su - sl < kRhoTol) ? 0.0 : 1.0);
+                }
+            });
+            direct = ineq[0] == 0.0;
+        }
+        if (prm.scaling > 0 && !direct) ruiz();
         else {
             cols([&](int j) { sh[L.sig() + j] = prm.sigma; });
             rows([&](int r) {
@@ -596,20 +614,6 @@ struct BandedQp {
                 sh[L.e2() + r] = (sl < -kInfty * kMinScaling && su > kInfty * kMinScaling) ? -kRhoMin : (su - sl < kRhoTol ? kRhoEqFactor : 1.0);
             });
             set_rho();
-        }
-        // polish != 0: a QP WITHOUT inequality rows (TensionSmoother2's: every row of tension_smoother_2.cpp:119-145 has l == u) is an
-        // equality-constrained QP - one KKT system.  It is solved as the polish solves it (all rows active, penalty 1/delta, proximal
-        // multiplier iterations as refinement, KKT test) at iteration 0: no ADMM iterations, `iters` = 0, the exact optimum where the
-        // reference's ADMM stops within eps of it.  QPs with inequality rows: polish == 1 ADMM + KKT-verified polish, == 2 the plain ADMM.
-        const bool polish_on = prm.polish == 1;
-        bool direct = false;
-        if (prm.polish != 0) {
-            double ineq[1];
-            ctx.template reduce_max<1>(ineq, [&](int t, double (&v)[1]) {
-                v[0] = 0.0;
-                for (int r = t; r < nc; r += T) v[0] = fmax(v[0], (sh[L.e2() + r] < 0.0 || is_equality_row(r)) ? 0.0 : 1.0);
-            });
-            direct = ineq[0] == 0.0;
         }
         if (!direct) factor();
         int status = PQP_STATUS_MAX_ITER, it = 0, polished = 0;
