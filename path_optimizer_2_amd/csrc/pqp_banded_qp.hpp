@@ -591,7 +591,7 @@ struct BandedQp {
         // polish != 0: a QP WITHOUT inequality rows (TensionSmoother2's: every row of tension_smoother_2.cpp:119-145 has l == u) is an
         // equality-constrained QP - one KKT system.  It is solved as the polish solves it (all rows active, penalty 1/delta, proximal
         // multiplier iterations as refinement, KKT test) at iteration 0: no equilibration, no ADMM iterations, `iters` = 0, the exact optimum
-        // where the reference's ADMM stops within eps of it.  QPs with inequality rows: polish == 1 ADMM + KKT-verified polish, == 2 the plain ADMM.
+        // where the reference's ADMM stops within eps of it.  QPs with inequality rows: polish == 2 the plain ADMM, == 1 see below.
         const bool polish_on = prm.polish == 1;
         bool direct = false;
         if (prm.polish != 0) {
@@ -604,7 +604,10 @@ struct BandedQp {
                     v[0] = fmax(v[0], (free_row || su - sl < kRhoTol) ? 0.0 : 1.0);
                 }
             });
-            direct = ineq[0] == 0.0;
+            // (polish == 1: QPs with inequality rows start the same way - the first active set is OSQP's rule applied to the cold start, the
+            //  active-set rounds do the rest: postSmooth's boxes are found in 1-4 rounds, 4-22 solves instead of 50-75 ADMM iterations -, and
+            //  fall back to equilibration + ADMM + periodic polish attempts when that first attempt is rejected)
+            direct = ineq[0] == 0.0 || prm.polish == 1;
         }
         if (prm.scaling > 0 && !direct) ruiz();
         else {
@@ -689,6 +692,7 @@ struct BandedQp {
                 polish_end(ok);
                 if (ok) { status = PQP_STATUS_SOLVED; polished = 1; break; }
                 if (was_converged) eps_scale *= 0.1;     // rejected: ADMM resumes one decade tighter
+                if (it == 0 && prm.scaling > 0) ruiz();  // (the direct attempt ran without equilibration)
                 factor();
                 continue;
             }

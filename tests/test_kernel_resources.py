@@ -49,7 +49,7 @@ def test_path_solve_kernel_keeps_its_lane_state_in_registers(kernels, nw, cert):
 @pytest.mark.parametrize("b,maxt,stage", [(3, 256, 1), (4, 256, 1), (9, 256, 1), (3, 512, 1), (4, 512, 1), (3, 512, 0), (4, 512, 0)])
 def test_banded_solve_kernel_registers(kernels, b, maxt, stage):
     r = _find(kernels, "banded_solve_kernel", f"ILi{b}ELi{maxt}ELb{stage}E")
-    assert r["ScratchSize"] <= 400, r         # spill slots of the setup code (180-376 B today); a BqLane<9> in scratch would be 700 B
+    assert r["ScratchSize"] <= 512, r         # spill slots of the setup / polish code (180-408 B today); a BqLane<9> in scratch would be 700 B
 
 
 def test_kernels_around_the_qps_do_not_use_scratch(kernels):
