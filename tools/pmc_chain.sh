@@ -5,7 +5,7 @@ tag=${1:-chain}; batch=${2:-1024}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-cmd="python $root/tools/bench_full_chain.py $batch 8 5"
+cmd="python $root/tools/bench_full_chain.py $batch 8 5 ${CHAIN_ARGS:-}"
 rocprofv3 --kernel-trace --stats -f csv -d $out/stats -- $cmd > $out/stats.log 2>&1
 i=0
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT" \
