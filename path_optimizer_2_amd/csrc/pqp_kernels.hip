@@ -1225,7 +1225,7 @@ static int smooth_tension2_impl(pqp_handle* h, int batch, int n, const int32_t* 
                        h->b_pband.as<double>(), h->b_q.as<double>(), h->b_aval.as<double>(), h->b_lo.as<double>(), h->b_up.as<double>());
     PQP_HIP(hipGetLastError());
     if ((rc = sm_solve(h, SM_TENSION2, batch, n, status, iters, info))) return rc;
-    hipLaunchKernelGGL(pqp::tension_finish_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, batch, n, n_of, 4 * n - 1, 4, h->b_x.as<double>(), out_x, out_y, out_s);
+    hipLaunchKernelGGL(pqp::tension_finish_kernel, dim3(batch), dim3(64), (size_t)n * 8, h->stream, batch, n, n_of, 4 * n - 1, 4, h->b_x.as<double>(), out_x, out_y, out_s);
     PQP_HIP(hipGetLastError());
     return PQP_OK;
 }
@@ -1257,7 +1257,7 @@ int pqp_smooth_tension_device(pqp_handle* h, int batch, int n, const double* x_l
                        h->b_pband.as<double>(), h->b_q.as<double>(), h->b_aval.as<double>(), h->b_lo.as<double>(), h->b_up.as<double>());
     PQP_HIP(hipGetLastError());
     if ((rc = sm_solve(h, SM_TENSION, batch, n, status, iters, info))) return rc;
-    hipLaunchKernelGGL(pqp::tension_finish_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, batch, n, (const int32_t*)nullptr, 3 * n, 3, h->b_x.as<double>(), out_x, out_y, out_s);
+    hipLaunchKernelGGL(pqp::tension_finish_kernel, dim3(batch), dim3(64), (size_t)n * 8, h->stream, batch, n, (const int32_t*)nullptr, 3 * n, 3, h->b_x.as<double>(), out_x, out_y, out_s);
     PQP_HIP(hipGetLastError());
     return PQP_OK;
 }
