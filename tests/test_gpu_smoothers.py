@@ -46,6 +46,25 @@ def test_tension2(hip_lib, n, batch):
     h.close(); h2.close()
 
 
+@pytest.mark.parametrize("n,batch,scaling", [(24, 5, 10), (80, 3, 0), (200, 2, 0)])
+def test_tension2_is_solved_directly_when_polish_is_on(hip_lib, n, batch, scaling):
+    """TensionSmoother2's QP has no inequality rows (tension_smoother_2.cpp:119-145: l == u in every row): with polish = 2 (and 1) the core
+    solves it as one KKT system at iteration 0 - no ADMM iteration, the exact optimum; bench.py --config 4 runs it this way."""
+    cases = [tension_inputs(n, seed=50 + b) for b in range(batch)]
+    arr = [np.stack([c[k] for c in cases]) for k in range(5)]
+    for mode in (2, 1):
+        h = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3, polish=mode, polish_every=25, scaling=scaling), max_batch=batch, max_n=n)
+        r = h.smooth_tension2(arr[0], arr[1], arr[2], arr[3], arr[4])
+        assert (r["status"] == 1).all() and (r["iters"] == 0).all()
+        for b in range(batch):
+            x, y, ang, k, s, _ = cases[b]
+            P, q, A, lo, up = O.assemble_tension2(x, y, ang, k, s)
+            assert (lo == up).all()
+            ref = O.osqp_admm(sp.csc_matrix(P), q, A, lo, up, TIGHT)
+            assert np.abs(r["x"][b] - ref["x"][:n]).max() < 1e-5 and np.abs(r["y"][b] - ref["x"][n:2 * n]).max() < 1e-5
+        h.close()
+
+
 @pytest.mark.parametrize("n,batch", [(20, 4), (80, 2), (150, 1)])
 def test_tension(hip_lib, n, batch):
     cases = [tension_inputs(n, seed=20 + b) for b in range(batch)]
