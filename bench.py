@@ -194,7 +194,7 @@ def main():
         from path_optimizer_2_amd.pipeline import SmootherPathPipeline
         # the smoother of the production setting: TensionSmoother2's QP has no inequality rows, so it is solved as ONE KKT system (polish = 2:
         # the exact optimum, no ADMM iterations); --reference-setting: the reference's 25 ADMM iterations to eps 1e-3
-        sm_prm = capi.default_params(eps_abs=1e-3, eps_rel=1e-3) if args.reference_setting else capi.default_params(eps_abs=1e-3, eps_rel=1e-3, polish=2, scaling=0)
+        sm_prm = capi.default_params(eps_abs=1e-3, eps_rel=1e-3) if args.reference_setting else capi.default_params(eps_abs=1e-3, eps_rel=1e-3, polish=2, scaling=0, polish_refine_iter=2)
         pipe = SmootherPathPipeline(batch, n, device=local_rank, seed=rank, path_params=prm, smoother_params=sm_prm)
         if cost_order:
             pipe.hp.set_option(capi.OPT_ORDER_BY_COST, 1)

@@ -666,27 +666,34 @@ struct BandedQp {
                     for (int k = 0; k < prm.polish_refine_iter; ++k) iterate();
                     residuals(res);
                     const double tol = prm.polish_tol;
-                    // ill-conditioned Hessians (the 3rd-difference weights of S2) need more refinement: keep going while the
-                    // residual is above the absolute tolerance and still shrinking
                     double prev = fmax(res[0], res[1]);
-                    for (int extra = 0; extra < 24 && prev > tol; extra += 2) {
-                        iterate(); iterate();
-                        residuals(res);
-                        const double cur = fmax(res[0], res[1]);
-                        if (cur > 0.7 * prev) break;
-                        prev = cur;
-                    }
-                    const double viol = polish_violation();
-                    const bool solve_ok = res[4] == 0.0 && res[0] <= tol * (1.0 + res[2]) && res[1] <= tol * (1.0 + res[3]);
-                    ok = solve_ok && viol <= tol;
+                    double viol = polish_violation();
+                    // A row that fails the KKT test by far more than the solve's own residual fails it at the converged point too: those rows
+                    // change sides now (the path QP's lazy refinement); only a point that might be accepted is refined further first.
+                    const bool lazy_move = res[4] == 0.0 && !conservative && viol > 10.0 * fmax(tol, prev);
+                    bool solve_ok = false;
+                    if (!lazy_move) {
+                        // ill-conditioned Hessians (the 3rd-difference weights of S2) need more refinement: keep going while the
+                        // residual is above the absolute tolerance and still shrinking
+                        for (int extra = 0; extra < 24 && prev > tol; extra += 2) {
+                            iterate(); iterate();
+                            residuals(res);
+                            const double cur = fmax(res[0], res[1]);
+                            if (cur > 0.7 * prev) break;
+                            prev = cur;
+                        }
+                        viol = polish_violation();
+                        solve_ok = res[4] == 0.0 && res[0] <= tol * (1.0 + res[2]) && res[1] <= tol * (1.0 + res[3]);
+                        ok = solve_ok && viol <= tol;
 #ifdef PQP_EMU_DEBUG
-                    printf("  bq polish qp %d it %d round %d: pri %.3e (norm %.2e) dua %.3e (norm %.2e) viol %.3e -> %s\n", qp, it, round, res[0], res[2], res[1], res[3], viol, ok ? "ACCEPT" : (solve_ok ? "next" : "solve failed"));
+                        printf("  bq polish qp %d it %d round %d: pri %.3e (norm %.2e) dua %.3e (norm %.2e) viol %.3e -> %s\n", qp, it, round, res[0], res[2], res[1], res[3], viol, ok ? "ACCEPT" : (solve_ok ? "next" : "solve failed"));
 #endif
-                    if (ok || !solve_ok) break;
+                        if (ok || !solve_ok) break;
+                    }
                     if (viol < 0.7 * best) { best = viol; stall = 0; } else { stall += 1; }
                     if (stall >= 3) conservative = true;
                     if (conservative && stall >= 16) break;
-                    polish_update_set(conservative ? fmax(tol, 0.9 * viol) : tol);
+                    polish_update_set(lazy_move ? 10.0 * fmax(tol, prev) : (conservative ? fmax(tol, 0.9 * viol) : tol));
                 }
                 polishing_ = false; alpha_ = prm.alpha;
                 polish_end(ok);

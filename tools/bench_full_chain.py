@@ -48,7 +48,7 @@ for _ in range(inflight):
     # --exact-s1 (polish = 2): only the former; postSmooth runs the reference's plain ADMM
     pol = 1 if "--exact-smoothers" in sys.argv else (2 if "--exact-s1" in sys.argv else 0)
     hs = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3, adaptive_rho_interval=100 if "--rho-interval-100" in sys.argv else 25,
-                                         polish=pol, polish_every=25 if pol == 1 else 0), device=0, max_batch=batch, max_n=128)
+                                         polish=pol, polish_every=25 if pol == 1 else 0, polish_refine_iter=2 if pol else 4), device=0, max_batch=batch, max_n=128)
     h.set_option(capi.OPT_STORE_WARM, 0); h.set_option(capi.OPT_ORDER_BY_COST, 1)
     # capacities sized to the workload (lines of 18..36 m): every smoother QP of the batch runs at the padded maximum size
     cfg = h.chain_config(raw_max=64, sample_max=48, layer_max=32, n_max=128) if "--default-capacities" not in sys.argv else h.chain_config()

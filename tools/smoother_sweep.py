@@ -14,7 +14,7 @@ tc = [tension_inputs(n, seed=1000 + b) for b in range(cases)]
 x, y, ang, kk, s, cl = (np.stack([c[k] for c in tc]) for k in range(6))
 pc = [post_inputs(n, seed=5000 + b) for b in range(cases)]
 ps = np.stack([c[0] for c in pc]); plb = np.stack([c[1] for c in pc]); pub = np.stack([c[2] for c in pc]); pl0 = np.array([c[3] for c in pc])
-exact = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3, polish=1, polish_every=25, adaptive_rho_interval=25), max_batch=cases, max_n=n)
+exact = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3, polish=1, polish_every=25, adaptive_rho_interval=25, polish_refine_iter=2), max_batch=cases, max_n=n)
 ref = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3, adaptive_rho_interval=25), max_batch=cases, max_n=n)
 for name, call in (("tension2", lambda h: h.smooth_tension2(x, y, ang, kk, s)), ("tension", lambda h: h.smooth_tension(x, y, ang, cl)),
                    ("post", lambda h: h.post_smooth(ps, plb, pub, pl0))):
