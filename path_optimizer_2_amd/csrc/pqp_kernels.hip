@@ -1376,7 +1376,8 @@ int pqp_corridor_bounds_device(pqp_handle* h, int batch, int n, int m, const dou
     const size_t lds = pqp::CorridorLds{m, n}.total_bytes();
     if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_corridor_bounds: scenario too large for one CU's LDS (about 9 m + 31 n doubles)");
     if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::corridor_bounds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    threads = 1024;                  // the sample loops are strided: a full workgroup keeps more gathers in flight
+    threads = 512;                   // the sample loops are strided; 512 lanes per scenario keep the most gathers in flight per CU (measured at batch
+                                     // 1024 x n = 80: 1024 lanes 142 us - two scenarios per CU -, 512: 121, 256: 120, 128: 146)
     hipLaunchKernelGGL(pqp::corridor_bounds_kernel, dim3(batch), dim3(threads), lds, h->stream, a);
     PQP_HIP(hipGetLastError());
     PQP_HIP(hipEventRecord(h->ev1, h->stream));
