@@ -399,7 +399,11 @@ __global__ void __launch_bounds__(64 * NW, (NW <= 2) ? PQP_SOLVE_OCC : 1) path_s
         solver.run();
         __syncthreads();
 #ifdef PQP_TIMING
-        if (threadIdx.x == 0) args.out[(size_t)qp * args.n * PQP_OUT_STRIDE + 8] = (double)(t_ticket1 - t_ticket0);     // debug build only
+        if (threadIdx.x == 0) {                                                                                          // debug build only
+            double* dbg = args.out + (size_t)qp * args.n * PQP_OUT_STRIDE;
+            dbg[8] = (double)(t_ticket1 - t_ticket0);
+            dbg[9] = (double)t_ticket0; dbg[10] = (double)(long long)wall_clock64(); dbg[11] = (double)blockIdx.x;       // the schedule: start, end, slot
+        }
 #endif
     }
     if (args.cost_key) order_next_launch(args);

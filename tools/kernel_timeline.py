@@ -38,6 +38,7 @@ if __name__ == "__main__":
     out = torch.zeros((batch, n, 7), dtype=torch.float64, device=dev)
     info = torch.zeros((batch, 8), dtype=torch.float64, device=dev)
     h = capi.Handle(capi.production_params(**over), device=0, max_batch=batch, max_n=n)
+    h.set_option(capi.OPT_STORE_WARM, 0); h.set_option(capi.OPT_ORDER_BY_COST, int(os.environ.get("PQP_ORDER", "1")))     # bench.py's handle options
     for _ in range(3):
         h.solve_device(batch, n, ref, bounds, scal, out, passes=1, info=info)
     h.sync()
@@ -50,6 +51,19 @@ if __name__ == "__main__":
     print(f"  sum of means (0..6) {t[:, :7].sum(1).mean():.1f} us")
     tk = out.cpu().numpy().reshape(batch, -1)[:, 8] / 100.0
     print(f"    kernel loop: ticket -> QP known     mean {tk.mean():8.1f} us   max {tk.max():8.1f}")
+    sch = out.cpu().numpy().reshape(batch, -1)[:, 9:12]
+    t0 = sch[:, 0].min(); st, en, slot = (sch[:, 0] - t0) / 100.0, (sch[:, 1] - t0) / 100.0, sch[:, 2].astype(int)
+    nslot = slot.max() + 1
+    slot_end = np.zeros(nslot); slot_busy = np.zeros(nslot); np.maximum.at(slot_end, slot, en); np.add.at(slot_busy, slot, en - st)
+    last = int(np.argmax(en))
+    print(f"    schedule: {nslot} slots, span {en.max():.1f} us, busy {slot_busy.sum() / (nslot * en.max()):.2f} of slot time; the QP that ends last: qp {last} "
+          f"start {st[last]:.1f} end {en[last]:.1f} (slot's QPs: {int((slot == slot[last]).sum())}); longest QP {np.max(en - st):.1f} us starts at {st[np.argmax(en - st)]:.1f}")
+    print(f"    slot end times: p10 {np.percentile(slot_end, 10):.0f} p50 {np.percentile(slot_end, 50):.0f} p90 {np.percentile(slot_end, 90):.0f} p99 {np.percentile(slot_end, 99):.0f} max {slot_end.max():.0f} us;"
+          f" first-round starts: max {np.sort(st)[nslot - 1]:.1f} us")
+    dur = en - st
+    print("    the 12 longest QPs (us, start): " + "  ".join(f"{dur[q]:.0f}@{st[q]:.0f}" for q in np.argsort(-dur)[:12]))
+    first = np.argsort(st)[:nslot]
+    print(f"    first-round QPs: duration min {dur[first].min():.0f} p10 {np.percentile(dur[first], 10):.0f} median {np.median(dur[first]):.0f}; later QPs: median {np.median(np.delete(dur, first)):.0f} p90 {np.percentile(np.delete(dur, first), 90):.0f} max {np.delete(dur, first).max():.0f}")
     sub = out.cpu().numpy().reshape(batch, -1)[:, :8] / 100.0      # the timing build writes the cold operations' sub-times over out[qp][0][0..7]
     for k, nm in enumerate(["load", "assemble", "ruiz", "start_transition_rows", "polish begin / apply set", "factor", "polish update set", "polish end (reject)"]):
         print(f"    cold: {nm:28s} mean {sub[:, k].mean():8.1f} us   max {sub[:, k].max():8.1f}")
