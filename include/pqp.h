@@ -464,6 +464,7 @@ typedef enum pqp_chain_stage {
     PQP_CHAIN_PATH_QP_FAILED = 8,        /* "Solving failed!" (path_optimizer.cpp:143-156); status says why */
     PQP_CHAIN_CAPACITY = 9               /* a line needs more points / samples / layers / waypoints than pqp_chain_config allows */
 } pqp_chain_stage;
+typedef enum pqp_smoothing_method { PQP_SMOOTHING_TENSION2 = 0, PQP_SMOOTHING_TENSION = 1 } pqp_smoothing_method;
 typedef struct pqp_chain_config {
     int32_t raw_max, sample_max, layer_max, n_max;   /* capacities per scenario: raw-line points (bSpline, about one per metre), 1 m samples of
                                                         the smoother QP (<= 256), DP layers (1.5 m, <= 341), waypoints of the path (<= 512) */
@@ -473,6 +474,9 @@ typedef struct pqp_chain_config {
     double smoothed_length_margin;       /* 3.0   tension_smoother.cpp:40: the smoothed line is declared 3 m longer than its last point */
     pqp_corridor_params corridor;
     pqp_dp_params dp;
+    int32_t smoothing_method;            /* PQP_SMOOTHING_TENSION2  FLAGS_smoothing_method, planning_flags.cpp:27 (ReferencePathSmoother::create,
+                                            reference_path_smoother.cpp:18-29).  TENSION: the clearance of the raw line's samples is looked up on
+                                            the device (tension_smoother.cpp:168) and sample_max is bounded by what one CU's LDS holds (about 190) */
 } pqp_chain_config;
 void pqp_chain_default_config(pqp_chain_config* c);
 int pqp_optimize_path_device(pqp_handle* h, pqp_handle* hs, const pqp_chain_config* cfg, int batch, int p_max, const double* points,
@@ -483,12 +487,16 @@ int pqp_optimize_path_device(pqp_handle* h, pqp_handle* hs, const pqp_chain_conf
  * (tension_smoother.cpp:168), gathered on the device from the same distance layer(s) pqp_corridor_bounds takes */
 int pqp_clearance_device(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const float* dist, const int32_t* map_of,
                          const pqp_grid_geometry* geom, double* clearance);
-/* the three steps of the chain that share one size per launch elsewhere, with a count per scenario (device pointers): a scenario with
+/* the steps of the chain that share one size per launch elsewhere, with a count per scenario (device pointers): a scenario with
  * fewer points is the same QP padded with decoupled dummies (same optimum); the spline table is padded with knots far beyond the line,
  * whose cubic coefficient is zero - term by term tk::spline's right-hand extrapolation */
 int pqp_smooth_tension2_var_device(pqp_handle* h, int batch, int n_max, const int32_t* n_of, const double* x_list, const double* y_list,
                                    const double* angle_list, const double* k_list, const double* s_list, double* out_x, double* out_y,
                                    double* out_s, int32_t* status, int32_t* iters, double* info);
+/* TensionSmoother::osqpSmooth (tension_smoother.cpp:49-100) with a point count per scenario (at least 4); clearance as for pqp_smooth_tension */
+int pqp_smooth_tension_var_device(pqp_handle* h, int batch, int n_max, const int32_t* n_of, const double* x_list, const double* y_list,
+                                  const double* angle_list, const double* clearance, double* out_x, double* out_y, double* out_s, int32_t* status,
+                                  int32_t* iters, double* info);
 int pqp_post_smooth_var_device(pqp_handle* h, int batch, int m_max, const int32_t* m_of, const double* layers_s, const double* lb, const double* ub,
                                const double* vehicle_l, double* out_l, int32_t* status, int32_t* iters, double* info);
 int pqp_spline_fit_var_device(pqp_handle* h, int batch, int m_max, const int32_t* m_of, const double* s, const double* x, const double* y,

@@ -51,7 +51,7 @@ class PqpDpParams(C.Structure):
 class PqpChainConfig(C.Structure):
     _fields_ = [("raw_max", C.c_int32), ("sample_max", C.c_int32), ("layer_max", C.c_int32), ("n_max", C.c_int32), ("output_spacing", C.c_double),
                 ("dynamic_segmentation", C.c_int32), ("max_steering_angle", C.c_double), ("smoothed_length_margin", C.c_double),
-                ("corridor", PqpCorridorParams), ("dp", PqpDpParams)]
+                ("corridor", PqpCorridorParams), ("dp", PqpDpParams), ("smoothing_method", C.c_int32)]
 
 
 class PqpSizes(C.Structure):
@@ -61,7 +61,7 @@ class PqpSizes(C.Structure):
 EXPORTS = [
     "pqp_default_params", "pqp_production_params", "pqp_last_error", "pqp_version", "pqp_create", "pqp_destroy", "pqp_set_params", "pqp_set_option",
     "pqp_stream_wait", "pqp_mark", "pqp_wait_mark", "pqp_get_stream",
-    "pqp_chain_default_config", "pqp_optimize_path_device", "pqp_clearance_device", "pqp_smooth_tension2_var_device", "pqp_post_smooth_var_device", "pqp_spline_fit_var_device",
+    "pqp_chain_default_config", "pqp_optimize_path_device", "pqp_clearance_device", "pqp_smooth_tension2_var_device", "pqp_smooth_tension_var_device", "pqp_post_smooth_var_device", "pqp_spline_fit_var_device",
     "pqp_shard_range", "pqp_multi_create", "pqp_multi_destroy", "pqp_multi_shards", "pqp_multi_handle", "pqp_multi_set_option", "pqp_multi_path_solve", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
     "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_solve_var_device", "pqp_path_solve_var", "pqp_path_get_solution",
     "pqp_last_kernel_ms", "pqp_kernel_ms_history", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
@@ -104,6 +104,7 @@ def load_library(path=None):
                                              vp, vp, vp, vp, vp, vp]
     lib.pqp_clearance_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.POINTER(PqpGridGeometry), vp]
     lib.pqp_smooth_tension2_var_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 12
+    lib.pqp_smooth_tension_var_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 11
     lib.pqp_post_smooth_var_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 9
     lib.pqp_spline_fit_var_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 6
     lib.pqp_shard_range.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
@@ -191,6 +192,7 @@ def _ptr(a):
 
 
 OPT_STORE_WARM, OPT_ORDER_BY_COST = 1, 2
+SMOOTHING_TENSION2, SMOOTHING_TENSION = 0, 1
 
 
 class MultiHandle:
@@ -527,6 +529,22 @@ class Handle:
         self._check(self.lib.pqp_smooth_tension(self._h, B, n, _ptr(c(x)), _ptr(c(y)), _ptr(c(angle)), _ptr(c(clearance)), _ptr(ox), _ptr(oy),
                                                 _ptr(os_), _ptr(st), _ptr(it)))
         return dict(x=ox, y=oy, s=os_, status=st, iters=it)
+
+    def smooth_tension_var(self, x, y, angle, clearance, n_of):
+        """pqp_smooth_tension_var_device (torch as the memory plumbing): lists [B][n_max], n_of [B] points per scenario."""
+        import torch
+        dev = torch.device("cuda", 0)
+        B, n = x.shape
+        t = lambda a, dt=np.float64: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+        d = [t(a) for a in (x, y, angle, clearance)]
+        d_n = t(n_of, np.int32)
+        o = [torch.zeros((B, n), dtype=torch.float64, device=dev) for _ in range(3)]
+        st, it = (torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2))
+        torch.cuda.synchronize()
+        p = lambda a: C.c_void_p(a.data_ptr())
+        self._check(self.lib.pqp_smooth_tension_var_device(self._h, B, n, p(d_n), p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(o[0]), p(o[1]), p(o[2]), p(st), p(it), None))
+        self.sync()
+        return dict(x=o[0].cpu().numpy(), y=o[1].cpu().numpy(), s=o[2].cpu().numpy(), status=st.cpu().numpy(), iters=it.cpu().numpy())
 
     def post_smooth(self, layers_s, lb, ub, vehicle_l):
         B, m = layers_s.shape

@@ -1247,23 +1247,36 @@ int pqp_smooth_tension2_var_device(pqp_handle* h, int batch, int n_max, const in
     return smooth_tension2_impl(h, batch, n_max, n_of, x_list, y_list, angle_list, k_list, s_list, out_x, out_y, out_s, status, iters, info);
 }
 
-// TensionSmoother::osqpSmooth (tension_smoother.cpp:49-100); clearance[batch][n] = Map::getObstacleDistance at each point
-int pqp_smooth_tension_device(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list,
-                              const double* clearance, double* out_x, double* out_y, double* out_s, int32_t* status, int32_t* iters, double* info) {
+// TensionSmoother::osqpSmooth (tension_smoother.cpp:49-100); clearance[batch][n] = Map::getObstacleDistance at each point; n_of [batch]
+// (device) or nullptr
+static int smooth_tension_impl(pqp_handle* h, int batch, int n, const int32_t* n_of, const double* x_list, const double* y_list, const double* angle_list,
+                               const double* clearance, double* out_x, double* out_y, double* out_s, int32_t* status, int32_t* iters, double* info) {
     if (!h || !x_list || !y_list || !angle_list || !clearance || !out_x || !out_y || !out_s || batch < 1 || n < 4)
         return fail(PQP_ERR_INVALID, "pqp_smooth_tension: bad argument");
     PQP_HIP(hipSetDevice(h->device));
     int rc;
     if ((rc = sm_alloc(h, SM_TENSION, batch, n))) return rc;
     const int total = batch * n;
-    hipLaunchKernelGGL(pqp::tension_assemble_kernel, dim3((total + 255) / 256), dim3(256), 0, h->stream, batch, n, x_list, y_list, angle_list, clearance,
+    hipLaunchKernelGGL(pqp::tension_assemble_kernel, dim3((total + 255) / 256), dim3(256), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance,
                        h->prm.cartesian_curvature_weight, h->prm.cartesian_curvature_rate_weight, h->prm.cartesian_deviation_weight,
                        h->b_pband.as<double>(), h->b_q.as<double>(), h->b_aval.as<double>(), h->b_lo.as<double>(), h->b_up.as<double>());
     PQP_HIP(hipGetLastError());
     if ((rc = sm_solve(h, SM_TENSION, batch, n, status, iters, info))) return rc;
-    hipLaunchKernelGGL(pqp::tension_finish_kernel, dim3(batch), dim3(64), (size_t)n * 8, h->stream, batch, n, (const int32_t*)nullptr, 3 * n, 3, h->b_x.as<double>(), out_x, out_y, out_s);
+    hipLaunchKernelGGL(pqp::tension_finish_kernel, dim3(batch), dim3(64), (size_t)n * 8, h->stream, batch, n, n_of, 3 * n, 3, h->b_x.as<double>(), out_x, out_y, out_s);
     PQP_HIP(hipGetLastError());
     return PQP_OK;
+}
+
+int pqp_smooth_tension_device(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list,
+                              const double* clearance, double* out_x, double* out_y, double* out_s, int32_t* status, int32_t* iters, double* info) {
+    return smooth_tension_impl(h, batch, n, nullptr, x_list, y_list, angle_list, clearance, out_x, out_y, out_s, status, iters, info);
+}
+
+int pqp_smooth_tension_var_device(pqp_handle* h, int batch, int n_max, const int32_t* n_of, const double* x_list, const double* y_list,
+                                  const double* angle_list, const double* clearance, double* out_x, double* out_y, double* out_s, int32_t* status,
+                                  int32_t* iters, double* info) {
+    if (!n_of) return fail(PQP_ERR_INVALID, "pqp_smooth_tension_var: n_of is null");
+    return smooth_tension_impl(h, batch, n_max, n_of, x_list, y_list, angle_list, clearance, out_x, out_y, out_s, status, iters, info);
 }
 
 // ReferencePathSmoother::postSmooth QP (reference_path_smoother.cpp:526-558): out_l[batch][m] = the lateral offsets l_i

@@ -5,6 +5,7 @@ sites as stages.  Run with -m gpu on an MI355X."""
 import numpy as np
 import pytest
 
+import corridor_oracle as K
 from path_optimizer_2_amd import capi
 from path_optimizer_2_amd.synth import make_scene
 
@@ -47,7 +48,12 @@ def _one_by_one(h, hs, sc, b, cfg):
     tab, ext = h.spline_fit(s0, x0, y0)
     seg = h.segment_raw_reference(tab, ext, s0[:, -1].copy(), cfg.sample_max)
     n1 = int(seg["count"][0])
-    sm = hs.smooth_tension2(*(seg[k][:, :n1] for k in ("x", "y", "angle", "k", "s")))
+    if cfg.smoothing_method == capi.SMOOTHING_TENSION:
+        gx, gy = seg["x"][:, :n1], seg["y"][:, :n1]
+        clr = np.array([[K.obstacle_distance(sc["dist"][mo[0]], sc["geom"], gx[0, i], gy[0, i]) for i in range(n1)]])      # Map::getObstacleDistance, the oracle's
+        sm = hs.smooth_tension(gx, gy, seg["angle"][:, :n1], clr)
+    else:
+        sm = hs.smooth_tension2(*(seg[k][:, :n1] for k in ("x", "y", "angle", "k", "s")))
     assert sm["status"][0] == 1
     tab, ext = h.spline_fit(sm["s"], sm["x"], sm["y"])
     ls, lb, ub, cnt, vl = h.dp_corridor(tab, ext, sm["s"][:, -1] + cfg.smoothed_length_margin, st, sc["dist"], sc["geom"], max_layers=cfg.layer_max, map_of=mo)
@@ -89,6 +95,35 @@ def test_ragged_batch_equals_the_steps_run_one_scenario_at_a_time(hip_lib):
     h.close(); hs.close()
 
 
+def test_the_tension_smoothing_method(hip_lib):
+    """FLAGS_smoothing_method = TENSION (planning_flags.cpp:27, ReferencePathSmoother::create reference_path_smoother.cpp:18-29): the chain
+    looks the clearance of the raw line's samples up on the device and runs TensionSmoother's QP (tension_smoother.cpp:49-177) in place of
+    TensionSmoother2's; against the steps run one scenario at a time with the clearance from the oracle's grid_map restatement."""
+    B = 10
+    sc = _scenarios(B, seed=11)
+    h = capi.Handle(capi.production_params(), max_batch=B, max_n=256)
+    hs = capi.Handle(_smoother_params(), max_batch=B, max_n=128)
+    cfg = h.chain_config(smoothing_method=capi.SMOOTHING_TENSION)
+    got = h.optimize_path(sc["pts"], sc["n_pts"], sc["start"], sc["target"], sc["dist"], sc["geom"], map_of=sc["map_of"], smoother=hs, cfg=cfg)
+    assert (got["stage"] == 0).sum() >= B - 2, got["stage"]
+    base = h.optimize_path(sc["pts"], sc["n_pts"], sc["start"], sc["target"], sc["dist"], sc["geom"], map_of=sc["map_of"], smoother=hs)
+    differs = 0
+    for b in range(B):
+        if got["stage"][b] != 0:
+            continue
+        want = _one_by_one(h, hs, sc, b, cfg)
+        nv = want["nv"]
+        assert got["n_out"][b] == nv and got["status"][b] == want["status"] == 1
+        # (TensionSmoother's QP is ill-conditioned - test_tension: both sides sit on a ~1e-5 round-off floor of the smoothed line)
+        assert np.abs(got["out"][b, :nv] - want["out"][:nv]).max() < 2e-4, (b, np.abs(got["out"][b, :nv] - want["out"][:nv]).max())
+        if base["stage"][b] == 0 and (base["n_out"][b] != nv or np.abs(base["out"][b, :nv] - got["out"][b, :nv]).max() > 1e-3):
+            differs += 1
+    assert differs >= 1                           # it is another smoother: the paths are not the TENSION2 ones
+    with pytest.raises(capi.PqpError):             # "No such smoother!" (reference_path_smoother.cpp:25-28)
+        h.optimize_path(sc["pts"], sc["n_pts"], sc["start"], sc["target"], sc["dist"], sc["geom"], map_of=sc["map_of"], smoother=hs, cfg=h.chain_config(smoothing_method=7))
+    h.close(); hs.close()
+
+
 def test_stages_are_the_reference_s_return_false_sites(hip_lib):
     sc = _scenarios(6, seed=9)
     sc["n_pts"][1] = 3                                               # "Few reference points" (reference_path_smoother.cpp:33-36)
@@ -112,7 +147,6 @@ def test_clearance_lookup_on_the_device(hip_lib):
     """pqp_clearance_device = Map::getObstacleDistance at the raw line's points (tension_smoother.cpp:168), against the restatement of
     grid_map's bilinear lookup in the corridor oracle; its output feeds pqp_smooth_tension."""
     import torch
-    import corridor_oracle as K
     sc = _scenarios(3, n_maps=3, seed=2)
     h = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3), max_batch=3, max_n=64)
     rng = np.random.default_rng(0)

@@ -105,3 +105,27 @@ def test_post_smooth(hip_lib, m, batch):
         assert abs(r["l"][b][0] - l0[b]) < 1e-7                   # the KKT acceptance tolerance (polish_tol)
         assert (r["l"][b][1:] >= lb[b][1:] - 1e-7).all() and (r["l"][b][1:] <= ub[b][1:] + 1e-7).all()
     h.close()
+
+
+def test_tension_with_a_point_count_per_scenario(hip_lib):
+    """pqp_smooth_tension_var_device: scenarios of 20..60 points in one launch of the 60-point pattern (the shorter ones padded with
+    decoupled dummies) against the oracle's assembly of each scenario at its own size - the difference windows of the cost and the
+    end point's +-0.5 m box (tension_smoother.cpp:108-124,161-162) must end at the scenario's last point."""
+    counts = np.array([60, 20, 37, 4, 59], dtype=np.int32)
+    n, B = 60, len(counts)
+    cases = [tension_inputs(int(c), seed=70 + b) for b, c in enumerate(counts)]
+    pad = lambda k: np.stack([np.concatenate([c[k], np.full(n - len(c[k]), np.nan)]) for c in cases])      # the padding is never read
+    h = capi.Handle(_polished(), max_batch=B, max_n=n)
+    r = h.smooth_tension_var(pad(0), pad(1), pad(2), pad(5), counts)
+    assert (r["status"] == 1).all()
+    for b, c in enumerate(counts):
+        x, y, ang, _, _, cl = cases[b]
+        P, q, A, lo, up = O.assemble_tension(x, y, ang, cl)
+        ref = O.osqp_admm(sp.csc_matrix(P), q, A, lo, up, O.OsqpSettings(eps_abs=1e-11, eps_rel=1e-11, max_iter=400000))
+        assert np.abs(r["x"][b, :c] - ref["x"][:c]).max() < 5e-5 and np.abs(r["y"][b, :c] - ref["x"][c:2 * c]).max() < 5e-5
+        np.testing.assert_allclose(r["s"][b, :c], _chord(r["x"][b, :c], r["y"][b, :c]), atol=1e-12)
+        assert np.all(r["x"][b, c:] == r["x"][b, c - 1]) and np.all(r["s"][b, c:] == r["s"][b, c - 1])          # the tail repeats the last point
+    # and the same numbers as the launch of one scenario at its own size
+    one = h.smooth_tension(*(cases[2][k][None] for k in (0, 1, 2, 5)))
+    assert np.abs(one["x"][0] - r["x"][2, :37]).max() < 1e-6 and np.abs(one["y"][0] - r["y"][2, :37]).max() < 1e-6
+    h.close()

@@ -52,6 +52,8 @@ for _ in range(inflight):
     h.set_option(capi.OPT_STORE_WARM, 0); h.set_option(capi.OPT_ORDER_BY_COST, 1)
     # capacities sized to the workload (lines of 18..36 m): every smoother QP of the batch runs at the padded maximum size
     cfg = h.chain_config(raw_max=64, sample_max=48, layer_max=32, n_max=128) if "--default-capacities" not in sys.argv else h.chain_config()
+    if "--tension" in sys.argv:            # FLAGS_smoothing_method = TENSION: clearance lookup + TensionSmoother's QP instead of TensionSmoother2's
+        cfg.smoothing_method = capi.SMOOTHING_TENSION
     out = torch.zeros((batch, cfg.n_max, 7), dtype=torch.float64, device=dev)
     n_out, status, stage, iters = (torch.zeros(batch, dtype=torch.int32, device=dev) for _ in range(4))
     lanes.append((h, hs, cfg, out, n_out, status, stage, iters))
