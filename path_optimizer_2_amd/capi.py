@@ -553,6 +553,26 @@ class Handle:
         self._check(self.lib.pqp_post_smooth(self._h, B, m, _ptr(c(layers_s)), _ptr(c(lb)), _ptr(c(ub)), _ptr(c(vehicle_l)), _ptr(ol), _ptr(st), _ptr(it)))
         return dict(l=ol, status=st, iters=it)
 
+    def post_smooth_var(self, layers_s, lb, ub, vehicle_l, m_of, info=False):
+        """pqp_post_smooth_var_device (torch as the memory plumbing): lists [B][m_max], m_of [B] layers per scenario."""
+        import torch
+        dev = torch.device("cuda", 0)
+        B, m = layers_s.shape
+        t = lambda a, dt=np.float64: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+        d = [t(a) for a in (layers_s, lb, ub, vehicle_l)]
+        d_m = t(m_of, np.int32)
+        ol = torch.zeros((B, m), dtype=torch.float64, device=dev)
+        st, it = (torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2))
+        inf = torch.zeros((B, 8), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        p = lambda a: C.c_void_p(a.data_ptr())
+        self._check(self.lib.pqp_post_smooth_var_device(self._h, B, m, p(d_m), p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(ol), p(st), p(it), p(inf) if info else None))
+        self.sync()
+        r = dict(l=ol.cpu().numpy(), status=st.cpu().numpy(), iters=it.cpu().numpy())
+        if info:
+            r["info"] = inf.cpu().numpy()
+        return r
+
     def kernel_ms_history(self, count):
         """HIP-event durations of the last `count` launches of this handle (oldest first)."""
         ms = np.zeros(count, dtype=np.float32)

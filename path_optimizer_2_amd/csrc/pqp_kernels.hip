@@ -1284,6 +1284,18 @@ static int post_smooth_impl(pqp_handle* h, int batch, int m, const int32_t* m_of
                             const double* vehicle_l, double* out_l, int32_t* status, int32_t* iters, double* info) {
     if (!h || !layers_s || !lb || !ub || !vehicle_l || !out_l || batch < 1 || m < 4) return fail(PQP_ERR_INVALID, "pqp_post_smooth: bad argument (m >= 4, reference_path_smoother.cpp:528)");
     PQP_HIP(hipSetDevice(h->device));
+    if (h->prm.polish == 1 && m <= 64) {
+        // exact optima asked for: the box QP in the offsets alone, one wavefront per scenario (post_exact_kernel)
+        if (!status) return fail(PQP_ERR_INVALID, "pqp_post_smooth: status is null");
+        h->next_event_pair();
+        PQP_HIP(hipEventRecord(h->ev0, h->stream));
+        hipLaunchKernelGGL(pqp::post_exact_kernel, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, h->prm.polish_tol, out_l, status,
+                           iters, info);
+        PQP_HIP(hipGetLastError());
+        PQP_HIP(hipEventRecord(h->ev1, h->stream));
+        h->timed = true;
+        return PQP_OK;
+    }
     int rc;
     if ((rc = sm_alloc(h, SM_POST, batch, m))) return rc;
     const int total = batch * m;

@@ -129,3 +129,83 @@ def test_tension_with_a_point_count_per_scenario(hip_lib):
     one = h.smooth_tension(*(cases[2][k][None] for k in (0, 1, 2, 5)))
     assert np.abs(one["x"][0] - r["x"][2, :37]).max() < 1e-6 and np.abs(one["y"][0] - r["y"][2, :37]).max() < 1e-6
     h.close()
+
+
+def _post_reduced_kkt(s, lb, ub, l0, l):
+    """Solver-free optimality check of a postSmooth result: V maps the offsets to the oracle's variables (l' and l'' from the two difference
+    rows, the last layer's l' minimised out, its l'' = 0); the box QP's KKT conditions with g = V^T P V l, P the oracle's.  Returns the
+    largest violation relative to 1 + |l|max."""
+    m = len(s)
+    P, q, A, lo, up = O.assemble_post(s, list(zip(lb, ub)), l0)
+    h = np.diff(s)
+    V = np.zeros((3 * m, m))
+    V[:m] = np.eye(m)
+    for i in range(m - 1):
+        V[m + i, i + 1] += 1 / h[i]; V[m + i, i] -= 1 / h[i]
+    if m >= 2:
+        V[2 * m - 1] = V[2 * m - 2] * (10.0 / (h[m - 2] ** 2 + 10.0))        # argmin over the last l' of 50 b^2 + 500 ((b - l'_{m-2}) / h)^2
+    for i in range(m - 1):
+        V[2 * m + i] = (V[m + i + 1] - V[m + i]) / h[i]
+    v = V @ l
+    assert np.abs(A @ v - np.clip(A @ v, lo, up))[m:].max(initial=0.0) < 1e-9           # the difference rows hold by construction
+    g = V.T @ (P @ v)
+    lo_l, up_l = lo[:m], up[:m]
+    viol = 0.0
+    for i in range(m):
+        if lo_l[i] == up_l[i]:
+            viol = max(viol, abs(l[i] - lo_l[i])); continue
+        viol = max(viol, lo_l[i] - l[i], l[i] - up_l[i])
+        if l[i] <= lo_l[i] + 1e-9: viol = max(viol, -g[i])
+        elif l[i] >= up_l[i] - 1e-9: viol = max(viol, g[i])
+        else: viol = max(viol, abs(g[i]))
+    return viol / (1.0 + np.abs(l).max())
+
+
+def test_post_smooth_exact_kernel(hip_lib):
+    """Handles that ask for exact optima (polish = 1) solve postSmooth's QP as a box QP in the offsets, one wavefront per scenario, for
+    corridors of up to 64 layers (post_exact_kernel): ragged batch, tight and pinned boxes, 64 layers; checked by the KKT conditions
+    of the oracle's matrices (no solver) and, for a few, against the oracle's ADMM run to 1e-9."""
+    rng = np.random.default_rng(3)
+    B, m = 96, 64
+    counts = rng.integers(4, m + 1, size=B).astype(np.int32); counts[:4] = [64, 4, 5, 63]
+    s = np.zeros((B, m)); lb = np.zeros((B, m)); ub = np.zeros((B, m)); l0 = np.zeros(B)
+    for b in range(B):
+        c = int(counts[b])
+        sb, lbb, ubb, v = post_inputs(c, seed=200 + b)
+        if b % 5 == 1:
+            half = rng.uniform(0.02, 0.15, size=c); mid = 0.5 * (lbb + ubb); lbb, ubb = mid - half, mid + half        # tight corridor: most boxes active
+        if b % 7 == 2:
+            k = int(rng.integers(1, c)); ubb[k] = lbb[k]                                                               # an interior layer pinned
+        if b % 11 == 3:
+            sb = np.concatenate([[0.0], np.cumsum(rng.uniform(0.8, 2.2, size=c - 1))])                               # uneven layer spacing
+        s[b, :c], lb[b, :c], ub[b, :c], l0[b] = sb, lbb, ubb, v
+        s[b, c:] = np.nan; lb[b, c:] = np.nan; ub[b, c:] = np.nan                                                       # never read
+    h = capi.Handle(_polished(), max_batch=B, max_n=m)
+    r = h.post_smooth_var(s, lb, ub, l0, counts, info=True)
+    assert (r["status"] == 1).all() and (r["iters"] == 0).all()
+    worst = 0.0
+    for b in range(B):
+        c = int(counts[b])
+        worst = max(worst, _post_reduced_kkt(s[b, :c], lb[b, :c], ub[b, :c], l0[b], r["l"][b, :c]))
+        assert np.all(r["l"][b, c:] == 0.0)
+    assert worst < 5e-7, worst
+    assert r["info"][:, 5].max() <= 40 and r["info"][:, 5].mean() < 8           # active-set rounds: a handful
+    for b in (0, 1, 6, 9, 14):
+        c = int(counts[b])
+        P, q, A, lo, up = O.assemble_post(s[b, :c], list(zip(lb[b, :c], ub[b, :c])), l0[b])
+        ref = O.osqp_admm(sp.csc_matrix(P), q, A, lo, up, TIGHT)
+        assert np.abs(r["l"][b, :c] - ref["x"][:c]).max() < 1e-5, b
+    # the certificate is not vacuous
+    assert _post_reduced_kkt(s[0, :64], lb[0, :64], ub[0, :64], l0[0], r["l"][0, :64] + 1e-4 * np.sin(np.arange(64))) > 1e-5
+    # an inverted box has no feasible point: OSQP's verdict
+    lb2 = lb.copy(); lb2[5, 2] = ub[5, 2] + 0.1
+    r2 = h.post_smooth_var(s, lb2, ub, l0, counts)
+    assert r2["status"][5] == 4 and (np.delete(r2["status"], 5) == 1).all()
+    # and the generic core (the reference's formulation) agrees where both run: polish = 1 but more than 64 layers takes the generic path
+    sb, lbb, ubb, v = post_inputs(40, seed=777)
+    big = capi.Handle(_polished(), max_batch=1, max_n=80)
+    pad = lambda a, fill: np.concatenate([a, np.full(40, fill)])[None]
+    want = big.post_smooth_var(pad(sb, 0.0), pad(lbb, 0.0), pad(ubb, 0.0), np.array([v]), np.array([40], dtype=np.int32))        # 80-layer pattern: generic
+    got = h.post_smooth_var(pad(sb, 0.0)[:, :64], pad(lbb, 0.0)[:, :64], pad(ubb, 0.0)[:, :64], np.array([v]), np.array([40], dtype=np.int32))
+    assert want["status"][0] == 1 and np.abs(want["l"][0, :40] - got["l"][0, :40]).max() < 1e-6
+    h.close(); big.close()
