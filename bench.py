@@ -410,7 +410,7 @@ def main():
                        "qp_start_order": "most expensive first by the previous step's cost (PQP_OPT_ORDER_BY_COST)" if cost_order else "index order",
                        "parallelism": f"{world} independent shard(s), no collective in the timed region", "batches_in_flight": max(args.inflight, 1),
                        **({"smoother": "TensionSmoother2 QP (equality rows only) " + ("as the reference runs it: ADMM to eps 1e-3" if args.reference_setting else
-                                       "solved as one KKT system (pqp_params.polish = 2, no equilibration: exact optimum, no ADMM iterations)")} if pipe is not None else {})},
+                                       "solved exactly by one Riccati sweep per scenario (pqp_params.polish = 2: tension2_exact_kernel, no ADMM iterations)")} if pipe is not None else {})},
             "admm_iters": {"min": int(it_np.min()), "median": float(np.median(it_np)), "p99": float(np.percentile(it_np, 99)),
                            "max": int(it_np.max()), "mean": float(it_np.mean())},
             "out_sha1": out_sha, "gather_check": gathered_ok, "solved": int((st_np == 1).sum()), "batch": batch,

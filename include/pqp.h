@@ -124,11 +124,13 @@ typedef struct pqp_params {
      * refinement) and ACCEPTED ONLY IF the polished point passes a KKT check (primal feasibility of inactive
      * rows, dual signs of active rows, stationarity) - i.e. it is then the exact optimum of the QP.  A
      * rejected polish resumes ADMM with a 10x tighter internal tolerance and tries again later. */
-    int32_t polish;                   /* 0 (reference) ; bench and parity tests use 1.  Smoother QPs with polish != 0: a QP without
-                                         inequality rows (TensionSmoother2's) is solved as ONE KKT system at iteration 0 - all rows active,
-                                         KKT-verified, the exact optimum, iters = 0; a QP with inequality rows runs the plain ADMM (2) or (1)
-                                         starts with the same active-set solve from the cold start and falls back to ADMM + KKT-verified
-                                         polish attempts when that is rejected.  The path QP treats 2 like 1 */
+    int32_t polish;                   /* 0 (reference) ; bench and parity tests use 1.  Smoother QPs with polish != 0 return exact optima
+                                         with iters = 0 where the QP's structure allows: TensionSmoother2's (equality rows only: a linear-
+                                         quadratic control problem) by one Riccati sweep per scenario; with polish == 1 postSmooth's (a box
+                                         QP in the offsets) by a KKT-verified active-set solve, one wavefront per corridor of up to 64
+                                         layers.  Other QPs with inequality rows run the plain ADMM (2) or (1) start with an active-set
+                                         solve from the cold start on the generic core and fall back to ADMM + KKT-verified polish attempts
+                                         when that is rejected.  The path QP treats 2 like 1 */
     int32_t polish_refine_iter;       /* 4     */
     int32_t polish_every;             /* 0: only when the residual test passes; k: also try every k iterations */
     int32_t polish_warm_set;          /* 1: a warm re-linearised re-solve starts with a polish on the previous pass's active set;

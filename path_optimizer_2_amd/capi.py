@@ -530,6 +530,22 @@ class Handle:
                                                 _ptr(os_), _ptr(st), _ptr(it)))
         return dict(x=ox, y=oy, s=os_, status=st, iters=it)
 
+    def smooth_tension2_var(self, x, y, angle, k, s, n_of):
+        """pqp_smooth_tension2_var_device (torch as the memory plumbing): lists [B][n_max], n_of [B] points per scenario."""
+        import torch
+        dev = torch.device("cuda", 0)
+        B, n = x.shape
+        t = lambda a, dt=np.float64: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+        d = [t(a) for a in (x, y, angle, k, s)]
+        d_n = t(n_of, np.int32)
+        o = [torch.zeros((B, n), dtype=torch.float64, device=dev) for _ in range(3)]
+        st, it = (torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2))
+        torch.cuda.synchronize()
+        p = lambda a: C.c_void_p(a.data_ptr())
+        self._check(self.lib.pqp_smooth_tension2_var_device(self._h, B, n, p(d_n), p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(o[0]), p(o[1]), p(o[2]), p(st), p(it), None))
+        self.sync()
+        return dict(x=o[0].cpu().numpy(), y=o[1].cpu().numpy(), s=o[2].cpu().numpy(), status=st.cpu().numpy(), iters=it.cpu().numpy())
+
     def smooth_tension_var(self, x, y, angle, clearance, n_of):
         """pqp_smooth_tension_var_device (torch as the memory plumbing): lists [B][n_max], n_of [B] points per scenario."""
         import torch

@@ -1222,6 +1222,23 @@ static int smooth_tension2_impl(pqp_handle* h, int batch, int n, const int32_t* 
         return fail(PQP_ERR_INVALID, "pqp_smooth_tension2: bad argument");
     PQP_HIP(hipSetDevice(h->device));
     int rc;
+    if (h->prm.polish != 0) {
+        // exact optima asked for: the QP has equality rows only - its optimum by one Riccati sweep per scenario (tension2_exact_kernel)
+        if (!status) return fail(PQP_ERR_INVALID, "pqp_smooth_tension2: status is null");
+        if ((rc = h->b_pband.ensure((size_t)batch * n * 5 * 8)) || (rc = h->b_aval.ensure((size_t)batch * n * 6 * 8))) return rc;
+        hipLaunchKernelGGL(pqp::tension2_stage_kernel, dim3((batch * n + 255) / 256), dim3(256), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, k_list,
+                           s_list, h->b_aval.as<double>());
+        PQP_HIP(hipGetLastError());
+        h->next_event_pair();
+        PQP_HIP(hipEventRecord(h->ev0, h->stream));
+        hipLaunchKernelGGL(pqp::tension2_exact_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list,
+                           h->prm.tension2_deviation_weight, h->prm.tension2_curvature_weight, h->prm.tension2_curvature_rate_weight, h->b_aval.as<double>(),
+                           h->b_pband.as<double>(), out_x, out_y, out_s, status, iters, info);
+        PQP_HIP(hipGetLastError());
+        PQP_HIP(hipEventRecord(h->ev1, h->stream));
+        h->timed = true;
+        return PQP_OK;
+    }
     if ((rc = sm_alloc(h, SM_TENSION2, batch, n))) return rc;
     const int total = batch * n;
     hipLaunchKernelGGL(pqp::tension2_assemble_kernel, dim3((total + 255) / 256), dim3(256), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list,

@@ -209,3 +209,39 @@ def test_post_smooth_exact_kernel(hip_lib):
     got = h.post_smooth_var(pad(sb, 0.0)[:, :64], pad(lbb, 0.0)[:, :64], pad(ubb, 0.0)[:, :64], np.array([v]), np.array([40], dtype=np.int32))
     assert want["status"][0] == 1 and np.abs(want["l"][0, :40] - got["l"][0, :40]).max() < 1e-6
     h.close(); big.close()
+
+
+def test_tension2_exact_kernel_with_a_point_count_per_scenario(hip_lib):
+    """Handles with polish != 0 solve TensionSmoother2's equality-constrained QP by a Riccati sweep, one lane per scenario
+    (tension2_exact_kernel): a ragged batch (3..256 points, uneven spacing) against the oracle's assembly of each scenario at its own size
+    solved to 1e-9, the chord lengths, the repeated tail - and against the generic core's direct KKT solve of the 4n-variable formulation
+    (polish = 0 handles keep it; here: the reference's ADMM run to 1e-9 on the device)."""
+    rng = np.random.default_rng(8)
+    counts = np.array([256, 3, 4, 5, 17, 64, 65, 130, 200, 255], dtype=np.int32)
+    n, B = 256, len(counts)
+    arr = [np.full((B, n), np.nan) for _ in range(5)]
+    cases = []
+    for b, c in enumerate(counts):
+        x, y, ang, k, s, _ = tension_inputs(int(c), seed=300 + b, ds=1.0 if b % 2 else 0.7 + 0.1 * b)
+        cases.append((x, y, ang, k, s))
+        for j, a in enumerate((x, y, ang, k, s)):
+            arr[j][b, :c] = a
+    h = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3, polish=2), max_batch=B, max_n=n)
+    r = h.smooth_tension2_var(*arr, counts)
+    assert (r["status"] == 1).all() and (r["iters"] == 0).all()
+    for b, c in enumerate(counts):
+        x, y, ang, k, s = cases[b]
+        P, q, A, lo, up = O.assemble_tension2(x, y, ang, k, s)
+        K = np.block([[P, A.T], [A, np.zeros((A.shape[0], A.shape[0]))]])               # every row is an equality: the optimum is one linear system
+        sol = np.linalg.solve(K, np.r_[-q, lo])
+        assert np.abs(r["x"][b, :c] - sol[:c]).max() < 1e-7 and np.abs(r["y"][b, :c] - sol[c:2 * c]).max() < 1e-7, (b, c)
+        np.testing.assert_allclose(r["s"][b, :c], _chord(r["x"][b, :c], r["y"][b, :c]), atol=1e-11)
+        assert np.all(r["x"][b, c:] == r["x"][b, c - 1]) and np.all(r["y"][b, c:] == r["y"][b, c - 1]) and np.all(r["s"][b, c:] == r["s"][b, c - 1])
+    h.close()
+    # the reference's formulation on the generic core, run to convergence, lands on the same line
+    x, y, ang, k, s = cases[4]
+    g = capi.Handle(capi.default_params(eps_abs=1e-9, eps_rel=1e-9, max_iter=20000), max_batch=1, max_n=17)
+    want = g.smooth_tension2(x[None], y[None], ang[None], k[None], s[None])
+    assert want["status"][0] == 1 and want["iters"][0] > 0
+    assert np.abs(want["x"][0] - r["x"][4, :17]).max() < 1e-6 and np.abs(want["y"][0] - r["y"][4, :17]).max() < 1e-6
+    g.close()
