@@ -201,6 +201,10 @@ def test_post_smooth_exact_kernel(hip_lib):
     lb2 = lb.copy(); lb2[5, 2] = ub[5, 2] + 0.1
     r2 = h.post_smooth_var(s, lb2, ub, l0, counts)
     assert r2["status"][5] == 4 and (np.delete(r2["status"], 5) == 1).all()
+    # two layers at the same abscissa make the difference rows singular: NUMERICAL, zeros, the neighbours in the batch untouched
+    s3 = s.copy(); s3[7, 3] = s3[7, 2]
+    r3 = h.post_smooth_var(s3, lb, ub, l0, counts)
+    assert r3["status"][7] == 3 and np.all(r3["l"][7] == 0.0) and (np.delete(r3["status"], 7) == 1).all()
     # and the generic core (the reference's formulation) agrees where both run: polish = 1 but more than 64 layers takes the generic path
     sb, lbb, ubb, v = post_inputs(40, seed=777)
     big = capi.Handle(_polished(), max_batch=1, max_n=80)
