@@ -127,8 +127,8 @@ typedef struct pqp_params {
     int32_t polish;                   /* 0 (reference) ; bench and parity tests use 1.  Smoother QPs with polish != 0 return exact optima
                                          with iters = 0 where the QP's structure allows: TensionSmoother2's (equality rows only: a linear-
                                          quadratic control problem) by one Riccati sweep per scenario; with polish == 1 postSmooth's (a box
-                                         QP in the offsets) by a KKT-verified active-set solve, one wavefront per corridor of up to 64
-                                         layers.  Other QPs with inequality rows run the plain ADMM (2) or (1) start with an active-set
+                                         QP in the offsets) by a KKT-verified active-set solve, one wavefront per corridor (up to 384
+                                         layers).  Other QPs with inequality rows run the plain ADMM (2) or (1) start with an active-set
                                          solve from the cold start on the generic core and fall back to ADMM + KKT-verified polish attempts
                                          when that is rejected.  The path QP treats 2 like 1 */
     int32_t polish_refine_iter;       /* 4     */

@@ -1301,13 +1301,16 @@ static int post_smooth_impl(pqp_handle* h, int batch, int m, const int32_t* m_of
                             const double* vehicle_l, double* out_l, int32_t* status, int32_t* iters, double* info) {
     if (!h || !layers_s || !lb || !ub || !vehicle_l || !out_l || batch < 1 || m < 4) return fail(PQP_ERR_INVALID, "pqp_post_smooth: bad argument (m >= 4, reference_path_smoother.cpp:528)");
     PQP_HIP(hipSetDevice(h->device));
-    if (h->prm.polish == 1 && m <= 64) {
+    if (h->prm.polish == 1 && m <= 384) {
         // exact optima asked for: the box QP in the offsets alone, one wavefront per scenario (post_exact_kernel)
         if (!status) return fail(PQP_ERR_INVALID, "pqp_post_smooth: status is null");
         h->next_event_pair();
         PQP_HIP(hipEventRecord(h->ev0, h->stream));
-        hipLaunchKernelGGL(pqp::post_exact_kernel, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, h->prm.polish_tol, out_l, status,
-                           iters, info);
+        const double tol = h->prm.polish_tol;
+        if (m <= 64) hipLaunchKernelGGL(pqp::post_exact_kernel<1>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info);
+        else if (m <= 128) hipLaunchKernelGGL(pqp::post_exact_kernel<2>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info);
+        else if (m <= 256) hipLaunchKernelGGL(pqp::post_exact_kernel<4>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info);
+        else hipLaunchKernelGGL(pqp::post_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info);
         PQP_HIP(hipGetLastError());
         PQP_HIP(hipEventRecord(h->ev1, h->stream));
         h->timed = true;

@@ -163,7 +163,7 @@ def _post_reduced_kkt(s, lb, ub, l0, l):
 
 def test_post_smooth_exact_kernel(hip_lib):
     """Handles that ask for exact optima (polish = 1) solve postSmooth's QP as a box QP in the offsets, one wavefront per scenario, for
-    corridors of up to 64 layers (post_exact_kernel): ragged batch, tight and pinned boxes, 64 layers; checked by the KKT conditions
+    corridors (post_exact_kernel; here up to 64 layers, one per lane): ragged batch, tight and pinned boxes, 64 layers; checked by the KKT conditions
     of the oracle's matrices (no solver) and, for a few, against the oracle's ADMM run to 1e-9."""
     rng = np.random.default_rng(3)
     B, m = 96, 64
@@ -205,14 +205,38 @@ def test_post_smooth_exact_kernel(hip_lib):
     s3 = s.copy(); s3[7, 3] = s3[7, 2]
     r3 = h.post_smooth_var(s3, lb, ub, l0, counts)
     assert r3["status"][7] == 3 and np.all(r3["l"][7] == 0.0) and (np.delete(r3["status"], 7) == 1).all()
-    # and the generic core (the reference's formulation) agrees where both run: polish = 1 but more than 64 layers takes the generic path
-    sb, lbb, ubb, v = post_inputs(40, seed=777)
-    big = capi.Handle(_polished(), max_batch=1, max_n=80)
-    pad = lambda a, fill: np.concatenate([a, np.full(40, fill)])[None]
-    want = big.post_smooth_var(pad(sb, 0.0), pad(lbb, 0.0), pad(ubb, 0.0), np.array([v]), np.array([40], dtype=np.int32))        # 80-layer pattern: generic
-    got = h.post_smooth_var(pad(sb, 0.0)[:, :64], pad(lbb, 0.0)[:, :64], pad(ubb, 0.0)[:, :64], np.array([v]), np.array([40], dtype=np.int32))
-    assert want["status"][0] == 1 and np.abs(want["l"][0, :40] - got["l"][0, :40]).max() < 1e-6
-    h.close(); big.close()
+    h.close()
+
+
+@pytest.mark.parametrize("m", [100, 200, 341])
+def test_post_smooth_exact_kernel_on_long_corridors(hip_lib, m):
+    """More than 64 layers: two, four or six layers per lane of the same wavefront (post_exact_kernel<K>); ragged counts across the slot
+    boundaries (63, 64, 65, 128, 129 ...), the KKT certificate of the oracle's matrices, and the generic core - the reference's
+    formulation, ADMM run to 1e-9 on the device - on one of them."""
+    rng = np.random.default_rng(m)
+    counts = np.array([m, 63, 64, 65, 4, min(m, 128), min(m, 129), m - 1, min(m, 193), (m + 64) // 2], dtype=np.int32)
+    B = len(counts)
+    s = np.full((B, m), np.nan); lb = np.full((B, m), np.nan); ub = np.full((B, m), np.nan); l0 = np.zeros(B)
+    for b in range(B):
+        c = int(counts[b])
+        sb, lbb, ubb, v = post_inputs(c, seed=500 + 7 * b + m)
+        if b % 3 == 1:
+            half = rng.uniform(0.02, 0.15, size=c); mid = 0.5 * (lbb + ubb); lbb, ubb = mid - half, mid + half
+        s[b, :c], lb[b, :c], ub[b, :c], l0[b] = sb, lbb, ubb, v
+    h = capi.Handle(_polished(), max_batch=B, max_n=m)
+    r = h.post_smooth_var(s, lb, ub, l0, counts, info=True)
+    assert (r["status"] == 1).all() and (r["iters"] == 0).all()
+    for b in range(B):
+        c = int(counts[b])
+        assert _post_reduced_kkt(s[b, :c], lb[b, :c], ub[b, :c], l0[b], r["l"][b, :c]) < 5e-7, b
+        assert np.all(r["l"][b, c:] == 0.0)
+    h.close()
+    b, c = 3, 65
+    g = capi.Handle(capi.default_params(eps_abs=1e-9, eps_rel=1e-9, max_iter=200000, adaptive_rho_interval=25), max_batch=1, max_n=c)
+    want = g.post_smooth(s[b:b + 1, :c], lb[b:b + 1, :c], ub[b:b + 1, :c], l0[b:b + 1])
+    assert want["status"][0] == 1 and want["iters"][0] > 0
+    assert np.abs(want["l"][0] - r["l"][b, :c]).max() < 1e-6
+    g.close()
 
 
 def test_tension2_exact_kernel_with_a_point_count_per_scenario(hip_lib):
