@@ -127,10 +127,11 @@ typedef struct pqp_params {
     int32_t polish;                   /* 0 (reference) ; bench and parity tests use 1.  Smoother QPs with polish != 0 return exact optima
                                          with iters = 0 where the QP's structure allows: TensionSmoother2's (equality rows only: a linear-
                                          quadratic control problem) by one Riccati sweep per scenario; with polish == 1 postSmooth's (a box
-                                         QP in the offsets) by a KKT-verified active-set solve, one wavefront per corridor (up to 384
-                                         layers).  Other QPs with inequality rows run the plain ADMM (2) or (1) start with an active-set
-                                         solve from the cold start on the generic core and fall back to ADMM + KKT-verified polish attempts
-                                         when that is rejected.  The path QP treats 2 like 1 */
+                                         QP in the offsets) and TensionSmoother's (a box QP in the lateral shifts) by a KKT-verified
+                                         active-set solve, one wavefront per scenario (up to 384 layers / points; beyond: the generic
+                                         core's active-set solve from the cold start, with ADMM + KKT-verified polish attempts as the
+                                         fallback).  With polish == 2 QPs with inequality rows run the plain ADMM.  The path QP treats 2
+                                         like 1 */
     int32_t polish_refine_iter;       /* 4     */
     int32_t polish_every;             /* 0: only when the residual test passes; k: also try every k iterations */
     int32_t polish_warm_set;          /* 1: a warm re-linearised re-solve starts with a polish on the previous pass's active set;
@@ -478,7 +479,8 @@ typedef struct pqp_chain_config {
     pqp_dp_params dp;
     int32_t smoothing_method;            /* PQP_SMOOTHING_TENSION2  FLAGS_smoothing_method, planning_flags.cpp:27 (ReferencePathSmoother::create,
                                             reference_path_smoother.cpp:18-29).  TENSION: the clearance of the raw line's samples is looked up on
-                                            the device (tension_smoother.cpp:168) and sample_max is bounded by what one CU's LDS holds (about 190) */
+                                            the device (tension_smoother.cpp:168); on a smoother handle without polish = 1 (the reference's ADMM on the 3n-variable
+                                            formulation) sample_max is bounded by what one CU's LDS holds (about 190) */
 } pqp_chain_config;
 void pqp_chain_default_config(pqp_chain_config* c);
 int pqp_optimize_path_device(pqp_handle* h, pqp_handle* hs, const pqp_chain_config* cfg, int batch, int p_max, const double* points,

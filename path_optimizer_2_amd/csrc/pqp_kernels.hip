@@ -1272,6 +1272,21 @@ static int smooth_tension_impl(pqp_handle* h, int batch, int n, const int32_t* n
         return fail(PQP_ERR_INVALID, "pqp_smooth_tension: bad argument");
     PQP_HIP(hipSetDevice(h->device));
     int rc;
+    if (h->prm.polish == 1 && n <= 384) {
+        // exact optima asked for: the box QP in the lateral shifts alone, one wavefront per scenario (tension_exact_kernel)
+        if (!status) return fail(PQP_ERR_INVALID, "pqp_smooth_tension: status is null");
+        h->next_event_pair();
+        PQP_HIP(hipEventRecord(h->ev0, h->stream));
+        const double wk = h->prm.cartesian_curvature_weight, wdk = h->prm.cartesian_curvature_rate_weight, wdev = h->prm.cartesian_deviation_weight, tol = h->prm.polish_tol;
+        if (n <= 64) hipLaunchKernelGGL(pqp::tension_exact_kernel<1>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info);
+        else if (n <= 128) hipLaunchKernelGGL(pqp::tension_exact_kernel<2>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info);
+        else if (n <= 256) hipLaunchKernelGGL(pqp::tension_exact_kernel<4>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info);
+        else hipLaunchKernelGGL(pqp::tension_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info);
+        PQP_HIP(hipGetLastError());
+        PQP_HIP(hipEventRecord(h->ev1, h->stream));
+        h->timed = true;
+        return PQP_OK;
+    }
     if ((rc = sm_alloc(h, SM_TENSION, batch, n))) return rc;
     const int total = batch * n;
     hipLaunchKernelGGL(pqp::tension_assemble_kernel, dim3((total + 255) / 256), dim3(256), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance,

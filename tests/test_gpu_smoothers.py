@@ -81,13 +81,51 @@ def test_tension(hip_lib, n, batch):
     h.close()
 
 
-def test_tension_too_large_for_one_cu_is_an_error(hip_lib):
-    """750 variables in 9 x 9 blocks need more LDS than a CU has: PQP_ERR_CAPACITY, nothing launched"""
-    xs, ys, ang, kk, ss, cl = tension_inputs(250, seed=1)
-    h = capi.Handle(_polished(), max_batch=1, max_n=250)
-    with pytest.raises(capi.PqpError):
-        h.smooth_tension(xs[None], ys[None], ang[None], cl[None])
-    h.close()
+def _tension_kkt_certificate(x_list, y_list, ang, cl, gx, gy):
+    """Solver-free optimality check of a TensionSmoother result: eliminate the oracle's equality rows (x = X + c d, y = Y + s d), and test
+    the box QP's KKT conditions in d - feasibility, stationarity of the free shifts, the gradient's sign at the active ones - with the
+    oracle's P.  Returns the largest violation relative to 1 + |d|max."""
+    n = len(x_list)
+    P, q, A, lo, up = O.assemble_tension(x_list, y_list, ang, cl)
+    c, s = -np.diag(A[:n, 2 * n:]), -np.diag(A[n:2 * n, 2 * n:])
+    d = (gx - x_list) * c + (gy - y_list) * s                       # (c, s) is a unit vector
+    assert np.abs(gx - x_list - c * d).max() < 1e-9 and np.abs(gy - y_list - s * d).max() < 1e-9       # the equality rows hold
+    H = P[:n, :n]
+    g = c * (H @ gx) + s * (H @ gy) + np.diag(P[2 * n:, 2 * n:]) * d
+    dl, du = lo[2 * n:], up[2 * n:]
+    viol = 0.0
+    for i in range(n):
+        if dl[i] == du[i]:
+            viol = max(viol, abs(d[i] - dl[i])); continue
+        viol = max(viol, dl[i] - d[i], d[i] - du[i])
+        if d[i] <= dl[i] + 1e-9: viol = max(viol, -g[i])
+        elif d[i] >= du[i] - 1e-9: viol = max(viol, g[i])
+        else: viol = max(viol, abs(g[i]))
+    return viol / (1.0 + np.abs(d).max())
+
+
+def test_tension_sizes_beyond_the_9x9_formulation(hip_lib):
+    """750 variables in 9 x 9 blocks need more LDS than a CU has: the reference's ADMM setting is PQP_ERR_CAPACITY at n = 250 (nothing
+    launched).  A handle that asks for exact optima (polish = 1) solves the same QP as a box QP in the lateral shifts, one wavefront per
+    scenario (tension_exact_kernel), for up to 384 points; checked by the KKT conditions of the oracle's matrices, no solver involved."""
+    for n, seeds in ((250, (1, 2, 3)), (384, (4,)), (130, (5, 6))):
+        cases = [tension_inputs(n, seed=sd) for sd in seeds]
+        x, y, ang, cl = (np.stack([c[k] for c in cases]) for k in (0, 1, 2, 5))
+        if n == 250:
+            h = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3), max_batch=len(seeds), max_n=n)
+            with pytest.raises(capi.PqpError):
+                h.smooth_tension(x, y, ang, cl)
+            h.close()
+        h = capi.Handle(_polished(), max_batch=len(seeds), max_n=n)
+        r = h.smooth_tension(x, y, ang, cl)
+        assert (r["status"] == 1).all() and (r["iters"] == 0).all()
+        for b in range(len(seeds)):
+            assert _tension_kkt_certificate(x[b], y[b], ang[b], cl[b], r["x"][b], r["y"][b]) < 1e-6, (n, b)
+            np.testing.assert_allclose(r["s"][b], _chord(r["x"][b], r["y"][b]), atol=1e-11)
+        h.close()
+    # the certificate is not vacuous: a point moved off the optimum fails it by orders of magnitude
+    bad = _tension_kkt_certificate(x[0], y[0], ang[0], cl[0], r["x"][0] + 1e-3 * np.cos(ang[0] + np.pi / 2) * np.sin(np.arange(n)), r["y"][0] + 1e-3 * np.sin(ang[0] + np.pi / 2) * np.sin(np.arange(n)))
+    assert bad > 1e-3
 
 
 @pytest.mark.parametrize("m,batch", [(18, 4), (60, 2), (150, 1)])

@@ -25,7 +25,7 @@ for label, prm in (("reference setting (eps 1e-3, no polish)", capi.default_para
                    ("... rho adapted every 50 iterations", capi.default_params(eps_abs=1e-3, eps_rel=1e-3, adaptive_rho_interval=50)),
                    ("... rho adapted every 25 iterations", capi.default_params(eps_abs=1e-3, eps_rel=1e-3, adaptive_rho_interval=25)),
                    ("polish = 2: TensionSmoother2 exact (Riccati sweep), the others plain ADMM", capi.default_params(eps_abs=1e-3, eps_rel=1e-3, polish=2, adaptive_rho_interval=25, polish_refine_iter=2)),
-                   ("polish = 1: exact optima (S1 Riccati, S3 box QP, S2 active set / ADMM + KKT-verified polish)", capi.default_params(eps_abs=1e-3, eps_rel=1e-3, polish=1, polish_every=25, adaptive_rho_interval=25, polish_refine_iter=2))):
+                   ("polish = 1: exact optima (S1 Riccati sweep, S2 and S3 box QPs in a wavefront)", capi.default_params(eps_abs=1e-3, eps_rel=1e-3, polish=1, polish_every=25, adaptive_rho_interval=25, polish_refine_iter=2))):
     h = capi.Handle(prm, device=0, max_batch=batch, max_n=n)
     lib = h.lib
     runs = {
