@@ -191,8 +191,11 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *   PQP_OPT_ORDER_BY_COST (default 0)  start the QPs of a batch most-expensive-first, by the reduced-KKT solves and
  *                                      factorisations each QP needed in the handle's previous solve of the same batch and n
  *                                      (a planner re-solves nearly the same scenarios every cycle).  The first solve of a shape
- *                                      runs in index order. */
-typedef enum pqp_option { PQP_OPT_STORE_WARM = 1, PQP_OPT_ORDER_BY_COST = 2 } pqp_option;
+ *                                      runs in index order.
+ *   PQP_OPT_RESERVE_CUS (default 0)    compute units the path QP's persistent workgroups leave free.  Their wavefronts own a SIMD's whole
+ *                                      register file, so kernels of another stream (the smoother chain of the next batch, configs[4]) only
+ *                                      get onto the chip when a unit is left to them. */
+typedef enum pqp_option { PQP_OPT_STORE_WARM = 1, PQP_OPT_ORDER_BY_COST = 2, PQP_OPT_RESERVE_CUS = 3 } pqp_option;
 int pqp_set_option(pqp_handle* h, int option, int value);
 int pqp_get_stream(pqp_handle* h, void** hip_stream);   /* hipStream_t */
 /* The handle's stream is created non-blocking: work the caller enqueued on ANOTHER stream (the inputs of a *_device call produced by

@@ -191,7 +191,7 @@ def _ptr(a):
     return C.c_void_p(int(a))      # raw device pointer (e.g. torch.Tensor.data_ptr())
 
 
-OPT_STORE_WARM, OPT_ORDER_BY_COST = 1, 2
+OPT_STORE_WARM, OPT_ORDER_BY_COST, OPT_RESERVE_CUS = 1, 2, 3
 SMOOTHING_TENSION2, SMOOTHING_TENSION = 0, 1
 
 

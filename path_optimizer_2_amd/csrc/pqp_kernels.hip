@@ -684,7 +684,7 @@ struct pqp_handle {
     unsigned long long ticket_next = 0;
     long long solves = 0;                       // solve launches so far (parity selects the cost histogram being filled)
     int hist_batch = 0, hist_n = 0;             // shape of the solve whose costs cost_key / cost_hist hold (0: none)
-    int opt_store_warm = 1, opt_order_by_cost = 0;
+    int opt_store_warm = 1, opt_order_by_cost = 0, opt_reserve_cus = 0;
     int num_cu = 0;
     int blocks_per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // occupancy of the solve kernel variants [log2(nw)][cert]
     DevBuf s_ref, s_lin, s_bounds, s_scal;      // staging for the host-pointer entry points
@@ -765,6 +765,7 @@ int pqp_set_option(pqp_handle* h, int option, int value) {
     switch (option) {
         case PQP_OPT_STORE_WARM: h->opt_store_warm = value ? 1 : 0; return PQP_OK;
         case PQP_OPT_ORDER_BY_COST: h->opt_order_by_cost = value ? 1 : 0; h->hist_batch = 0; return PQP_OK;
+        case PQP_OPT_RESERVE_CUS: h->opt_reserve_cus = value < 0 ? 0 : value; return PQP_OK;
         default: return fail(PQP_ERR_INVALID, "pqp_set_option: unknown option");
     }
 }
@@ -940,7 +941,8 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
         PQP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * nw, lds));
         if (per_cu < 1) per_cu = 1;
     }
-    const long long resident = (long long)per_cu * h->num_cu;
+    const int cus = h->num_cu - h->opt_reserve_cus > 1 ? h->num_cu - h->opt_reserve_cus : 1;
+    const long long resident = (long long)per_cu * cus;
     const int grid = (int)(batch < resident ? batch : resident);
     if (!save_lds) {          // more than 256 lanes per QP: the save area and the parked Ruiz vectors live in the workgroup slot's global memory
         if ((rc = h->wsave.ensure((size_t)grid * 64 * nw * PQP_SAVE_STRIDE * 8))) return rc;

@@ -50,6 +50,7 @@ for _ in range(inflight):
     hs = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3, adaptive_rho_interval=100 if "--rho-interval-100" in sys.argv else 25,
                                          polish=pol, polish_every=25 if pol == 1 else 0, polish_refine_iter=2 if pol else 4), device=0, max_batch=batch, max_n=128)
     h.set_option(capi.OPT_STORE_WARM, 0); h.set_option(capi.OPT_ORDER_BY_COST, 1)
+    h.set_option(capi.OPT_RESERVE_CUS, int(os.environ.get("PQP_RESERVE_CUS", "0")))     # (experiments: CUs the path QP leaves to the other kernels in flight)
     # capacities sized to the workload (lines of 18..36 m): every smoother QP of the batch runs at the padded maximum size
     cfg = h.chain_config(raw_max=64, sample_max=48, layer_max=32, n_max=128) if "--default-capacities" not in sys.argv else h.chain_config()
     if "--tension" in sys.argv:            # FLAGS_smoothing_method = TENSION: clearance lookup + TensionSmoother's QP instead of TensionSmoother2's
