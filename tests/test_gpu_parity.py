@@ -328,6 +328,11 @@ def test_solve_is_deterministic_run_to_run(hip_lib, n, batch):
         again = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
         assert np.array_equal(first["out"], again["out"]) and np.array_equal(first["iters"], again["iters"])
         assert np.array_equal(first["info"][:, 5:7], again["info"][:, 5:7])
+    # handle options change the launch geometry and the order the QPs start in, never a result
+    h.set_option(capi.OPT_RESERVE_CUS, 96); h.set_option(capi.OPT_ORDER_BY_COST, 1); h.set_option(capi.OPT_STORE_WARM, 0)
+    for _ in range(2):
+        again = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+        assert np.array_equal(first["out"], again["out"]) and np.array_equal(first["iters"], again["iters"])
     h.close()
 
 
