@@ -52,6 +52,16 @@ def test_banded_solve_kernel_registers(kernels, b, maxt, stage):
     assert r["ScratchSize"] <= 512, r         # spill slots of the setup / polish code (180-408 B today); a BqLane<9> in scratch would be 700 B
 
 
+@pytest.mark.parametrize("name,tag", [("post_exact_kernel", "ILi1E"), ("post_exact_kernel", "ILi2E"), ("post_exact_kernel", "ILi4E"), ("post_exact_kernel", "ILi6E"),
+                                      ("tension_exact_kernel", "ILi1E"), ("tension_exact_kernel", "ILi2E"), ("tension_exact_kernel", "ILi4E"), ("tension_exact_kernel", "ILi6E"),
+                                      ("tension2_exact_kernel", ""), ("tension2_stage_kernel", "")])
+def test_exact_smoother_kernels_live_in_registers(kernels, name, tag):
+    """one wavefront (or one lane) per scenario, up to six layers / points per lane in register arrays: a dynamic index into one of them
+    would put it in scratch"""
+    r = _find(kernels, name, tag)
+    assert r["ScratchSize"] == 0, r
+
+
 def test_kernels_around_the_qps_do_not_use_scratch(kernels):
     for name in ("corridor_bounds_kernel", "reference_states_kernel", "spline_fit_kernel", "dp_corridor_kernel"):
         assert _find(kernels, name)["ScratchSize"] == 0, name
