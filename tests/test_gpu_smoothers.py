@@ -7,7 +7,7 @@ import scipy.sparse as sp
 
 import pqp_oracle as O
 from path_optimizer_2_amd import capi
-from smoother_cases import post_inputs, tension_inputs
+from smoother_cases import post_inputs, post_reduced_kkt as _post_reduced_kkt, tension_inputs, tension_kkt_certificate as _tension_kkt_certificate
 
 pytestmark = pytest.mark.gpu
 TIGHT = O.OsqpSettings(eps_abs=1e-9, eps_rel=1e-9, max_iter=100000)
@@ -81,29 +81,6 @@ def test_tension(hip_lib, n, batch):
     h.close()
 
 
-def _tension_kkt_certificate(x_list, y_list, ang, cl, gx, gy):
-    """Solver-free optimality check of a TensionSmoother result: eliminate the oracle's equality rows (x = X + c d, y = Y + s d), and test
-    the box QP's KKT conditions in d - feasibility, stationarity of the free shifts, the gradient's sign at the active ones - with the
-    oracle's P.  Returns the largest violation relative to 1 + |d|max."""
-    n = len(x_list)
-    P, q, A, lo, up = O.assemble_tension(x_list, y_list, ang, cl)
-    c, s = -np.diag(A[:n, 2 * n:]), -np.diag(A[n:2 * n, 2 * n:])
-    d = (gx - x_list) * c + (gy - y_list) * s                       # (c, s) is a unit vector
-    assert np.abs(gx - x_list - c * d).max() < 1e-9 and np.abs(gy - y_list - s * d).max() < 1e-9       # the equality rows hold
-    H = P[:n, :n]
-    g = c * (H @ gx) + s * (H @ gy) + np.diag(P[2 * n:, 2 * n:]) * d
-    dl, du = lo[2 * n:], up[2 * n:]
-    viol = 0.0
-    for i in range(n):
-        if dl[i] == du[i]:
-            viol = max(viol, abs(d[i] - dl[i])); continue
-        viol = max(viol, dl[i] - d[i], d[i] - du[i])
-        if d[i] <= dl[i] + 1e-9: viol = max(viol, -g[i])
-        elif d[i] >= du[i] - 1e-9: viol = max(viol, g[i])
-        else: viol = max(viol, abs(g[i]))
-    return viol / (1.0 + np.abs(d).max())
-
-
 def test_tension_sizes_beyond_the_9x9_formulation(hip_lib):
     """750 variables in 9 x 9 blocks need more LDS than a CU has: the reference's ADMM setting is PQP_ERR_CAPACITY at n = 250 (nothing
     launched).  A handle that asks for exact optima (polish = 1) solves the same QP as a box QP in the lateral shifts, one wavefront per
@@ -167,36 +144,6 @@ def test_tension_with_a_point_count_per_scenario(hip_lib):
     one = h.smooth_tension(*(cases[2][k][None] for k in (0, 1, 2, 5)))
     assert np.abs(one["x"][0] - r["x"][2, :37]).max() < 1e-6 and np.abs(one["y"][0] - r["y"][2, :37]).max() < 1e-6
     h.close()
-
-
-def _post_reduced_kkt(s, lb, ub, l0, l):
-    """Solver-free optimality check of a postSmooth result: V maps the offsets to the oracle's variables (l' and l'' from the two difference
-    rows, the last layer's l' minimised out, its l'' = 0); the box QP's KKT conditions with g = V^T P V l, P the oracle's.  Returns the
-    largest violation relative to 1 + |l|max."""
-    m = len(s)
-    P, q, A, lo, up = O.assemble_post(s, list(zip(lb, ub)), l0)
-    h = np.diff(s)
-    V = np.zeros((3 * m, m))
-    V[:m] = np.eye(m)
-    for i in range(m - 1):
-        V[m + i, i + 1] += 1 / h[i]; V[m + i, i] -= 1 / h[i]
-    if m >= 2:
-        V[2 * m - 1] = V[2 * m - 2] * (10.0 / (h[m - 2] ** 2 + 10.0))        # argmin over the last l' of 50 b^2 + 500 ((b - l'_{m-2}) / h)^2
-    for i in range(m - 1):
-        V[2 * m + i] = (V[m + i + 1] - V[m + i]) / h[i]
-    v = V @ l
-    assert np.abs(A @ v - np.clip(A @ v, lo, up))[m:].max(initial=0.0) < 1e-9           # the difference rows hold by construction
-    g = V.T @ (P @ v)
-    lo_l, up_l = lo[:m], up[:m]
-    viol = 0.0
-    for i in range(m):
-        if lo_l[i] == up_l[i]:
-            viol = max(viol, abs(l[i] - lo_l[i])); continue
-        viol = max(viol, lo_l[i] - l[i], l[i] - up_l[i])
-        if l[i] <= lo_l[i] + 1e-9: viol = max(viol, -g[i])
-        elif l[i] >= up_l[i] - 1e-9: viol = max(viol, g[i])
-        else: viol = max(viol, abs(g[i]))
-    return viol / (1.0 + np.abs(l).max())
 
 
 def test_post_smooth_exact_kernel(hip_lib):
