@@ -68,7 +68,7 @@ def _one_by_one(h, hs, sc, b, cfg):
     bounds, nv = h.corridor_bounds(ref, tab, ext, sc["dist"], sc["geom"], map_of=mo, n_of=count)
     scal = np.array([[err[0, 0], err[0, 1], 0.0, tg[0, 2], 1.0 if nv[0] < count[0] else 0.0, cfg.max_steering_angle]])
     res = h.solve_var(nv, ref, bounds, scal, passes=1)
-    return dict(n0=n0, n1=n1, layers=k, count=int(count[0]), nv=int(nv[0]), out=res["out"][0], status=int(res["status"][0]))
+    return dict(n0=n0, n1=n1, layers=k, count=int(count[0]), nv=int(nv[0]), out=res["out"][0], status=int(res["status"][0]), ref=ref, bounds=bounds, scal=scal)
 
 
 def test_ragged_batch_equals_the_steps_run_one_scenario_at_a_time(hip_lib):
@@ -92,6 +92,30 @@ def test_ragged_batch_equals_the_steps_run_one_scenario_at_a_time(hip_lib):
         assert np.abs(got["out"][b, :nv] - want["out"][:nv]).max() < 2e-5, (b, np.abs(got["out"][b, :nv] - want["out"][:nv]).max())
         assert np.all(got["out"][b, nv:] == 0.0)
     assert len(seen) >= 6                          # the batch really was ragged
+    h.close(); hs.close()
+
+
+def test_configs0_the_demo_s_single_path(hip_lib):
+    """BASELINE configs[0]: one scenario, a line of about 60 waypoints, fixed start and goal on an obstacle map - the reference's demo
+    (CPU OSQP).  Here: batch 1 through the device-resident chain, the reference's smoother setting (OSQP defaults) and the production path
+    QP; the path against the C restatement of OSQP run to 1e-9 on the reference states and corridor the chain produced - the north_star
+    bar: 1e-4 in lateral offset and heading."""
+    import pqp_oracle_c as OC
+    sc = _scenarios(1, n_maps=1, seed=21)
+    sc["n_pts"][0] = 9                                             # ~24 m of input polygon -> ~18 m of line after the search: ~60 waypoints
+    h = capi.Handle(capi.production_params(), max_batch=1, max_n=256)
+    hs = capi.Handle(_smoother_params(), max_batch=1, max_n=128)
+    cfg = h.chain_config()
+    got = h.optimize_path(sc["pts"], sc["n_pts"], sc["start"], sc["target"], sc["dist"], sc["geom"], map_of=sc["map_of"], smoother=hs, cfg=cfg)
+    assert got["stage"][0] == 0 and got["status"][0] == 1
+    nv = int(got["n_out"][0])
+    assert 40 <= nv <= 90, nv
+    want = _one_by_one(h, hs, sc, 0, cfg)
+    assert want["nv"] == nv
+    ref = OC.solve_batch(OC.params(eps_abs=1e-9, eps_rel=1e-9, max_iter=200000), want["ref"][:, :nv].copy(), want["bounds"][:, :nv].copy(), want["scal"], passes=1)
+    assert ref["solved"] == 1
+    assert np.abs(got["out"][0, :nv, 3:5] - ref["out"][0, :, 3:5]).max() < 1e-4
+    assert np.abs(got["out"][0, :nv, 0:2] - ref["out"][0, :, 0:2]).max() < 1e-4
     h.close(); hs.close()
 
 
