@@ -1,8 +1,6 @@
 """Synthetic inputs for the three smoother QPs (shared by CPU and GPU tests)."""
 import numpy as np
 
-import pqp_oracle as O
-
 
 def tension_inputs(n, seed=0, ds=1.0):
     """A noisy curved polyline re-sampled at ~1 m (what segmentRawReference hands to osqpSmooth,
@@ -30,6 +28,7 @@ def tension_kkt_certificate(x_list, y_list, ang, cl, gx, gy):
     """Solver-free optimality check of a TensionSmoother result: eliminate the oracle's equality rows (x = X + c d, y = Y + s d), and test
     the box QP's KKT conditions in d - feasibility, stationarity of the free shifts, the gradient's sign at the active ones - with the
     oracle's P.  Returns the largest violation relative to 1 + |d|max."""
+    import pqp_oracle as O           # (imported here: tools/ share the input generators above and must not depend on oracle/)
     n = len(x_list)
     P, q, A, lo, up = O.assemble_tension(x_list, y_list, ang, cl)
     c, s = -np.diag(A[:n, 2 * n:]), -np.diag(A[n:2 * n, 2 * n:])
@@ -53,6 +52,7 @@ def post_reduced_kkt(s, lb, ub, l0, l):
     """Solver-free optimality check of a postSmooth result: V maps the offsets to the oracle's variables (l' and l'' from the two difference
     rows, the last layer's l' minimised out, its l'' = 0); the box QP's KKT conditions with g = V^T P V l, P the oracle's.  Returns the
     largest violation relative to 1 + |l|max."""
+    import pqp_oracle as O
     m = len(s)
     P, q, A, lo, up = O.assemble_post(s, list(zip(lb, ub)), l0)
     h = np.diff(s)

@@ -2,7 +2,7 @@
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for d_ in ("", "tests", "oracle"):
+for d_ in ("", "tests"):
     sys.path.insert(0, os.path.join(ROOT, d_))
 from path_optimizer_2_amd import capi
 from smoother_cases import tension_inputs
