@@ -48,8 +48,9 @@ def test_tension2(hip_lib, n, batch):
 
 @pytest.mark.parametrize("n,batch,scaling", [(24, 5, 10), (80, 3, 0), (200, 2, 0)])
 def test_tension2_is_solved_directly_when_polish_is_on(hip_lib, n, batch, scaling):
-    """TensionSmoother2's QP has no inequality rows (tension_smoother_2.cpp:119-145: l == u in every row): with polish = 2 (and 1) the core
-    solves it as one KKT system at iteration 0 - no ADMM iteration, the exact optimum; bench.py --config 4 runs it this way."""
+    """TensionSmoother2's QP has no inequality rows (tension_smoother_2.cpp:119-145: l == u in every row): with polish = 2 (and 1) it is
+    solved exactly - no ADMM iteration, iters = 0 - by tension2_exact_kernel's Riccati sweep (whatever `scaling` says: nothing is
+    equilibrated); bench.py --config 4 runs it this way."""
     cases = [tension_inputs(n, seed=50 + b) for b in range(batch)]
     arr = [np.stack([c[k] for c in cases]) for k in range(5)]
     for mode in (2, 1):
