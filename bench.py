@@ -109,7 +109,7 @@ def pmc_child(argv_core, kernel_substr, timeout_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=2000, help="timed steps (default: 0.65 s of configs[1] steps, so that the timed region is visible to a 10 Hz sampler)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4], help="BASELINE.json configs[k] (default: 1 at --gpus 1, else 3)")
     ap.add_argument("--batch", type=int, default=None, help="QPs per GPU (default: the config's)")
