@@ -88,7 +88,38 @@ def make_line_fixture(name, seed):
     print(name, "raw points", len(x), "samples", len(seg[2]))
 
 
+def make_smoother_fixture(name):
+    """The three smoothing QPs: inputs and the optimum of the oracle's assembly of the reference's formulation -
+    TensionSmoother2's from the dense KKT system (it has equality rows only), TensionSmoother's and postSmooth's from the oracle's ADMM
+    run to 1e-11 / 1e-10."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from smoother_cases import post_inputs, tension_inputs
+    out = {}
+    for tag, n, seed in (("a", 24, 901), ("b", 60, 902)):
+        x, y, ang, k, s, cl = tension_inputs(n, seed=seed)
+        P, q, A, lo, up = O.assemble_tension2(x, y, ang, k, s)
+        sol = np.linalg.solve(np.block([[P, A.T], [A, np.zeros((A.shape[0], A.shape[0]))]]), np.r_[-q, lo])
+        P2, q2, A2, lo2, up2 = O.assemble_tension(x, y, ang, cl)
+        r2 = O.osqp_admm(sp.csc_matrix(P2), q2, A2, lo2, up2, O.OsqpSettings(eps_abs=1e-11, eps_rel=1e-11, max_iter=800000))
+        assert r2["status"] == "solved"
+        for key, val in (("x", x), ("y", y), ("angle", ang), ("k", k), ("s", s), ("clearance", cl), ("t2_x", sol[:n]), ("t2_y", sol[n:2 * n]),
+                         ("t_x", r2["x"][:n]), ("t_y", r2["x"][n:2 * n])):
+            out[f"{tag}_{key}"] = val
+    for tag, m, seed in (("c", 18, 903), ("d", 60, 904)):
+        s, lb, ub, l0 = post_inputs(m, seed=seed)
+        P, q, A, lo, up = O.assemble_post(s, list(zip(lb, ub)), l0)
+        r = O.osqp_admm(sp.csc_matrix(P), q, A, lo, up, O.OsqpSettings(eps_abs=1e-10, eps_rel=1e-10, max_iter=400000))
+        assert r["status"] == "solved"
+        for key, val in (("s", s), ("lb", lb), ("ub", ub), ("l0", np.array(l0)), ("l", r["x"][:m])):
+            out[f"{tag}_{key}"] = val
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, sorted(out)[:6], "...")
+
+
 if __name__ == "__main__":
+    if "smoothers" in sys.argv[1:]:
+        make_smoother_fixture("smoothers"); sys.exit(0)
+    make_smoother_fixture("smoothers")
     make_line_fixture("line_a", 3)
     make("path_n8", 8, 4, "varied")
     make("path_n80", 80, 4, "uniform")

@@ -259,3 +259,36 @@ def test_tension2_exact_kernel_with_a_point_count_per_scenario(hip_lib):
     assert want["status"][0] == 1 and want["iters"][0] > 0
     assert np.abs(want["x"][0] - r["x"][4, :17]).max() < 1e-6 and np.abs(want["y"][0] - r["y"][4, :17]).max() < 1e-6
     g.close()
+
+
+def test_golden_smoother_fixtures_through_the_hip_path(hip_lib):
+    """Committed golden vectors of the three smoothing QPs (tests/golden/smoothers.npz, make_golden.py): the exact kernels land on the
+    stored optima, the reference's ADMM setting (eps 1e-3) within its own tolerance of them."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "smoothers.npz"))
+    for tag in ("a", "b"):
+        x, y, ang, k, s, cl = (g[f"{tag}_{key}"][None] for key in ("x", "y", "angle", "k", "s", "clearance"))
+        n = x.shape[1]
+        h = capi.Handle(_polished(), max_batch=1, max_n=n)
+        r = h.smooth_tension2(x, y, ang, k, s)
+        assert r["status"][0] == 1 and np.abs(r["x"][0] - g[f"{tag}_t2_x"]).max() < 1e-7 and np.abs(r["y"][0] - g[f"{tag}_t2_y"]).max() < 1e-7
+        r = h.smooth_tension(x, y, ang, cl)
+        assert r["status"][0] == 1 and np.abs(r["x"][0] - g[f"{tag}_t_x"]).max() < 5e-5 and np.abs(r["y"][0] - g[f"{tag}_t_y"]).max() < 5e-5
+        h.close()
+        h = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3), max_batch=1, max_n=n)          # the reference's setting
+        r = h.smooth_tension2(x, y, ang, k, s)
+        assert r["status"][0] == 1 and r["iters"][0] > 0 and np.abs(r["x"][0] - g[f"{tag}_t2_x"]).max() < 2e-2
+        r = h.smooth_tension(x, y, ang, cl)
+        # (TensionSmoother's QP is ill-conditioned: OSQP's eps 1e-3 residual test passes decimetres away from the optimum at the far end of the line)
+        assert r["status"][0] == 1 and r["iters"][0] > 0 and np.abs(r["x"][0] - g[f"{tag}_t_x"]).max() < 0.5
+        h.close()
+    for tag in ("c", "d"):
+        s, lb, ub, l0 = g[f"{tag}_s"][None], g[f"{tag}_lb"][None], g[f"{tag}_ub"][None], np.array([float(g[f"{tag}_l0"])])
+        h = capi.Handle(_polished(), max_batch=1, max_n=s.shape[1])
+        r = h.post_smooth(s, lb, ub, l0)
+        assert r["status"][0] == 1 and np.abs(r["l"][0] - g[f"{tag}_l"]).max() < 1e-6
+        h.close()
+        h = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3), max_batch=1, max_n=s.shape[1])
+        r = h.post_smooth(s, lb, ub, l0)
+        assert r["status"][0] == 1 and r["iters"][0] > 0 and np.abs(r["l"][0] - g[f"{tag}_l"]).max() < 2e-2
+        h.close()

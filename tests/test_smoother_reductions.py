@@ -72,3 +72,22 @@ def test_riccati_sweep_solves_tension_smoother_2():
         sol = np.linalg.solve(np.block([[P, A.T], [A, np.zeros((A.shape[0], A.shape[0]))]]), np.r_[-q, lo])
         gx, gy = riccati_tension2(x, y, ang, k, s)
         assert np.abs(gx + x[0] - sol[:n]).max() < 1e-8 and np.abs(gy + y[0] - sol[n:2 * n]).max() < 1e-8, n
+
+
+def test_golden_smoother_fixture():
+    """tests/golden/smoothers.npz (make_golden.py): the committed optima are what the oracle gives today, satisfy the reduced problems' KKT
+    conditions, and TensionSmoother2's is what the Riccati sweep gives."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "smoothers.npz"))
+    for tag in ("a", "b"):
+        x, y, ang, k, s, cl = (g[f"{tag}_{key}"] for key in ("x", "y", "angle", "k", "s", "clearance"))
+        n = len(x)
+        P, q, A, lo, up = O.assemble_tension2(x, y, ang, k, s)
+        sol = np.linalg.solve(np.block([[P, A.T], [A, np.zeros((A.shape[0], A.shape[0]))]]), np.r_[-q, lo])
+        assert np.abs(sol[:n] - g[f"{tag}_t2_x"]).max() < 1e-9 and np.abs(sol[n:2 * n] - g[f"{tag}_t2_y"]).max() < 1e-9
+        gx, gy = riccati_tension2(x, y, ang, k, s)
+        assert np.abs(gx + x[0] - g[f"{tag}_t2_x"]).max() < 1e-8 and np.abs(gy + y[0] - g[f"{tag}_t2_y"]).max() < 1e-8
+        assert tension_kkt_certificate(x, y, ang, cl, g[f"{tag}_t_x"], g[f"{tag}_t_y"]) < 2e-5
+    for tag in ("c", "d"):
+        s, lb, ub, l0, l = (g[f"{tag}_{key}"] for key in ("s", "lb", "ub", "l0", "l"))
+        assert post_reduced_kkt(s, lb, ub, float(l0), l) < 1e-6
