@@ -101,6 +101,13 @@ def test_tension_sizes_beyond_the_9x9_formulation(hip_lib):
             assert _tension_kkt_certificate(x[b], y[b], ang[b], cl[b], r["x"][b], r["y"][b]) < 1e-6, (n, b)
             np.testing.assert_allclose(r["s"][b], _chord(r["x"][b], r["y"][b]), atol=1e-11)
         h.close()
+    # lines on which the active-set rounds cycle with the cautious threshold of 0.5 (1 in 1000, tools/active_set_sweep.py): single moves end them
+    for n2, sd in ((24, 1877), (48, 1960), (80, 1325)):
+        c2 = tension_inputs(n2, seed=sd)
+        h = capi.Handle(_polished(), max_batch=1, max_n=n2)
+        r2 = h.smooth_tension(c2[0][None], c2[1][None], c2[2][None], c2[5][None])
+        assert r2["status"][0] == 1 and _tension_kkt_certificate(c2[0], c2[1], c2[2], c2[5], r2["x"][0], r2["y"][0]) < 1e-6, (n2, sd)
+        h.close()
     # the certificate is not vacuous: a point moved off the optimum fails it by orders of magnitude
     bad = _tension_kkt_certificate(x[0], y[0], ang[0], cl[0], r["x"][0] + 1e-3 * np.cos(ang[0] + np.pi / 2) * np.sin(np.arange(n)), r["y"][0] + 1e-3 * np.sin(ang[0] + np.pi / 2) * np.sin(np.arange(n)))
     assert bad > 1e-3
