@@ -52,6 +52,7 @@ CONFIGS = {
 
 
 def algorithmic_bytes(n, kkt_solves, admm_iters, factors, setups):
+    # kkt_solves / admm_iters / factors: one entry per QP of the launch (their length is the batch); setups: assemblies per QP (2)
     """Streaming-model bytes of SURVEY.md §8(d), fp64, default flags:
          B_io   = 152 N + 40   per solve   (read 12 doubles/waypoint + 5 scalars, write 7 doubles/waypoint)
          B_asm  = 656 N        per solve   (assembled P, A, l, u, q written once and read once)
@@ -60,10 +61,11 @@ def algorithmic_bytes(n, kkt_solves, admm_iters, factors, setups):
        only - §8(d)'s literal wording -, bytes with factorisations and Ruiz passes added:
          B_fac  = 752 N per factorisation, B_ruiz = 3440 N per setup)."""
     b_io, b_asm, b_iter, b_fac, b_ruiz = 152 * n + 40, 656 * n, 1040 * n, 752 * n, 3440 * n
-    fixed = float(np.sum(setups * (b_io + b_asm)))
+    batch = len(np.atleast_1d(kkt_solves))
+    fixed = float(batch * setups * (b_io + b_asm))              # (round 2 forgot `batch` here: 132 MB per 1024 x 80 launch)
     with_kkt = fixed + float(np.sum(np.asarray(kkt_solves, dtype=np.float64) * b_iter))
     admm_only = fixed + float(np.sum(np.asarray(admm_iters, dtype=np.float64) * b_iter))
-    ext = with_kkt + float(np.sum(np.asarray(factors, dtype=np.float64) * b_fac + setups * b_ruiz))
+    ext = with_kkt + float(np.sum(np.asarray(factors, dtype=np.float64) * b_fac)) + float(batch * setups * b_ruiz)
     return with_kkt, admm_only, ext
 
 
@@ -150,11 +152,26 @@ def main():
     if args.seed is None:
         args.seed = BASE_SEED
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver would
+        # (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...), and hand its exit code on
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        sys.stderr.write(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd)}\n")
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: launch one rank per GPU (or give --gpus alone and let bench.py start them)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but this node shows {torch.cuda.device_count()} device(s)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:

@@ -266,6 +266,12 @@ int pqp_path_solve_var(pqp_handle* h, int batch, int n_max, const int32_t* n_of,
  * getSolution(), base_solver.cpp:89,112): x [batch][vars], y [batch][cons].  HOST buffers; either may be NULL. */
 int pqp_path_get_solution(pqp_handle* h, int batch, int n, int precise, double* x, double* y);
 
+/* constrainAngle (include/tools/tools.hpp:24-35: wrap to [-pi, pi], both ends inclusive) exactly as the kernels of this library evaluate
+ * it for the end-heading rule (base_solver.cpp:254-258) and the unpack (base_solver.cpp:272-275): out[i] = constrainAngle(in[i]).
+ * DEVICE pointers.  It exists so that the helper can be pinned bit for bit against the reference's own template
+ * (oracle/_ref/libref_types.so, tests/test_ref_types.py). */
+int pqp_constrain_angle_device(pqp_handle* h, int count, const double* in, double* out);
+
 /* ---- one node, several GPUs -----------------------------------------------------------------------------------
  * The QPs of a batch are independent: the batch is cut into contiguous shards (pqp_shard_range: the first total % world shards get one
  * QP more), every shard has its own handle - GPU, stream, workspaces - and its own host thread; pqp_multi_path_solve moves each
@@ -449,7 +455,7 @@ int pqp_dp_corridor(pqp_handle* h, int batch, int m, int max_layers, const doubl
  * pointers; nothing is copied to the host between the steps; the call returns when everything is enqueued (pqp_sync(h) waits).
  *   h  : the handle whose parameters the path QP uses (pqp_production_params or the reference's pqp_default_params);
  *   hs : the handle the two smoother QPs run on - the reference solves them at OSQP's default eps 1e-3 (tension_smoother_2.cpp:32-36),
- *        i.e. pqp_default_params with eps_abs = eps_rel = 1e-3 - or NULL: h's own parameters.  The two handles are ordered by marks 6, 7.
+ *        i.e. pqp_default_params with eps_abs = eps_rel = 1e-3 - or NULL: h's own parameters.  The two handles must live on the same device (PQP_ERR_INVALID otherwise); they are ordered by events of the chain's own (pqp_mark's slots stay the caller's).
  *   points [batch][p_max][2], n_points [batch]  PathOptimizer::solve's reference_points (fewer than 4: "Few reference points")
  *   start, target [batch][3]                    x, y, heading of the vehicle's start and target state (the PathOptimizer constructor)
  *   start_k [batch] or NULL                     curvature of the start state (NULL: 0, State's default)

@@ -11,7 +11,8 @@ namespace PathOptimizationNS {
 
 struct State {
     State() = default;
-    State(double x_, double y_, double heading_ = 0.0, double k_ = 0.0, double s_ = 0.0) : x(x_), y(y_), heading(heading_), k(k_), s(s_) {}
+    State(double x_, double y_, double heading_ = 0.0, double k_ = 0.0, double s_ = 0.0, double v_ = 0.0, double a_ = 0.0)
+        : x(x_), y(y_), heading(heading_), k(k_), s(s_), v(v_), a(a_) {}          // data_struct.hpp:16-17 (d_k has no constructor argument)
     double x{}, y{}, heading{}, k{}, d_k{}, s{}, v{}, a{};
 };
 

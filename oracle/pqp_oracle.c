@@ -67,6 +67,8 @@ static double constrain_angle(double a) {          /* tools.hpp:24-35 */
     }
 }
 
+double pqo_constrain_angle(double a) { return constrain_angle(a); }   /* for tests/test_ref_types.py: pinned against the reference's template */
+
 static void soft_bounds(double lb, double ub, double margin, double min_clearance, double* lo, double* up) {   /* :290-295 */
     double clearance = ub - lb;
     double remain = fmax(min_clearance, clearance - 2 * margin);

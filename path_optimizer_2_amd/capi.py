@@ -60,7 +60,7 @@ class PqpSizes(C.Structure):
 
 EXPORTS = [
     "pqp_default_params", "pqp_production_params", "pqp_last_error", "pqp_version", "pqp_create", "pqp_destroy", "pqp_set_params", "pqp_set_option",
-    "pqp_stream_wait", "pqp_mark", "pqp_wait_mark", "pqp_get_stream",
+    "pqp_constrain_angle_device", "pqp_stream_wait", "pqp_mark", "pqp_wait_mark", "pqp_get_stream",
     "pqp_chain_default_config", "pqp_optimize_path_device", "pqp_clearance_device", "pqp_smooth_tension2_var_device", "pqp_smooth_tension_var_device", "pqp_post_smooth_var_device", "pqp_spline_fit_var_device",
     "pqp_shard_range", "pqp_multi_create", "pqp_multi_destroy", "pqp_multi_shards", "pqp_multi_handle", "pqp_multi_set_option", "pqp_multi_path_solve", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
     "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_solve_var_device", "pqp_path_solve_var", "pqp_path_get_solution",
@@ -96,6 +96,7 @@ def load_library(path=None):
     lib.pqp_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.pqp_stream_wait.argtypes = [vp, vp]
     lib.pqp_mark.argtypes = [vp, C.c_int]
+    lib.pqp_constrain_angle_device.argtypes = [vp, C.c_int, vp, vp]
     lib.pqp_wait_mark.argtypes = [vp, vp, C.c_int]
     lib.pqp_get_stream.argtypes = [vp, C.POINTER(vp)]
     lib.pqp_chain_default_config.argtypes = [C.POINTER(PqpChainConfig)]
@@ -247,6 +248,7 @@ class Handle:
         self.lib = load_library()
         self.params = params or default_params(self.lib)
         self._h = C.c_void_p()
+        self.device = int(device)          # the torch helpers below allocate and synchronise on the handle's own GPU
         self._check(self.lib.pqp_create(C.byref(self._h), C.byref(self.params), device, max_batch, max_n))
 
     def _check(self, rc):
@@ -278,6 +280,17 @@ class Handle:
     def mark(self, slot):
         self._check(self.lib.pqp_mark(self._h, slot))
 
+    def constrain_angle(self, angles):
+        """pqp_constrain_angle_device on a host array (torch as the memory plumbing)."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        a = torch.from_numpy(np.ascontiguousarray(angles, dtype=np.float64).ravel()).to(dev)
+        o = torch.empty_like(a)
+        torch.cuda.synchronize(dev)
+        self._check(self.lib.pqp_constrain_angle_device(self._h, a.numel(), C.c_void_p(a.data_ptr()), C.c_void_p(o.data_ptr())))
+        self.sync()
+        return o.cpu().numpy().reshape(np.shape(angles))
+
     def wait_mark(self, other, slot):
         """Everything enqueued on this handle from now on waits for `other`'s mark `slot` (pqp_wait_mark)."""
         self._check(self.lib.pqp_wait_mark(self._h, other._h, slot))
@@ -304,7 +317,7 @@ class Handle:
         points [B][p_max][2], n_points [B], start / target [B][3], dist [n_maps][rows][cols] float32.  smoother: the handle the two
         smoother QPs run on (None: this one).  Returns dict(out [B][n_max][7], n_out, status, stage, iters)."""
         import torch
-        dev = torch.device("cuda", 0)
+        dev = torch.device("cuda", self.device)
         cfg = cfg or self.chain_config()
         t = lambda a, dt: None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
         dist = np.asarray(dist, dtype=np.float32)
@@ -316,7 +329,7 @@ class Handle:
         d_map, d_k = t(map_of, np.int32), t(start_k, np.float64)
         out = torch.zeros((B, cfg.n_max, 7), dtype=torch.float64, device=dev)
         ints = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(4)]
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(dev)
         p = lambda x: None if x is None else C.c_void_p(x.data_ptr())
         self._check(self.lib.pqp_optimize_path_device(self._h, smoother._h if smoother is not None else None, C.byref(cfg), B, p_max, p(d_pts), p(d_np),
                                                       p(d_st), p(d_tg), p(d_dist), p(d_map), C.byref(geom), p(d_k), p(out), p(ints[0]), p(ints[1]),
@@ -533,14 +546,14 @@ class Handle:
     def smooth_tension2_var(self, x, y, angle, k, s, n_of):
         """pqp_smooth_tension2_var_device (torch as the memory plumbing): lists [B][n_max], n_of [B] points per scenario."""
         import torch
-        dev = torch.device("cuda", 0)
+        dev = torch.device("cuda", self.device)
         B, n = x.shape
         t = lambda a, dt=np.float64: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
         d = [t(a) for a in (x, y, angle, k, s)]
         d_n = t(n_of, np.int32)
         o = [torch.zeros((B, n), dtype=torch.float64, device=dev) for _ in range(3)]
         st, it = (torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2))
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(dev)
         p = lambda a: C.c_void_p(a.data_ptr())
         self._check(self.lib.pqp_smooth_tension2_var_device(self._h, B, n, p(d_n), p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(o[0]), p(o[1]), p(o[2]), p(st), p(it), None))
         self.sync()
@@ -549,14 +562,14 @@ class Handle:
     def smooth_tension_var(self, x, y, angle, clearance, n_of):
         """pqp_smooth_tension_var_device (torch as the memory plumbing): lists [B][n_max], n_of [B] points per scenario."""
         import torch
-        dev = torch.device("cuda", 0)
+        dev = torch.device("cuda", self.device)
         B, n = x.shape
         t = lambda a, dt=np.float64: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
         d = [t(a) for a in (x, y, angle, clearance)]
         d_n = t(n_of, np.int32)
         o = [torch.zeros((B, n), dtype=torch.float64, device=dev) for _ in range(3)]
         st, it = (torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2))
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(dev)
         p = lambda a: C.c_void_p(a.data_ptr())
         self._check(self.lib.pqp_smooth_tension_var_device(self._h, B, n, p(d_n), p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(o[0]), p(o[1]), p(o[2]), p(st), p(it), None))
         self.sync()
@@ -572,7 +585,7 @@ class Handle:
     def post_smooth_var(self, layers_s, lb, ub, vehicle_l, m_of, info=False):
         """pqp_post_smooth_var_device (torch as the memory plumbing): lists [B][m_max], m_of [B] layers per scenario."""
         import torch
-        dev = torch.device("cuda", 0)
+        dev = torch.device("cuda", self.device)
         B, m = layers_s.shape
         t = lambda a, dt=np.float64: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
         d = [t(a) for a in (layers_s, lb, ub, vehicle_l)]
@@ -580,7 +593,7 @@ class Handle:
         ol = torch.zeros((B, m), dtype=torch.float64, device=dev)
         st, it = (torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2))
         inf = torch.zeros((B, 8), dtype=torch.float64, device=dev)
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(dev)
         p = lambda a: C.c_void_p(a.data_ptr())
         self._check(self.lib.pqp_post_smooth_var_device(self._h, B, m, p(d_m), p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(ol), p(st), p(it), p(inf) if info else None))
         self.sync()

@@ -320,7 +320,13 @@ struct DevCtx {
 __device__ void order_next_launch(const PathSolveArgs& args) {
     __shared__ int start[kCostBins];
     __shared__ int s_last;
-    if (threadIdx.x == 0) s_last = atomicAdd(args.cost_hist + kCostBins, 1) == (int)gridDim.x - 1;
+    // release / acquire around the count-out: this workgroup's keys and bin counts (relaxed agent-scope atomics of record_cost) are
+    // visible before its count is, and the last workgroup reads the other XCDs' keys only after it has seen every count
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(args.cost_hist + kCostBins, 1) == (int)gridDim.x - 1;
+        __threadfence();
+    }
     __syncthreads();
     if (!s_last) return;
     const int nt = blockDim.x;
@@ -364,7 +370,7 @@ __global__ void __launch_bounds__(64 * NW, (NW <= 2) ? PQP_SOLVE_OCC : 1) path_s
         __syncthreads();
         const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
         __syncthreads();
-        if (ticket >= args.batch) break;
+        if ((unsigned)ticket >= (unsigned)args.batch) break;      // (unsigned: a ticket below the base - a host/device counter mismatch - ends the workgroup too)
         const int qp = args.order ? args.order[ticket] : ticket;
         // (written out rather than through PathQp::count_of: with the call here the register allocator spills 170 VGPRs of the loop)
         if ((args.n_of ? args.n_of[qp] : args.n) < 2) {
@@ -617,6 +623,12 @@ __global__ void path_gather_solution(RefIndex R, int batch, const double* __rest
     }
 }
 
+// constrainAngle (include/tools/tools.hpp:24-35) as the kernels of this library evaluate it: what pqp_constrain_angle_device exposes
+__global__ void constrain_angle_kernel(int count, const double* __restrict__ in, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = constrain_angle(in[i]);
+}
+
 }  // namespace pqp
 
 #include "pqp_smoother_kernels.inc"
@@ -672,7 +684,8 @@ struct pqp_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;      // the pair of the launch being recorded
     bool timed = false;
     static constexpr int kMarks = 8;
-    hipEvent_t marks[kMarks] = {};             // pqp_mark / pqp_wait_mark: ordering between the streams of two handles
+    static constexpr int kChainMarks = 2;      // + two events of pqp_optimize_path_device's own
+    hipEvent_t marks[kMarks + kChainMarks] = {};   // pqp_mark / pqp_wait_mark: ordering between the streams of two handles
     void next_event_pair() { ev0 = evs0[ev_count % kEvRing]; ev1 = evs1[ev_count % kEvRing]; ev_count += 1; }
     int warm_batch = 0, warm_n = 0;
     bool warm_stored = false;                   // the last solve wrote its final iterate to wx / wy / wye
@@ -719,7 +732,7 @@ int pqp_create(pqp_handle** out, const pqp_params* params, int device, int max_b
         PQP_HIP(hipDeviceGetAttribute(&h->num_cu, hipDeviceAttributeMultiprocessorCount, device));
         PQP_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         for (int k = 0; k < pqp_handle::kEvRing; ++k) { PQP_HIP(hipEventCreate(&h->evs0[k])); PQP_HIP(hipEventCreate(&h->evs1[k])); }
-        for (int k = 0; k < pqp_handle::kMarks; ++k) PQP_HIP(hipEventCreateWithFlags(&h->marks[k], hipEventDisableTiming));
+        for (int k = 0; k < pqp_handle::kMarks + pqp_handle::kChainMarks; ++k) PQP_HIP(hipEventCreateWithFlags(&h->marks[k], hipEventDisableTiming));
         int rc;
         if ((rc = h->ticket.ensure(8)) || (rc = h->cost_hist.ensure(2 * pqp::kCostBins * 4))) return rc;
         if (max_batch > 0 && max_n > 0) {
@@ -748,7 +761,7 @@ int pqp_destroy(pqp_handle* h) {
                       &h->c_buf[11]})
         b->release();
     for (int k = 0; k < pqp_handle::kEvRing; ++k) { if (h->evs0[k]) (void)hipEventDestroy(h->evs0[k]); if (h->evs1[k]) (void)hipEventDestroy(h->evs1[k]); }
-    for (int k = 0; k < pqp_handle::kMarks; ++k) if (h->marks[k]) (void)hipEventDestroy(h->marks[k]);
+    for (int k = 0; k < pqp_handle::kMarks + pqp_handle::kChainMarks; ++k) if (h->marks[k]) (void)hipEventDestroy(h->marks[k]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PQP_OK;
@@ -953,7 +966,9 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     a.store_warm = h->opt_store_warm;
     a.ticket = h->ticket.as<unsigned long long>();
     a.ticket_base = h->ticket_next;
-    h->ticket_next += (unsigned long long)batch + (unsigned long long)grid;
+    // Host-side bookkeeping of the launch (ticket base of the next launch, launch parity, shape of the cost histogram) is committed
+    // only after the launch has been accepted: a failing step below (allocation, memset, event, launch) leaves the device ticket
+    // counter and the host's idea of it in step.
     if (h->opt_order_by_cost) {
         // most expensive QPs first, by what they cost in this handle's previous solve of the same shape (a planner re-solves
         // nearly the same scenarios cycle after cycle); results do not depend on the order
@@ -962,18 +977,23 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
         int32_t* order_read = h->order.as<int32_t>() + (size_t)(h->solves & 1) * batch;
         int32_t* order_write = h->order.as<int32_t>() + (size_t)((h->solves + 1) & 1) * batch;
         if (h->hist_batch == batch && h->hist_n == n) a.order = order_read;
-        else PQP_HIP(hipMemsetAsync(h->cost_hist.p, 0, (pqp::kCostBins + 1) * 4, h->stream));      // (a shape change: stale counts)
+        else { h->hist_batch = 0; h->hist_n = 0; PQP_HIP(hipMemsetAsync(h->cost_hist.p, 0, (pqp::kCostBins + 1) * 4, h->stream)); }     // (a shape change: stale counts)
         a.cost_key = h->cost_key.as<int32_t>();
         a.cost_hist = h->cost_hist.as<int32_t>();
         a.order_next = order_write;
-        h->hist_batch = batch; h->hist_n = n;
     }
-    h->solves += 1;
     h->next_event_pair();
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
     void* kargs[] = {(void*)&a};
-    PQP_HIP(hipLaunchKernel(fn, dim3(grid), dim3(64 * nw), kargs, lds, h->stream));
-    PQP_HIP(hipGetLastError());
+    hipError_t le = hipLaunchKernel(fn, dim3(grid), dim3(64 * nw), kargs, lds, h->stream);
+    if (le == hipSuccess) le = hipGetLastError();
+    if (le != hipSuccess) {
+        h->hist_batch = 0; h->hist_n = 0;          // (the histogram may have been cleared for a launch that never ran)
+        return fail(PQP_ERR_HIP, std::string("hipLaunchKernel(path_solve_kernel): ") + hipGetErrorString(le));
+    }
+    h->ticket_next += (unsigned long long)batch + (unsigned long long)grid;
+    if (h->opt_order_by_cost) { h->hist_batch = batch; h->hist_n = n; }
+    h->solves += 1;
     PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     h->warm_batch = batch; h->warm_n = n;
@@ -1091,6 +1111,14 @@ int pqp_path_get_solution(pqp_handle* h, int batch, int n, int precise, double* 
     if (x) PQP_HIP(hipMemcpyAsync(x, h->s_a.p, (size_t)batch * R.vars() * 8, hipMemcpyDeviceToHost, h->stream));
     if (y) PQP_HIP(hipMemcpyAsync(y, h->s_l.p, (size_t)batch * R.cons() * 8, hipMemcpyDeviceToHost, h->stream));
     PQP_HIP(hipStreamSynchronize(h->stream));
+    return PQP_OK;
+}
+
+int pqp_constrain_angle_device(pqp_handle* h, int count, const double* in, double* out) {
+    if (!h || !in || !out || count < 1) return fail(PQP_ERR_INVALID, "pqp_constrain_angle: bad argument");
+    PQP_HIP(hipSetDevice(h->device));
+    hipLaunchKernelGGL(pqp::constrain_angle_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, count, in, out);
+    PQP_HIP(hipGetLastError());
     return PQP_OK;
 }
 

@@ -104,6 +104,27 @@ def make_batch(batch, n, profile="uniform", seed=BASE_SEED, first_qp=0):
     return dict(ref=np.ascontiguousarray(ref), bounds=np.ascontiguousarray(bounds), scal=np.ascontiguousarray(scal))
 
 
+F_JITTER = 13
+
+
+def jitter_batch(host, variant, rel=0.05, seed=BASE_SEED, first_qp=0):
+    """The same scenarios one planning cycle later: every QP's corridor sides and its start state (init_err_l, init_err_psi, start_k) are
+    scaled by independent factors 1 + rel * U[-1, 1] drawn from the counter (seed, qp, F_JITTER, 8 * variant + j).  variant 0 returns the
+    batch itself.  What bench.py cycles through so that PQP_OPT_ORDER_BY_COST sees SIMILAR, not identical, batches from step to step."""
+    if variant == 0:
+        return host
+    batch = host["ref"].shape[0]
+    qp = np.arange(first_qp, first_qp + batch, dtype=np.uint64)
+    f = [1.0 + rel * (2.0 * u01(seed, qp, F_JITTER, 8 * variant + j) - 1.0) for j in range(5)]
+    bounds = host["bounds"].copy()
+    bounds[:, :, 0::2] *= f[0][:, None, None]       # the three lower bounds (right side)
+    bounds[:, :, 1::2] *= f[1][:, None, None]       # the three upper bounds (left side)
+    scal = host["scal"].copy()
+    for j in range(3):
+        scal[:, j] *= f[2 + j]
+    return dict(ref=host["ref"], bounds=np.ascontiguousarray(bounds), scal=np.ascontiguousarray(scal))
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # synthetic scenes for the corridor-bounds step (obstacle distance map + reference line), deterministic in (seed)
 # ----------------------------------------------------------------------------------------------------------------------
