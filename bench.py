@@ -12,6 +12,12 @@ Workloads = BASELINE.json configs (`--config`; explicit --batch / --n / --profil
     4  batch 4096, N = 200 over 8 GPUs = 512 per GPU: TensionSmoother2 QP + path QP on two HIP streams (pipeline.py)
 Two batches are kept in flight by default (--inflight 2: consecutive steps alternate between two handles / HIP streams; every step is
 still one pass over one whole batch, and K steps are timed); --inflight 1 and its figure in "secondary" = one launch strictly after the other.
+Consecutive steps solve SIMILAR, not identical, batches (--variants 8: the scenarios one planning cycle later, synth.jitter_batch: corridor
+sides and start state scaled by 1 +- 5 %), so that the most-expensive-first start order (previous step's cost) has no perfect foresight;
+`secondary.identical_batch_every_step` is round 2's headline (the same batch re-solved every step).
+Batches of at least 24 576 QPs (PQP_OPT_STREAM_BATCH) run on the lane-per-QP kernel (path_stream_kernel: HBM-streaming, its roofline is
+measured traffic): `--config 3 --batch 65536` is configs[3]'s whole batch on one GPU, timed in every default run under
+`secondary.configs3_whole_batch_one_gpu_stream_kernel`.
 Solver setting: the engine's production setting (pqp_production_params: ADMM to eps 1e-4 + KKT-verified polish — every returned path
 is the exact optimum of its QP, inside the 1e-4 parity bar).  The literal metric ("ADMM iters to 1e-4", plain OSQP termination, no
 polish) and the reference's own setting (eps 2e-3) are timed in the same run and reported under "secondary".
@@ -69,6 +75,27 @@ def algorithmic_bytes(n, kkt_solves, admm_iters, factors, setups):
     return with_kkt, admm_only, ext
 
 
+# bytes per waypoint of one sweep of path_stream_kernel (fields read + written, fp64 problem data / gains / point,
+# fp32 interior-point state); "1": a pass linearised around (0, 0, k_ref) streams 3 of the 8 transition doubles, "2": a re-linearised pass all 8
+STREAM_BYTES = {"prep1": 184, "init": 232, "ipm1": 336, "ipm2": 416, "guess1": 172, "guess2": 212, "fset1": 144, "fset2": 184,
+                "bset1": 104, "bset2": 144, "prep2": 104, "warm": 128, "unpack": 136}
+
+
+def stream_algorithmic_bytes(n, info):
+    """Workspace + I/O bytes the lane-per-QP kernel's algorithm moves for the sweeps each QP actually ran (info rows of pqp_path_solve:
+    [2] interior-point iterations of the first pass, [3] of both, [5] active-set rounds of the first pass, [7] of both).  Every byte is HBM
+    (or Infinity-Cache) traffic by construction: nothing is kept on chip between two sweeps.  A wavefront also moves the lines of lanes that
+    have finished while a neighbour in the same 128-byte line has not, so measured traffic is 1.2-1.35x this."""
+    B = STREAM_BYTES
+    it1, it = info[:, 2], info[:, 3]
+    s1, st = info[:, 5], info[:, 7]
+    it2, s2 = it - it1, st - s1
+    two = (info[:, 4] >= 2) | (it2 > 0)
+    per_wp = (B["prep1"] + B["init"] + it1 * B["ipm1"] + B["guess1"] + s1 * B["fset1"] + np.maximum(s1 - 1, 0) * B["bset1"] + B["unpack"]
+              + two * (B["prep2"] + B["warm"] + B["guess2"]) + it2 * B["ipm2"] + s2 * B["fset2"] + np.maximum(s2 - 1, 0) * B["bset2"])
+    return float(np.sum(per_wp) * n)
+
+
 def cpu_baseline(make_sample, n, eps, budget_s):
     """The oracle (C restatement of the OSQP-paper algorithm, oracle/pqp_oracle.c) timed on this box's host cores over
     a bounded sample of the same workload.  kind = "port": OSQP itself is not in this image."""
@@ -77,7 +104,7 @@ def cpu_baseline(make_sample, n, eps, budget_s):
     return OC.timed_baseline(make_sample, n, eps, budget_s)
 
 
-def pmc_child(argv_core, kernel_substr, timeout_s):
+def pmc_child(argv_core, kernel_substr, timeout_s, steps=6):
     """Hardware counters of THIS command's dominant kernel, measured now: three rocprofv3 --pmc passes (SQ counters; the TCC byte counters
     FETCH_SIZE / WRITE_SIZE in a pass each: they do not fit one) of a short child run of bench.py, --kernel-trace only
     beside --pmc (MI355X_MICROARCH.md, rocprofv3 PMC section).  Returns per-launch averages or None (never raises)."""
@@ -88,7 +115,7 @@ def pmc_child(argv_core, kernel_substr, timeout_s):
         for pmc in passes:
             with tempfile.TemporaryDirectory(dir="/tmp") as d:
                 cmd = ["rocprofv3", "--kernel-trace", "--pmc", *pmc.split(), "-f", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
-                       *argv_core, "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-secondary", "--pmc", "off", "--sustain", "0",
+                       *argv_core, "--steps", str(steps), "--warmup", "3", "--no-cpu-baseline", "--no-secondary", "--pmc", "off", "--sustain", "0",
                        "--inflight", "1"]          # (one kernel at a time: the counters of a launch are its own)
                 env = dict(os.environ, TMPDIR="/tmp")
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
@@ -132,6 +159,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight: consecutive steps (independent batches) go round-robin to k handles / HIP "
                     "streams, as a planning server keeps independent batches in flight: the next batch's QPs fill the slots the slow tail of "
                     "this one leaves idle.  1 = strictly one launch after the other (reported under secondary.one_batch_at_a_time)")
+    ap.add_argument("--variants", type=int, default=8, help="input variants cycled through by consecutive steps: variant v = the batch one planning cycle "
+                    "later (synth.jitter_batch: corridor sides and start state scaled by 1 +- 5 %%); 1: the identical batch every step")
     ap.add_argument("--no-cost-order", action="store_true", help="start the QPs of a batch in index order instead of most-expensive-first by "
                     "their cost in the previous step (PQP_OPT_ORDER_BY_COST)")
     ap.add_argument("--reference-setting", action="store_true", help="the reference's solver setting instead of the production one: "
@@ -148,7 +177,7 @@ def main():
     import torch
     from path_optimizer_2_amd import capi
     from path_optimizer_2_amd.shard import gather_paths
-    from path_optimizer_2_amd.synth import BASE_SEED, make_batch
+    from path_optimizer_2_amd.synth import BASE_SEED, jitter_batch, make_batch
     if args.seed is None:
         args.seed = BASE_SEED
 
@@ -188,6 +217,8 @@ def main():
     total = batch * world
     polish = not args.no_polish and not args.reference_setting
     cost_order = not args.no_cost_order
+    STREAM_BATCH = 24576           # the handle's default PQP_OPT_STREAM_BATCH (include/pqp.h): from here on the lane-per-QP kernel runs
+    stream = polish and cfg_id != 4 and batch >= STREAM_BATCH
 
     def production(**over):
         kw = dict(eps_abs=args.eps, eps_rel=args.eps, polish=1 if polish else 0, polish_warm_set=args.polish_warm_set if polish else 0,
@@ -227,8 +258,13 @@ def main():
     else:
         host = make_batch(batch, n, profile, seed=args.seed, first_qp=rank * batch)          # this rank's shard of the global batch
         ref = torch.from_numpy(host["ref"]).to(dev)
-        bounds = torch.from_numpy(host["bounds"]).to(dev)
-        scal = torch.from_numpy(host["scal"]).to(dev)
+        n_var = max(1, args.variants)
+        # variant v: the same scenarios one planning cycle later (corridor sides and start state moved by up to 5 %); the reference line stays
+        var_in = []
+        for v in range(n_var):
+            hv = jitter_batch(host, v, seed=args.seed, first_qp=rank * batch)
+            var_in.append((torch.from_numpy(hv["bounds"]).to(dev), torch.from_numpy(hv["scal"]).to(dev)))
+        bounds, scal = var_in[0]
 
         def make_lane(p, order):
             h = capi.Handle(p, device=local_rank, max_batch=batch, max_n=n)
@@ -244,8 +280,9 @@ def main():
 
         def step():
             hh, o, st, it, inf = lanes[counter[0] % len(lanes)]
+            bv, sv = var_in[counter[0] % n_var]
             counter[0] += 1
-            hh.solve_device(batch, n, ref, bounds, scal, o, passes=1, status=st, iters=it, info=inf)
+            hh.solve_device(batch, n, ref, bv, sv, o, passes=1, status=st, iters=it, info=inf)
 
         def sync_all():
             for hh, *_ in lanes:
@@ -304,6 +341,11 @@ def main():
             dt_long = float(tl.item())
         sustained = {"value": total * k_long / dt_long, "unit": "paths/s", "steps": k_long, "seconds": dt_long}
 
+    if pipe is None:
+        # the checksum's step: variant 0 on the first handle, whatever K and the number of variants were
+        hh, o, st, it, inf = lanes[0]
+        hh.solve_device(batch, n, ref, var_in[0][0], var_in[0][1], o, passes=1, status=st, iters=it, info=inf)
+        sync_all()
     if pipe is not None:
         res = pipe.result((counter[0] - 1))
         it_np, st_np = res["it"], res["st"]
@@ -320,35 +362,98 @@ def main():
     # ---------------------------------------------------------------------------------------------------------------------------
     secondary = None
     if not args.no_secondary and world == 1 and pipe is None and not args.reference_setting and polish:
-        def timed(p, order, steps, warm=3):
-            ln = make_lane(p, order)
-            hh, o, st, it, inf = ln
-            for _ in range(warm):
-                hh.solve_device(batch, n, ref, bounds, scal, o, passes=1, status=st, iters=it, info=inf)
-            hh.sync()
+        def timed(p, order, steps, warm=3, inflight=1, variants=None):
+            """`steps` steps round-robin over `inflight` fresh handles; variants: the (bounds, scal) sets consecutive steps cycle through"""
+            variants = variants or var_in
+            lns = [make_lane(p, order) for _ in range(inflight)]
+            k = [0]
+
+            def one():
+                hh, o, st, it, inf = lns[k[0] % len(lns)]
+                bv, sv = variants[k[0] % len(variants)]
+                k[0] += 1
+                hh.solve_device(batch, n, ref, bv, sv, o, passes=1, status=st, iters=it, info=inf)
+
+            def wait():
+                for ln in lns:
+                    ln[0].sync()
+            for _ in range(warm * inflight):
+                one()
+            wait()
             ta = time.perf_counter()
             for _ in range(steps):
-                hh.solve_device(batch, n, ref, bounds, scal, o, passes=1, status=st, iters=it, info=inf)
-            hh.sync()
+                one()
+            wait()
             tb = time.perf_counter() - ta
+            hh, o, st, it, inf = lns[0]
+            hh.solve_device(batch, n, ref, variants[0][0], variants[0][1], o, passes=1, status=st, iters=it, info=inf)      # the checksum's step
+            hh.sync()
             itn, stn = it.cpu().numpy(), st.cpu().numpy()
-            r = {"value": batch * steps / tb, "unit": "paths/s", "steps": steps, "ms_per_step": tb / steps * 1e3,
-                 "kernel_ms": float(np.mean(hh.kernel_ms_history(min(steps, 256)))), "solved": int((stn == 1).sum()),
+            r = {"value": batch * steps / tb, "unit": "paths/s", "steps": steps, "ms_per_step": tb / steps * 1e3, "batches_in_flight": inflight,
+                 "kernel_ms": float(np.mean(np.concatenate([ln[0].kernel_ms_history(min(max(steps // inflight, 1), 256)) for ln in lns]))),
+                 "solved": int((stn == 1).sum()),
                  "admm_iters": {"min": int(itn.min()), "median": float(np.median(itn)), "p99": float(np.percentile(itn, 99)), "max": int(itn.max()),
                                 "mean": float(itn.mean())}, "out_sha1": hashlib.sha1(o.cpu().numpy().tobytes()).hexdigest()[:16]}
-            hh.close()
+            for ln in lns:
+                ln[0].close()
             return r
+        nfl = len(lanes)
         secondary = {
             "one_batch_at_a_time": dict(timed(prm, cost_order, args.steps), setting="the headline setting, one launch strictly after the other (--inflight 1)")
-            if len(lanes) > 1 else None,
-            "index_order": dict(timed(prm, not cost_order, args.steps), setting="the headline setting with the QPs started in index order"
-                                if cost_order else "the headline setting with the QPs started most-expensive-first (previous step's cost)"),
+            if nfl > 1 else None,
+            "index_order": dict(timed(prm, not cost_order, args.steps), setting="one launch after the other with the QPs started in index order"
+                                if cost_order else "one launch after the other with the QPs started most-expensive-first (previous step's cost)"),
+            "inflight2_index_order": dict(timed(prm, False, args.steps, inflight=2), setting="two batches in flight, QPs started in index order"),
+            "identical_batch_every_step": dict(timed(prm, cost_order, args.steps, inflight=nfl, variants=var_in[:1]),
+                                               setting="the headline setting with the SAME batch re-solved every step (round 2's headline: the start "
+                                                       "order then has perfect foresight of every QP's cost)") if n_var > 1 else None,
             "plain_admm_eps_1e-4": dict(timed(capi.default_params(eps_abs=1e-4, eps_rel=1e-4), False, max(3, args.steps // 8)),
                                         setting="the literal metric: OSQP termination at eps_abs = eps_rel = 1e-4, OSQP defaults, no polish "
                                                 "(pqp_default_params); paths 1e-5..2e-3 from the optimum"),
             "reference_setting_eps_2e-3": dict(timed(capi.default_params(), False, max(3, args.steps // 4)),
                                                setting="what base_solver.cpp:61-62 runs: eps 2e-3, OSQP defaults, no polish; paths 2e-4..2e-2 from the optimum"),
         }
+        if not stream and cfg_id == 1 and preset_shape:
+            # BASELINE configs[3]'s WHOLE batch (65 536 QPs, N = 80) on this one GPU: the size at which the lane-per-QP kernel takes over
+            # (PQP_OPT_STREAM_BATCH) - measured HBM roofline: `python bench.py --config 3 --batch 65536`, profiles/r03*_bench_stream*
+            try:
+                bb = 65536
+                hb = make_batch(bb, 80, "uniform", seed=args.seed)
+                t_ref, t_b, t_s = (torch.from_numpy(hb[k]).to(dev) for k in ("ref", "bounds", "scal"))
+                res_w = {}
+                for name, thr in (("lane_per_qp_stream_kernel", 1), ("lane_per_waypoint_kernel", 0)):
+                    hh = capi.Handle(prm, device=local_rank, max_batch=bb, max_n=80)
+                    hh.set_option(capi.OPT_STORE_WARM, 0); hh.set_option(capi.OPT_ORDER_BY_COST, 1); hh.set_option(capi.OPT_STREAM_BATCH, thr)
+                    o = torch.zeros((bb, 80, 7), dtype=torch.float64, device=dev); stt = torch.zeros(bb, dtype=torch.int32, device=dev)
+                    inf = torch.zeros((bb, 8), dtype=torch.float64, device=dev)
+                    torch.cuda.synchronize()
+                    for _ in range(2):
+                        hh.solve_device(bb, 80, t_ref, t_b, t_s, o, passes=1, status=stt, info=inf)
+                    hh.sync()
+                    ta = time.perf_counter()
+                    ks = 4
+                    for _ in range(ks):
+                        hh.solve_device(bb, 80, t_ref, t_b, t_s, o, passes=1, status=stt, info=inf)
+                    hh.sync()
+                    tb = (time.perf_counter() - ta) / ks
+                    kms = float(np.mean(hh.kernel_ms_history(ks)))
+                    res_w[name] = {"value": bb / tb, "unit": "paths/s", "ms_per_step": tb * 1e3, "kernel_ms": kms, "solved": int((stt == 1).sum().item()),
+                                   "out_sha1": hashlib.sha1(o.cpu().numpy().tobytes()).hexdigest()[:16]}
+                    if thr:
+                        ab = stream_algorithmic_bytes(80, inf.cpu().numpy())
+                        res_w[name]["roofline"] = {"bound": "hbm", "kernel": "path_stream_kernel", "algorithmic_bytes_per_launch": ab, "achieved": ab / (kms * 1e-3) / 1e9,
+                                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                                   "note": "bytes the algorithm streams through its HBM workspace for the sweeps each QP ran (DESIGN.md 3b) / kernel time; "
+                                                           "measured traffic (rocprofv3 FETCH_SIZE / WRITE_SIZE): the roofline of `python bench.py --config 3 --batch 65536`, profiles/"}
+                    else:
+                        oa = o.cpu().numpy()
+                    hh.close()
+                    del o, inf
+                secondary["configs3_whole_batch_one_gpu"] = dict(res_w, workload="configs[3]: batch = 65 536 QPs, N = 80, the whole batch on ONE GPU, one launch after the other",
+                                                                 speedup_stream_over_lane_per_waypoint=res_w["lane_per_qp_stream_kernel"]["value"] / res_w["lane_per_waypoint_kernel"]["value"])
+                del t_ref, t_b, t_s
+            except Exception as e:          # (out of memory on a shared box, ...: the headline does not depend on it)
+                secondary["configs3_whole_batch_one_gpu"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---------------------------------------------------------------------------------------------------------------------------
     # roofline of the dominant kernel
@@ -356,38 +461,55 @@ def main():
     roofline, roofline_issue = None, None
     if pipe is None:
         setups = 2.0
-        abytes, abytes_admm, abytes_ext = algorithmic_bytes(n, kkt_np, it_np, fac_np, setups)
-        achieved = abytes / avg_kernel_s / 1e9
+        kernel_name = "path_stream_kernel" if stream else "path_solve_kernel"
+        if stream:
+            abytes = stream_algorithmic_bytes(n, info_np)
+            abytes_admm = abytes_ext = abytes
+        else:
+            abytes, abytes_admm, abytes_ext = algorithmic_bytes(n, kkt_np, it_np, fac_np, setups)
         pmc = None
         if args.pmc == "auto" and world == 1 and rank == 0:
-            core = ["--config", str(cfg_id), "--batch", str(batch), "--n", str(n), "--profile", profile, "--eps", str(args.eps), "--seed", str(args.seed)]
+            core = ["--config", str(cfg_id), "--batch", str(batch), "--n", str(n), "--profile", profile, "--eps", str(args.eps), "--seed", str(args.seed),
+                    "--variants", "1"]            # (the counters of the batch whose sweep / solve counts the byte model above uses)
             core += ["--no-cost-order"] if not cost_order else []
             core += ["--no-polish"] if args.no_polish else []
             core += ["--reference-setting"] if args.reference_setting else []
-            pmc = pmc_child(core, "path_solve_kernel", args.pmc_timeout)
+            pmc = pmc_child(core, kernel_name, args.pmc_timeout, steps=3 if stream else 6)
         traffic = None
         if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
             # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 tallies a wide read at half its bytes (MICROARCH guide, HBM): x2 on the reads
             traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
-        true_io = 2.0 * batch * (152 * n + 40)
         # launches of different handles overlap: mean number of solve kernels running at a time over the timed region
         concurrency = max(1.0, args.steps * avg_kernel_s / dt) if len(main_handles) > 1 else 1.0
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "kernels_running_at_a_time": concurrency, "frac_chip_wide": achieved * concurrency / HBM_PEAK_GBS,
-                    "traffic": traffic, "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command, after the timed region, "
-                                                           f"{pmc['_launches']} launches averaged; FETCH_SIZE x 2 (gfx950 wide-read tally)") if traffic else None,
-                    "kernel": "path_solve_kernel", "kernel_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_launch": abytes,
-                    "frac_admm_iterations_only": abytes_admm / avg_kernel_s / 1e9 / HBM_PEAK_GBS,
-                    "achieved_incl_factor_and_scaling": abytes_ext / avg_kernel_s / 1e9,
-                    "true_io_bytes_per_launch": true_io, "traffic_over_true_io": (traffic / true_io) if traffic else None,
-                    "fetch_size_kib": pmc.get("FETCH_SIZE") if pmc else None, "write_size_kib": pmc.get("WRITE_SIZE") if pmc else None,
-                    "launches_in_flight": len(main_handles),
-                    "note": "achieved / frac are per LAUNCH (bytes of one launch / its own event-timed duration); with two launches in flight each "
-                            "one shares the chip and lasts longer, frac_chip_wide = frac x kernels running at a time. They are SURVEY.md 8(d)'s STREAMING MODEL (bytes an HBM-streaming ADMM would move: 1040 N per reduced-KKT "
-                            "solve, polish refinement solves included; frac_admm_iterations_only charges ADMM iterations only) divided by the "
-                            "measured kernel time - a model, not traffic: the iterates are register/LDS resident and the kernel is bound by fp64 "
-                            "VALU issue + LDS latency (roofline_issue), `traffic` is what HBM really moved"}
-        if secondary and secondary.get("plain_admm_eps_1e-4"):
+        per_launch = lambda b: b / avg_kernel_s / 1e9 / HBM_PEAK_GBS
+        common = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": kernel_name, "kernel_ms": avg_kernel_s * 1e3,
+                  "launches_in_flight": len(main_handles), "kernels_running_at_a_time": concurrency, "traffic": traffic,
+                  "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command (one launch at a time, the identical batch), after the "
+                                     f"timed region, {pmc['_launches']} launches averaged; FETCH_SIZE x 2 (gfx950 wide-read tally, MI355X_MICROARCH.md)") if traffic else None,
+                  "fetch_size_kib": pmc.get("FETCH_SIZE") if pmc else None, "write_size_kib": pmc.get("WRITE_SIZE") if pmc else None,
+                  # what HBM really moved per second of ONE launch's own duration, as a fraction of the 8 TB/s peak
+                  "hbm_measured_frac": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None}
+        if stream:
+            roofline = dict(common, achieved=abytes / avg_kernel_s / 1e9, frac=per_launch(abytes), frac_chip_wide=per_launch(abytes) * concurrency,
+                            algorithmic_bytes_per_launch=abytes, traffic_over_algorithmic=(traffic / abytes) if traffic else None,
+                            note="path_stream_kernel keeps nothing on chip between two sweeps: achieved = the bytes its algorithm reads and writes in its HBM workspace "
+                                 "for the sweeps every QP ran (DESIGN.md 3b: 336 / 416 B per waypoint and interior-point iteration, 248 / 328 B per active-set round, "
+                                 "+ prep / init / unpack) / the launch's event-timed duration.  `traffic` (rocprofv3) is larger: a wavefront moves a 128-byte line "
+                                 "as long as ONE of its 16 lanes is still iterating.  hbm_measured_frac = traffic / kernel time / 8 TB/s")
+        else:
+            true_io = 2.0 * batch * (152 * n + 40)
+            roofline = dict(common, achieved=abytes_admm / avg_kernel_s / 1e9, frac=per_launch(abytes_admm), frac_chip_wide=per_launch(abytes_admm) * concurrency,
+                            frac_all_solves=per_launch(abytes), frac_all_solves_chip_wide=per_launch(abytes) * concurrency,
+                            algorithmic_bytes_per_launch=abytes_admm, algorithmic_bytes_all_solves_per_launch=abytes,
+                            achieved_all_solves=abytes / avg_kernel_s / 1e9, achieved_incl_factor_and_scaling=abytes_ext / avg_kernel_s / 1e9,
+                            true_io_bytes_per_launch=true_io, traffic_over_true_io=(traffic / true_io) if traffic else None,
+                            note="achieved / frac: SURVEY.md 8(d)'s STREAMING MODEL taken literally - B_path = 2 B_io + 2 B_asm + (ADMM iterations) x 1040 N bytes - per LAUNCH "
+                                 "(one launch's bytes / its own event-timed duration); frac_all_solves also charges 1040 N for every polish refinement solve; *_chip_wide "
+                                 "= x kernels running at a time (two launches in flight share the chip).  A MODEL, not traffic: the iterates of path_solve_kernel are "
+                                 "register / LDS resident, it is bound by fp64 VALU issue + LDS latency (roofline_issue); what HBM really moved is `traffic`, "
+                                 "hbm_measured_frac = traffic / kernel time / 8 TB/s.  The kernel whose roofline IS measured traffic is path_stream_kernel "
+                                 "(batches >= 24 576: secondary.configs3_whole_batch_one_gpu, `bench.py --config 3 --batch 65536`)")
+        if secondary and secondary.get("plain_admm_eps_1e-4") and not stream:
             # what the model says about the solver the metric names: OSQP's plain ADMM streaming its data from HBM every iteration
             its = secondary["plain_admm_eps_1e-4"]["admm_iters"]["mean"]
             b_path = 2.0 * (152 * n + 40 + 656 * n) + its * 1040 * n
@@ -401,7 +523,7 @@ def main():
             gui = pmc.get("GRBM_GUI_ACTIVE")                                      # summed over the 8 XCDs
             kernel_cycles = gui / 8.0 if gui else avg_kernel_s * 2.4e9
             valu_cycles = pmc["SQ_ACTIVE_INST_VALU"] * 4.0                       # quad-cycles -> cycles
-            roofline_issue = {"bound": "fp64_valu_issue", "achieved": valu_cycles / (SIMDS * kernel_cycles), "peak": 1.0, "unit": "fraction of the "
+            roofline_issue = {"bound": "fp64_valu_issue", "kernel": kernel_name, "achieved": valu_cycles / (SIMDS * kernel_cycles), "peak": 1.0, "unit": "fraction of the "
                               "chip's VALU issue cycles (VALU-active cycles / (1024 SIMDs x kernel cycles))", "frac": valu_cycles / (SIMDS * kernel_cycles),
                               "valu_active_frac_of_wave_cycles": pmc["SQ_ACTIVE_INST_VALU"] / wc, "lds_active_frac": pmc.get("SQ_ACTIVE_INST_LDS", 0.0) / wc,
                               "scalar_active_frac": pmc.get("SQ_ACTIVE_INST_SCA", 0.0) / wc, "any_active_frac": pmc.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
@@ -419,7 +541,12 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "config_id": cfg_id, "batch_per_gpu": batch, "n_waypoints": n, "profile": profile,
                        "eps_abs": args.eps, "eps_rel": args.eps, "polish": polish, "setting": setting,
-                       "solver": "ADMM to eps 1e-4 + KKT-verified active-set polish (every path is the exact QP optimum)" if polish else "plain OSQP termination",
+                       "solver": ("lane-per-QP kernel: interior-point rounds + KKT-verifying active-set rounds on the QP as a linear-quadratic control problem "
+                                  "(every path is the exact QP optimum; iterations below are interior-point iterations, not ADMM's)") if stream else
+                                 ("lane-per-waypoint kernel: ADMM iterations + KKT-verified active-set polish (every path is the exact QP optimum, inside the metric's "
+                                  "1e-4; the metric's literal 'ADMM iters to 1e-4' is secondary.plain_admm_eps_1e-4)") if polish else "plain OSQP termination (ADMM to eps)",
+                       "kernel": "path_stream_kernel" if stream else "path_solve_kernel",
+                       "scenarios_per_step": f"{n_var} variants cycled: the batch and its +-5 % jittered planning cycles (synth.jitter_batch)" if pipe is None and n_var > 1 else "the identical batch every step",
                        "polish_every": prm.polish_every, "adaptive_rho_interval": prm.adaptive_rho_interval, "check_termination": prm.check_termination,
                        "ruiz_passes": prm.scaling, "polish_lazy": prm.polish_lazy,
                        "polish_refine_iter": args.polish_refine, "polish_max_rounds": args.polish_max_rounds, "polish_warm_set": args.polish_warm_set,
@@ -433,7 +560,11 @@ def main():
             "out_sha1": out_sha, "gather_check": gathered_ok, "solved": int((st_np == 1).sum()), "batch": batch,
             "sustained": sustained, "secondary": secondary, "roofline": roofline, "roofline_issue": roofline_issue,
         }
-        if info_np is not None:
+        if info_np is not None and stream:
+            line["riccati_sweeps"] = {"mean": float(fac_np.mean()), "p99": float(np.percentile(fac_np, 99)), "max": float(fac_np.max())}
+            line["active_set_rounds"] = {"mean": float(info_np[:, 7].mean()), "max": float(info_np[:, 7].max())}
+            line["verified"] = int((info_np[:, 4] >= 2).sum())
+        elif info_np is not None:
             line["kkt_solves"] = {"mean": float(kkt_np.mean()), "p99": float(np.percentile(kkt_np, 99)), "max": float(kkt_np.max())}
             line["factorisations"] = {"mean": float(fac_np.mean()), "max": float(fac_np.max())}
             line["polished"] = int((info_np[:, 4] >= 2).sum())

@@ -194,8 +194,19 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      runs in index order.
  *   PQP_OPT_RESERVE_CUS (default 0)    compute units the path QP's persistent workgroups leave free.  Their wavefronts own a SIMD's whole
  *                                      register file, so kernels of another stream (the smoother chain of the next batch, configs[4]) only
- *                                      get onto the chip when a unit is left to them. */
-typedef enum pqp_option { PQP_OPT_STORE_WARM = 1, PQP_OPT_ORDER_BY_COST = 2, PQP_OPT_RESERVE_CUS = 3 } pqp_option;
+ *                                      get onto the chip when a unit is left to them.
+ *   PQP_OPT_STREAM_BATCH (default 24 576; 0: never)  cold solves (warm == 0) of at least this many QPs on a handle with polish != 0 and
+ *                                      PQP_OPT_STORE_WARM off run on the lane-per-QP kernel (one QP per lane, 64 per wavefront, the
+ *                                      per-waypoint state streamed through a batch-interleaved workspace of 256 n bytes per QP in HBM;
+ *                                      csrc/pqp_path_lq.hpp): the path QP as a linear-quadratic control problem, interior-point rounds +
+ *                                      active-set rounds whose last round is the KKT test, i.e. the same exact optimum as the lane-per-
+ *                                      waypoint kernel's verified polish.  It wins where the batch fills the chip's 65 536 lanes (65 536
+ *                                      QPs of 80 waypoints: 2.0x, measured crossover ~20 000); it keeps no warm state
+ *                                      (hence the PQP_OPT_STORE_WARM condition), iters[] counts its interior-point iterations and info[] =
+ *                                      {row residual, complementarity, iterations of the first pass, iterations, solved passes, active-set
+ *                                      rounds of the first pass, Riccati sweeps, active-set rounds}.  PQP_OPT_ORDER_BY_COST there: the 64
+ *                                      lanes of a wavefront get QPs that took equally many sweeps in the previous solve of the shape. */
+typedef enum pqp_option { PQP_OPT_STORE_WARM = 1, PQP_OPT_ORDER_BY_COST = 2, PQP_OPT_RESERVE_CUS = 3, PQP_OPT_STREAM_BATCH = 4 } pqp_option;
 int pqp_set_option(pqp_handle* h, int option, int value);
 int pqp_get_stream(pqp_handle* h, void** hip_stream);   /* hipStream_t */
 /* The handle's stream is created non-blocking: work the caller enqueued on ANOTHER stream (the inputs of a *_device call produced by
@@ -238,7 +249,8 @@ int pqp_path_assemble_device(pqp_handle* h, int batch, int n, int precise, const
  *   info (may be NULL) [batch][PQP_INFO_STRIDE]: primal residual, dual residual, final rho, ADMM iterations of the
  *   last pass, number of accepted polishes, total reduced-KKT solves (ADMM iterations + polish refinement),
  *   number of factorisations, reserved.
- *   2 <= n <= 512 waypoints (one lane per waypoint: 1, 2, 4 or 8 wavefronts per QP); any batch.  Which solver runs is decided
+ *   n >= 2 waypoints, any batch.  Up to 512 waypoints: one lane per waypoint (1, 2, 4 or 8 wavefronts per QP); beyond (and for large batches,
+ *   PQP_OPT_STREAM_BATCH): one lane per QP, which needs polish != 0 and warm == 0 and keeps no warm state (PQP_ERR_CAPACITY otherwise).  Which solver runs is decided
  *   by the handle's pqp_params: pqp_default_params = the reference's OSQP setting (eps 2e-3, no polish, infeasibility certificate),
  *   pqp_production_params = eps 1e-4 + KKT-verified polish.  out[q] holds the last iterate also when status[q] != SOLVED (the
  *   reference's solve() returns false there and leaves its output vector untouched).

@@ -29,23 +29,10 @@
 // The same source compiles for the device (path_stream_kernel, pqp_path_stream.inc) and, for tests only, for the host (tests/emu).
 #pragma once
 #include "pqp_path_lane.hpp"
+#include "pqp_path_lq_abi.hpp"
 
 namespace pqp {
 namespace lq {
-
-// workspace fields per waypoint (doubles); element (waypoint i, field f) of a lane sits at base[(i * kFields + f) * lane_stride]
-enum Field {
-    F_M00 = 0, F_M01, F_M10, F_M11, F_M12, F_C0, F_C1, F_DS,      // transition i -> i + 1 (i < n - 1)
-    F_LOF, F_UPF, F_LOR, F_UPR,                                    // soft boxes of the collision rows (rear off: up = +inf)
-    F_K0, F_K1, F_K2, F_KK,                                        // feedback law u_i = -K x_i - k
-    F_X0, F_X1, F_X2,                                              // the point of the last active-set round
-    F_GPF, F_GPR, F_GPK,                                           // row values of the last interior-point roll-out
-    F_GF, F_ZLF, F_ZUF, F_GR, F_ZLR, F_ZUR,                        // interior-point state of the two collision rows (t = g - lo, up - g)
-    F_GK, F_TLK, F_TUK, F_ZLK, F_ZUK,                              // ... of the kappa row (infeasible start: its own t)
-    kFields
-};
-constexpr int F_ACT = F_GF;       // active-set rounds: the three rows' states packed as f + 3 r + 9 k + 13 (aliases the interior-point state)
-constexpr int F_LAM = F_GK;       //                    multiplier of the kappa row
 
 constexpr double kBig = 1e29;           // a bound beyond this is no bound (OSQP_INFTY = 1e30)
 constexpr double kDelta = 1e-9;         // hard active rows: penalty 1 / delta around the bound shifted by delta * multiplier
@@ -56,21 +43,6 @@ constexpr double kMuWarm = 1e-3;        // complementarity a re-linearised pass 
 constexpr double kEqWidth = 1e-6;       // a collision box narrower than this is an equality row (weight w_s at its upper bound)
 constexpr int kIpmMaxIter = 60;
 constexpr int kPolishMaxRounds = 12;
-
-struct Args {
-    int batch, n, passes;
-    const int32_t* n_of;        // [batch] or nullptr
-    const double* ref;          // [batch][n][5]
-    const double* lin;          // [batch][n][3] or nullptr
-    const double* bounds;       // [batch][n][6]
-    const double* scal;         // [batch][6]
-    double* out;                // [batch][n][7]
-    int32_t* status;            // [batch] or nullptr
-    int32_t* iters;             // [batch] or nullptr: interior-point iterations over all passes
-    double* info;               // [batch][PQP_INFO_STRIDE] or nullptr
-    double* ws;                 // [ceil(batch / 64)][n][kFields][64]
-    pqp_params prm;
-};
 
 // a two-sided row of the interior-point rounds
 struct Row { double g, tl, tu, zl, zu; };
@@ -90,27 +62,29 @@ PQP_HD void row_weight(const Row& r, double lo, double up, double sm, double& d,
     const double e = sm * (itu - itl) - r.zu * itu * ru + r.zl * itl * rl;
     tgt = r.g - e * rcp(d);
 }
-// the step of a row's state towards the Newton point whose row value is gp
-PQP_HD RowStep row_step(const Row& r, double lo, double up, double sm, double gp) {
+// the step of a row's state towards the Newton point whose row value is g + dg
+PQP_HD RowStep row_step(const Row& r, double lo, double up, double sm, double dg) {
     const double itl = rcp(r.tl), itu = rcp(r.tu);
     const double rl = r.g - lo - r.tl, ru = up - r.g - r.tu;
     RowStep s;
-    s.dg = gp - r.g;
+    s.dg = dg;
     s.dtl = s.dg + rl;
     s.dtu = -s.dg + ru;
     s.dzl = (sm - r.zl * s.dtl) * itl - r.zl;
     s.dzu = (sm - r.zu * s.dtu) * itu - r.zu;
     return s;
 }
-PQP_HD void row_accumulate(const Row& r, const RowStep& s, double lo, double up, Acc& a) {
+PQP_HD void row_accumulate(const Row& r, const RowStep& s, double lo, double up, Acc& a, bool hard = true) {
     const double itl = rcp(r.tl), itu = rcp(r.tu), izl = rcp(r.zl), izu = rcp(r.zu);
     a.rho = fmax(fmax(a.rho, -s.dtl * itl), fmax(-s.dtu * itu, fmax(-s.dzl * izl, -s.dzu * izu)));
     a.s0 += r.tl * r.zl + r.tu * r.zu;
     a.s1 += r.tl * s.dzl + r.zl * s.dtl + r.tu * s.dzu + r.zu * s.dtu;
     a.s2 += s.dtl * s.dzl + s.dtu * s.dzu;
     a.cnt += 2.0;
-    a.res = fmax(a.res, fmax(fabs(r.g - lo - r.tl), fabs(up - r.g - r.tu)));
+    if (hard) a.res = fmax(a.res, fmax(fabs(r.g - lo - r.tl), fabs(up - r.g - r.tu)));      // (a collision row's residual is the rounding of its fp32 slacks)
 }
+// what the roll-out hands to the next backward sweep goes through an fp32 field: both sweeps use the value as stored
+PQP_HD double as_stored(double v) { return (double)(float)v; }
 PQP_HD void row_apply(Row& r, const RowStep& s, double alpha) {
     r.g += alpha * s.dg; r.tl += alpha * s.dtl; r.tu += alpha * s.dtu; r.zl += alpha * s.dzl; r.zu += alpha * s.dzu;
 }
@@ -174,106 +148,200 @@ struct Solver {
     double lam_el, lam_ep;
     // interior-point scalars
     double alpha, sm_prev, mu, res;
-    int ipm_iters, set_rounds, fac;
+    int ipm_iters, set_rounds, fac, ipm_iters_first, set_rounds_first;
+    bool lin0;                    // this pass linearises around (0, 0, k_ref): M = [[1, ds, 0], [m10, 1, ds], [0, 0, 1]], c = (0, c1)
 
     PQP_HD Solver(const Args& a_, int qp_, WS ws_) : a(a_), ws(ws_), qp(qp_) {}
 
     PQP_HD Stage load_stage(int i) const {
         Stage s;
-        s.m00 = ws.ld(F_M00, i); s.m01 = ws.ld(F_M01, i); s.m10 = ws.ld(F_M10, i); s.m11 = ws.ld(F_M11, i); s.m12 = ws.ld(F_M12, i);
-        s.c0 = ws.ld(F_C0, i); s.c1 = ws.ld(F_C1, i); s.ds = ws.ld(F_DS, i);
+        s.m10 = ws.ld(D_M10, i); s.c1 = ws.ld(D_C1, i); s.ds = ws.ld(D_DS, i);
+        if (lin0) { s.m00 = 1.0; s.m01 = s.ds; s.m11 = 1.0; s.m12 = s.ds; s.c0 = 0.0; }      // (3 of the 8 doubles: the first pass's share of the traffic)
+        else { s.m00 = ws.ld(D_M00, i); s.m01 = ws.ld(D_M01, i); s.m11 = ws.ld(D_M11, i); s.m12 = ws.ld(D_M12, i); s.c0 = ws.ld(D_C0, i); }
         return s;
     }
 
     // ---- stage data of a pass: the transition rows around the linearisation point (base_solver.cpp:165-186) -----------------------
     // src 0: (0, 0, k_ref) (path_optimizer.cpp:128-137), 1: a.lin, 2: the previous pass's optimum (F_X*)
     PQP_HD void lin_at(int src, int i, double& l, double& psi, double& k) const {
-        if (src == 2) { l = ws.ld(F_X0, i); psi = ws.ld(F_X1, i); k = ws.ld(F_X2, i); }
+        if (src == 2) { l = ws.ld(D_X0, i); psi = ws.ld(D_X1, i); k = ws.ld(D_X2, i); }
         else if (src == 1) { const double* p = a.lin + ((size_t)qp * a.n + i) * PQP_LIN_STRIDE; l = p[0]; psi = p[1]; k = p[2]; }
         else { l = 0.0; psi = 0.0; k = a.ref[((size_t)qp * a.n + i) * PQP_REF_STRIDE + 1]; }
     }
+    struct PrepIn { double l, psi, k, s, kref, b[6]; };
     PQP_HD void prep(int src, bool with_bounds) {
         const double* rq = a.ref + (size_t)qp * a.n * PQP_REF_STRIDE;
         const double* bq = a.bounds + (size_t)qp * a.n * PQP_BOUNDS_STRIDE;
-        double l, psi, k;
-        lin_at(src, 0, l, psi, k);
-        for (int i = 0; i < n; ++i) {
-            if (i < n - 1) {
-                double ln, pn, kn;
-                lin_at(src, i + 1, ln, pn, kn);
+        PrepIn prev;
+        lin0 = src == 0;
+        sweep_up<kDepth, PrepIn>(0, n, [&](int i) {
+            PrepIn in;
+            lin_at(src, i, in.l, in.psi, in.k);
+            in.s = rq[PQP_REF_STRIDE * i]; in.kref = rq[PQP_REF_STRIDE * i + 1];
+            if (with_bounds) for (int k = 0; k < 6; ++k) in.b[k] = bq[PQP_BOUNDS_STRIDE * i + k];
+            return in;
+        }, [&](int i, const PrepIn& in) {
+            if (i > 0) {            // transition i - 1 -> i around the linearisation point of waypoint i - 1
+                const double l = prev.l, psi = prev.psi, k = prev.k;
                 const double t = tan(psi), cs = cos(psi);
                 const double df00 = -k * t, df01 = (1 - k * l) / (cs * cs);
                 const double df10 = -k * k / cs, df11 = (1 - k * l) * k * t / cs, df12 = (1 - k * l) / cs;
-                const double ds = rq[PQP_REF_STRIDE * (i + 1)] - rq[PQP_REF_STRIDE * i];
-                const double f0 = (1 - k * l) * t, f1 = (1 - k * l) * k / cs - rq[PQP_REF_STRIDE * i + 1];
-                ws.st(F_M00, i, ds * df00 + 1.0); ws.st(F_M01, i, ds * df01);
-                ws.st(F_M10, i, ds * df10); ws.st(F_M11, i, ds * df11 + 1.0); ws.st(F_M12, i, ds * df12);
-                ws.st(F_C0, i, ds * (f0 - (df00 * l + df01 * psi)));
-                ws.st(F_C1, i, ds * (f1 - (df10 * l + df11 * psi + df12 * k)));
-                ws.st(F_DS, i, ds);
-                l = ln; psi = pn; k = kn;
+                const double ds = in.s - prev.s;
+                const double f0 = (1 - k * l) * t, f1 = (1 - k * l) * k / cs - prev.kref;
+                ws.st(D_M00, i - 1, ds * df00 + 1.0); ws.st(D_M01, i - 1, ds * df01);
+                ws.st(D_M10, i - 1, ds * df10); ws.st(D_M11, i - 1, ds * df11 + 1.0); ws.st(D_M12, i - 1, ds * df12);
+                ws.st(D_C0, i - 1, ds * (f0 - (df00 * l + df01 * psi)));
+                ws.st(D_C1, i - 1, ds * (f1 - (df10 * l + df11 * psi + df12 * k)));
+                ws.st(D_DS, i - 1, ds);
             }
             if (with_bounds) {
-                const double* b = bq + PQP_BOUNDS_STRIDE * i;
-                const bool rough = a.prm.rough_constraints_far_away && !(rq[PQP_REF_STRIDE * i] < a.prm.precise_planning_length);
+                const bool rough = a.prm.rough_constraints_far_away && !(in.s < a.prm.precise_planning_length);
                 double lo, up;
                 if (!rough) {
-                    soft_bounds(b[0], b[1], a.prm.expected_safety_margin, a.prm.min_clearance, lo, up);
-                    ws.st(F_LOF, i, lo); ws.st(F_UPF, i, up);
-                    soft_bounds(b[2], b[3], a.prm.expected_safety_margin, a.prm.min_clearance, lo, up);
-                    ws.st(F_LOR, i, lo); ws.st(F_UPR, i, up);
+                    soft_bounds(in.b[0], in.b[1], a.prm.expected_safety_margin, a.prm.min_clearance, lo, up);
+                    ws.st(D_LOF, i, lo); ws.st(D_UPF, i, up);
+                    soft_bounds(in.b[2], in.b[3], a.prm.expected_safety_margin, a.prm.min_clearance, lo, up);
+                    ws.st(D_LOR, i, lo); ws.st(D_UPR, i, up);
                 } else {            // base_solver.cpp:201-205,241-247: one row on l alone with the centre circle's box
-                    soft_bounds(b[4], b[5], a.prm.expected_safety_margin, a.prm.min_clearance, lo, up);
-                    ws.st(F_LOF, i, lo); ws.st(F_UPF, i, up);
-                    ws.st(F_LOR, i, -kInfty); ws.st(F_UPR, i, kInfty);
+                    soft_bounds(in.b[4], in.b[5], a.prm.expected_safety_margin, a.prm.min_clearance, lo, up);
+                    ws.st(D_LOF, i, lo); ws.st(D_UPF, i, up);
+                    ws.st(D_LOR, i, -kInfty); ws.st(D_UPR, i, kInfty);
+                }
+            }
+            prev = in;
+        });
+    }
+
+    // ---- software pipelining ---------------------------------------------------------------------------------------------------
+    // Every sweep is a dependency chain in the waypoint index whose loads depend on nothing: with one wavefront per SIMD nothing else
+    // hides their latency (~1.5 us per waypoint measured, profiles/r03a_stream_first.txt), so the loads of waypoint i -+ D are issued before
+    // waypoint i is computed.  D buffers in registers (the D-step inner loops unroll: static indices), D * 26 doubles at most.
+    template <int D, class In, class Load, class Body>
+    PQP_HD void sweep_down(int i0, int i_last, Load load, Body body) {
+        In buf[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) if (i0 - k >= i_last) buf[k] = load(i0 - k);
+        for (int i = i0; i >= i_last; i -= D) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const int ii = i - k;
+                if (ii >= i_last) {
+                    const In cur = buf[k];
+                    if (ii - D >= i_last) buf[k] = load(ii - D);
+                    body(ii, cur);
                 }
             }
         }
+    }
+    template <int D, class In, class Load, class Body>
+    PQP_HD void sweep_up(int i0, int i_end, Load load, Body body) {          // i0 <= i < i_end
+        In buf[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) if (i0 + k < i_end) buf[k] = load(i0 + k);
+        for (int i = i0; i < i_end; i += D) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const int ii = i + k;
+                if (ii < i_end) {
+                    const In cur = buf[k];
+                    if (ii + D < i_end) buf[k] = load(ii + D);
+                    body(ii, cur);
+                }
+            }
+        }
+    }
+#ifndef PQP_STREAM_DEPTH
+#define PQP_STREAM_DEPTH 1
+#endif
+    static constexpr int kDepth = PQP_STREAM_DEPTH;
+
+    // what a sweep reads per waypoint
+    struct Box { double lof, upf, lor, upr; };
+    struct IpmRows { float tlf, tuf, zlf, zuf, tlr, tur, zlr, zur, tlk, tuk, zlk, zuk; double gk; };
+    struct BackIn { Stage s; Box b; IpmRows r; float dgf, dgr, dgk; double act, lam; };
+    struct FwdIn { Stage s; double K0, K1, K2, kk; Box b; IpmRows r; double act, lam; };     // stage / gains of transition i, rows of waypoint i + 1
+
+    PQP_HD Box load_box(int i) const { Box b; b.lof = ws.ld(D_LOF, i); b.upf = ws.ld(D_UPF, i); b.lor = ws.ld(D_LOR, i); b.upr = ws.ld(D_UPR, i); return b; }
+    PQP_HD IpmRows load_rows(int i) const {
+        IpmRows r;
+        r.tlf = ws.ldf(S_TLF, i); r.tuf = ws.ldf(S_TUF, i); r.zlf = ws.ldf(S_ZLF, i); r.zuf = ws.ldf(S_ZUF, i);
+        r.tlr = ws.ldf(S_TLR, i); r.tur = ws.ldf(S_TUR, i); r.zlr = ws.ldf(S_ZLR, i); r.zur = ws.ldf(S_ZUR, i);
+        r.tlk = ws.ldf(S_TLK, i); r.tuk = ws.ldf(S_TUK, i); r.zlk = ws.ldf(S_ZLK, i); r.zuk = ws.ldf(S_ZUK, i);
+        r.gk = ws.ld(D_GK, i);
+        return r;
+    }
+    // a collision row's state: its value is lo + t_l by definition (the slack absorbs the rest), t_u carries its own rounding
+    PQP_HD static Row soft_row(float tl, float tu, float zl, float zu, double lo) { Row r; r.tl = tl; r.tu = tu; r.zl = zl; r.zu = zu; r.g = lo + r.tl; return r; }
+    PQP_HD static Row hard_row(double g, float tl, float tu, float zl, float zu) { Row r; r.g = g; r.tl = tl; r.tu = tu; r.zl = zl; r.zu = zu; return r; }
+    PQP_HD void store_f(int i, const Row& r) const { ws.stf(S_TLF, i, r.tl); ws.stf(S_TUF, i, r.tu); ws.stf(S_ZLF, i, r.zl); ws.stf(S_ZUF, i, r.zu); }
+    PQP_HD void store_r(int i, const Row& r) const { ws.stf(S_TLR, i, r.tl); ws.stf(S_TUR, i, r.tu); ws.stf(S_ZLR, i, r.zl); ws.stf(S_ZUR, i, r.zu); }
+    PQP_HD void store_k(int i, const Row& r) const { ws.st(D_GK, i, r.g); ws.stf(S_TLK, i, r.tl); ws.stf(S_TUK, i, r.tu); ws.stf(S_ZLK, i, r.zl); ws.stf(S_ZUK, i, r.zu); }
+    template <int MODE>
+    PQP_HD BackIn load_back(int i) const {           // transition i (i < n - 1) and the rows of waypoint i (i > 0)
+        BackIn in;
+        if (i < n - 1) in.s = load_stage(i);
+        if (i > 0) {
+            in.b = load_box(i);
+            if (MODE == MODE_IPM || MODE == MODE_GUESS) { in.r = load_rows(i); in.dgf = ws.ldf(S_DGF, i); in.dgr = ws.ldf(S_DGR, i); in.dgk = ws.ldf(S_DGK, i); }
+            if (MODE == MODE_SET) { in.act = ws.ld(D_ACT, i); in.lam = ws.ld(D_LAM, i); }
+        }
+        return in;
+    }
+    template <int MODE>
+    PQP_HD FwdIn load_fwd(int i) const {
+        FwdIn in;
+        in.s = load_stage(i);
+        if (MODE == MODE_IPM) { in.K0 = ws.ldf(S_K0, i); in.K1 = ws.ldf(S_K1, i); in.K2 = ws.ldf(S_K2, i); in.kk = ws.ldf(S_KK, i); }
+        else { in.K0 = ws.ld(D_K0, i); in.K1 = ws.ld(D_K1, i); in.K2 = ws.ld(D_K2, i); in.kk = ws.ld(D_KK, i); }
+        in.b = load_box(i + 1);
+        if (MODE == MODE_IPM) in.r = load_rows(i + 1);
+        if (MODE == MODE_SET) { in.act = ws.ld(D_ACT, i + 1); in.lam = ws.ld(D_LAM, i + 1); }
+        return in;
     }
 
     // ---- one backward sweep -------------------------------------------------------------------------------------------------------
     // row terms of waypoint i in the given mode; for MODE_IPM / MODE_GUESS the waypoint's interior-point state first takes the step of
     // the previous roll-out (alpha, sm_prev), which is where that state is updated
-    PQP_HD void stage_cost(int mode, int i, double sm, Value& v) {
+    template <int MODE>
+    PQP_HD void stage_cost(int i, const BackIn& in, double sm, Value& v) {
         v.P[0] += w_l; v.P[5] += w_k;
         if (i == 0) return;                                   // x_0 is given: its rows are constants
-        const double lof = ws.ld(F_LOF, i), upf = ws.ld(F_UPF, i), lor = ws.ld(F_LOR, i), upr = ws.ld(F_UPR, i);
+        const double lof = in.b.lof, upf = in.b.upf, lor = in.b.lor, upr = in.b.upr;
         const double L0 = lor <= -kBig ? 0.0 : Lf;            // a rough waypoint: one row on l alone
         const bool live_f = upf - lof > kEqWidth, live_r = upr < kBig && upr - lor > kEqWidth, on_r = upr < kBig;
-        if (mode == MODE_INIT) {
+        if (MODE == MODE_INIT) {
             const double w0 = 1.0, ws0 = w_s * w0 / (w_s + w0);
             add_lpsi_term(v, ws0, L0, live_f ? 0.5 * (lof + upf) : upf);
             if (on_r) add_lpsi_term(v, ws0, Lr, live_r ? 0.5 * (lor + upr) : upr);
             v.P[5] += w0;                                     // kappa towards 0, the middle of its box
             return;
         }
-        if (mode == MODE_SET) {
-            const int code = (int)ws.ld(F_ACT, i);
+        if (MODE == MODE_SET) {
+            const int code = (int)in.act;
             const int af = code % 3 - 1, ar = (code / 3) % 3 - 1, ak = code / 9 - 1;
             if (af != 0) add_lpsi_term(v, w_s, L0, af > 0 ? upf : lof);
             if (ar != 0) add_lpsi_term(v, w_s, Lr, ar > 0 ? upr : lor);
-            if (ak != 0) { const double w = 1.0 / kDelta; v.P[5] += w; v.p[2] -= w * (ak * kl - kDelta * ws.ld(F_LAM, i)); }
+            if (ak != 0) { const double w = 1.0 / kDelta; v.P[5] += w; v.p[2] -= w * (ak * kl - kDelta * in.lam); }
             return;
         }
         // interior-point state of the waypoint: previous step applied, then this iteration's weights (or the set it predicts)
-        Row rf, rr, rk;
-        rf.g = ws.ld(F_GF, i); rf.zl = ws.ld(F_ZLF, i); rf.zu = ws.ld(F_ZUF, i); rf.tl = rf.g - lof; rf.tu = upf - rf.g;
-        rr.g = ws.ld(F_GR, i); rr.zl = ws.ld(F_ZLR, i); rr.zu = ws.ld(F_ZUR, i); rr.tl = rr.g - lor; rr.tu = upr - rr.g;
-        rk.g = ws.ld(F_GK, i); rk.tl = ws.ld(F_TLK, i); rk.tu = ws.ld(F_TUK, i); rk.zl = ws.ld(F_ZLK, i); rk.zu = ws.ld(F_ZUK, i);
+        Row rf = soft_row(in.r.tlf, in.r.tuf, in.r.zlf, in.r.zuf, lof), rr = soft_row(in.r.tlr, in.r.tur, in.r.zlr, in.r.zur, lor);
+        Row rk = hard_row(in.r.gk, in.r.tlk, in.r.tuk, in.r.zlk, in.r.zuk);
         if (alpha > 0.0) {
-            if (live_f) { row_apply(rf, row_step(rf, lof, upf, sm_prev, ws.ld(F_GPF, i)), alpha); rf.tl = rf.g - lof; rf.tu = upf - rf.g; }
-            if (live_r) { row_apply(rr, row_step(rr, lor, upr, sm_prev, ws.ld(F_GPR, i)), alpha); rr.tl = rr.g - lor; rr.tu = upr - rr.g; }
-            row_apply(rk, row_step(rk, -kl, kl, sm_prev, ws.ld(F_GPK, i)), alpha);
+            if (live_f) row_apply(rf, row_step(rf, lof, upf, sm_prev, in.dgf), alpha);
+            if (live_r) row_apply(rr, row_step(rr, lor, upr, sm_prev, in.dgr), alpha);
+            row_apply(rk, row_step(rk, -kl, kl, sm_prev, in.dgk), alpha);
         }
-        if (mode == MODE_IPM) {
+        if (MODE == MODE_IPM) {
             double d, tgt;
-            if (live_f) { row_weight(rf, lof, upf, sm, d, tgt); add_lpsi_term(v, w_s * d * rcp(w_s + d), L0, tgt); ws.st(F_GF, i, rf.g); ws.st(F_ZLF, i, rf.zl); ws.st(F_ZUF, i, rf.zu); }
+            // (weights from the state AS STORED: the roll-out recomputes them from what it reads back)
+            if (live_f) { store_f(i, rf); rf = soft_row((float)rf.tl, (float)rf.tu, (float)rf.zl, (float)rf.zu, lof); row_weight(rf, lof, upf, sm, d, tgt); add_lpsi_term(v, w_s * d * rcp(w_s + d), L0, tgt); }
             else add_lpsi_term(v, w_s, L0, upf);
-            if (live_r) { row_weight(rr, lor, upr, sm, d, tgt); add_lpsi_term(v, w_s * d * rcp(w_s + d), Lr, tgt); ws.st(F_GR, i, rr.g); ws.st(F_ZLR, i, rr.zl); ws.st(F_ZUR, i, rr.zu); }
+            if (live_r) { store_r(i, rr); rr = soft_row((float)rr.tl, (float)rr.tu, (float)rr.zl, (float)rr.zu, lor); row_weight(rr, lor, upr, sm, d, tgt); add_lpsi_term(v, w_s * d * rcp(w_s + d), Lr, tgt); }
             else if (on_r) add_lpsi_term(v, w_s, Lr, upr);
+            store_k(i, rk); rk = hard_row(rk.g, (float)rk.tl, (float)rk.tu, (float)rk.zl, (float)rk.zu);
             row_weight(rk, -kl, kl, sm, d, tgt);
             v.P[5] += d; v.p[2] -= d * tgt;
-            ws.st(F_GK, i, rk.g); ws.st(F_TLK, i, rk.tl); ws.st(F_TUK, i, rk.tu); ws.st(F_ZLK, i, rk.zl); ws.st(F_ZUK, i, rk.zu);
             return;
         }
         // MODE_GUESS: a side is active when its multiplier outweighs its slack
@@ -281,8 +349,8 @@ struct Solver {
         const int ar = !on_r ? 0 : (!live_r ? 1 : (rr.zu > rr.tu ? 1 : (rr.zl > rr.tl ? -1 : 0)));
         const int ak = rk.zu > rk.tu ? 1 : (rk.zl > rk.tl ? -1 : 0);
         const double lam = ak > 0 ? rk.zu : (ak < 0 ? -rk.zl : 0.0);
-        ws.st(F_ACT, i, (double)((af + 1) + 3 * (ar + 1) + 9 * (ak + 1)));
-        ws.st(F_LAM, i, lam);
+        ws.st(D_ACT, i, (double)((af + 1) + 3 * (ar + 1) + 9 * (ak + 1)));
+        ws.st(D_LAM, i, lam);
         if (af != 0) add_lpsi_term(v, w_s, L0, af > 0 ? upf : lof);
         if (ar != 0) add_lpsi_term(v, w_s, Lr, ar > 0 ? upr : lor);
         if (ak != 0) { const double w = 1.0 / kDelta; v.P[5] += w; v.p[2] -= w * (ak * kl - kDelta * lam); }
@@ -298,8 +366,8 @@ struct Solver {
         }
         if (mode == MODE_IPM || mode == MODE_GUESS) {
             if (alpha > 0.0) {
-                row_apply(el, row_step(el, -L, L, sm_prev, gp_el), alpha);
-                if (has_ep) row_apply(ep, row_step(ep, psi_lo, psi_hi, sm_prev, gp_ep), alpha);
+                row_apply(el, row_step(el, -L, L, sm_prev, gp_el - el.g), alpha);
+                if (has_ep) row_apply(ep, row_step(ep, psi_lo, psi_hi, sm_prev, gp_ep - ep.g), alpha);
             }
             if (mode == MODE_IPM) {
                 double d, tgt;
@@ -318,29 +386,32 @@ struct Solver {
     }
     double gp_el, gp_ep;          // end-row values of the last interior-point roll-out
 
-    PQP_HD void backward(int mode, double sm) {
+    template <int MODE>
+    PQP_HD void backward(double sm) {
         Value v;
         for (int k = 0; k < 6; ++k) v.P[k] = 0.0;
         v.p[0] = v.p[1] = v.p[2] = 0.0;
-        stage_cost(mode, n - 1, sm, v);
-        end_cost(mode, sm, v);
-        for (int i = n - 2; i >= 0; --i) {
-            const Stage s = load_stage(i);
-            double K[3], kk;
-            riccati_step(s, w_u, v, K, kk);
-            ws.st(F_K0, i, K[0]); ws.st(F_K1, i, K[1]); ws.st(F_K2, i, K[2]); ws.st(F_KK, i, kk);
-            if (i > 0) stage_cost(mode, i, sm, v);
-        }
+        sweep_down<kDepth, BackIn>(n - 1, 0, [&](int i) { return load_back<MODE>(i); }, [&](int i, const BackIn& in) {
+            if (i < n - 1) {
+                double K[3], kk;
+                riccati_step(in.s, w_u, v, K, kk);
+                if (MODE == MODE_IPM) { ws.stf(S_K0, i, K[0]); ws.stf(S_K1, i, K[1]); ws.stf(S_K2, i, K[2]); ws.stf(S_KK, i, kk); }
+                else { ws.st(D_K0, i, K[0]); ws.st(D_K1, i, K[1]); ws.st(D_K2, i, K[2]); ws.st(D_KK, i, kk); }
+                if (i > 0) stage_cost<MODE>(i, in, sm, v);
+            } else {
+                stage_cost<MODE>(i, in, sm, v);
+                end_cost(MODE, sm, v);
+            }
+        });
         fac += 1;
     }
 
     // ---- roll-outs ------------------------------------------------------------------------------------------------------------------
-    PQP_HD void advance(int i, double* x) const {          // x_i -> x_{i+1}
-        const Stage s = load_stage(i);
-        const double u = -(ws.ld(F_K0, i) * x[0] + ws.ld(F_K1, i) * x[1] + ws.ld(F_K2, i) * x[2]) - ws.ld(F_KK, i);
-        const double y0 = s.m00 * x[0] + s.m01 * x[1] + s.c0;
-        const double y1 = s.m10 * x[0] + s.m11 * x[1] + s.m12 * x[2] + s.c1;
-        x[2] = x[2] + s.ds * u; x[0] = y0; x[1] = y1;
+    PQP_HD void advance(const FwdIn& in, double* x) const {          // x_i -> x_{i+1}
+        const double u = -(in.K0 * x[0] + in.K1 * x[1] + in.K2 * x[2]) - in.kk;
+        const double y0 = in.s.m00 * x[0] + in.s.m01 * x[1] + in.s.c0;
+        const double y1 = in.s.m10 * x[0] + in.s.m11 * x[1] + in.s.m12 * x[2] + in.s.c1;
+        x[2] = x[2] + in.s.ds * u; x[0] = y0; x[1] = y1;
     }
     // after the initial solve: the interior-point state of every row, strictly inside its box where the row has a slack
     PQP_HD void forward_init() {
@@ -357,21 +428,21 @@ struct Solver {
             acc.res = fmax(acc.res, fmax(fabs(r.g - lo - r.tl), fabs(up - r.g - r.tu)));
             return r;
         };
-        for (int i = 0; i < n - 1; ++i) {
-            advance(i, x);
+        sweep_up<kDepth, FwdIn>(0, n - 1, [&](int i) { return load_fwd<MODE_INIT>(i); }, [&](int i, const FwdIn& in) {
+            advance(in, x);
             const int j = i + 1;
-            const double lof = ws.ld(F_LOF, j), upf = ws.ld(F_UPF, j), lor = ws.ld(F_LOR, j), upr = ws.ld(F_UPR, j);
+            const double lof = in.b.lof, upf = in.b.upf, lor = in.b.lor, upr = in.b.upr;
             const double L0 = lor <= -kBig ? 0.0 : Lf;
-            if (upf - lof > kEqWidth) { const Row r = start(x[0] + L0 * x[1], lof, upf, true); ws.st(F_GF, j, r.g); ws.st(F_ZLF, j, r.zl); ws.st(F_ZUF, j, r.zu); }
-            if (upr < kBig && upr - lor > kEqWidth) { const Row r = start(x[0] + Lr * x[1], lor, upr, true); ws.st(F_GR, j, r.g); ws.st(F_ZLR, j, r.zl); ws.st(F_ZUR, j, r.zu); }
-            const Row r = start(x[2], -kl, kl, false);
-            ws.st(F_GK, j, r.g); ws.st(F_TLK, j, r.tl); ws.st(F_TUK, j, r.tu); ws.st(F_ZLK, j, r.zl); ws.st(F_ZUK, j, r.zu);
-        }
+            if (upf - lof > kEqWidth) store_f(j, start(x[0] + L0 * x[1], lof, upf, true));
+            if (upr < kBig && upr - lor > kEqWidth) store_r(j, start(x[0] + Lr * x[1], lor, upr, true));
+            store_k(j, start(x[2], -kl, kl, false));
+        });
         el = start(x[0], -a.prm.end_l_bound, a.prm.end_l_bound, false);
         if (psi_hi < kBig) ep = start(x[1], psi_lo, psi_hi, false);
         mu = acc.s0 / acc.cnt; res = acc.res; alpha = 0.0;
     }
     // a re-linearised pass: the interior-point state out of the previous pass's optimum, its active set and multipliers
+    struct WarmIn { double xl, xp, xk, act, lam; Box b; };
     PQP_HD void warm_init() {
         const double mu_w = kMuWarm, sq = sqrt(kMuWarm);
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -386,61 +457,65 @@ struct Solver {
             acc.res = fmax(acc.res, fmax(fabs(r.g - lo - r.tl), fabs(up - r.g - r.tu)));
             return r;
         };
-        for (int j = 1; j < n; ++j) {
-            const double xl = ws.ld(F_X0, j), xp = ws.ld(F_X1, j), xk = ws.ld(F_X2, j);
-            const int code = (int)ws.ld(F_ACT, j);
+        const double x_end_l = ws.ld(D_X0, n - 1), x_end_p = ws.ld(D_X1, n - 1);
+        sweep_up<kDepth, WarmIn>(1, n, [&](int j) {
+            WarmIn in;
+            in.xl = ws.ld(D_X0, j); in.xp = ws.ld(D_X1, j); in.xk = ws.ld(D_X2, j); in.act = ws.ld(D_ACT, j); in.lam = ws.ld(D_LAM, j); in.b = load_box(j);
+            return in;
+        }, [&](int j, const WarmIn& in) {
+            const int code = (int)in.act;
             const int af = code % 3 - 1, ar = (code / 3) % 3 - 1, ak = code / 9 - 1;
-            const double lam = ws.ld(F_LAM, j);
-            const double lof = ws.ld(F_LOF, j), upf = ws.ld(F_UPF, j), lor = ws.ld(F_LOR, j), upr = ws.ld(F_UPR, j);
+            const double lof = in.b.lof, upf = in.b.upf, lor = in.b.lor, upr = in.b.upr;
             const double L0 = lor <= -kBig ? 0.0 : Lf;
-            // (the three reads above alias what is written below: all reads of waypoint j come first)
-            Row rf, rr, rk;
-            const bool live_f = upf - lof > kEqWidth, live_r = upr < kBig && upr - lor > kEqWidth;
-            if (live_f) { const double v = xl + L0 * xp; rf = start(v, af > 0 ? w_s * (v - upf) : (af < 0 ? w_s * (v - lof) : 0.0), lof, upf, true); }
-            if (live_r) { const double v = xl + Lr * xp; rr = start(v, ar > 0 ? w_s * (v - upr) : (ar < 0 ? w_s * (v - lor) : 0.0), lor, upr, true); }
-            rk = start(xk, ak != 0 ? lam : 0.0, -kl, kl, false);
-            if (live_f) { ws.st(F_GF, j, rf.g); ws.st(F_ZLF, j, rf.zl); ws.st(F_ZUF, j, rf.zu); }
-            if (live_r) { ws.st(F_GR, j, rr.g); ws.st(F_ZLR, j, rr.zl); ws.st(F_ZUR, j, rr.zu); }
-            ws.st(F_GK, j, rk.g); ws.st(F_TLK, j, rk.tl); ws.st(F_TUK, j, rk.tu); ws.st(F_ZLK, j, rk.zl); ws.st(F_ZUK, j, rk.zu);
-        }
-        el = start(ws.ld(F_X0, n - 1), act_el != 0 ? lam_el : 0.0, -a.prm.end_l_bound, a.prm.end_l_bound, false);
-        if (psi_hi < kBig) ep = start(ws.ld(F_X1, n - 1), act_ep != 0 ? lam_ep : 0.0, psi_lo, psi_hi, false);
+            if (upf - lof > kEqWidth) {
+                const double v = in.xl + L0 * in.xp;
+                store_f(j, start(v, af > 0 ? w_s * (v - upf) : (af < 0 ? w_s * (v - lof) : 0.0), lof, upf, true));
+            }
+            if (upr < kBig && upr - lor > kEqWidth) {
+                const double v = in.xl + Lr * in.xp;
+                store_r(j, start(v, ar > 0 ? w_s * (v - upr) : (ar < 0 ? w_s * (v - lor) : 0.0), lor, upr, true));
+            }
+            store_k(j, start(in.xk, ak != 0 ? in.lam : 0.0, -kl, kl, false));
+        });
+        el = start(x_end_l, act_el != 0 ? lam_el : 0.0, -a.prm.end_l_bound, a.prm.end_l_bound, false);
+        if (psi_hi < kBig) ep = start(x_end_p, act_ep != 0 ? lam_ep : 0.0, psi_lo, psi_hi, false);
         mu = acc.s0 / acc.cnt; res = acc.res; alpha = 0.0;
     }
     // roll-out of an interior-point iteration: row values of the Newton point, the step to the boundary, next complementarity
     PQP_HD void forward_ipm(double sm) {
         double x[3] = {x0[0], x0[1], x0[2]};
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        for (int i = 0; i < n - 1; ++i) {
-            advance(i, x);
+        sweep_up<kDepth, FwdIn>(0, n - 1, [&](int i) { return load_fwd<MODE_IPM>(i); }, [&](int i, const FwdIn& in) {
+            advance(in, x);
             const int j = i + 1;
-            const double lof = ws.ld(F_LOF, j), upf = ws.ld(F_UPF, j), lor = ws.ld(F_LOR, j), upr = ws.ld(F_UPR, j);
+            const double lof = in.b.lof, upf = in.b.upf, lor = in.b.lor, upr = in.b.upr;
             const double L0 = lor <= -kBig ? 0.0 : Lf;
             if (upf - lof > kEqWidth) {
-                Row r; r.g = ws.ld(F_GF, j); r.zl = ws.ld(F_ZLF, j); r.zu = ws.ld(F_ZUF, j); r.tl = r.g - lof; r.tu = upf - r.g;
+                const Row r = soft_row(in.r.tlf, in.r.tuf, in.r.zlf, in.r.zuf, lof);
                 double d, tgt;
                 row_weight(r, lof, upf, sm, d, tgt);
                 const double v = x[0] + L0 * x[1];
-                const double gp = v - d * rcp(w_s + d) * (v - tgt);           // + the slack of the Newton point
-                ws.st(F_GPF, j, gp);
-                row_accumulate(r, row_step(r, lof, upf, sm, gp), lof, upf, acc);
+                const double dg = as_stored(v - d * rcp(w_s + d) * (v - tgt) - r.g);           // (+ the slack of the Newton point)
+                ws.stf(S_DGF, j, dg);
+                row_accumulate(r, row_step(r, lof, upf, sm, dg), lof, upf, acc, false);
             }
             if (upr < kBig && upr - lor > kEqWidth) {
-                Row r; r.g = ws.ld(F_GR, j); r.zl = ws.ld(F_ZLR, j); r.zu = ws.ld(F_ZUR, j); r.tl = r.g - lor; r.tu = upr - r.g;
+                const Row r = soft_row(in.r.tlr, in.r.tur, in.r.zlr, in.r.zur, lor);
                 double d, tgt;
                 row_weight(r, lor, upr, sm, d, tgt);
                 const double v = x[0] + Lr * x[1];
-                const double gp = v - d * rcp(w_s + d) * (v - tgt);
-                ws.st(F_GPR, j, gp);
-                row_accumulate(r, row_step(r, lor, upr, sm, gp), lor, upr, acc);
+                const double dg = as_stored(v - d * rcp(w_s + d) * (v - tgt) - r.g);
+                ws.stf(S_DGR, j, dg);
+                row_accumulate(r, row_step(r, lor, upr, sm, dg), lor, upr, acc, false);
             }
-            Row r; r.g = ws.ld(F_GK, j); r.tl = ws.ld(F_TLK, j); r.tu = ws.ld(F_TUK, j); r.zl = ws.ld(F_ZLK, j); r.zu = ws.ld(F_ZUK, j);
-            ws.st(F_GPK, j, x[2]);
-            row_accumulate(r, row_step(r, -kl, kl, sm, x[2]), -kl, kl, acc);
-        }
+            const Row r = hard_row(in.r.gk, in.r.tlk, in.r.tuk, in.r.zlk, in.r.zuk);
+            const double dg = as_stored(x[2] - r.g);
+            ws.stf(S_DGK, j, dg);
+            row_accumulate(r, row_step(r, -kl, kl, sm, dg), -kl, kl, acc);
+        });
         gp_el = x[0]; gp_ep = x[1];
-        row_accumulate(el, row_step(el, -a.prm.end_l_bound, a.prm.end_l_bound, sm, gp_el), -a.prm.end_l_bound, a.prm.end_l_bound, acc);
-        if (psi_hi < kBig) row_accumulate(ep, row_step(ep, psi_lo, psi_hi, sm, gp_ep), psi_lo, psi_hi, acc);
+        row_accumulate(el, row_step(el, -a.prm.end_l_bound, a.prm.end_l_bound, sm, gp_el - el.g), -a.prm.end_l_bound, a.prm.end_l_bound, acc);
+        if (psi_hi < kBig) row_accumulate(ep, row_step(ep, psi_lo, psi_hi, sm, gp_ep - ep.g), psi_lo, psi_hi, acc);
         alpha = acc.rho > 0.995 ? 0.995 * rcp(acc.rho) : 1.0;
         sm_prev = sm;
         mu = (acc.s0 + alpha * (acc.s1 + alpha * acc.s2)) / acc.cnt;      // complementarity after the step
@@ -452,7 +527,7 @@ struct Solver {
         double x[3] = {x0[0], x0[1], x0[2]};
         bool changed = false;
         double pin = 0.0;
-        ws.st(F_X0, 0, x[0]); ws.st(F_X1, 0, x[1]); ws.st(F_X2, 0, x[2]);
+        ws.st(D_X0, 0, x[0]); ws.st(D_X1, 0, x[1]); ws.st(D_X2, 0, x[2]);
         auto soft = [&](int act, double v, double lo, double up) {
             // consistent within the tolerance: keep; else what the point asks for
             const bool keep = (act == 1 && v >= up - kSetTol) || (act == -1 && v <= lo + kSetTol) || (act == 0 && v <= up + kSetTol && v >= lo - kSetTol);
@@ -470,22 +545,22 @@ struct Solver {
             lam = 0.0;
             return v > up + kSetTol ? 1 : (v < lo - kSetTol ? -1 : 0);
         };
-        for (int i = 0; i < n - 1; ++i) {
-            advance(i, x);
+        sweep_up<kDepth, FwdIn>(0, n - 1, [&](int i) { return load_fwd<MODE_SET>(i); }, [&](int i, const FwdIn& in) {
+            advance(in, x);
             const int j = i + 1;
-            ws.st(F_X0, j, x[0]); ws.st(F_X1, j, x[1]); ws.st(F_X2, j, x[2]);
-            const double lof = ws.ld(F_LOF, j), upf = ws.ld(F_UPF, j), lor = ws.ld(F_LOR, j), upr = ws.ld(F_UPR, j);
+            ws.st(D_X0, j, x[0]); ws.st(D_X1, j, x[1]); ws.st(D_X2, j, x[2]);
+            const double lof = in.b.lof, upf = in.b.upf, lor = in.b.lor, upr = in.b.upr;
             const double L0 = lor <= -kBig ? 0.0 : Lf;
-            const int code = (int)ws.ld(F_ACT, j);
+            const int code = (int)in.act;
             const int af = code % 3 - 1, ar = (code / 3) % 3 - 1, ak = code / 9 - 1;
             const int nf = upf - lof > kEqWidth ? soft(af, x[0] + L0 * x[1], lof, upf) : 1;
             const int nr = upr >= kBig ? 0 : (upr - lor > kEqWidth ? soft(ar, x[0] + Lr * x[1], lor, upr) : 1);
-            double lam = ws.ld(F_LAM, j);
+            double lam = in.lam;
             const int nk = hard(ak, lam, x[2], -kl, kl);
             changed = changed || nf != af || nr != ar || nk != ak;
-            ws.st(F_ACT, j, (double)((nf + 1) + 3 * (nr + 1) + 9 * (nk + 1)));
-            ws.st(F_LAM, j, lam);
-        }
+            ws.st(D_ACT, j, (double)((nf + 1) + 3 * (nr + 1) + 9 * (nk + 1)));
+            ws.st(D_LAM, j, lam);
+        });
         const int ne = hard(act_el, lam_el, x[0], -a.prm.end_l_bound, a.prm.end_l_bound);
         changed = changed || ne != act_el; act_el = ne;
         if (psi_hi < kBig) { const int np = hard(act_ep, lam_ep, x[1], psi_lo, psi_hi); changed = changed || np != act_ep; act_ep = np; }
@@ -493,64 +568,78 @@ struct Solver {
         return !changed && pin <= kPinTol;
     }
 
-    // ---- one pass: interior-point rounds to complementarity mu_stop, then active-set rounds until the set is confirmed ------------
-    PQP_HD bool solve_pass(bool warm) {
+    // Returns PQP_STATUS_SOLVED, or why not.  A QP whose hard rows cannot all hold (an end box out of the controls' reach, say) shows in
+    // the interior-point rounds as steps that shrink to nothing while the row residual stays: PQP_STATUS_PRIMAL_INFEASIBLE - the
+    // verdict OSQP's certificate gives the lane-per-waypoint kernel on the same QP.
+    PQP_HD int solve_pass(bool warm) {
         for (int attempt = 0; attempt < 2; ++attempt) {
             const double mu_stop = attempt == 0 ? kMuStop : 1e-9;
-            if (attempt > 0 || !warm) { backward(MODE_INIT, 0.0); forward_init(); }
+            if (attempt > 0 || !warm) { backward<MODE_INIT>(0.0); forward_init(); }
             else warm_init();
             bool first = true;
-            int it = 0;
-            while (!(mu < mu_stop && res < 1e-6) && it < kIpmMaxIter) {
+            int it = 0, stall = 0;
+            while (!(mu < mu_stop && res < 1e-6) && it < kIpmMaxIter && stall < 6) {
                 const double sigma = (first || alpha <= 0.9) ? 0.2 : 0.05;
                 const double sm = sigma * mu;
-                backward(MODE_IPM, sm);
+                backward<MODE_IPM>(sm);
                 forward_ipm(sm);
+                stall = (alpha < 1e-3 && res > 1e-6) ? stall + 1 : 0;
                 first = false;
                 it += 1;
             }
             ipm_iters += it;
-            if (!(mu == mu)) return false;                    // NaN: numerical failure
-            backward(MODE_GUESS, 0.0);
+            if (!(mu == mu)) return PQP_STATUS_NUMERICAL;
+            if (!(res < 1e-6)) return PQP_STATUS_PRIMAL_INFEASIBLE;
+            if (!(mu < mu_stop)) return PQP_STATUS_MAX_ITER;
+            backward<MODE_GUESS>(0.0);
             for (int r = 0; r < kPolishMaxRounds; ++r) {
-                if (forward_set()) return true;
-                backward(MODE_SET, 0.0);
+                if (forward_set()) return PQP_STATUS_SOLVED;
+                backward<MODE_SET>(0.0);
             }
         }
-        return false;
+        return PQP_STATUS_MAX_ITER;
     }
 
     // BaseSolver::getOptimizedPath (base_solver.cpp:263-288)
+    struct OutIn { double l, dpsi, k, K0, K1, K2, kk, angle, rx, ry; };
     PQP_HD void unpack() {
         const double* rq = a.ref + (size_t)qp * a.n * PQP_REF_STRIDE;
         double* oq = a.out + (size_t)qp * a.n * PQP_OUT_STRIDE;
-        for (int i = 0; i < n; ++i) {
-            const double l = ws.ld(F_X0, i), dpsi = ws.ld(F_X1, i), k = ws.ld(F_X2, i);
-            double dk = 0.0;
-            if (i < n - 1) dk = -(ws.ld(F_K0, i) * l + ws.ld(F_K1, i) * dpsi + ws.ld(F_K2, i) * k) - ws.ld(F_KK, i);
-            const double angle = rq[PQP_REF_STRIDE * i + 2];
-            const double new_angle = constrain_angle(angle + kPi2);
+        sweep_up<kDepth, OutIn>(0, n, [&](int i) {
+            OutIn in;
+            in.l = ws.ld(D_X0, i); in.dpsi = ws.ld(D_X1, i); in.k = ws.ld(D_X2, i);
+            in.K0 = in.K1 = in.K2 = in.kk = 0.0;
+            if (i < n - 1) { in.K0 = ws.ld(D_K0, i); in.K1 = ws.ld(D_K1, i); in.K2 = ws.ld(D_K2, i); in.kk = ws.ld(D_KK, i); }
+            in.angle = rq[PQP_REF_STRIDE * i + 2]; in.rx = rq[PQP_REF_STRIDE * i + 3]; in.ry = rq[PQP_REF_STRIDE * i + 4];
+            return in;
+        }, [&](int i, const OutIn& in) {
+            const double dk = i < n - 1 ? -(in.K0 * in.l + in.K1 * in.dpsi + in.K2 * in.k) - in.kk : 0.0;
+            const double new_angle = constrain_angle(in.angle + kPi2);
             double* o = oq + PQP_OUT_STRIDE * i;
-            o[0] = rq[PQP_REF_STRIDE * i + 3] + l * cos(new_angle);
-            o[1] = rq[PQP_REF_STRIDE * i + 4] + l * sin(new_angle);
-            o[2] = constrain_angle(angle + dpsi);
-            o[3] = l; o[4] = dpsi; o[5] = k; o[6] = dk;
-        }
+            o[0] = in.rx + in.l * cos(new_angle);
+            o[1] = in.ry + in.l * sin(new_angle);
+            o[2] = constrain_angle(in.angle + in.dpsi);
+            o[3] = in.l; o[4] = in.dpsi; o[5] = in.k; o[6] = dk;
+        });
     }
 
+    PQP_HD void zero_point() {
+        for (int i = 0; i < n; ++i) { ws.st(D_X0, i, 0.0); ws.st(D_X1, i, 0.0); ws.st(D_X2, i, 0.0); ws.st(D_K0, i, 0.0); ws.st(D_K1, i, 0.0); ws.st(D_K2, i, 0.0); ws.st(D_KK, i, 0.0); }
+    }
     PQP_HD void finish(int status, int solved_passes) {
         if (a.status) a.status[qp] = status;
         if (a.iters) a.iters[qp] = ipm_iters;
+        if (a.cost) a.cost[qp] = fac;
         if (a.info) {
             double* f = a.info + (size_t)qp * PQP_INFO_STRIDE;
-            f[0] = res; f[1] = mu; f[2] = 0.0; f[3] = (double)ipm_iters; f[4] = (double)solved_passes; f[5] = (double)(fac); f[6] = (double)fac;
-            f[7] = (double)set_rounds;
+            f[0] = res; f[1] = mu; f[2] = (double)ipm_iters_first; f[3] = (double)ipm_iters; f[4] = (double)solved_passes; f[5] = (double)set_rounds_first;
+            f[6] = (double)fac; f[7] = (double)set_rounds;
         }
     }
 
     PQP_HD void run() {
         n = a.n_of ? a.n_of[qp] : a.n;
-        ipm_iters = 0; set_rounds = 0; fac = 0; mu = 0.0; res = 0.0; alpha = 0.0; sm_prev = 0.0;
+        ipm_iters = 0; set_rounds = 0; fac = 0; ipm_iters_first = 0; set_rounds_first = 0; mu = 0.0; res = 0.0; alpha = 0.0; sm_prev = 0.0;
         if (n > a.n) n = a.n;
         if (n < 2) { finish(PQP_STATUS_UNSOLVED, 0); return; }
         const pqp_params& p = a.prm;
@@ -567,30 +656,36 @@ struct Solver {
         prep(a.lin ? 1 : 0, true);
         if (!(fabs(x0[2]) <= kl)) {
             // the start curvature violates its own box (kappa row 0 against the fixed x_0): no point satisfies the rows
-            for (int i = 0; i < n; ++i) { ws.st(F_X0, i, 0.0); ws.st(F_X1, i, 0.0); ws.st(F_X2, i, 0.0); ws.st(F_K0, i, 0.0); ws.st(F_K1, i, 0.0); ws.st(F_K2, i, 0.0); ws.st(F_KK, i, 0.0); }
+            zero_point();
             unpack();
             finish(PQP_STATUS_PRIMAL_INFEASIBLE, 0);
             return;
         }
         int solved = 0;
-        bool ok = solve_pass(false);
-        if (ok) solved += 1;
-        for (int pass = 0; ok && pass < a.passes; ++pass) {
+        int st = solve_pass(false);
+        ipm_iters_first = ipm_iters; set_rounds_first = set_rounds;
+        if (st == PQP_STATUS_SOLVED) solved += 1;
+        for (int pass = 0; st == PQP_STATUS_SOLVED && pass < a.passes; ++pass) {
             prep(2, false);
-            ok = solve_pass(true);
-            if (ok) solved += 1;
+            st = solve_pass(true);
+            if (st == PQP_STATUS_SOLVED) solved += 1;
         }
+        if (solved == 0) zero_point();          // (no active-set round ever ran: F_X* hold nothing)
         unpack();
-        finish(ok ? PQP_STATUS_SOLVED : (mu == mu ? PQP_STATUS_MAX_ITER : PQP_STATUS_NUMERICAL), solved);
+        finish(st, solved);
     }
 };
 
-// workspace views
+// a lane's view of its wavefront's workspace block (layout: pqp_path_lq_abi.hpp)
 struct StridedWs {
-    double* p;
-    size_t stride;          // doubles between consecutive (waypoint, field) elements of this lane
-    PQP_HD double ld(int f, int i) const { return p[((size_t)i * kFields + f) * stride]; }
-    PQP_HD void st(int f, int i, double v) const { p[((size_t)i * kFields + f) * stride] = v; }
+    double* block;          // the wavefront's block
+    int lane;
+    int lanes;              // lanes per block: 64 on the device, 1 in the host emulation
+    PQP_HD double ld(int f, int i) const { return block[((size_t)i * kBlockDoubles + f) * lanes + lane]; }
+    PQP_HD void st(int f, int i, double v) const { block[((size_t)i * kBlockDoubles + f) * lanes + lane] = v; }
+    PQP_HD float* floats(int i) const { return reinterpret_cast<float*>(block + ((size_t)i * kBlockDoubles + kFieldsD) * lanes); }
+    PQP_HD float ldf(int f, int i) const { return floats(i)[(size_t)f * lanes + lane]; }
+    PQP_HD void stf(int f, int i, double v) const { floats(i)[(size_t)f * lanes + lane] = (float)v; }
 };
 
 }  // namespace lq

@@ -1,0 +1,53 @@
+// pqp_path_lq_abi.hpp - what the host side (pqp_kernels.hip) and the kernel (pqp_path_stream.hip, pqp_path_lq.hpp) of the lane-per-QP path
+// solver share: the kernel's argument block and the layout of its workspace.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/pqp.h"
+
+namespace pqp {
+namespace lq {
+
+// Workspace: per waypoint and lane kFieldsD doubles followed by kFieldsF floats; element (waypoint i, field f) of lane j of a
+// wavefront's block sits at block[(i * kBlockDoubles + f) * 64 + j] (doubles) resp. ((float*)(block + (i * kBlockDoubles + kFieldsD) * 64))[f * 64 + j].
+// fp64: everything an ACTIVE-SET round reads or writes (problem data, gains, the point) - those rounds return the result.  fp32: what only
+// the interior-point rounds exchange between their sweeps (slacks, multipliers, row steps, gains): they only have to predict the active set.
+enum FieldD {
+    D_M00 = 0, D_M01, D_M10, D_M11, D_M12, D_C0, D_C1, D_DS,      // transition i -> i + 1 (i < n - 1)
+    D_LOF, D_UPF, D_LOR, D_UPR,                                    // soft boxes of the collision rows (rear off: up = +inf)
+    D_K0, D_K1, D_K2, D_KK,                                        // feedback law u_i = -K x_i - k of the last active-set round
+    D_X0, D_X1, D_X2,                                              // the point of the last active-set round
+    D_GK,                                                          // interior-point rounds: value of the kappa row (its residual needs all digits)
+    D_ACT, D_LAM,                                                  // active-set rounds: the three rows' states packed as f + 3 r + 9 k + 13; multiplier of the kappa row
+    kFieldsD
+};
+enum FieldF {
+    S_K0 = 0, S_K1, S_K2, S_KK,                                    // feedback law of the last interior-point sweep
+    S_DGF, S_DGR, S_DGK,                                           // row steps of the last interior-point roll-out
+    S_TLF, S_TUF, S_ZLF, S_ZUF, S_TLR, S_TUR, S_ZLR, S_ZUR, S_TLK, S_TUK, S_ZLK, S_ZUK,     // slacks and multipliers of the three rows
+    S_PAD,
+    kFieldsF
+};
+constexpr int kBlockDoubles = kFieldsD + kFieldsF / 2;            // 32 doubles = 256 bytes per waypoint and QP
+static_assert(kFieldsF % 2 == 0, "the float fields fill whole doubles");
+
+struct Args {
+    int batch, n, passes;
+    const int32_t* n_of;        // [batch] or nullptr
+    const double* ref;          // [batch][n][5]
+    const double* lin;          // [batch][n][3] or nullptr
+    const double* bounds;       // [batch][n][6]
+    const double* scal;         // [batch][6]
+    double* out;                // [batch][n][7]
+    int32_t* status;            // [batch] or nullptr
+    int32_t* iters;             // [batch] or nullptr: interior-point iterations over all passes
+    double* info;               // [batch][PQP_INFO_STRIDE] or nullptr
+    double* ws;                 // [ceil(batch / 64)][n][kBlockDoubles][64]
+    const int32_t* order;       // [batch] lane slot -> QP, or nullptr: slot k solves QP k.  QPs of similar cost share a wavefront (a
+                                // wavefront runs as long as its slowest lane); results do not depend on it
+    int32_t* cost;              // [batch] or nullptr: Riccati sweeps each QP took (the key of the next launch's order)
+    pqp_params prm;
+};
+
+}  // namespace lq
+}  // namespace pqp

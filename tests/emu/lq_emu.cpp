@@ -10,7 +10,7 @@
 extern "C" {
 void pqp_emu_lq_production_params(pqp_params* p) { pqp::production_params(p); }
 
-int pqp_emu_lq_fields(void) { return pqp::lq::kFields; }
+int pqp_emu_lq_fields(void) { return pqp::lq::kBlockDoubles; }
 
 void pqp_emu_lq_solve(const pqp_params* prm, int batch, int n, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
                       const double* scal, int passes, double* out, int32_t* status, int32_t* iters, double* info) {
@@ -18,11 +18,11 @@ void pqp_emu_lq_solve(const pqp_params* prm, int batch, int n, const int32_t* n_
     std::memset(&a, 0, sizeof(a));
     a.batch = batch; a.n = n; a.passes = passes; a.n_of = n_of; a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
     a.status = status; a.iters = iters; a.info = info; a.prm = *prm;
-    std::vector<double> ws((size_t)n * pqp::lq::kFields);
+    std::vector<double> ws((size_t)n * pqp::lq::kBlockDoubles);
     a.ws = ws.data();
     for (int q = 0; q < batch; ++q) {
         std::fill(ws.begin(), ws.end(), 0.0);
-        pqp::lq::Solver<pqp::lq::StridedWs> s(a, q, pqp::lq::StridedWs{ws.data(), 1});
+        pqp::lq::Solver<pqp::lq::StridedWs> s(a, q, pqp::lq::StridedWs{ws.data(), 0, 1});
         s.run();
     }
 }

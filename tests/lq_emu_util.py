@@ -1,0 +1,47 @@
+"""Build + drive tests/emu/liblq_emu.so: the lane-per-QP solver source (csrc/pqp_path_lq.hpp) compiled for the host (test infrastructure)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from path_optimizer_2_amd.capi import PqpParams
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "emu", "lq_emu.cpp")
+LIB = os.path.join(HERE, "emu", "liblq_emu.so")
+_DEPS = [SRC] + [os.path.join(ROOT, "path_optimizer_2_amd", "csrc", f) for f in ("pqp_path_lq.hpp", "pqp_path_lane.hpp", "pqp_defaults.hpp")] + \
+        [os.path.join(ROOT, "include", "pqp.h")]
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in _DEPS):
+            subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC], check=True)
+        _lib = C.CDLL(LIB)
+    return _lib
+
+
+def production(**over):
+    p = PqpParams()
+    load().pqp_emu_lq_production_params(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def solve(ref, bounds, scal, passes=1, n_of=None, lin=None, prm=None):
+    lib = load()
+    B, n = ref.shape[:2]
+    prm = prm or production()
+    vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    out = np.zeros((B, n, 7)); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); info = np.zeros((B, 8))
+    ref = np.ascontiguousarray(ref, dtype=np.float64); bounds = np.ascontiguousarray(bounds, dtype=np.float64)
+    scal = np.ascontiguousarray(scal, dtype=np.float64)
+    lin = None if lin is None else np.ascontiguousarray(lin, dtype=np.float64)
+    n_of = None if n_of is None else np.ascontiguousarray(n_of, dtype=np.int32)
+    lib.pqp_emu_lq_solve(C.byref(prm), B, n, vp(n_of), vp(ref), vp(lin), vp(bounds), vp(scal), passes, vp(out), vp(st), vp(it), vp(info))
+    return dict(out=out, status=st, iters=it, info=info)

@@ -1,0 +1,213 @@
+"""The lane-per-QP path-QP kernel (path_stream_kernel, csrc/pqp_path_lq.hpp; PQP_OPT_STREAM_BATCH) on the GPU, through the C ABI, against
+the converged C oracle, against the lane-per-waypoint kernel, and - at BASELINE configs[3]'s full size - by properties."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _handle(capi, batch, n, stream=True, **over):
+    h = capi.Handle(capi.production_params(**over), device=0, max_batch=batch, max_n=n)
+    h.set_option(capi.OPT_STORE_WARM, 0)
+    h.set_option(capi.OPT_STREAM_BATCH, 1 if stream else 0)
+    return h
+
+
+def _oracle(b, k, n_of=None):
+    import pqp_oracle_c as OC
+    prm = OC.params(eps_abs=1e-9, eps_rel=1e-9, max_iter=40000)
+    if n_of is None:
+        return OC.solve_batch(prm, b["ref"][:k], b["bounds"][:k], b["scal"][:k], passes=1)["out"]
+    outs = []
+    for q in range(k):
+        m = int(n_of[q])
+        outs.append(OC.solve_path(prm, b["ref"][q, :m], b["bounds"][q, :m], b["scal"][q], passes=1)["out"])
+    return outs
+
+
+@pytest.mark.parametrize("n,profile,batch", [(80, "uniform", 256), (120, "varied", 192), (200, "uniform", 128), (35, "varied", 130)])
+def test_stream_kernel_against_the_converged_oracle(hip_lib, n, profile, batch):
+    from path_optimizer_2_amd import capi
+    from path_optimizer_2_amd.synth import make_batch
+    b = make_batch(batch, n, profile, seed=11)
+    h = _handle(capi, batch, n)
+    r = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    h.close()
+    assert (r["status"] == 1).all()
+    want = _oracle(b, 48)
+    err = np.abs(r["out"][:48, :, 3:5] - want[:, :, 3:5]).max(axis=(1, 2))
+    assert err.max() < 1e-4 and np.median(err) < 1e-6, (err.max(), np.median(err))
+    assert np.abs(r["out"][:48] - want).max() < 1e-4          # x, y, heading, kappa, kappa' too
+    assert (r["info"][:, 4] == 2).all()                       # both passes verified by an active-set round
+
+
+def test_stream_kernel_equals_the_lane_per_waypoint_kernel(hip_lib):
+    from path_optimizer_2_amd import capi
+    from path_optimizer_2_amd.synth import make_batch
+    batch, n = 1024, 80
+    b = make_batch(batch, n)
+    ha, hb = _handle(capi, batch, n, stream=False), _handle(capi, batch, n, stream=True)
+    ra = ha.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    rb = hb.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    ha.close(); hb.close()
+    assert (ra["status"] == 1).all() and (rb["status"] == 1).all()
+    d = np.abs(ra["out"][:, :, 3:5] - rb["out"][:, :, 3:5]).max(axis=(1, 2))
+    assert d.max() < 2e-5 and np.median(d) < 1e-7, (d.max(), np.median(d))
+
+
+def test_stream_kernel_lane_order_by_cost_does_not_change_a_bit(hip_lib):
+    """PQP_OPT_ORDER_BY_COST on the lane-per-QP kernel: from the second solve of a shape on the lanes of a wavefront are QPs of equal cost."""
+    import torch
+    from path_optimizer_2_amd import capi
+    from path_optimizer_2_amd.synth import make_batch
+    batch, n = 4100, 80                                         # (not a multiple of 64: the last wavefront is ragged)
+    b = make_batch(batch, n, seed=2)
+    dev = torch.device("cuda", 0)
+    ref, bounds, scal = (torch.from_numpy(b[k]).to(dev) for k in ("ref", "bounds", "scal"))
+    h = _handle(capi, batch, n)
+    h.set_option(capi.OPT_ORDER_BY_COST, 1)
+    outs, kms = [], []
+    for _ in range(3):
+        out = torch.full((batch, n, 7), float("nan"), dtype=torch.float64, device=dev)
+        st = torch.zeros(batch, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        h.solve_device(batch, n, ref, bounds, scal, out, passes=1, status=st)
+        h.sync()
+        outs.append(out.cpu().numpy()); kms.append(h.last_kernel_ms())
+        assert (st.cpu().numpy() == 1).all()
+    h.close()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert kms[2] < kms[0]                                       # ... and the sorted launch is the faster one
+
+
+def test_stream_kernel_first_solve_only_and_a_given_linearisation_point(hip_lib):
+    """passes = 0 is BaseSolver::solve alone; lin != NULL is updateProblemFormulationAndSolve's QP solved cold."""
+    import pqp_oracle_c as OC
+    from path_optimizer_2_amd import capi
+    from path_optimizer_2_amd.synth import make_batch
+    batch, n = 96, 80
+    b = make_batch(batch, n, seed=5)
+    h = _handle(capi, batch, n)
+    r0 = h.solve(b["ref"], b["bounds"], b["scal"], passes=0)
+    lin = np.ascontiguousarray(r0["out"][:, :, 3:6])
+    r1 = h.solve(b["ref"], b["bounds"], b["scal"], passes=0, lin=lin)
+    r01 = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    h.close()
+    prm = OC.params(eps_abs=1e-9, eps_rel=1e-9, max_iter=40000)
+    for q in range(12):
+        w0 = OC.solve_path(prm, b["ref"][q], b["bounds"][q], b["scal"][q], passes=0)["out"]
+        assert np.abs(r0["out"][q, :, 3:5] - w0[:, 3:5]).max() < 1e-5
+    assert np.abs(r1["out"] - r01["out"]).max() < 1e-7           # the two-step route gives the fused launch's paths
+
+
+def test_stream_kernel_with_a_waypoint_count_per_qp_and_an_infeasible_start(hip_lib):
+    import torch
+    from path_optimizer_2_amd import capi
+    from path_optimizer_2_amd.synth import make_batch
+    batch, n = 70, 96
+    b = make_batch(batch, n, "varied", seed=3)
+    rng = np.random.default_rng(1)
+    n_of = rng.integers(2, n + 1, batch).astype(np.int32)
+    n_of[0] = n; n_of[1] = 2; n_of[2] = 1                        # full, the shortest QP, nothing to optimise
+    b["scal"][n_of < n, 4] = 1.0                                 # a road cut short is blocked: no end-heading row (base_solver.cpp:254)
+    b["scal"][5, 2] = 1.0                                        # a start curvature outside its box: no feasible point
+    h = _handle(capi, batch, n)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ref, bounds, scal, cnt = t(b["ref"]), t(b["bounds"]), t(b["scal"]), t(n_of)
+    out = torch.zeros((batch, n, 7), dtype=torch.float64, device=dev)
+    st = torch.zeros(batch, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    h.solve_var_device(batch, n, cnt, ref, bounds, scal, out, passes=1, status=st)
+    h.sync()
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    h.close()
+    assert st[2] == 0 and st[5] == 4                             # PQP_STATUS_UNSOLVED, PQP_STATUS_PRIMAL_INFEASIBLE
+    ok = np.ones(batch, bool); ok[[2, 5]] = False
+    assert (st[ok] == 1).all()
+    want = _oracle(b, 16, n_of)
+    for q in range(16):
+        if ok[q]:
+            m = int(n_of[q])
+            assert np.abs(out[q, :m, 3:5] - want[q][:, 3:5]).max() < 2e-5, q
+            assert (out[q, m:] == 0).all()                       # rows beyond a QP's own count are not written
+
+
+def test_stream_kernel_rough_constraints_far_away(hip_lib):
+    """base_solver.cpp:25-34,201-205: beyond precise_planning_length one collision row per waypoint on the centre circle."""
+    import pqp_oracle as O
+    from path_optimizer_2_amd import capi
+    from path_optimizer_2_amd.synth import make_batch
+    batch, n = 64, 80
+    b = make_batch(batch, n, seed=9)
+    b["bounds"][:, :, 4] -= 0.15; b["bounds"][:, :, 5] += 0.1   # a centre box of its own
+    h = _handle(capi, batch, n, rough_constraints_far_away=1, precise_planning_length=12.0)
+    r = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    h.close()
+    assert (r["status"] == 1).all()
+    prm = O.PathQpParams(rough_constraints_far_away=True, precise_planning_length=12.0)
+    st = O.OsqpSettings(eps_abs=1e-9, eps_rel=1e-9, max_iter=40000)
+    for q in range(4):
+        want = O.solve_path(b["ref"][q], b["bounds"][q], b["scal"][q], prm=prm, st=st)[-1]["out"]
+        assert np.abs(r["out"][q, :, 3:5] - want[:, 3:5]).max() < 2e-5, q
+
+
+def test_stream_kernel_on_the_whole_of_configs_3(hip_lib):
+    """BASELINE configs[3] at its full 65 536 QPs of 80 waypoints on ONE GPU: every QP verified, deterministic run to run, and a sample
+    of the paths against the converged oracle."""
+    import torch
+    from path_optimizer_2_amd import capi
+    from path_optimizer_2_amd.synth import make_batch
+    batch, n = 65536, 80
+    b = make_batch(batch, n)
+    dev = torch.device("cuda", 0)
+    ref, bounds, scal = (torch.from_numpy(b[k]).to(dev) for k in ("ref", "bounds", "scal"))
+    h = _handle(capi, batch, n)
+    shas = []
+    for _ in range(2):
+        out = torch.zeros((batch, n, 7), dtype=torch.float64, device=dev)
+        st = torch.zeros(batch, dtype=torch.int32, device=dev)
+        info = torch.zeros((batch, 8), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        h.solve_device(batch, n, ref, bounds, scal, out, passes=1, status=st, info=info)
+        h.sync()
+        o = out.cpu().numpy()
+        shas.append(hashlib.sha1(o.tobytes()).hexdigest())
+    h.close()
+    assert (st.cpu().numpy() == 1).all()
+    assert shas[0] == shas[1]
+    # properties of an optimum that need no oracle: start state, curvature box, end box, x / y consistent with l
+    assert np.abs(o[:, 0, 3] - b["scal"][:, 0]).max() < 1e-12 and np.abs(o[:, 0, 5] - b["scal"][:, 2]).max() < 1e-12
+    assert np.abs(o[:, :, 5]).max() <= np.tan(35 * np.pi / 180) / 2.5 + 1e-8
+    assert np.abs(o[:, -1, 3]).max() <= 1.0 + 1e-8
+    nx = b["ref"][:, :, 3] + o[:, :, 3] * np.cos(b["ref"][:, :, 2] + np.pi / 2)
+    assert np.abs(o[:, :, 0] - nx).max() < 1e-9
+    idx = np.linspace(0, batch - 1, 24).astype(int)
+    want = _oracle({k: v[idx] for k, v in b.items()}, 24)
+    assert np.abs(o[idx][:, :, 3:5] - want[:, :, 3:5]).max() < 2e-5
+
+
+def test_paths_of_more_than_512_waypoints(hip_lib):
+    """The reference has no size limit (an 80 m line at 0.15 m spacing: 530 waypoints, reference_path_impl.cpp:321-336).  Beyond the
+    lane-per-waypoint kernel's 512 lanes pqp_path_solve runs the lane-per-QP kernel whatever the batch."""
+    import pqp_oracle_c as OC
+    from path_optimizer_2_amd import capi
+    from path_optimizer_2_amd.synth import make_batch
+    batch, n = 24, 700
+    b = make_batch(batch, n, "varied", seed=17)
+    h = capi.Handle(capi.production_params(), device=0, max_batch=batch, max_n=n)       # (default options: warm state on, no stream threshold touched)
+    r = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    assert (r["status"] == 1).all()
+    prm = OC.params(eps_abs=1e-9, eps_rel=1e-9, max_iter=60000)
+    for q in range(3):
+        want = OC.solve_path(prm, b["ref"][q], b["bounds"][q], b["scal"][q], passes=1)["out"]
+        assert np.abs(r["out"][q][:, 3:5] - want[:, 3:5]).max() < 1e-4, q
+    with pytest.raises(capi.PqpError):
+        h.solve(b["ref"], b["bounds"], b["scal"], passes=0, warm=True)                   # no warm state behind that kernel
+    h.close()
+    h = capi.Handle(capi.default_params(), device=0, max_batch=batch, max_n=n)          # the reference's ADMM setting: still the 512-lane limit
+    with pytest.raises(capi.PqpError):
+        h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    h.close()

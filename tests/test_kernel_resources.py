@@ -46,6 +46,22 @@ def test_path_solve_kernel_keeps_its_lane_state_in_registers(kernels, nw, cert):
     assert r["Occupancy"] >= 1
 
 
+@pytest.mark.parametrize("cert", [0, 1])
+def test_path_solve_kernel_of_512_lanes_spills_no_more_than_today(kernels, cert):
+    """NW = 8 (257-512 waypoints): a 512-lane workgroup is 8 wavefronts on one compute unit's 4 SIMDs, i.e. two per SIMD and 256 registers per
+    lane whatever the launch bounds say - half of what the lane state + temporaries take (496 at NW <= 4).  The spill slots that follow are
+    the price of one lane per waypoint at that size (1 024-1 184 B today); beyond them the lane struct itself would go."""
+    r = _find(kernels, "path_solve_kernel", f"ILi8ELb{cert}E")
+    assert r["ScratchSize"] <= 1280, r
+    assert r["VGPRs"] <= 256 and r["Occupancy"] >= 2
+
+
+def test_path_stream_kernel_has_no_scratch(kernels):
+    """the lane-per-QP kernel at its default prefetch depth: 256 VGPR + AGPRs, nothing in scratch memory (depth 2 and more spill: DESIGN.md 3b)"""
+    r = _find(kernels, "path_stream_kernel")
+    assert r["ScratchSize"] == 0, r
+
+
 @pytest.mark.parametrize("b,maxt,stage", [(3, 256, 1), (4, 256, 1), (9, 256, 1), (3, 512, 1), (4, 512, 1), (3, 512, 0), (4, 512, 0)])
 def test_banded_solve_kernel_registers(kernels, b, maxt, stage):
     r = _find(kernels, "banded_solve_kernel", f"ILi{b}ELi{maxt}ELb{stage}E")
