@@ -98,10 +98,19 @@ def stream_algorithmic_bytes(n, info):
 
 def cpu_baseline(make_sample, n, eps, budget_s):
     """The oracle (C restatement of the OSQP-paper algorithm, oracle/pqp_oracle.c) timed on this box's host cores over
-    a bounded sample of the same workload.  kind = "port": OSQP itself is not in this image."""
+    a bounded sample of the same workload.  kind = "port": OSQP itself is not in this image.  Beside it, as a second CPU line, the
+    engine's OWN lane-per-QP algorithm (csrc/pqp_path_lq.hpp) compiled for the host by the test infrastructure (tests/emu): what the
+    same arithmetic does on the box's cores - a baseline measurement, never the product path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pqp_oracle_c as OC
-    return OC.timed_baseline(make_sample, n, eps, budget_s)
+    base = OC.timed_baseline(make_sample, n, eps, 0.7 * budget_s)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import lq_emu_util as LE
+        base["same_algorithm_on_host"] = LE.timed_rate(make_sample, n, 0.3 * budget_s)
+    except Exception as e:
+        base["same_algorithm_on_host"] = {"error": f"{type(e).__name__}: {e}"}
+    return base
 
 
 def pmc_child(argv_core, kernel_substr, timeout_s, steps=6):
@@ -363,9 +372,17 @@ def main():
     secondary = None
     if not args.no_secondary and world == 1 and pipe is None and not args.reference_setting and polish:
         def timed(p, order, steps, warm=3, inflight=1, variants=None):
-            """`steps` steps round-robin over `inflight` fresh handles; variants: the (bounds, scal) sets consecutive steps cycle through"""
+            """`steps` steps round-robin over `inflight` handles; variants: the (bounds, scal) sets consecutive steps cycle through.  Two batches in
+            flight run on the headline's own two handles (parameters / start order set for the measurement): streams created later may share a
+            hardware queue with each other and then do not overlap."""
             variants = variants or var_in
-            lns = [make_lane(p, order) for _ in range(inflight)]
+            own = inflight == 1
+            if own:
+                lns = [make_lane(p, order)]
+            else:
+                lns = lanes[:inflight]
+                for ln in lns:
+                    ln[0].set_params(p); ln[0].set_option(capi.OPT_ORDER_BY_COST, 1 if order else 0)
             k = [0]
 
             def one():
@@ -395,7 +412,10 @@ def main():
                  "admm_iters": {"min": int(itn.min()), "median": float(np.median(itn)), "p99": float(np.percentile(itn, 99)), "max": int(itn.max()),
                                 "mean": float(itn.mean())}, "out_sha1": hashlib.sha1(o.cpu().numpy().tobytes()).hexdigest()[:16]}
             for ln in lns:
-                ln[0].close()
+                if own:
+                    ln[0].close()
+                else:
+                    ln[0].set_params(prm); ln[0].set_option(capi.OPT_ORDER_BY_COST, 1 if cost_order else 0)
             return r
         nfl = len(lanes)
         secondary = {
@@ -403,7 +423,7 @@ def main():
             if nfl > 1 else None,
             "index_order": dict(timed(prm, not cost_order, args.steps), setting="one launch after the other with the QPs started in index order"
                                 if cost_order else "one launch after the other with the QPs started most-expensive-first (previous step's cost)"),
-            "inflight2_index_order": dict(timed(prm, False, args.steps, inflight=2), setting="two batches in flight, QPs started in index order"),
+            "inflight2_index_order": dict(timed(prm, False, args.steps, inflight=2), setting="two batches in flight, QPs started in index order") if nfl >= 2 else None,
             "identical_batch_every_step": dict(timed(prm, cost_order, args.steps, inflight=nfl, variants=var_in[:1]),
                                                setting="the headline setting with the SAME batch re-solved every step (round 2's headline: the start "
                                                        "order then has perfect foresight of every QP's cost)") if n_var > 1 else None,
@@ -488,7 +508,8 @@ def main():
                                      f"timed region, {pmc['_launches']} launches averaged; FETCH_SIZE x 2 (gfx950 wide-read tally, MI355X_MICROARCH.md)") if traffic else None,
                   "fetch_size_kib": pmc.get("FETCH_SIZE") if pmc else None, "write_size_kib": pmc.get("WRITE_SIZE") if pmc else None,
                   # what HBM really moved per second of ONE launch's own duration, as a fraction of the 8 TB/s peak
-                  "hbm_measured_frac": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None}
+                  "hbm_measured_frac": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                  "hbm_measured_frac_chip_wide": (traffic * concurrency / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None}
         if stream:
             roofline = dict(common, achieved=abytes / avg_kernel_s / 1e9, frac=per_launch(abytes), frac_chip_wide=per_launch(abytes) * concurrency,
                             algorithmic_bytes_per_launch=abytes, traffic_over_algorithmic=(traffic / abytes) if traffic else None,

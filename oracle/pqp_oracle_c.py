@@ -95,7 +95,14 @@ def timed_baseline(make_sample, n, eps, budget_s=15.0, rho_interval=100):
 
     k, dt, r = run(False, 0.5 * budget_s)
     kd, dtd, rd = run(True, 0.5 * budget_s)
-    return {"value": k / dt, "unit": "paths/s", "cores": cores, "kind": "port",
+    # one thread alone (128 SMT threads hide what one core does)
+    one = make_sample(24)
+    t0 = time.perf_counter()
+    solve_batch(prm, one["ref"], one["bounds"], one["scal"], threads=1)
+    dt1 = time.perf_counter() - t0
+    solve_batch(prm, one["ref"][:1], one["bounds"][:1], one["scal"][:1], threads=cores)      # (omp_set_num_threads is process-wide: back to all)
+    return {"single_thread": {"value": 24 / dt1, "unit": "paths/s", "sample": f"24 paths on one thread in {dt1:.2f} s"},
+            "value": k / dt, "unit": "paths/s", "cores": cores, "kind": "port",
             "sample": f"{k} paths of the bench distribution (N={n}) in {dt:.1f} s, OSQP-paper restatement in C (oracle/pqp_oracle.c), "
                       f"eps {eps:g}, no polish, direct O(N) assembly, one path per OpenMP task over {cores} threads; mean ADMM iterations "
                       f"{float(r['iters'].mean()):.0f}; solved {r['solved']}/{k}",

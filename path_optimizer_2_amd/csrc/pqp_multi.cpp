@@ -1,10 +1,19 @@
-// pqp_multi.cpp — the multi-GPU driver of the C ABI (include/pqp.h: pqp_multi_*): the batch of independent QPs is cut
-// into contiguous shards, every shard has its own handle (= its own GPU, stream and workspaces) and its own host thread; a call moves
-// each shard's slice of the caller's host arrays to its GPU, solves it there and brings the paths back - per-GPU copies, no
-// collective: with the consumer on the host that is strictly better than a device-side gather; the device-resident
-// RCCL all-gather of the result slabs is path_optimizer_2_amd/shard.py (torch.distributed, one process per GPU).
-// Plain host C++ over the entry points of pqp_kernels.hip; part of libpqp_hip.so.
+// pqp_multi.cpp — the multi-GPU host loop of the C ABI (include/pqp.h: pqp_multi_*): the batch of independent QPs is cut
+// into contiguous shards; every shard has its own handle (= its own GPU, stream and workspaces), its own PERSISTENT host thread
+// (created in pqp_multi_create, parked on a condition variable between calls), pinned staging buffers and device buffers.  A call
+// hands every worker its slice of the caller's host arrays; the worker stages it into pinned memory, enqueues H2D copies, the
+// device-resident solve and the D2H copies on its handle's stream - true asynchronous DMA, so the copies of one shard run beside the
+// solves of the others also when two shards share a GPU - waits for its stream and writes the caller's output slice.  No collective:
+// with the consumer on the host per-GPU copies beat a device-side gather; the device-resident RCCL all-gather of the
+// result slabs is path_optimizer_2_amd/shard.py (torch.distributed, one process per GPU).
+// Plain host C++ over the entry points of pqp_kernels.hip + the HIP runtime's memory API; part of libpqp_hip.so.
+// The reference has no counterpart (one path per call, single-threaded: base_solver.cpp:56-95).
+#include <hip/hip_runtime_api.h>
+
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -13,17 +22,147 @@
 
 extern "C" void pqp_set_last_error(const char* msg);      // pqp_kernels.hip (thread-local message of pqp_last_error)
 
-struct pqp_multi {
-    std::vector<pqp_handle*> shards;
-    std::vector<int> devices;
-};
-
 namespace {
 int mfail(int code, const std::string& msg) {
     pqp_set_last_error(msg.c_str());
     return code;
 }
+
+struct Job {
+    int count = 0, n = 0, passes = 0;
+    const int32_t* n_of = nullptr;
+    const double *ref = nullptr, *lin = nullptr, *bounds = nullptr, *scal = nullptr;
+    double* out = nullptr;
+    int32_t *status = nullptr, *iters = nullptr;
+    double* info = nullptr;
+};
+
+// a buffer pair: pinned host memory + device memory of the same size, grown on demand
+struct Staged {
+    void *pin = nullptr, *dev = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        release();
+        hipError_t e = hipHostMalloc(&pin, need, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(&dev, need);
+        if (e != hipSuccess) { release(); return e; }
+        bytes = need;
+        return hipSuccess;
+    }
+    void release() {
+        if (pin) (void)hipHostFree(pin);
+        if (dev) (void)hipFree(dev);
+        pin = dev = nullptr; bytes = 0;
+    }
+};
+
+struct Shard {
+    pqp_handle* h = nullptr;
+    int device = 0;
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool has_job = false, done = false, quit = false;
+    Job job;
+    int rc = PQP_OK;
+    std::string err;
+    Staged ref, lin, bounds, scal, counts, out, status, iters, info;
+
+    int hip(hipError_t e, const char* what) {
+        if (e == hipSuccess) return PQP_OK;
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return PQP_ERR_HIP;
+    }
+
+    // one shard's slice: host -> pinned -> device, solve, device -> pinned -> host
+    int run(const Job& j) {
+        int rc_;
+        if ((rc_ = hip(hipSetDevice(device), "hipSetDevice"))) return rc_;
+        void* sv = nullptr;
+        if (pqp_get_stream(h, &sv) != PQP_OK) { err = pqp_last_error(); return PQP_ERR_INVALID; }
+        hipStream_t stream = (hipStream_t)sv;
+        const size_t bn = (size_t)j.count * j.n, b = (size_t)j.count;
+        struct In { Staged* s; const void* src; size_t bytes; };
+        const In ins[] = {{&ref, j.ref, bn * PQP_REF_STRIDE * 8}, {&lin, j.lin, j.lin ? bn * PQP_LIN_STRIDE * 8 : 0}, {&bounds, j.bounds, bn * PQP_BOUNDS_STRIDE * 8},
+                          {&scal, j.scal, b * PQP_SCAL_STRIDE * 8}, {&counts, j.n_of, j.n_of ? b * 4 : 0}};
+        for (const In& in : ins) {
+            if (!in.bytes) continue;
+            if ((rc_ = hip(in.s->ensure(in.bytes), "staging buffer"))) return rc_;
+            std::memcpy(in.s->pin, in.src, in.bytes);
+            if ((rc_ = hip(hipMemcpyAsync(in.s->dev, in.s->pin, in.bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D"))) return rc_;
+        }
+        if ((rc_ = hip(out.ensure(bn * PQP_OUT_STRIDE * 8), "staging buffer")) || (rc_ = hip(status.ensure(b * 4), "staging buffer")) ||
+            (rc_ = hip(iters.ensure(b * 4), "staging buffer")) || (rc_ = hip(info.ensure(b * PQP_INFO_STRIDE * 8), "staging buffer")))
+            return rc_;
+        if (j.n_of && (rc_ = hip(hipMemsetAsync(out.dev, 0, bn * PQP_OUT_STRIDE * 8, stream), "hipMemsetAsync"))) return rc_;      // rows beyond a QP's own count
+        const double* d_lin = j.lin ? (const double*)lin.dev : nullptr;
+        int rc_solve;
+        if (j.n_of)
+            rc_solve = pqp_path_solve_var_device(h, j.count, j.n, (const int32_t*)counts.dev, (const double*)ref.dev, d_lin, (const double*)bounds.dev,
+                                                 (const double*)scal.dev, j.passes, 0, (double*)out.dev, (int32_t*)status.dev, (int32_t*)iters.dev, (double*)info.dev);
+        else
+            rc_solve = pqp_path_solve_device(h, j.count, j.n, (const double*)ref.dev, d_lin, (const double*)bounds.dev, (const double*)scal.dev, j.passes, 0,
+                                             (double*)out.dev, (int32_t*)status.dev, (int32_t*)iters.dev, (double*)info.dev);
+        if (rc_solve != PQP_OK) { err = pqp_last_error(); (void)hipStreamSynchronize(stream); return rc_solve; }
+        if ((rc_ = hip(hipMemcpyAsync(out.pin, out.dev, bn * PQP_OUT_STRIDE * 8, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"))) return rc_;
+        if (j.status && (rc_ = hip(hipMemcpyAsync(status.pin, status.dev, b * 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"))) return rc_;
+        if (j.iters && (rc_ = hip(hipMemcpyAsync(iters.pin, iters.dev, b * 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"))) return rc_;
+        if (j.info && (rc_ = hip(hipMemcpyAsync(info.pin, info.dev, b * PQP_INFO_STRIDE * 8, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"))) return rc_;
+        if ((rc_ = hip(hipStreamSynchronize(stream), "hipStreamSynchronize"))) return rc_;
+        std::memcpy(j.out, out.pin, bn * PQP_OUT_STRIDE * 8);
+        if (j.status) std::memcpy(j.status, status.pin, b * 4);
+        if (j.iters) std::memcpy(j.iters, iters.pin, b * 4);
+        if (j.info) std::memcpy(j.info, info.pin, b * PQP_INFO_STRIDE * 8);
+        return PQP_OK;
+    }
+
+    void loop() {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return has_job || quit; });
+                if (quit) return;
+                j = job;
+                has_job = false;
+            }
+            err.clear();
+            const int r = j.count > 0 ? run(j) : PQP_OK;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                rc = r;
+                done = true;
+            }
+            cv.notify_all();
+        }
+    }
+    void submit(const Job& j) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = j; has_job = true; done = false;
+        }
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+    }
+    void stop() {
+        if (worker.joinable()) {
+            { std::lock_guard<std::mutex> lk(mu); quit = true; }
+            cv.notify_all();
+            worker.join();
+        }
+        (void)hipSetDevice(device);
+        for (Staged* s : {&ref, &lin, &bounds, &scal, &counts, &out, &status, &iters, &info}) s->release();
+    }
+};
 }  // namespace
+
+struct pqp_multi {
+    std::vector<Shard*> shards;
+};
 
 extern "C" {
 
@@ -49,8 +188,13 @@ int pqp_multi_create(pqp_multi** out, const pqp_params* params, int n_shards, co
             (void)pqp_multi_destroy(m);
             return mfail(rc, "pqp_multi_create: shard " + std::to_string(g) + " on device " + std::to_string(dev) + ": " + why);
         }
-        m->shards.push_back(h);
-        m->devices.push_back(dev);
+        Shard* s = new (std::nothrow) Shard();
+        if (!s) { (void)pqp_destroy(h); (void)pqp_multi_destroy(m); return mfail(PQP_ERR_INVALID, "pqp_multi_create: out of host memory"); }
+        s->h = h; s->device = dev;
+        // a caller of the multi driver takes its paths home after every call: nobody reads the handles' warm state
+        (void)pqp_set_option(h, PQP_OPT_STORE_WARM, 0);
+        m->shards.push_back(s);
+        s->worker = std::thread([s] { s->loop(); });            // the shard's host thread, for the life of the driver
     }
     *out = m;
     return PQP_OK;
@@ -58,7 +202,11 @@ int pqp_multi_create(pqp_multi** out, const pqp_params* params, int n_shards, co
 
 int pqp_multi_destroy(pqp_multi* m) {
     if (!m) return PQP_OK;
-    for (pqp_handle* h : m->shards) (void)pqp_destroy(h);
+    for (Shard* s : m->shards) {
+        s->stop();
+        (void)pqp_destroy(s->h);
+        delete s;
+    }
     delete m;
     return PQP_OK;
 }
@@ -66,13 +214,13 @@ int pqp_multi_destroy(pqp_multi* m) {
 int pqp_multi_shards(const pqp_multi* m) { return m ? (int)m->shards.size() : 0; }
 
 pqp_handle* pqp_multi_handle(pqp_multi* m, int shard) {
-    return (m && shard >= 0 && shard < (int)m->shards.size()) ? m->shards[shard] : nullptr;
+    return (m && shard >= 0 && shard < (int)m->shards.size()) ? m->shards[shard]->h : nullptr;
 }
 
 int pqp_multi_set_option(pqp_multi* m, int option, int value) {
     if (!m) return mfail(PQP_ERR_INVALID, "pqp_multi_set_option: null handle");
-    for (pqp_handle* h : m->shards) {
-        const int rc = pqp_set_option(h, option, value);
+    for (Shard* s : m->shards) {
+        const int rc = pqp_set_option(s->h, option, value);
         if (rc != PQP_OK) return rc;
     }
     return PQP_OK;
@@ -82,34 +230,44 @@ int pqp_multi_path_solve(pqp_multi* m, int batch, int n, const int32_t* n_of, co
                          const double* scal, int passes, double* out, int32_t* status, int32_t* iters, double* info) {
     if (!m || !ref || !bounds || !scal || !out || batch < 1 || n < 2 || passes < 0)
         return mfail(PQP_ERR_INVALID, "pqp_multi_path_solve: bad argument");
+    // (an inverted collision box is refused as OSQP refuses it at setup - the host-pointer entry points' rule, pqp.h)
+    std::vector<int32_t> counts;
+    for (int q = 0; q < batch; ++q) {
+        const int cnt = n_of ? n_of[q] : n;
+        bool bad = false;
+        for (int i = 0; i < cnt && i < n && !bad; ++i) {
+            const double* b = bounds + ((size_t)q * n + i) * PQP_BOUNDS_STRIDE;
+            bad = b[0] > b[1] || b[2] > b[3] || b[4] > b[5];
+        }
+        if (bad) {
+            if (counts.empty()) { if (n_of) counts.assign(n_of, n_of + batch); else counts.assign(batch, n); }
+            counts[q] = -1;
+        }
+    }
+    const int32_t* cnt_ptr = counts.empty() ? n_of : counts.data();
     const int world = (int)m->shards.size();
-    std::vector<int> rcs(world, PQP_OK);
-    std::vector<std::string> errs(world);
-    auto work = [&](int g) {
+    for (int g = 0; g < world; ++g) {
         int first = 0, count = 0;
         pqp_shard_range(batch, world, g, &first, &count);
-        if (count == 0) return;
-        const size_t o = (size_t)first;
-        const size_t on = o * (size_t)n;
-        const double* lin_g = lin ? lin + on * PQP_LIN_STRIDE : nullptr;
-        int rc;
-        if (n_of)
-            rc = pqp_path_solve_var(m->shards[g], count, n, n_of + o, ref + on * PQP_REF_STRIDE, lin_g, bounds + on * PQP_BOUNDS_STRIDE,
-                                    scal + o * PQP_SCAL_STRIDE, passes, 0, out + on * PQP_OUT_STRIDE, status ? status + o : nullptr,
-                                    iters ? iters + o : nullptr, info ? info + o * PQP_INFO_STRIDE : nullptr);
-        else
-            rc = pqp_path_solve(m->shards[g], count, n, ref + on * PQP_REF_STRIDE, lin_g, bounds + on * PQP_BOUNDS_STRIDE,
-                                scal + o * PQP_SCAL_STRIDE, passes, 0, out + on * PQP_OUT_STRIDE, status ? status + o : nullptr,
-                                iters ? iters + o : nullptr, info ? info + o * PQP_INFO_STRIDE : nullptr);
-        rcs[g] = rc;
-        if (rc != PQP_OK) errs[g] = pqp_last_error();      // (thread-local in the worker: carried back by hand)
-    };
-    std::vector<std::thread> threads;          // one host thread per shard (a handle is single-owner; different handles may run concurrently)
-    for (int g = 1; g < world; ++g) threads.emplace_back(work, g);
-    work(0);
-    for (auto& t : threads) t.join();
-    for (int g = 0; g < world; ++g)
-        if (rcs[g] != PQP_OK) return mfail(rcs[g], "pqp_multi_path_solve: shard " + std::to_string(g) + ": " + errs[g]);
+        const size_t o = (size_t)first, on = o * (size_t)n;
+        Job j;
+        j.count = count; j.n = n; j.passes = passes;
+        j.n_of = cnt_ptr ? cnt_ptr + o : nullptr;
+        j.ref = ref + on * PQP_REF_STRIDE; j.lin = lin ? lin + on * PQP_LIN_STRIDE : nullptr; j.bounds = bounds + on * PQP_BOUNDS_STRIDE;
+        j.scal = scal + o * PQP_SCAL_STRIDE; j.out = out + on * PQP_OUT_STRIDE;
+        j.status = status ? status + o : nullptr; j.iters = iters ? iters + o : nullptr; j.info = info ? info + o * PQP_INFO_STRIDE : nullptr;
+        m->shards[g]->submit(j);
+    }
+    int rc = PQP_OK;
+    std::string why;
+    for (int g = 0; g < world; ++g) {
+        m->shards[g]->wait();
+        if (m->shards[g]->rc != PQP_OK && rc == PQP_OK) { rc = m->shards[g]->rc; why = "pqp_multi_path_solve: shard " + std::to_string(g) + ": " + m->shards[g]->err; }
+    }
+    if (rc != PQP_OK) return mfail(rc, why);
+    if (!counts.empty() && status)
+        for (int q = 0; q < batch; ++q)
+            if (counts[q] < 0) status[q] = PQP_STATUS_PRIMAL_INFEASIBLE;
     return PQP_OK;
 }
 

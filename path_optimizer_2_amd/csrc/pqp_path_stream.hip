@@ -14,10 +14,12 @@ namespace pqp {
 #define PQP_STREAM_OCC 1
 #endif
 __global__ void __launch_bounds__(64, PQP_STREAM_OCC) path_stream_kernel(const lq::Args a) {
-    const int slot = blockIdx.x * 64 + threadIdx.x;
+    // (blockDim.x = lanes per wavefront in use: 64, or 32 - half-filled wavefronts, two per SIMD: PQP_STREAM_LANES)
+    const int lanes = (int)blockDim.x;
+    const int slot = blockIdx.x * lanes + threadIdx.x;
     if (slot >= a.batch) return;
     const int qp = a.order ? a.order[slot] : slot;
-    lq::StridedWs ws{a.ws + (size_t)blockIdx.x * a.n * lq::kBlockDoubles * 64, (int)threadIdx.x, 64};
+    lq::StridedWs ws{a.ws + (size_t)blockIdx.x * a.n * lq::kBlockDoubles * lanes, (int)threadIdx.x, lanes};
     lq::Solver<lq::StridedWs> s(a, qp, ws);
     s.run();
 }
@@ -45,7 +47,12 @@ extern "C" hipError_t pqp_stream_order_launch(int batch, const int32_t* cost, in
     return hipGetLastError();
 }
 
+#ifndef PQP_STREAM_LANES
+#define PQP_STREAM_LANES 64
+#endif
 extern "C" hipError_t pqp_stream_launch(const pqp::lq::Args* a, int waves, void* stream) {
-    hipLaunchKernelGGL(pqp::path_stream_kernel, dim3(waves), dim3(64), 0, (hipStream_t)stream, *a);
+    (void)waves;
+    const int lanes = PQP_STREAM_LANES;
+    hipLaunchKernelGGL(pqp::path_stream_kernel, dim3((a->batch + lanes - 1) / lanes), dim3(lanes), 0, (hipStream_t)stream, *a);
     return hipGetLastError();
 }

@@ -3,6 +3,9 @@
 // oracle in a container without a GPU; nothing in the product links it.
 #include <cstring>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../../path_optimizer_2_amd/csrc/pqp_defaults.hpp"
 #include "../../path_optimizer_2_amd/csrc/pqp_path_lq.hpp"
@@ -18,12 +21,24 @@ void pqp_emu_lq_solve(const pqp_params* prm, int batch, int n, const int32_t* n_
     std::memset(&a, 0, sizeof(a));
     a.batch = batch; a.n = n; a.passes = passes; a.n_of = n_of; a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
     a.status = status; a.iters = iters; a.info = info; a.prm = *prm;
-    std::vector<double> ws((size_t)n * pqp::lq::kBlockDoubles);
-    a.ws = ws.data();
-    for (int q = 0; q < batch; ++q) {
-        std::fill(ws.begin(), ws.end(), 0.0);
-        pqp::lq::Solver<pqp::lq::StridedWs> s(a, q, pqp::lq::StridedWs{ws.data(), 0, 1});
-        s.run();
+    // (one QP per OpenMP task when built with -fopenmp: bench.py's "same algorithm on the host cores" line; serial otherwise)
+#pragma omp parallel
+    {
+        std::vector<double> ws((size_t)n * pqp::lq::kBlockDoubles);
+#pragma omp for schedule(dynamic, 16)
+        for (int q = 0; q < batch; ++q) {
+            std::fill(ws.begin(), ws.end(), 0.0);
+            pqp::lq::Solver<pqp::lq::StridedWs> s(a, q, pqp::lq::StridedWs{ws.data(), 0, 1});
+            s.run();
+        }
     }
+}
+
+int pqp_emu_lq_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
 }
 }

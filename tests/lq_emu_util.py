@@ -20,7 +20,7 @@ def load():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in _DEPS):
-            subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC], check=True)
+            subprocess.run(["g++", "-O3", "-march=native", "-fopenmp", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC], check=True)
         _lib = C.CDLL(LIB)
     return _lib
 
@@ -45,3 +45,23 @@ def solve(ref, bounds, scal, passes=1, n_of=None, lin=None, prm=None):
     n_of = None if n_of is None else np.ascontiguousarray(n_of, dtype=np.int32)
     lib.pqp_emu_lq_solve(C.byref(prm), B, n, vp(n_of), vp(ref), vp(lin), vp(bounds), vp(scal), passes, vp(out), vp(st), vp(it), vp(info))
     return dict(out=out, status=st, iters=it, info=info)
+
+
+def timed_rate(make_sample, n, budget_s=6.0):
+    """bench.py's cpu_baseline.same_algorithm_on_host: the product's lane-per-QP algorithm source compiled for the host (test infrastructure,
+    tests/emu/lq_emu.cpp), one QP per OpenMP task over all host threads, on a bounded sample of the bench workload."""
+    import time
+    lib = load()
+    cores = lib.pqp_emu_lq_threads()
+    probe = make_sample(64 * cores)
+    t0 = time.perf_counter()
+    solve(probe["ref"], probe["bounds"], probe["scal"])
+    per = (time.perf_counter() - t0) / (64 * cores)
+    k = int(min(1 << 20, max(64 * cores, budget_s / max(per, 1e-8))))
+    b = make_sample(k)
+    t0 = time.perf_counter()
+    r = solve(b["ref"], b["bounds"], b["scal"])
+    dt = time.perf_counter() - t0
+    return {"value": k / dt, "unit": "paths/s", "cores": cores, "per_core": k / dt / cores, "solved": int((r["status"] == 1).sum()),
+            "sample": f"{k} paths of the bench distribution (N={n}) in {dt:.1f} s: csrc/pqp_path_lq.hpp (interior-point + active-set rounds, every path the "
+                      f"exact optimum) compiled for the host with g++ -O3 -march=native -fopenmp, one QP per task over {cores} threads"}

@@ -68,18 +68,17 @@ def test_stream_kernel_lane_order_by_cost_does_not_change_a_bit(hip_lib):
     ref, bounds, scal = (torch.from_numpy(b[k]).to(dev) for k in ("ref", "bounds", "scal"))
     h = _handle(capi, batch, n)
     h.set_option(capi.OPT_ORDER_BY_COST, 1)
-    outs, kms = [], []
+    outs = []
     for _ in range(3):
         out = torch.full((batch, n, 7), float("nan"), dtype=torch.float64, device=dev)
         st = torch.zeros(batch, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
         h.solve_device(batch, n, ref, bounds, scal, out, passes=1, status=st)
         h.sync()
-        outs.append(out.cpu().numpy()); kms.append(h.last_kernel_ms())
+        outs.append(out.cpu().numpy())
         assert (st.cpu().numpy() == 1).all()
     h.close()
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
-    assert kms[2] < kms[0]                                       # ... and the sorted launch is the faster one
 
 
 def test_stream_kernel_first_solve_only_and_a_given_linearisation_point(hip_lib):
