@@ -10,7 +10,10 @@
 // The reference has no counterpart (one path per call, single-threaded: base_solver.cpp:56-95).
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -78,6 +81,10 @@ struct Shard {
     // one shard's slice: host -> pinned -> device, solve, device -> pinned -> host
     int run(const Job& j) {
         int rc_;
+        static const bool trace = std::getenv("PQP_MULTI_TRACE") != nullptr;         // phase times of every call on stderr (debugging aid)
+        const auto t0 = std::chrono::steady_clock::now();
+        auto us = [&] { return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
+        long t_stage = 0, t_enq = 0, t_sync = 0;
         if ((rc_ = hip(hipSetDevice(device), "hipSetDevice"))) return rc_;
         void* sv = nullptr;
         if (pqp_get_stream(h, &sv) != PQP_OK) { err = pqp_last_error(); return PQP_ERR_INVALID; }
@@ -92,6 +99,7 @@ struct Shard {
             std::memcpy(in.s->pin, in.src, in.bytes);
             if ((rc_ = hip(hipMemcpyAsync(in.s->dev, in.s->pin, in.bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync H2D"))) return rc_;
         }
+        t_stage = us();
         if ((rc_ = hip(out.ensure(bn * PQP_OUT_STRIDE * 8), "staging buffer")) || (rc_ = hip(status.ensure(b * 4), "staging buffer")) ||
             (rc_ = hip(iters.ensure(b * 4), "staging buffer")) || (rc_ = hip(info.ensure(b * PQP_INFO_STRIDE * 8), "staging buffer")))
             return rc_;
@@ -109,11 +117,15 @@ struct Shard {
         if (j.status && (rc_ = hip(hipMemcpyAsync(status.pin, status.dev, b * 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"))) return rc_;
         if (j.iters && (rc_ = hip(hipMemcpyAsync(iters.pin, iters.dev, b * 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"))) return rc_;
         if (j.info && (rc_ = hip(hipMemcpyAsync(info.pin, info.dev, b * PQP_INFO_STRIDE * 8, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"))) return rc_;
+        t_enq = us();
         if ((rc_ = hip(hipStreamSynchronize(stream), "hipStreamSynchronize"))) return rc_;
+        t_sync = us();
         std::memcpy(j.out, out.pin, bn * PQP_OUT_STRIDE * 8);
         if (j.status) std::memcpy(j.status, status.pin, b * 4);
         if (j.iters) std::memcpy(j.iters, iters.pin, b * 4);
         if (j.info) std::memcpy(j.info, info.pin, b * PQP_INFO_STRIDE * 8);
+        if (trace) std::fprintf(stderr, "[pqp_multi] device %d, %d QPs: staged + H2D enqueued %ld us, solve + D2H enqueued %ld us, stream done %ld us, copied out %ld us\n",
+                                device, j.count, t_stage, t_enq, t_sync, us());
         return PQP_OK;
     }
 
