@@ -204,8 +204,7 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      QPs of 80 waypoints: 2.0x, measured crossover ~20 000); it keeps no warm state
  *                                      (hence the PQP_OPT_STORE_WARM condition), iters[] counts its interior-point iterations and info[] =
  *                                      {row residual, complementarity, iterations of the first pass, iterations, solved passes, active-set
- *                                      rounds of the first pass, Riccati sweeps, active-set rounds}.  PQP_OPT_ORDER_BY_COST there: the 64
- *                                      lanes of a wavefront get QPs that took equally many sweeps in the previous solve of the shape. */
+ *                                      rounds of the first pass, Riccati sweeps, active-set rounds}.  (PQP_OPT_ORDER_BY_COST has no effect on it.) */
 typedef enum pqp_option { PQP_OPT_STORE_WARM = 1, PQP_OPT_ORDER_BY_COST = 2, PQP_OPT_RESERVE_CUS = 3, PQP_OPT_STREAM_BATCH = 4 } pqp_option;
 int pqp_set_option(pqp_handle* h, int option, int value);
 int pqp_get_stream(pqp_handle* h, void** hip_stream);   /* hipStream_t */
@@ -312,7 +311,10 @@ int pqp_smooth_tension2_device(pqp_handle* h, int batch, int n, const double* x_
                                const double* k_list, const double* s_list, double* out_x, double* out_y, double* out_s,
                                int32_t* status, int32_t* iters, double* info);
 /* TensionSmoother::osqpSmooth    src/reference_path_smoother/tension_smoother.cpp:49-100; clearance = Map::getObstacleDistance
- * at each input point (the distance-map lookup itself, tension_smoother.cpp:168, stays on the caller's side) */
+ * at each input point (the distance-map lookup itself, tension_smoother.cpp:168, stays on the caller's side; pqp_clearance_device does it).
+ * 4 <= n <= 384 points.  Up to ~166 points a handle in the reference's ADMM setting (polish == 0) runs OSQP's iteration on the 9 x 9-block
+ * core; beyond that core's LDS capacity - and for polish == 1 at any size - the QP is solved exactly (iters = 0), which meets OSQP's
+ * termination test at any eps. */
 int pqp_smooth_tension(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list,
                        const double* clearance, double* out_x, double* out_y, double* out_s, int32_t* status, int32_t* iters);
 int pqp_smooth_tension_device(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list,

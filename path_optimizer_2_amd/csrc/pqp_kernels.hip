@@ -699,8 +699,7 @@ struct pqp_handle {
     long long solves = 0;                       // solve launches so far (parity selects the cost histogram being filled)
     int hist_batch = 0, hist_n = 0;             // shape of the solve whose costs cost_key / cost_hist hold (0: none)
     int opt_store_warm = 1, opt_order_by_cost = 0, opt_reserve_cus = 0, opt_stream_batch = 24576;
-    DevBuf stream_ws, stream_cost, stream_order;        // path_stream_kernel: workspace, sweeps per QP of the last launch, lane slot -> QP
-    int stream_hist_batch = 0, stream_hist_n = 0;
+    DevBuf stream_ws;                           // workspace of path_stream_kernel
     int num_cu = 0;
     int blocks_per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // occupancy of the solve kernel variants [log2(nw)][cert]
     DevBuf s_ref, s_lin, s_bounds, s_scal;      // staging for the host-pointer entry points
@@ -756,7 +755,7 @@ int pqp_destroy(pqp_handle* h) {
     if (!h) return PQP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (DevBuf* b : {&h->stream_ws, &h->stream_cost, &h->stream_order, &h->chain_d, &h->chain_i, &h->wscale, &h->ticket, &h->cost_key, &h->cost_hist, &h->order, &h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
+    for (DevBuf* b : {&h->stream_ws, &h->chain_d, &h->chain_i, &h->wscale, &h->ticket, &h->cost_key, &h->cost_hist, &h->order, &h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
                       &h->s_status, &h->s_iters, &h->s_info, &h->s_a, &h->s_p, &h->s_l, &h->s_u, &h->s_idx, &h->b_pband, &h->b_q, &h->b_aval,
                       &h->b_lo, &h->b_up, &h->b_x, &h->b_y, &h->b_acol, &h->b_trow, &h->b_tslot, &h->b_in[0], &h->b_in[1], &h->b_in[2],
                       &h->b_in[3], &h->b_in[4], &h->b_out[0], &h->b_out[1], &h->b_out[2], &h->c_buf[0], &h->c_buf[1], &h->c_buf[2],
@@ -780,7 +779,7 @@ int pqp_set_option(pqp_handle* h, int option, int value) {
     if (!h) return fail(PQP_ERR_INVALID, "pqp_set_option: null handle");
     switch (option) {
         case PQP_OPT_STORE_WARM: h->opt_store_warm = value ? 1 : 0; return PQP_OK;
-        case PQP_OPT_ORDER_BY_COST: h->opt_order_by_cost = value ? 1 : 0; h->hist_batch = 0; h->stream_hist_batch = 0; return PQP_OK;
+        case PQP_OPT_ORDER_BY_COST: h->opt_order_by_cost = value ? 1 : 0; h->hist_batch = 0; return PQP_OK;
         case PQP_OPT_RESERVE_CUS: h->opt_reserve_cus = value < 0 ? 0 : value; return PQP_OK;
         case PQP_OPT_STREAM_BATCH: h->opt_stream_batch = value < 0 ? 0 : value; return PQP_OK;
         default: return fail(PQP_ERR_INVALID, "pqp_set_option: unknown option");
@@ -916,7 +915,6 @@ int pqp_path_assemble(pqp_handle* h, int batch, int n, int precise, const double
 }
 
 extern "C" hipError_t pqp_stream_launch(const pqp::lq::Args* a, int waves, void* stream);
-extern "C" hipError_t pqp_stream_order_launch(int batch, const int32_t* cost, int32_t* order, void* stream);
 
 // Large batches (PQP_OPT_STREAM_BATCH): one lane per QP, state streamed through HBM (pqp_path_lq.hpp).  Same optimum as the
 // lane-per-waypoint kernel's KKT-verified polish; no warm state is kept (warm == 1 and pqp_path_get_solution need the other kernel).
@@ -929,21 +927,11 @@ static int path_stream_impl(pqp_handle* h, int batch, int n, const int32_t* n_of
     std::memset(&a, 0, sizeof(a));
     a.batch = batch; a.n = n; a.passes = passes; a.n_of = n_of; a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
     a.status = status; a.iters = iters; a.info = info; a.ws = h->stream_ws.as<double>(); a.prm = h->prm;
-    if (h->opt_order_by_cost) {
-        // PQP_OPT_ORDER_BY_COST for this kernel: lanes of a wavefront = QPs that took equally many sweeps in the previous solve of this shape
-        if ((rc = h->stream_cost.ensure((size_t)batch * 4)) || (rc = h->stream_order.ensure((size_t)batch * 4))) return rc;
-        if (h->stream_hist_batch == batch && h->stream_hist_n == n) {
-            PQP_HIP(pqp_stream_order_launch(batch, h->stream_cost.as<int32_t>(), h->stream_order.as<int32_t>(), (void*)h->stream));
-            a.order = h->stream_order.as<int32_t>();
-        }
-        a.cost = h->stream_cost.as<int32_t>();
-    }
     h->next_event_pair();
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
     PQP_HIP(pqp_stream_launch(&a, waves, (void*)h->stream));      // path_stream_kernel lives in its own translation unit (pqp_path_stream.hip)
     PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
-    h->stream_hist_batch = a.cost ? batch : 0; h->stream_hist_n = a.cost ? n : 0;
     h->warm_batch = batch; h->warm_n = n;
     h->warm_stored = false;
     return PQP_OK;
@@ -1346,8 +1334,16 @@ static int smooth_tension_impl(pqp_handle* h, int batch, int n, const int32_t* n
         return fail(PQP_ERR_INVALID, "pqp_smooth_tension: bad argument");
     PQP_HIP(hipSetDevice(h->device));
     int rc;
-    if (h->prm.polish == 1 && n <= 384) {
-        // exact optima asked for: the box QP in the lateral shifts alone, one wavefront per scenario (tension_exact_kernel)
+    // The generic block-cyclic-reduction core keeps a QP's vectors, factor rows and row data in one compute unit's LDS: in TensionSmoother's
+    // 9 x 9 blocks that ends near 166 points.  The reference has no such limit (tension_smoother.cpp:49-100; segmentRawReference gives a
+    // point per metre of line).  Beyond it, also a handle in the reference's ADMM setting gets the exact kernel's optimum: a point with
+    // zero residuals meets OSQP's termination test at any eps, so it IS a valid result of that setting (iters = 0; OSQP itself would
+    // stop at a less accurate one).
+    const SmShape sh9 = sm_shape(SM_TENSION, n);
+    const pqp::BqLayout lay9{sh9.nv, sh9.nc, sh9.bw};
+    const bool generic_fits = (size_t)lay9.total(false) * 8 <= 160 * 1024 && 64 * ((lay9.nbb() + 63) / 64) <= 1024;
+    if ((h->prm.polish == 1 || !generic_fits) && n <= 384) {
+        // exact optima asked for (or the only kernel that holds the QP): the box QP in the lateral shifts alone, one wavefront per scenario (tension_exact_kernel)
         if (!status) return fail(PQP_ERR_INVALID, "pqp_smooth_tension: status is null");
         h->next_event_pair();
         PQP_HIP(hipEventRecord(h->ev0, h->stream));

@@ -36,6 +36,7 @@ namespace lq {
 
 constexpr double kBig = 1e29;           // a bound beyond this is no bound (OSQP_INFTY = 1e30)
 constexpr double kDelta = 1e-9;         // hard active rows: penalty 1 / delta around the bound shifted by delta * multiplier
+constexpr double kInvDelta = 1e9;
 constexpr double kSetTol = 1e-7;        // a row changes sides when it fails its test by more than this (pqp_params.polish_tol's role)
 constexpr double kPinTol = 1e-9;        // accepted points hold their hard active rows to this
 constexpr double kMuStop = 1e-6;        // complementarity at which the interior-point rounds hand over to the active-set rounds
@@ -45,6 +46,25 @@ constexpr int kIpmMaxIter = 60;
 constexpr int kPolishMaxRounds = 12;
 
 // a two-sided row of the interior-point rounds
+// reciprocal: the hardware seed (4.6e-8, tools/probes/rcp_probe.hip) + ONE Newton step = 2.2e-15 relative - a third fewer instructions than
+// pqp::rcp's two steps in a kernel whose row arithmetic is mostly reciprocals (PQP_STREAM_RCP2: the two-step one, for A/B runs)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PQP_STREAM_RCP2)
+PQP_HD double rcpq(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+#else
+PQP_HD double rcpq(double x) { return rcp(x); }
+#endif
+
+// The sweeps of the solver as functions of their own on the device (PQP_LQ_NOINLINE): the solver object then lives in the lane's private
+// memory between them and every sweep gets a register allocation of its own, instead of one allocation over the whole inlined solve.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PQP_LQ_NOINLINE)
+#define PQP_SWEEP __device__ __attribute__((noinline))
+#else
+#define PQP_SWEEP PQP_HD
+#endif
+
 struct Row { double g, tl, tu, zl, zu; };
 struct RowStep { double dg, dtl, dtu, dzl, dzu; };
 
@@ -56,15 +76,15 @@ struct Acc {          // what a roll-out accumulates for the step length and the
 
 // Newton target of a row: weight d and target of the quadratic term that replaces the barrier (sm = sigma * mu)
 PQP_HD void row_weight(const Row& r, double lo, double up, double sm, double& d, double& tgt) {
-    const double itl = rcp(r.tl), itu = rcp(r.tu);
+    const double itl = rcpq(r.tl), itu = rcpq(r.tu);
     const double rl = r.g - lo - r.tl, ru = up - r.g - r.tu;
     d = r.zu * itu + r.zl * itl;
     const double e = sm * (itu - itl) - r.zu * itu * ru + r.zl * itl * rl;
-    tgt = r.g - e * rcp(d);
+    tgt = r.g - e * rcpq(d);
 }
 // the step of a row's state towards the Newton point whose row value is g + dg
 PQP_HD RowStep row_step(const Row& r, double lo, double up, double sm, double dg) {
-    const double itl = rcp(r.tl), itu = rcp(r.tu);
+    const double itl = rcpq(r.tl), itu = rcpq(r.tu);
     const double rl = r.g - lo - r.tl, ru = up - r.g - r.tu;
     RowStep s;
     s.dg = dg;
@@ -75,7 +95,7 @@ PQP_HD RowStep row_step(const Row& r, double lo, double up, double sm, double dg
     return s;
 }
 PQP_HD void row_accumulate(const Row& r, const RowStep& s, double lo, double up, Acc& a, bool hard = true) {
-    const double itl = rcp(r.tl), itu = rcp(r.tu), izl = rcp(r.zl), izu = rcp(r.zu);
+    const double itl = rcpq(r.tl), itu = rcpq(r.tu), izl = rcpq(r.zl), izu = rcpq(r.zu);
     a.rho = fmax(fmax(a.rho, -s.dtl * itl), fmax(-s.dtu * itu, fmax(-s.dzl * izl, -s.dzu * izu)));
     a.s0 += r.tl * r.zl + r.tu * r.zu;
     a.s1 += r.tl * s.dzl + r.zl * s.dtl + r.tu * s.dzu + r.zu * s.dtu;
@@ -98,7 +118,7 @@ struct Stage { double m00, m01, m10, m11, m12, c0, c1, ds; };
 PQP_HD void riccati_step(const Stage& s, double w_u, Value& v, double* K, double& kk) {
     const double g0 = v.P[2], g1 = v.P[4], g2 = v.P[5];
     const double S = w_u + s.ds * s.ds * g2;
-    const double iS = rcp(S);
+    const double iS = rcpq(S);
     const double r = s.ds * s.ds * iS, wS = w_u * iS, f = s.ds * iS;
     // Pb = P - r g g^T, its last row / column in the cancellation-free form g w_u / S; pb likewise
     const double b00 = v.P[0] - r * g0 * g0, b01 = v.P[1] - r * g0 * g1, b11 = v.P[3] - r * g1 * g1;
@@ -169,7 +189,7 @@ struct Solver {
         else { l = 0.0; psi = 0.0; k = a.ref[((size_t)qp * a.n + i) * PQP_REF_STRIDE + 1]; }
     }
     struct PrepIn { double l, psi, k, s, kref, b[6]; };
-    PQP_HD void prep(int src, bool with_bounds) {
+    PQP_SWEEP void prep(int src, bool with_bounds) {
         const double* rq = a.ref + (size_t)qp * a.n * PQP_REF_STRIDE;
         const double* bq = a.bounds + (size_t)qp * a.n * PQP_BOUNDS_STRIDE;
         PrepIn prev;
@@ -321,7 +341,7 @@ struct Solver {
             const int af = code % 3 - 1, ar = (code / 3) % 3 - 1, ak = code / 9 - 1;
             if (af != 0) add_lpsi_term(v, w_s, L0, af > 0 ? upf : lof);
             if (ar != 0) add_lpsi_term(v, w_s, Lr, ar > 0 ? upr : lor);
-            if (ak != 0) { const double w = 1.0 / kDelta; v.P[5] += w; v.p[2] -= w * (ak * kl - kDelta * in.lam); }
+            if (ak != 0) { const double w = kInvDelta; v.P[5] += w; v.p[2] -= w * (ak * kl - kDelta * in.lam); }
             return;
         }
         // interior-point state of the waypoint: previous step applied, then this iteration's weights (or the set it predicts)
@@ -335,9 +355,9 @@ struct Solver {
         if (MODE == MODE_IPM) {
             double d, tgt;
             // (weights from the state AS STORED: the roll-out recomputes them from what it reads back)
-            if (live_f) { store_f(i, rf); rf = soft_row((float)rf.tl, (float)rf.tu, (float)rf.zl, (float)rf.zu, lof); row_weight(rf, lof, upf, sm, d, tgt); add_lpsi_term(v, w_s * d * rcp(w_s + d), L0, tgt); }
+            if (live_f) { store_f(i, rf); rf = soft_row((float)rf.tl, (float)rf.tu, (float)rf.zl, (float)rf.zu, lof); row_weight(rf, lof, upf, sm, d, tgt); add_lpsi_term(v, w_s * d * rcpq(w_s + d), L0, tgt); }
             else add_lpsi_term(v, w_s, L0, upf);
-            if (live_r) { store_r(i, rr); rr = soft_row((float)rr.tl, (float)rr.tu, (float)rr.zl, (float)rr.zu, lor); row_weight(rr, lor, upr, sm, d, tgt); add_lpsi_term(v, w_s * d * rcp(w_s + d), Lr, tgt); }
+            if (live_r) { store_r(i, rr); rr = soft_row((float)rr.tl, (float)rr.tu, (float)rr.zl, (float)rr.zu, lor); row_weight(rr, lor, upr, sm, d, tgt); add_lpsi_term(v, w_s * d * rcpq(w_s + d), Lr, tgt); }
             else if (on_r) add_lpsi_term(v, w_s, Lr, upr);
             store_k(i, rk); rk = hard_row(rk.g, (float)rk.tl, (float)rk.tu, (float)rk.zl, (float)rk.zu);
             row_weight(rk, -kl, kl, sm, d, tgt);
@@ -353,7 +373,7 @@ struct Solver {
         ws.st(D_LAM, i, lam);
         if (af != 0) add_lpsi_term(v, w_s, L0, af > 0 ? upf : lof);
         if (ar != 0) add_lpsi_term(v, w_s, Lr, ar > 0 ? upr : lor);
-        if (ak != 0) { const double w = 1.0 / kDelta; v.P[5] += w; v.p[2] -= w * (ak * kl - kDelta * lam); }
+        if (ak != 0) { const double w = kInvDelta; v.P[5] += w; v.p[2] -= w * (ak * kl - kDelta * lam); }
     }
     // the two end rows (base_solver.cpp:208-209,250-259), part of waypoint n - 1
     PQP_HD void end_cost(int mode, double sm, Value& v) {
@@ -380,14 +400,14 @@ struct Solver {
             act_ep = !has_ep ? 0 : (ep.zu > ep.tu ? 1 : (ep.zl > ep.tl ? -1 : 0));
             lam_ep = act_ep > 0 ? ep.zu : (act_ep < 0 ? -ep.zl : 0.0);
         }
-        const double w = 1.0 / kDelta;
+        const double w = kInvDelta;
         if (act_el != 0) { v.P[0] += w; v.p[0] -= w * (act_el * L - kDelta * lam_el); }
         if (act_ep != 0) { v.P[3] += w; v.p[1] -= w * ((act_ep > 0 ? psi_hi : psi_lo) - kDelta * lam_ep); }
     }
     double gp_el, gp_ep;          // end-row values of the last interior-point roll-out
 
     template <int MODE>
-    PQP_HD void backward(double sm) {
+    PQP_SWEEP void backward(double sm) {
         Value v;
         for (int k = 0; k < 6; ++k) v.P[k] = 0.0;
         v.p[0] = v.p[1] = v.p[2] = 0.0;
@@ -414,7 +434,7 @@ struct Solver {
         x[2] = x[2] + in.s.ds * u; x[0] = y0; x[1] = y1;
     }
     // after the initial solve: the interior-point state of every row, strictly inside its box where the row has a slack
-    PQP_HD void forward_init() {
+    PQP_SWEEP void forward_init() {
         const double theta = 0.05, mu0 = 0.1;
         double x[3] = {x0[0], x0[1], x0[2]};
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -423,7 +443,7 @@ struct Solver {
             const double wd = up - lo;
             r.g = slack ? fmin(fmax(v, lo + theta * wd), up - theta * wd) : v;
             r.tl = fmax(r.g - lo, theta * wd); r.tu = fmax(up - r.g, theta * wd);
-            r.zl = mu0 * rcp(r.tl); r.zu = mu0 * rcp(r.tu);
+            r.zl = mu0 * rcpq(r.tl); r.zu = mu0 * rcpq(r.tu);
             acc.s0 += r.tl * r.zl + r.tu * r.zu; acc.cnt += 2.0;
             acc.res = fmax(acc.res, fmax(fabs(r.g - lo - r.tl), fabs(up - r.g - r.tu)));
             return r;
@@ -443,16 +463,16 @@ struct Solver {
     }
     // a re-linearised pass: the interior-point state out of the previous pass's optimum, its active set and multipliers
     struct WarmIn { double xl, xp, xk, act, lam; Box b; };
-    PQP_HD void warm_init() {
+    PQP_SWEEP void warm_init() {
         const double mu_w = kMuWarm, sq = sqrt(kMuWarm);
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         auto start = [&](double v, double y, double lo, double up, bool slack) {
             Row r;
             r.zu = fmax(y, 0.0); r.zl = fmax(-y, 0.0);
-            const double tl_min = mu_w * rcp(fmax(r.zl, sq)), tu_min = mu_w * rcp(fmax(r.zu, sq));
+            const double tl_min = mu_w * rcpq(fmax(r.zl, sq)), tu_min = mu_w * rcpq(fmax(r.zu, sq));
             if (slack) { r.g = fmin(fmax(fmin(fmax(v, lo), up), lo + tl_min), up - tu_min); r.tl = r.g - lo; r.tu = up - r.g; }
             else { r.g = v; r.tl = fmax(v - lo, tl_min); r.tu = fmax(up - v, tu_min); }
-            r.zl = fmax(r.zl, mu_w * rcp(fmax(r.tl, sq))); r.zu = fmax(r.zu, mu_w * rcp(fmax(r.tu, sq)));
+            r.zl = fmax(r.zl, mu_w * rcpq(fmax(r.tl, sq))); r.zu = fmax(r.zu, mu_w * rcpq(fmax(r.tu, sq)));
             acc.s0 += r.tl * r.zl + r.tu * r.zu; acc.cnt += 2.0;
             acc.res = fmax(acc.res, fmax(fabs(r.g - lo - r.tl), fabs(up - r.g - r.tu)));
             return r;
@@ -482,7 +502,7 @@ struct Solver {
         mu = acc.s0 / acc.cnt; res = acc.res; alpha = 0.0;
     }
     // roll-out of an interior-point iteration: row values of the Newton point, the step to the boundary, next complementarity
-    PQP_HD void forward_ipm(double sm) {
+    PQP_SWEEP void forward_ipm(double sm) {
         double x[3] = {x0[0], x0[1], x0[2]};
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         sweep_up<kDepth, FwdIn>(0, n - 1, [&](int i) { return load_fwd<MODE_IPM>(i); }, [&](int i, const FwdIn& in) {
@@ -495,7 +515,7 @@ struct Solver {
                 double d, tgt;
                 row_weight(r, lof, upf, sm, d, tgt);
                 const double v = x[0] + L0 * x[1];
-                const double dg = as_stored(v - d * rcp(w_s + d) * (v - tgt) - r.g);           // (+ the slack of the Newton point)
+                const double dg = as_stored(v - d * rcpq(w_s + d) * (v - tgt) - r.g);           // (+ the slack of the Newton point)
                 ws.stf(S_DGF, j, dg);
                 row_accumulate(r, row_step(r, lof, upf, sm, dg), lof, upf, acc, false);
             }
@@ -504,7 +524,7 @@ struct Solver {
                 double d, tgt;
                 row_weight(r, lor, upr, sm, d, tgt);
                 const double v = x[0] + Lr * x[1];
-                const double dg = as_stored(v - d * rcp(w_s + d) * (v - tgt) - r.g);
+                const double dg = as_stored(v - d * rcpq(w_s + d) * (v - tgt) - r.g);
                 ws.stf(S_DGR, j, dg);
                 row_accumulate(r, row_step(r, lor, upr, sm, dg), lor, upr, acc, false);
             }
@@ -516,14 +536,14 @@ struct Solver {
         gp_el = x[0]; gp_ep = x[1];
         row_accumulate(el, row_step(el, -a.prm.end_l_bound, a.prm.end_l_bound, sm, gp_el - el.g), -a.prm.end_l_bound, a.prm.end_l_bound, acc);
         if (psi_hi < kBig) row_accumulate(ep, row_step(ep, psi_lo, psi_hi, sm, gp_ep - ep.g), psi_lo, psi_hi, acc);
-        alpha = acc.rho > 0.995 ? 0.995 * rcp(acc.rho) : 1.0;
+        alpha = acc.rho > 0.995 ? 0.995 * rcpq(acc.rho) : 1.0;
         sm_prev = sm;
         mu = (acc.s0 + alpha * (acc.s1 + alpha * acc.s2)) / acc.cnt;      // complementarity after the step
         res = (1.0 - alpha) * acc.res;
     }
     // roll-out of an active-set round: the point, the set it asks for, the multipliers of its hard rows.  Returns true when the point
     // confirms its set (the KKT test) and holds its hard rows.
-    PQP_HD bool forward_set() {
+    PQP_SWEEP bool forward_set() {
         double x[3] = {x0[0], x0[1], x0[2]};
         bool changed = false;
         double pin = 0.0;
@@ -536,7 +556,7 @@ struct Solver {
         auto hard = [&](int act, double& lam, double v, double lo, double up) {
             if (act != 0) {
                 const double bnd = act > 0 ? up : lo;
-                const double y = lam + (v - bnd) / kDelta;              // multiplier of the active row
+                const double y = lam + (v - bnd) * kInvDelta;              // multiplier of the active row
                 if (act * y < -kSetTol) { lam = 0.0; return 0; }       // wrong sign: released
                 pin = fmax(pin, fabs(v - bnd));
                 lam = y;
@@ -602,7 +622,7 @@ struct Solver {
 
     // BaseSolver::getOptimizedPath (base_solver.cpp:263-288)
     struct OutIn { double l, dpsi, k, K0, K1, K2, kk, angle, rx, ry; };
-    PQP_HD void unpack() {
+    PQP_SWEEP void unpack() {
         const double* rq = a.ref + (size_t)qp * a.n * PQP_REF_STRIDE;
         double* oq = a.out + (size_t)qp * a.n * PQP_OUT_STRIDE;
         sweep_up<kDepth, OutIn>(0, n, [&](int i) {
@@ -629,7 +649,6 @@ struct Solver {
     PQP_HD void finish(int status, int solved_passes) {
         if (a.status) a.status[qp] = status;
         if (a.iters) a.iters[qp] = ipm_iters;
-        if (a.cost) a.cost[qp] = fac;
         if (a.info) {
             double* f = a.info + (size_t)qp * PQP_INFO_STRIDE;
             f[0] = res; f[1] = mu; f[2] = (double)ipm_iters_first; f[3] = (double)ipm_iters; f[4] = (double)solved_passes; f[5] = (double)set_rounds_first;

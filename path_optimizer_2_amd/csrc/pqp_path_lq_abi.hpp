@@ -43,9 +43,6 @@ struct Args {
     int32_t* iters;             // [batch] or nullptr: interior-point iterations over all passes
     double* info;               // [batch][PQP_INFO_STRIDE] or nullptr
     double* ws;                 // [ceil(batch / 64)][n][kBlockDoubles][64]
-    const int32_t* order;       // [batch] lane slot -> QP, or nullptr: slot k solves QP k.  QPs of similar cost share a wavefront (a
-                                // wavefront runs as long as its slowest lane); results do not depend on it
-    int32_t* cost;              // [batch] or nullptr: Riccati sweeps each QP took (the key of the next launch's order)
     pqp_params prm;
 };
 

@@ -16,36 +16,18 @@ namespace pqp {
 __global__ void __launch_bounds__(64, PQP_STREAM_OCC) path_stream_kernel(const lq::Args a) {
     // (blockDim.x = lanes per wavefront in use: 64, or 32 - half-filled wavefronts, two per SIMD: PQP_STREAM_LANES)
     const int lanes = (int)blockDim.x;
-    const int slot = blockIdx.x * lanes + threadIdx.x;
-    if (slot >= a.batch) return;
-    const int qp = a.order ? a.order[slot] : slot;
+    // (Sorting the QPs by the sweeps they took in the previous solve, so that a wavefront's 64 lanes finish together, was built and
+    // measured: 11 % less traffic and 14 % fewer instructions, the same 10.7 ms at 65 536 QPs - every wavefront is resident at once and the
+    // launch lasts as long as its slowest one - and its ordering kernel waited milliseconds for a free slot behind a second launch in
+    // flight.  Dropped: profiles/r03d_stream_ordered.txt.)
+    const int qp = blockIdx.x * lanes + threadIdx.x;
+    if (qp >= a.batch) return;
     lq::StridedWs ws{a.ws + (size_t)blockIdx.x * a.n * lq::kBlockDoubles * lanes, (int)threadIdx.x, lanes};
     lq::Solver<lq::StridedWs> s(a, qp, ws);
     s.run();
 }
 
-// lane slot -> QP of the next launch: QPs sorted by the Riccati sweeps they took in the previous solve of the same batch (a planner
-// re-solves nearly the same scenarios cycle after cycle), so that the 64 lanes of a wavefront finish together.  Counting sort in one
-// workgroup: 128 bins in LDS; the order inside a bin is whatever the atomics give (results do not depend on the order).
-__global__ void __launch_bounds__(1024) stream_order_kernel(int batch, const int32_t* __restrict__ cost, int32_t* __restrict__ order) {
-    __shared__ int start[128];
-    for (int b = threadIdx.x; b < 128; b += blockDim.x) start[b] = 0;
-    __syncthreads();
-    for (int q = threadIdx.x; q < batch; q += blockDim.x) atomicAdd(&start[min(max(cost[q], 0), 127)], 1);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int b = 127; b >= 0; --b) { const int c = start[b]; start[b] = acc; acc += c; }       // most expensive first
-    }
-    __syncthreads();
-    for (int q = threadIdx.x; q < batch; q += blockDim.x) order[atomicAdd(&start[min(max(cost[q], 0), 127)], 1)] = q;
-}
 }  // namespace pqp
-
-extern "C" hipError_t pqp_stream_order_launch(int batch, const int32_t* cost, int32_t* order, void* stream) {
-    hipLaunchKernelGGL(pqp::stream_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, batch, cost, order);
-    return hipGetLastError();
-}
 
 #ifndef PQP_STREAM_LANES
 #define PQP_STREAM_LANES 64

@@ -57,30 +57,6 @@ def test_stream_kernel_equals_the_lane_per_waypoint_kernel(hip_lib):
     assert d.max() < 2e-5 and np.median(d) < 1e-7, (d.max(), np.median(d))
 
 
-def test_stream_kernel_lane_order_by_cost_does_not_change_a_bit(hip_lib):
-    """PQP_OPT_ORDER_BY_COST on the lane-per-QP kernel: from the second solve of a shape on the lanes of a wavefront are QPs of equal cost."""
-    import torch
-    from path_optimizer_2_amd import capi
-    from path_optimizer_2_amd.synth import make_batch
-    batch, n = 4100, 80                                         # (not a multiple of 64: the last wavefront is ragged)
-    b = make_batch(batch, n, seed=2)
-    dev = torch.device("cuda", 0)
-    ref, bounds, scal = (torch.from_numpy(b[k]).to(dev) for k in ("ref", "bounds", "scal"))
-    h = _handle(capi, batch, n)
-    h.set_option(capi.OPT_ORDER_BY_COST, 1)
-    outs = []
-    for _ in range(3):
-        out = torch.full((batch, n, 7), float("nan"), dtype=torch.float64, device=dev)
-        st = torch.zeros(batch, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
-        h.solve_device(batch, n, ref, bounds, scal, out, passes=1, status=st)
-        h.sync()
-        outs.append(out.cpu().numpy())
-        assert (st.cpu().numpy() == 1).all()
-    h.close()
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
-
-
 def test_stream_kernel_first_solve_only_and_a_given_linearisation_point(hip_lib):
     """passes = 0 is BaseSolver::solve alone; lin != NULL is updateProblemFormulationAndSolve's QP solved cold."""
     import pqp_oracle_c as OC
