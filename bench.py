@@ -77,7 +77,7 @@ def algorithmic_bytes(n, kkt_solves, admm_iters, factors, setups):
 
 # bytes per waypoint of one sweep of path_stream_kernel (fields read + written, fp64 problem data / gains / point,
 # fp32 interior-point state); "1": a pass linearised around (0, 0, k_ref) streams 3 of the 8 transition doubles, "2": a re-linearised pass all 8
-STREAM_BYTES = {"prep1": 184, "init": 232, "ipm1": 336, "ipm2": 416, "guess1": 172, "guess2": 212, "fset1": 144, "fset2": 184,
+STREAM_BYTES = {"prep1": 184, "init": 232, "ipm1": 368, "ipm2": 448, "guess1": 172, "guess2": 212, "fset1": 144, "fset2": 184,
                 "bset1": 104, "bset2": 144, "prep2": 104, "warm": 128, "unpack": 136}
 
 

@@ -30,6 +30,9 @@
 #pragma once
 #include "pqp_path_lane.hpp"
 #include "pqp_path_lq_abi.hpp"
+#if defined(PQP_LQ_DEBUG) && !defined(__HIP_DEVICE_COMPILE__)
+#include <cstdio>
+#endif
 
 namespace pqp {
 namespace lq {
@@ -42,7 +45,7 @@ constexpr double kPinTol = 1e-9;        // accepted points hold their hard activ
 constexpr double kMuStop = 1e-6;        // complementarity at which the interior-point rounds hand over to the active-set rounds
 constexpr double kMuWarm = 1e-3;        // complementarity a re-linearised pass starts from
 constexpr double kEqWidth = 1e-6;       // a collision box narrower than this is an equality row (weight w_s at its upper bound)
-constexpr int kIpmMaxIter = 60;
+constexpr int kIpmMaxIter = 100;
 constexpr int kPolishMaxRounds = 12;
 
 // a two-sided row of the interior-point rounds
@@ -96,6 +99,12 @@ PQP_HD RowStep row_step(const Row& r, double lo, double up, double sm, double dg
 }
 PQP_HD void row_accumulate(const Row& r, const RowStep& s, double lo, double up, Acc& a, bool hard = true) {
     const double itl = rcpq(r.tl), itu = rcpq(r.tu), izl = rcpq(r.zl), izu = rcpq(r.zu);
+#if defined(PQP_LQ_DEBUG) && !defined(__HIP_DEVICE_COMPILE__)
+    {
+        const double m = fmax(fmax(-s.dtl * itl, -s.dtu * itu), fmax(-s.dzl * izl, -s.dzu * izu));
+        if (m > a.rho && m > 100.0) std::fprintf(stderr, "    blocking row (hard %d): g %.9g lo %.9g up %.9g | tl %.3e tu %.3e zl %.3e zu %.3e | dg %.3e dtl %.3e dtu %.3e dzl %.3e dzu %.3e\n", (int)hard, r.g, lo, up, r.tl, r.tu, r.zl, r.zu, s.dg, s.dtl, s.dtu, s.dzl, s.dzu);
+    }
+#endif
     a.rho = fmax(fmax(a.rho, -s.dtl * itl), fmax(-s.dtu * itu, fmax(-s.dzl * izl, -s.dzu * izu)));
     a.s0 += r.tl * r.zl + r.tu * r.zu;
     a.s1 += r.tl * s.dzl + r.zl * s.dtl + r.tu * s.dzu + r.zu * s.dtu;
@@ -105,6 +114,15 @@ PQP_HD void row_accumulate(const Row& r, const RowStep& s, double lo, double up,
 }
 // what the roll-out hands to the next backward sweep goes through an fp32 field: both sweeps use the value as stored
 PQP_HD double as_stored(double v) { return (double)(float)v; }
+// Centrality safeguard after a step (the role of IPOPT's kappa_Sigma): a multiplier is kept within [mu / (kappa t), kappa mu / t].  Without it a
+// row that blocks several consecutive 0.995-steps loses its slack 200x per step while its multiplier stands still, the pair leaves every
+// neighbourhood of the central path and the steps shrink to nothing (seen on QPs whose end-heading box lies 1 rad off the line's heading).
+constexpr double kCentral = 1e3;
+PQP_HD void row_centre(Row& r, double mu) {
+    const double itl = rcpq(r.tl), itu = rcpq(r.tu);
+    r.zl = fmin(fmax(r.zl, mu * itl * (1.0 / kCentral)), kCentral * mu * itl);
+    r.zu = fmin(fmax(r.zu, mu * itu * (1.0 / kCentral)), kCentral * mu * itu);
+}
 PQP_HD void row_apply(Row& r, const RowStep& s, double alpha) {
     r.g += alpha * s.dg; r.tl += alpha * s.dtl; r.tu += alpha * s.dtu; r.zl += alpha * s.dzl; r.zu += alpha * s.dzu;
 }
@@ -311,8 +329,7 @@ struct Solver {
     PQP_HD FwdIn load_fwd(int i) const {
         FwdIn in;
         in.s = load_stage(i);
-        if (MODE == MODE_IPM) { in.K0 = ws.ldf(S_K0, i); in.K1 = ws.ldf(S_K1, i); in.K2 = ws.ldf(S_K2, i); in.kk = ws.ldf(S_KK, i); }
-        else { in.K0 = ws.ld(D_K0, i); in.K1 = ws.ld(D_K1, i); in.K2 = ws.ld(D_K2, i); in.kk = ws.ld(D_KK, i); }
+        in.K0 = ws.ld(D_K0, i); in.K1 = ws.ld(D_K1, i); in.K2 = ws.ld(D_K2, i); in.kk = ws.ld(D_KK, i);
         in.b = load_box(i + 1);
         if (MODE == MODE_IPM) in.r = load_rows(i + 1);
         if (MODE == MODE_SET) { in.act = ws.ld(D_ACT, i + 1); in.lam = ws.ld(D_LAM, i + 1); }
@@ -348,9 +365,9 @@ struct Solver {
         Row rf = soft_row(in.r.tlf, in.r.tuf, in.r.zlf, in.r.zuf, lof), rr = soft_row(in.r.tlr, in.r.tur, in.r.zlr, in.r.zur, lor);
         Row rk = hard_row(in.r.gk, in.r.tlk, in.r.tuk, in.r.zlk, in.r.zuk);
         if (alpha > 0.0) {
-            if (live_f) row_apply(rf, row_step(rf, lof, upf, sm_prev, in.dgf), alpha);
-            if (live_r) row_apply(rr, row_step(rr, lor, upr, sm_prev, in.dgr), alpha);
-            row_apply(rk, row_step(rk, -kl, kl, sm_prev, in.dgk), alpha);
+            if (live_f) { row_apply(rf, row_step(rf, lof, upf, sm_prev, in.dgf), alpha); row_centre(rf, mu); }
+            if (live_r) { row_apply(rr, row_step(rr, lor, upr, sm_prev, in.dgr), alpha); row_centre(rr, mu); }
+            row_apply(rk, row_step(rk, -kl, kl, sm_prev, in.dgk), alpha); row_centre(rk, mu);
         }
         if (MODE == MODE_IPM) {
             double d, tgt;
@@ -380,14 +397,17 @@ struct Solver {
         const bool has_ep = psi_hi < kBig;
         const double L = a.prm.end_l_bound;
         if (mode == MODE_INIT) {
-            v.P[0] += 1.0;
-            if (has_ep) { v.P[3] += 1.0; v.p[1] -= 0.5 * (psi_lo + psi_hi); }
+            // the initial point reaches for the middle of the end boxes with a weight the controls cannot ignore: an end heading a radian off
+            // the line's would otherwise start the hard rows a radian infeasible, and the infeasible start then crawls (40 iterations)
+            const double we = 1e3;
+            v.P[0] += we;
+            if (has_ep) { v.P[3] += we; v.p[1] -= we * 0.5 * (psi_lo + psi_hi); }
             return;
         }
         if (mode == MODE_IPM || mode == MODE_GUESS) {
             if (alpha > 0.0) {
-                row_apply(el, row_step(el, -L, L, sm_prev, gp_el - el.g), alpha);
-                if (has_ep) row_apply(ep, row_step(ep, psi_lo, psi_hi, sm_prev, gp_ep - ep.g), alpha);
+                row_apply(el, row_step(el, -L, L, sm_prev, gp_el - el.g), alpha); row_centre(el, mu);
+                if (has_ep) { row_apply(ep, row_step(ep, psi_lo, psi_hi, sm_prev, gp_ep - ep.g), alpha); row_centre(ep, mu); }
             }
             if (mode == MODE_IPM) {
                 double d, tgt;
@@ -415,8 +435,7 @@ struct Solver {
             if (i < n - 1) {
                 double K[3], kk;
                 riccati_step(in.s, w_u, v, K, kk);
-                if (MODE == MODE_IPM) { ws.stf(S_K0, i, K[0]); ws.stf(S_K1, i, K[1]); ws.stf(S_K2, i, K[2]); ws.stf(S_KK, i, kk); }
-                else { ws.st(D_K0, i, K[0]); ws.st(D_K1, i, K[1]); ws.st(D_K2, i, K[2]); ws.st(D_KK, i, kk); }
+                ws.st(D_K0, i, K[0]); ws.st(D_K1, i, K[1]); ws.st(D_K2, i, K[2]); ws.st(D_KK, i, kk);
                 if (i > 0) stage_cost<MODE>(i, in, sm, v);
             } else {
                 stage_cost<MODE>(i, in, sm, v);
@@ -442,7 +461,10 @@ struct Solver {
             Row r;
             const double wd = up - lo;
             r.g = slack ? fmin(fmax(v, lo + theta * wd), up - theta * wd) : v;
-            r.tl = fmax(r.g - lo, theta * wd); r.tu = fmax(up - r.g, theta * wd);
+            // (a hard row that starts outside its box gets slacks as large as its violation: with small ones the steps of the infeasible
+            //  start are cut by those very slacks and the residual falls by a few per cent per iteration)
+            const double viol = fmax(fmax(lo - r.g, r.g - up), 0.0);
+            r.tl = fmax(fmax(r.g - lo, theta * wd), viol); r.tu = fmax(fmax(up - r.g, theta * wd), viol);
             r.zl = mu0 * rcpq(r.tl); r.zu = mu0 * rcpq(r.tu);
             acc.s0 += r.tl * r.zl + r.tu * r.zu; acc.cnt += 2.0;
             acc.res = fmax(acc.res, fmax(fabs(r.g - lo - r.tl), fabs(up - r.g - r.tu)));
@@ -471,7 +493,7 @@ struct Solver {
             r.zu = fmax(y, 0.0); r.zl = fmax(-y, 0.0);
             const double tl_min = mu_w * rcpq(fmax(r.zl, sq)), tu_min = mu_w * rcpq(fmax(r.zu, sq));
             if (slack) { r.g = fmin(fmax(fmin(fmax(v, lo), up), lo + tl_min), up - tu_min); r.tl = r.g - lo; r.tu = up - r.g; }
-            else { r.g = v; r.tl = fmax(v - lo, tl_min); r.tu = fmax(up - v, tu_min); }
+            else { const double viol = fmax(fmax(lo - v, v - up), 0.0); r.g = v; r.tl = fmax(fmax(v - lo, tl_min), viol); r.tu = fmax(fmax(up - v, tu_min), viol); }
             r.zl = fmax(r.zl, mu_w * rcpq(fmax(r.tl, sq))); r.zu = fmax(r.zu, mu_w * rcpq(fmax(r.tu, sq)));
             acc.s0 += r.tl * r.zl + r.tu * r.zu; acc.cnt += 2.0;
             acc.res = fmax(acc.res, fmax(fabs(r.g - lo - r.tl), fabs(up - r.g - r.tu)));
@@ -598,19 +620,28 @@ struct Solver {
             else warm_init();
             bool first = true;
             int it = 0, stall = 0;
-            while (!(mu < mu_stop && res < 1e-6) && it < kIpmMaxIter && stall < 6) {
+            int slow = 0;          // iterations in a row with a step below 1e-3 although the rows are feasible: complementarity has stopped falling
+            const double res0 = res;
+            // (a QP whose hard rows start far outside their boxes - an end heading a radian off what the curvature limit can reach early on the
+            //  line - crawls: 2 % of residual per iteration.  Every QP of the bench distributions is feasible within 12 iterations; one that
+            //  has not shed 90 % of its initial residual after 30 gives up as PQP_STATUS_MAX_ITER instead of holding its wavefront for 100)
+            while (!(mu < mu_stop && res < 1e-6) && it < kIpmMaxIter && stall < 6 && slow < 3 && !(it >= 30 && res > 0.1 * res0 && res > 1e-6)) {
                 const double sigma = (first || alpha <= 0.9) ? 0.2 : 0.05;
                 const double sm = sigma * mu;
                 backward<MODE_IPM>(sm);
                 forward_ipm(sm);
                 stall = (alpha < 1e-3 && res > 1e-6) ? stall + 1 : 0;
+                slow = (alpha < 1e-3 && res <= 1e-6) ? slow + 1 : 0;
+#if defined(PQP_LQ_DEBUG) && !defined(__HIP_DEVICE_COMPILE__)
+                std::fprintf(stderr, "  qp %d attempt %d it %d: sigma %.2f alpha %.3e mu %.3e res %.3e\n", qp, attempt, it, sigma, alpha, mu, res);
+#endif
                 first = false;
                 it += 1;
             }
             ipm_iters += it;
             if (!(mu == mu)) return PQP_STATUS_NUMERICAL;
-            if (!(res < 1e-6)) return PQP_STATUS_PRIMAL_INFEASIBLE;
-            if (!(mu < mu_stop)) return PQP_STATUS_MAX_ITER;
+            if (!(res < 1e-6)) return stall >= 6 ? PQP_STATUS_PRIMAL_INFEASIBLE : PQP_STATUS_MAX_ITER;
+            if (!(mu < 1e-3)) return PQP_STATUS_MAX_ITER;              // (short of mu_stop but below 1e-3: the active-set rounds get their chance)
             backward<MODE_GUESS>(0.0);
             for (int r = 0; r < kPolishMaxRounds; ++r) {
                 if (forward_set()) return PQP_STATUS_SOLVED;

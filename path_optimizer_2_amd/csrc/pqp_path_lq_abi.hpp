@@ -11,24 +11,24 @@ namespace lq {
 // Workspace: per waypoint and lane kFieldsD doubles followed by kFieldsF floats; element (waypoint i, field f) of lane j of a
 // wavefront's block sits at block[(i * kBlockDoubles + f) * 64 + j] (doubles) resp. ((float*)(block + (i * kBlockDoubles + kFieldsD) * 64))[f * 64 + j].
 // fp64: everything an ACTIVE-SET round reads or writes (problem data, gains, the point) - those rounds return the result.  fp32: what only
-// the interior-point rounds exchange between their sweeps (slacks, multipliers, row steps, gains): they only have to predict the active set.
+// the interior-point rounds exchange between their sweeps (slacks, multipliers, row steps): they only have to predict the active set.
 enum FieldD {
     D_M00 = 0, D_M01, D_M10, D_M11, D_M12, D_C0, D_C1, D_DS,      // transition i -> i + 1 (i < n - 1)
     D_LOF, D_UPF, D_LOR, D_UPR,                                    // soft boxes of the collision rows (rear off: up = +inf)
-    D_K0, D_K1, D_K2, D_KK,                                        // feedback law u_i = -K x_i - k of the last active-set round
+    D_K0, D_K1, D_K2, D_KK,                                        // feedback law u_i = -K x_i - k of the last backward sweep
     D_X0, D_X1, D_X2,                                              // the point of the last active-set round
     D_GK,                                                          // interior-point rounds: value of the kappa row (its residual needs all digits)
     D_ACT, D_LAM,                                                  // active-set rounds: the three rows' states packed as f + 3 r + 9 k + 13; multiplier of the kappa row
     kFieldsD
 };
 enum FieldF {
-    S_K0 = 0, S_K1, S_K2, S_KK,                                    // feedback law of the last interior-point sweep
-    S_DGF, S_DGR, S_DGK,                                           // row steps of the last interior-point roll-out
+    S_DGF = 0, S_DGR, S_DGK,                                       // row steps of the last interior-point roll-out
     S_TLF, S_TUF, S_ZLF, S_ZUF, S_TLR, S_TUR, S_ZLR, S_ZUR, S_TLK, S_TUK, S_ZLK, S_ZUK,     // slacks and multipliers of the three rows
-    S_PAD,
+    S_PAD,      // (the gains stay fp64 in every round: an fp32 gain times a state of order 1 is 1e-8 of noise in a row value, more than the slack
+                // of a tightly active row near the end of the interior-point rounds - the steps then shrink to nothing)
     kFieldsF
 };
-constexpr int kBlockDoubles = kFieldsD + kFieldsF / 2;            // 32 doubles = 256 bytes per waypoint and QP
+constexpr int kBlockDoubles = kFieldsD + kFieldsF / 2;            // 30 doubles = 240 bytes per waypoint and QP
 static_assert(kFieldsF % 2 == 0, "the float fields fill whole doubles");
 
 struct Args {

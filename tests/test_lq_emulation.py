@@ -124,3 +124,38 @@ def test_narrow_and_degenerate_corridors():
     for q in range(3):
         want = OC.solve_path(OC.params(**TIGHT_C), b["ref"][q], b["bounds"][q], b["scal"][q], passes=1)["out"]
         assert np.abs(r["out"][q][:, 3:5] - want[:, 3:5]).max() < 2e-5, q
+
+
+def test_fuzzed_scenarios_are_solved_right_or_reported_unsolved():
+    """Corridors 0.1-3 m wide around a wandering centre, start states up to 2 m / 0.5 rad off the line, steering limits of 8-20 degrees,
+    blocked roads, end headings up to 3 rad off, 2-130 waypoints.  Whatever is reported SOLVED is the oracle's path; what the oracle
+    solves is solved here too unless the scenario is one of the end-heading U-turns (status MAX_ITER, reported after 30 iterations)."""
+    rng = np.random.default_rng(0)
+    prm = OC.params(**TIGHT_C)
+    solved = wrong = missed = 0
+    for trial in range(10):
+        n = int(rng.choice([2, 3, 5, 17, 40, 80, 130]))
+        B = 24
+        b = make_batch(B, n, str(rng.choice(["uniform", "varied"])), seed=int(rng.integers(1, 1 << 30)))
+        mode = trial % 5
+        if mode == 1:
+            w = rng.uniform(0.05, 1.5, (B, 1)); c = rng.uniform(-0.5, 0.5, (B, n))
+            b["bounds"][:, :, 0] = c - w; b["bounds"][:, :, 1] = c + w; b["bounds"][:, :, 2] = c - w * rng.uniform(0.5, 1.5, (B, 1)); b["bounds"][:, :, 3] = c + w
+        if mode == 2:
+            b["scal"][:, 0] = rng.uniform(-2, 2, B); b["scal"][:, 1] = rng.uniform(-0.5, 0.5, B)
+        if mode == 3:
+            b["scal"][:, 5] = np.deg2rad(rng.uniform(8, 20, B)); b["scal"][:, 4] = rng.integers(0, 2, B)
+        if mode == 4:
+            b["scal"][:, 3] = rng.uniform(-3, 3, B)
+        r = E.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+        for q in range(B):
+            o = OC.solve_path(prm, b["ref"][q], b["bounds"][q], b["scal"][q], passes=1)
+            if r["status"][q] == 1:
+                solved += 1
+                if o["ok"] and np.abs(o["out"][:, 3:5] - r["out"][q][:, 3:5]).max() > 1e-4:
+                    wrong += 1
+            elif o["ok"] and mode != 4:
+                missed += 1
+            assert r["iters"][q] <= 260                         # (two passes of at most 100 + the retry: nobody iterates for ever)
+    assert wrong == 0 and missed == 0, (wrong, missed)
+    assert solved > 150

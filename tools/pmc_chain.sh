@@ -26,13 +26,15 @@ dur = {}
 for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         dur[row["Name"].split("(")[0].replace("void ", "")] = (float(row["AverageNs"]), int(row["Calls"]), float(row["Percentage"]))
-print("kernel | calls | avg us | % of GPU time | HBM MB/launch (2 x FETCH_SIZE + WRITE_SIZE) | GB/s | VALU-active / wave cycles | LDS-active | waiting | VALU instr/launch | LDS instr/launch")
+print("kernel | calls | avg us | % of GPU time | HBM MB/launch (2 x FETCH_SIZE + WRITE_SIZE) | GB/s | HBM roofline frac (of 8 TB/s) | VALU issue roofline frac (VALU-active cycles / (1024 SIMDs x kernel cycles)) | VALU-active / wave cycles | LDS-active | waiting | VALU instr/launch | LDS instr/launch")
 for k, (ns, calls, pct) in sorted(dur.items(), key=lambda kv: -kv[1][2]):
     if k not in acc: continue
     a = {c: acc[k][c] / cnt[k][c] for c in acc[k]}
     mb = (2 * a.get("FETCH_SIZE", 0) + a.get("WRITE_SIZE", 0)) * 1024 / 1e6
     wc = a.get("SQ_WAVE_CYCLES", 0) or 1
-    print(f"{k} | {calls} | {ns/1e3:.1f} | {pct:.1f} | {mb:.2f} | {mb*1e6/ns:.0f} | {a.get('SQ_ACTIVE_INST_VALU',0)/wc:.2f} | {a.get('SQ_ACTIVE_INST_LDS',0)/wc:.2f} | {a.get('SQ_WAIT_ANY',0)/wc:.2f} | {a.get('SQ_INSTS_VALU',0):.3g} | {a.get('SQ_INSTS_LDS',0):.3g}")
+    kc = (a.get("GRBM_GUI_ACTIVE", 0) / 8.0) or ns * 2.4
+    issue = a.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / (1024 * kc)
+    print(f"{k} | {calls} | {ns/1e3:.1f} | {pct:.1f} | {mb:.2f} | {mb*1e6/ns:.0f} | {mb*1e6/ns/8000:.4f} | {issue:.3f} | {a.get('SQ_ACTIVE_INST_VALU',0)/wc:.2f} | {a.get('SQ_ACTIVE_INST_LDS',0)/wc:.2f} | {a.get('SQ_WAIT_ANY',0)/wc:.2f} | {a.get('SQ_INSTS_VALU',0):.3g} | {a.get('SQ_INSTS_LDS',0):.3g}")
 PY
 find $out -name "*.csv" -size +1M -delete
 cat $out/chain_pmc.txt
