@@ -128,7 +128,7 @@ def test_multi_driver_overlaps_its_shards_and_keeps_its_threads(hip_lib):
     np.testing.assert_array_equal(got["out"], want["out"])
     # an inverted collision box is refused as by the single-handle host entry point
     bad = {k: v.copy() for k, v in b1.items()}
-    bad["bounds"][7, 11, 0] = 3.0
+    bad["bounds"][7, 11, 0] = 9.0                       # (lower bound above the upper one)
     r = two.solve(bad["ref"][:64], bad["bounds"][:64], bad["scal"][:64], passes=1)
     assert r["status"][7] == 4 and (r["out"][7] == 0).all() and (np.delete(r["status"], 7) == 1).all()
     print(f"multi driver: one shard {r1 / 1e6:.2f} M paths/s, two shards on one device {r2 / 1e6:.2f} M paths/s")
