@@ -128,6 +128,26 @@ def test_assemble_rough_constraints(hip_lib):
     h.close()
 
 
+def test_solve_in_rough_constraints_mode(hip_lib):
+    """base_solver.cpp:25-34,201-205 SOLVED on the GPU (the lane-per-waypoint kernel, production setting and the reference's ADMM setting):
+    beyond precise_planning_length one collision row per waypoint on the centre circle's box, P < N."""
+    n = 70
+    b = make_batch(6, n, seed=4)
+    b["bounds"][:, :, 4] -= 0.15; b["bounds"][:, :, 5] += 0.1            # a centre box of its own
+    oprm = O.PathQpParams(rough_constraints_far_away=True, precise_planning_length=9.0)
+    st = O.OsqpSettings(eps_abs=1e-9, eps_rel=1e-9, max_iter=40000)
+    want = [O.solve_path(b["ref"][q], b["bounds"][q], b["scal"][q], prm=oprm, st=st, passes=1)[-1]["out"] for q in range(3)]
+    for prm, tol in ((capi.production_params(rough_constraints_far_away=1, precise_planning_length=9.0), 2e-6),
+                     (capi.default_params(hip_lib, eps_abs=1e-8, eps_rel=1e-8, max_iter=40000, rough_constraints_far_away=1, precise_planning_length=9.0), 5e-5)):
+        h = capi.Handle(prm, max_batch=6, max_n=n)
+        assert h.sizes(n, b["ref"][0, :, 0].copy())["precise"] < n
+        r = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+        h.close()
+        assert (r["status"] == 1).all()
+        for q in range(3):
+            assert np.abs(r["out"][q][:, 3:6] - want[q][:, 3:6]).max() < tol, (q, tol)
+
+
 @pytest.mark.parametrize("n,profile,batch", [(80, "uniform", 6), (120, "varied", 4), (200, "varied", 2), (33, "varied", 3), (8, "uniform", 3)])
 def test_solve_matches_converged_oracle(hip_lib, n, profile, batch):
     b = make_batch(batch, n, profile)
