@@ -514,7 +514,7 @@ def main():
             roofline = dict(common, achieved=abytes / avg_kernel_s / 1e9, frac=per_launch(abytes), frac_chip_wide=per_launch(abytes) * concurrency,
                             algorithmic_bytes_per_launch=abytes, traffic_over_algorithmic=(traffic / abytes) if traffic else None,
                             note="path_stream_kernel keeps nothing on chip between two sweeps: achieved = the bytes its algorithm reads and writes in its HBM workspace "
-                                 "for the sweeps every QP ran (DESIGN.md 3b: 336 / 416 B per waypoint and interior-point iteration, 248 / 328 B per active-set round, "
+                                 "for the sweeps every QP ran (DESIGN.md 3b: 368 / 448 B per waypoint and interior-point iteration, 248 / 328 B per active-set round, "
                                  "+ prep / init / unpack) / the launch's event-timed duration.  `traffic` (rocprofv3) is larger: a wavefront moves a 128-byte line "
                                  "as long as ONE of its 16 lanes is still iterating.  hbm_measured_frac = traffic / kernel time / 8 TB/s")
         else:

@@ -197,11 +197,11 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      get onto the chip when a unit is left to them.
  *   PQP_OPT_STREAM_BATCH (default 24 576; 0: never)  cold solves (warm == 0) of at least this many QPs on a handle with polish != 0 and
  *                                      PQP_OPT_STORE_WARM off run on the lane-per-QP kernel (one QP per lane, 64 per wavefront, the
- *                                      per-waypoint state streamed through a batch-interleaved workspace of 256 n bytes per QP in HBM;
+ *                                      per-waypoint state streamed through a batch-interleaved workspace of 240 n bytes per QP in HBM;
  *                                      csrc/pqp_path_lq.hpp): the path QP as a linear-quadratic control problem, interior-point rounds +
  *                                      active-set rounds whose last round is the KKT test, i.e. the same exact optimum as the lane-per-
  *                                      waypoint kernel's verified polish.  It wins where the batch fills the chip's 65 536 lanes (65 536
- *                                      QPs of 80 waypoints: 2.0x, measured crossover ~20 000); it keeps no warm state
+ *                                      QPs of 80 waypoints: 1.8-2.0x, measured crossover ~20 000); it keeps no warm state
  *                                      (hence the PQP_OPT_STORE_WARM condition), iters[] counts its interior-point iterations and info[] =
  *                                      {row residual, complementarity, iterations of the first pass, iterations, solved passes, active-set
  *                                      rounds of the first pass, Riccati sweeps, active-set rounds}.  (PQP_OPT_ORDER_BY_COST has no effect on it.) */

@@ -3,7 +3,7 @@
 //
 // One wavefront = 64 QPs in lock-step, every per-waypoint quantity streamed through the batch-interleaved workspace
 // [wavefront][waypoint][field][lane]: each load / store instruction of a wavefront is one contiguous 512-byte line.  No LDS, no
-// cross-lane traffic: HBM (or the Infinity Cache, while the workspace of 256 n bytes per QP fits its 256 MiB) bandwidth bounds it.
+// cross-lane traffic: HBM (or the Infinity Cache, while the workspace of 240 n bytes per QP fits its 256 MiB) bandwidth bounds it.
 // Replaces: the OSQP solves called at src/solver/base_solver.cpp:88,110 for batches that fill the chip's 65 536 lanes.
 #include <hip/hip_runtime.h>
 
