@@ -249,7 +249,9 @@ int pqp_path_assemble_device(pqp_handle* h, int batch, int n, int precise, const
  *   last pass, number of accepted polishes, total reduced-KKT solves (ADMM iterations + polish refinement),
  *   number of factorisations, reserved.
  *   n >= 2 waypoints, any batch.  Up to 512 waypoints: one lane per waypoint (1, 2, 4 or 8 wavefronts per QP); beyond (and for large batches,
- *   PQP_OPT_STREAM_BATCH): one lane per QP, which needs polish != 0 and warm == 0 and keeps no warm state (PQP_ERR_CAPACITY otherwise).  Which solver runs is decided
+ *   PQP_OPT_STREAM_BATCH): one lane per QP, which returns exact optima in every solver setting (zero residuals meet OSQP's termination test at
+ *   any eps) and keeps no warm state: beyond 512 waypoints warm == 1 solves the QP around `lin` cold - same optimum - and
+ *   pqp_path_get_solution is not available.  Which solver runs is decided
  *   by the handle's pqp_params: pqp_default_params = the reference's OSQP setting (eps 2e-3, no polish, infeasibility certificate),
  *   pqp_production_params = eps 1e-4 + KKT-verified polish.  out[q] holds the last iterate also when status[q] != SOLVED (the
  *   reference's solve() returns false there and leaves its output vector untouched).

@@ -945,10 +945,12 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     // lane-per-QP kernel: large batches of a caller that keeps no warm state (PQP_OPT_STREAM_BATCH), and every path of more than 512
     // waypoints (the lane-per-waypoint kernel's workgroup ends there; a reference path of 80 m at 0.15 m spacing has 530:
     // reference_path_impl.cpp:321-336) - those with any batch size and without warm state
-    if (!warm && h->prm.polish != 0 && (n > 512 || (!h->opt_store_warm && h->opt_stream_batch > 0 && batch >= h->opt_stream_batch)))
+    // (warm == 1 beyond 512 waypoints: the QP around `lin` is solved cold - its optimum is unique, a warm start only saves iterations -
+    //  so BaseSolver::solve + updateProblemFormulationAndSolve work at any size; and there also a handle in the reference's ADMM setting
+    //  gets the exact optimum: zero residuals meet OSQP's termination test at any eps)
+    if ((n > 512 && (!warm || lin)) || (h->prm.polish != 0 && !warm && !h->opt_store_warm && h->opt_stream_batch > 0 && batch >= h->opt_stream_batch))
         return path_stream_impl(h, batch, n, n_of, ref, lin, bounds, scal, passes, out, status, iters, info);
-    if (n > 512) return fail(PQP_ERR_CAPACITY, "pqp_path_solve: more than 512 waypoints per path need the lane-per-QP kernel: a handle with polish != 0 and warm == 0 "
-                                               "(the lane-per-waypoint kernel is one lane per waypoint, 26 T + 160 doubles of LDS per QP)");
+    if (n > 512) return fail(PQP_ERR_CAPACITY, "pqp_path_solve: warm == 1 beyond 512 waypoints needs the linearisation point (`lin`): the lane-per-QP kernel keeps no warm state");
     if (warm && (h->warm_batch != batch || h->warm_n != n || !h->warm_stored))
         return fail(PQP_ERR_INVALID, "pqp_path_solve: warm == 1 needs a previous solve with the same batch and n (with PQP_OPT_STORE_WARM on)");
     const size_t bn = (size_t)batch * n;

@@ -179,10 +179,15 @@ def test_paths_of_more_than_512_waypoints(hip_lib):
     for q in range(3):
         want = OC.solve_path(prm, b["ref"][q], b["bounds"][q], b["scal"][q], passes=1)["out"]
         assert np.abs(r["out"][q][:, 3:5] - want[:, 3:5]).max() < 1e-4, q
+    # BaseSolver::solve, then updateProblemFormulationAndSolve (warm == 1 with the first solution as `lin`): beyond 512 waypoints the second
+    # QP is solved cold - the same optimum as the fused launch's
+    r0 = h.solve(b["ref"], b["bounds"], b["scal"], passes=0)
+    r1 = h.solve(b["ref"], b["bounds"], b["scal"], passes=0, warm=True, lin=np.ascontiguousarray(r0["out"][:, :, 3:6]))
+    assert (r1["status"] == 1).all() and np.abs(r1["out"] - r["out"]).max() < 1e-7
     with pytest.raises(capi.PqpError):
-        h.solve(b["ref"], b["bounds"], b["scal"], passes=0, warm=True)                   # no warm state behind that kernel
+        h.get_solution(batch, n)                                                         # (no OSQP-style workspace behind that kernel)
     h.close()
-    h = capi.Handle(capi.default_params(), device=0, max_batch=batch, max_n=n)          # the reference's ADMM setting: still the 512-lane limit
-    with pytest.raises(capi.PqpError):
-        h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    h = capi.Handle(capi.default_params(), device=0, max_batch=batch, max_n=n)          # the reference's ADMM setting (what the BaseSolver shim runs)
+    rd = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
     h.close()
+    assert (rd["status"] == 1).all() and np.array_equal(rd["out"], r["out"])             # exact optima there too: they meet eps 2e-3
