@@ -371,7 +371,7 @@ def main():
     # ---------------------------------------------------------------------------------------------------------------------------
     secondary = None
     if not args.no_secondary and world == 1 and pipe is None and not args.reference_setting and polish:
-        def timed(p, order, steps, warm=3, inflight=1, variants=None):
+        def timed(p, order, steps, warm=3, inflight=1, variants=None, carry=False):
             """`steps` steps round-robin over `inflight` handles; variants: the (bounds, scal) sets consecutive steps cycle through.  Two batches in
             flight run on the headline's own two handles (parameters / start order set for the measurement): streams created later may share a
             hardware queue with each other and then do not overlap."""
@@ -383,6 +383,8 @@ def main():
                 lns = lanes[:inflight]
                 for ln in lns:
                     ln[0].set_params(p); ln[0].set_option(capi.OPT_ORDER_BY_COST, 1 if order else 0)
+            for ln in lns:
+                ln[0].set_option(capi.OPT_CARRY_CYCLES, 1 if carry else 0)
             k = [0]
 
             def one():
@@ -406,6 +408,7 @@ def main():
             hh.solve_device(batch, n, ref, variants[0][0], variants[0][1], o, passes=1, status=st, iters=it, info=inf)      # the checksum's step
             hh.sync()
             itn, stn = it.cpu().numpy(), st.cpu().numpy()
+            info_rows = stream and p.polish != 0
             r = {"value": batch * steps / tb, "unit": "paths/s", "steps": steps, "ms_per_step": tb / steps * 1e3, "batches_in_flight": inflight,
                  "kernel_ms": float(np.mean(np.concatenate([ln[0].kernel_ms_history(min(max(steps // inflight, 1), 256)) for ln in lns]))),
                  "solved": int((stn == 1).sum()),
@@ -415,7 +418,10 @@ def main():
                 if own:
                     ln[0].close()
                 else:
-                    ln[0].set_params(prm); ln[0].set_option(capi.OPT_ORDER_BY_COST, 1 if cost_order else 0)
+                    ln[0].set_params(prm); ln[0].set_option(capi.OPT_ORDER_BY_COST, 1 if cost_order else 0); ln[0].set_option(capi.OPT_CARRY_CYCLES, 0)
+            if info_rows:
+                inf_np = inf.cpu().numpy()
+                r["riccati_sweeps_mean"] = float(inf_np[:, 6].mean())
             return r
         nfl = len(lanes)
         secondary = {
@@ -433,6 +439,11 @@ def main():
             "reference_setting_eps_2e-3": dict(timed(capi.default_params(), False, max(3, args.steps // 4)),
                                                setting="what base_solver.cpp:61-62 runs: eps 2e-3, OSQP defaults, no polish; paths 2e-4..2e-2 from the optimum"),
         }
+        if stream and n_var > 1:
+            secondary["carry_cycles"] = dict(timed(prm, cost_order, args.steps, inflight=nfl, carry=True),
+                                             setting="the headline setting with PQP_OPT_CARRY_CYCLES: the first pass of every QP starts from the optimum its slot had in the handle's "
+                                                     "previous solve (the jittered variant two steps earlier) instead of cold - what a planner that re-solves its scenarios every "
+                                                     "cycle would switch on; the reference constructs a fresh solver per cycle, so `value` is measured without it")
         if not stream and cfg_id == 1 and preset_shape:
             # BASELINE configs[3]'s WHOLE batch (65 536 QPs, N = 80) on this one GPU: the size at which the lane-per-QP kernel takes over
             # (PQP_OPT_STREAM_BATCH) - measured HBM roofline: `python bench.py --config 3 --batch 65536`, profiles/r03*_bench_stream*
@@ -460,6 +471,28 @@ def main():
                     res_w[name] = {"value": bb / tb, "unit": "paths/s", "ms_per_step": tb * 1e3, "kernel_ms": kms, "solved": int((stt == 1).sum().item()),
                                    "out_sha1": hashlib.sha1(o.cpu().numpy().tobytes()).hexdigest()[:16]}
                     if thr:
+                        # the same with PQP_OPT_CARRY_CYCLES over 4 jittered variants of the batch (the scenarios one planning cycle later)
+                        var_b = []
+                        for v in range(4):
+                            hv = jitter_batch(hb, v + 1, seed=args.seed)
+                            var_b.append((torch.from_numpy(hv["bounds"]).to(dev), torch.from_numpy(hv["scal"]).to(dev)))
+                        hh.set_option(capi.OPT_CARRY_CYCLES, 1)
+                        torch.cuda.synchronize()
+                        for v in range(4):
+                            hh.solve_device(bb, 80, t_ref, var_b[v][0], var_b[v][1], o, passes=1, status=stt, info=inf)
+                        hh.sync()
+                        tc = time.perf_counter()
+                        for v in range(4):
+                            hh.solve_device(bb, 80, t_ref, var_b[v][0], var_b[v][1], o, passes=1, status=stt, info=inf)
+                        hh.sync()
+                        tcd = (time.perf_counter() - tc) / 4
+                        res_w[name]["with_carry_cycles"] = {"value": bb / tcd, "unit": "paths/s", "ms_per_step": tcd * 1e3, "solved": int((stt == 1).sum().item()),
+                                                            "riccati_sweeps_mean": float(inf.cpu().numpy()[:, 6].mean()),
+                                                            "setting": "PQP_OPT_CARRY_CYCLES on 4 jittered variants of the batch: every QP's first pass starts from its slot's previous optimum"}
+                        hh.set_option(capi.OPT_CARRY_CYCLES, 0)
+                        del var_b
+                        hh.solve_device(bb, 80, t_ref, t_b, t_s, o, passes=1, status=stt, info=inf)
+                        hh.sync()
                         ab = stream_algorithmic_bytes(80, inf.cpu().numpy())
                         res_w[name]["roofline"] = {"bound": "hbm", "kernel": "path_stream_kernel", "algorithmic_bytes_per_launch": ab, "achieved": ab / (kms * 1e-3) / 1e9,
                                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,

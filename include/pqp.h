@@ -204,8 +204,14 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      QPs of 80 waypoints: 1.8-2.0x, measured crossover ~20 000); it keeps no warm state
  *                                      (hence the PQP_OPT_STORE_WARM condition), iters[] counts its interior-point iterations and info[] =
  *                                      {row residual, complementarity, iterations of the first pass, iterations, solved passes, active-set
- *                                      rounds of the first pass, Riccati sweeps, active-set rounds}.  (PQP_OPT_ORDER_BY_COST has no effect on it.) */
-typedef enum pqp_option { PQP_OPT_STORE_WARM = 1, PQP_OPT_ORDER_BY_COST = 2, PQP_OPT_RESERVE_CUS = 3, PQP_OPT_STREAM_BATCH = 4 } pqp_option;
+ *                                      rounds of the first pass, Riccati sweeps, active-set rounds}.  (PQP_OPT_ORDER_BY_COST has no effect on it.)
+ *   PQP_OPT_CARRY_CYCLES (default 0)   the lane-per-QP kernel starts the FIRST pass of QP k from the optimum QP k had in the handle's previous
+ *                                      solve of the same batch and n (it is still in the kernel's workspace) instead of cold - a planner re-solves
+ *                                      nearly the same scenarios cycle after cycle; the reference constructs a fresh BaseSolver every cycle
+ *                                      (path_optimizer.cpp:138).  The optimum returned is the same (unique; it agrees with the cold solve to the
+ *                                      1e-7 of the KKT test); interior-point iterations per path fall from 14 to 9 on scenarios that moved by 5 %.
+ *                                      A QP that differs wildly from its slot's previous one is still solved (the start is then merely poor). */
+typedef enum pqp_option { PQP_OPT_STORE_WARM = 1, PQP_OPT_ORDER_BY_COST = 2, PQP_OPT_RESERVE_CUS = 3, PQP_OPT_STREAM_BATCH = 4, PQP_OPT_CARRY_CYCLES = 5 } pqp_option;
 int pqp_set_option(pqp_handle* h, int option, int value);
 int pqp_get_stream(pqp_handle* h, void** hip_stream);   /* hipStream_t */
 /* The handle's stream is created non-blocking: work the caller enqueued on ANOTHER stream (the inputs of a *_device call produced by

@@ -698,7 +698,8 @@ struct pqp_handle {
     unsigned long long ticket_next = 0;
     long long solves = 0;                       // solve launches so far (parity selects the cost histogram being filled)
     int hist_batch = 0, hist_n = 0;             // shape of the solve whose costs cost_key / cost_hist hold (0: none)
-    int opt_store_warm = 1, opt_order_by_cost = 0, opt_reserve_cus = 0, opt_stream_batch = 24576;
+    int opt_store_warm = 1, opt_order_by_cost = 0, opt_reserve_cus = 0, opt_stream_batch = 24576, opt_carry = 0;
+    int stream_last_batch = 0, stream_last_n = 0;      // shape of the last path_stream_kernel launch (what its workspace still holds)
     DevBuf stream_ws;                           // workspace of path_stream_kernel
     int num_cu = 0;
     int blocks_per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // occupancy of the solve kernel variants [log2(nw)][cert]
@@ -782,6 +783,7 @@ int pqp_set_option(pqp_handle* h, int option, int value) {
         case PQP_OPT_ORDER_BY_COST: h->opt_order_by_cost = value ? 1 : 0; h->hist_batch = 0; return PQP_OK;
         case PQP_OPT_RESERVE_CUS: h->opt_reserve_cus = value < 0 ? 0 : value; return PQP_OK;
         case PQP_OPT_STREAM_BATCH: h->opt_stream_batch = value < 0 ? 0 : value; return PQP_OK;
+        case PQP_OPT_CARRY_CYCLES: h->opt_carry = value ? 1 : 0; h->stream_last_batch = 0; return PQP_OK;
         default: return fail(PQP_ERR_INVALID, "pqp_set_option: unknown option");
     }
 }
@@ -922,16 +924,20 @@ static int path_stream_impl(pqp_handle* h, int batch, int n, const int32_t* n_of
                             const double* scal, int passes, double* out, int32_t* status, int32_t* iters, double* info) {
     const int waves = (batch + 63) / 64;
     int rc;
+    const void* ws_before = h->stream_ws.p;
     if ((rc = h->stream_ws.ensure((size_t)waves * n * pqp::lq::kBlockDoubles * 64 * 8))) return rc;
     pqp::lq::Args a;
     std::memset(&a, 0, sizeof(a));
     a.batch = batch; a.n = n; a.passes = passes; a.n_of = n_of; a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
     a.status = status; a.iters = iters; a.info = info; a.ws = h->stream_ws.as<double>(); a.prm = h->prm;
+    // PQP_OPT_CARRY_CYCLES: the workspace still holds, slot by slot, the optimum of the previous launch of this very shape
+    a.carry = (h->opt_carry && h->stream_last_batch == batch && h->stream_last_n == n && h->stream_ws.p == ws_before) ? 1 : 0;
     h->next_event_pair();
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
     PQP_HIP(pqp_stream_launch(&a, waves, (void*)h->stream));      // path_stream_kernel lives in its own translation unit (pqp_path_stream.hip)
     PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
+    h->stream_last_batch = batch; h->stream_last_n = n;
     h->warm_batch = batch; h->warm_n = n;
     h->warm_stored = false;
     return PQP_OK;

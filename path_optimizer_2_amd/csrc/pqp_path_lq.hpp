@@ -1,13 +1,14 @@
 // pqp_path_lq.hpp — the path QP as a linear-quadratic control problem, ONE LANE PER QP, every per-waypoint quantity streamed through a
-// batch-interleaved workspace in HBM: the large-batch solver behind pqp_path_solve_device (PQP_OPT_STREAM_BATCH).
+// batch-interleaved workspace in HBM: the solver behind pqp_path_solve* for large batches (PQP_OPT_STREAM_BATCH) and for paths of more than
+// 512 waypoints.
 //
 // reference                                                   here
 //   BaseSolver::setCost          src/solver/base_solver.cpp:119-148   the stage costs of `backward()` (weights 0 / 20 / 100, slack weight 10)
 //   BaseSolver::setConstraints   :150-261                             `prep()`: the transition rows become the dynamics x_{i+1} = M_i x_i + b u_i + c_i
 //                                                                     (same expressions as :165-186), the kappa / collision / end rows become boxes
 //   getSoftBounds                :290-295                             soft_bounds() (pqp_path_lane.hpp)
-//   OsqpEigen solve              :88,110                              `ipm()` + `polish()` below (NOT OSQP's ADMM: see "algorithm")
-//   updateProblemFormulationAndSolve :97-117                          the pass loop of solve_one(): re-linearise around the previous optimum
+//   OsqpEigen solve              :88,110                              `solve_pass()`: interior-point rounds + active-set rounds (NOT OSQP's ADMM: see "Algorithm")
+//   updateProblemFormulationAndSolve :97-117                          the pass loop of `run()`: re-linearise around the previous optimum
 //   getOptimizedPath             :263-288                             `unpack()`
 //
 // Algorithm.  The QP's variables per waypoint are the state x_i = (l, psi, kappa)_i, the control u_i = kappa' and two slacks.  The
@@ -26,7 +27,8 @@
 //     the exact optimum of the QP - the same guarantee as the KKT-verified polish of the lane-per-waypoint kernel.
 // The re-linearised pass starts its interior-point rounds from the previous pass's optimum (complementarity reset to 1e-3).
 //
-// The same source compiles for the device (path_stream_kernel, pqp_path_stream.inc) and, for tests only, for the host (tests/emu).
+// The same source compiles for the device (path_stream_kernel, pqp_path_stream.hip) and, for tests and the bench's CPU line only, for the
+// host (tests/emu/lq_emu.cpp).
 #pragma once
 #include "pqp_path_lane.hpp"
 #include "pqp_path_lq_abi.hpp"
@@ -48,7 +50,6 @@ constexpr double kEqWidth = 1e-6;       // a collision box narrower than this is
 constexpr int kIpmMaxIter = 100;
 constexpr int kPolishMaxRounds = 12;
 
-// a two-sided row of the interior-point rounds
 // reciprocal: the hardware seed (4.6e-8, tools/probes/rcp_probe.hip) + ONE Newton step = 2.2e-15 relative - a third fewer instructions than
 // pqp::rcp's two steps in a kernel whose row arithmetic is mostly reciprocals (PQP_STREAM_RCP2: the two-step one, for A/B runs)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PQP_STREAM_RCP2)
@@ -68,6 +69,7 @@ PQP_HD double rcpq(double x) { return rcp(x); }
 #define PQP_SWEEP PQP_HD
 #endif
 
+// a two-sided row of the interior-point rounds: value, slacks to the two bounds, multipliers of the two bounds
 struct Row { double g, tl, tu, zl, zu; };
 struct RowStep { double dg, dtl, dtu, dzl, dzu; };
 
@@ -614,10 +616,14 @@ struct Solver {
     // the interior-point rounds as steps that shrink to nothing while the row residual stays: PQP_STATUS_PRIMAL_INFEASIBLE - the
     // verdict OSQP's certificate gives the lane-per-waypoint kernel on the same QP.
     PQP_HD int solve_pass(bool warm) {
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            const double mu_stop = attempt == 0 ? kMuStop : 1e-9;
-            if (attempt > 0 || !warm) { backward<MODE_INIT>(0.0); forward_init(); }
-            else warm_init();
+        // attempts: (from the previous optimum,) cold to complementarity 1e-6, cold to 1e-9.  A warm start that fails - the slot's previous QP may
+        // have nothing to do with this one - is no verdict on the QP: the cold attempts follow.
+        int verdict = PQP_STATUS_MAX_ITER;
+        for (int attempt = warm ? 0 : 1; attempt < 3; ++attempt) {
+            const bool from_previous = attempt == 0;
+            const double mu_stop = attempt < 2 ? kMuStop : 1e-9;
+            if (from_previous) warm_init();
+            else { backward<MODE_INIT>(0.0); forward_init(); }
             bool first = true;
             int it = 0, stall = 0;
             int slow = 0;          // iterations in a row with a step below 1e-3 although the rows are feasible: complementarity has stopped falling
@@ -639,16 +645,21 @@ struct Solver {
                 it += 1;
             }
             ipm_iters += it;
-            if (!(mu == mu)) return PQP_STATUS_NUMERICAL;
-            if (!(res < 1e-6)) return stall >= 6 ? PQP_STATUS_PRIMAL_INFEASIBLE : PQP_STATUS_MAX_ITER;
-            if (!(mu < 1e-3)) return PQP_STATUS_MAX_ITER;              // (short of mu_stop but below 1e-3: the active-set rounds get their chance)
-            backward<MODE_GUESS>(0.0);
-            for (int r = 0; r < kPolishMaxRounds; ++r) {
-                if (forward_set()) return PQP_STATUS_SOLVED;
-                backward<MODE_SET>(0.0);
+            if (!(mu == mu)) verdict = PQP_STATUS_NUMERICAL;
+            else if (!(res < 1e-6)) verdict = stall >= 6 ? PQP_STATUS_PRIMAL_INFEASIBLE : PQP_STATUS_MAX_ITER;
+            else if (!(mu < 1e-3)) verdict = PQP_STATUS_MAX_ITER;      // (short of mu_stop but below 1e-3: the active-set rounds get their chance)
+            else {
+                backward<MODE_GUESS>(0.0);
+                for (int r = 0; r < kPolishMaxRounds; ++r) {
+                    if (forward_set()) return PQP_STATUS_SOLVED;
+                    backward<MODE_SET>(0.0);
+                }
+                verdict = PQP_STATUS_MAX_ITER;
+                continue;                                              // the set was not confirmed: the next attempt
             }
+            if (!from_previous) return verdict;                        // a cold attempt's verdict on the rows stands
         }
-        return PQP_STATUS_MAX_ITER;
+        return verdict;
     }
 
     // BaseSolver::getOptimizedPath (base_solver.cpp:263-288)
@@ -703,6 +714,18 @@ struct Solver {
             if (end_psi < p.end_psi_max) { psi_lo = end_psi - p.end_psi_tol; psi_hi = end_psi + p.end_psi_tol; }
         }
         act_el = act_ep = 0; lam_el = lam_ep = 0.0; gp_el = gp_ep = 0.0;
+        // what the slot's previous QP left behind (waypoint 0's row fields are otherwise unused: x_0 is given): its end rows and its size
+        bool carried = false;
+        if (a.carry) {
+            const int code = (int)ws.ld(D_ACT, 0);
+            if (code >= 100 && code < 109 && (int)ws.ldf(S_PAD, 0) == n) {
+                carried = true;
+                act_el = (code - 100) % 3 - 1; act_ep = (code - 100) / 3 - 1;
+                lam_el = ws.ld(D_LAM, 0); lam_ep = ws.ld(D_GK, 0);
+                if (psi_hi >= kBig) { act_ep = 0; lam_ep = 0.0; }
+            }
+        }
+        ws.st(D_ACT, 0, 0.0);
         prep(a.lin ? 1 : 0, true);
         if (!(fabs(x0[2]) <= kl)) {
             // the start curvature violates its own box (kappa row 0 against the fixed x_0): no point satisfies the rows
@@ -712,7 +735,7 @@ struct Solver {
             return;
         }
         int solved = 0;
-        int st = solve_pass(false);
+        int st = solve_pass(carried);
         ipm_iters_first = ipm_iters; set_rounds_first = set_rounds;
         if (st == PQP_STATUS_SOLVED) solved += 1;
         for (int pass = 0; st == PQP_STATUS_SOLVED && pass < a.passes; ++pass) {
@@ -722,6 +745,9 @@ struct Solver {
         }
         if (solved == 0) zero_point();          // (no active-set round ever ran: F_X* hold nothing)
         unpack();
+        if (st == PQP_STATUS_SOLVED) {          // for the next planning cycle (Args::carry): the end rows' state and the size, in waypoint 0's free fields
+            ws.st(D_ACT, 0, (double)(100 + (act_el + 1) + 3 * (act_ep + 1))); ws.st(D_LAM, 0, lam_el); ws.st(D_GK, 0, lam_ep); ws.stf(S_PAD, 0, (double)n);
+        }
         finish(st, solved);
     }
 };

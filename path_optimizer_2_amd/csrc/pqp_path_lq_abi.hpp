@@ -43,6 +43,8 @@ struct Args {
     int32_t* iters;             // [batch] or nullptr: interior-point iterations over all passes
     double* info;               // [batch][PQP_INFO_STRIDE] or nullptr
     double* ws;                 // [ceil(batch / 64)][n][kBlockDoubles][64]
+    int carry;                  // 1: the workspace still holds what this very launch shape left there last time (PQP_OPT_CARRY_CYCLES): a QP's first pass
+                                // starts its interior-point rounds from its slot's previous optimum - the same scenario one planning cycle earlier
     pqp_params prm;
 };
 

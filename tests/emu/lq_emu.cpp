@@ -15,6 +15,20 @@ void pqp_emu_lq_production_params(pqp_params* p) { pqp::production_params(p); }
 
 int pqp_emu_lq_fields(void) { return pqp::lq::kBlockDoubles; }
 
+// carry != 0: `persist` [batch][n * kBlockDoubles] keeps every QP's workspace between calls (Args::carry: the next call's first pass starts from it)
+void pqp_emu_lq_solve_carry(const pqp_params* prm, int batch, int n, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
+                            const double* scal, int passes, double* out, int32_t* status, int32_t* iters, double* info, double* persist, int carry) {
+    pqp::lq::Args a;
+    std::memset(&a, 0, sizeof(a));
+    a.batch = batch; a.n = n; a.passes = passes; a.n_of = n_of; a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
+    a.status = status; a.iters = iters; a.info = info; a.prm = *prm; a.carry = carry; a.ws = persist;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int q = 0; q < batch; ++q) {
+        pqp::lq::Solver<pqp::lq::StridedWs> s(a, q, pqp::lq::StridedWs{persist + (size_t)q * n * pqp::lq::kBlockDoubles, 0, 1});
+        s.run();
+    }
+}
+
 void pqp_emu_lq_solve(const pqp_params* prm, int batch, int n, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
                       const double* scal, int passes, double* out, int32_t* status, int32_t* iters, double* info) {
     pqp::lq::Args a;

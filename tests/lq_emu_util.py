@@ -47,6 +47,26 @@ def solve(ref, bounds, scal, passes=1, n_of=None, lin=None, prm=None):
     return dict(out=out, status=st, iters=it, info=info)
 
 
+class Carried:
+    """A batch whose per-QP workspaces persist between solves (the device keeps them on the handle): PQP_OPT_CARRY_CYCLES in emulation."""
+
+    def __init__(self, batch, n):
+        self.ws = np.zeros((batch, n * load().pqp_emu_lq_fields()))
+        self.first = True
+
+    def solve(self, ref, bounds, scal, passes=1, prm=None, carry=True):
+        lib = load()
+        B, n = ref.shape[:2]
+        prm = prm or production()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        out = np.zeros((B, n, 7)); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); info = np.zeros((B, 8))
+        ref = np.ascontiguousarray(ref, dtype=np.float64); bounds = np.ascontiguousarray(bounds, dtype=np.float64); scal = np.ascontiguousarray(scal, dtype=np.float64)
+        lib.pqp_emu_lq_solve_carry(C.byref(prm), B, n, None, vp(ref), None, vp(bounds), vp(scal), passes, vp(out), vp(st), vp(it), vp(info), vp(self.ws),
+                                   1 if (carry and not self.first) else 0)
+        self.first = False
+        return dict(out=out, status=st, iters=it, info=info)
+
+
 def timed_rate(make_sample, n, budget_s=6.0):
     """bench.py's cpu_baseline.same_algorithm_on_host: the product's lane-per-QP algorithm source compiled for the host (test infrastructure,
     tests/emu/lq_emu.cpp), one QP per OpenMP task over all host threads, on a bounded sample of the bench workload."""

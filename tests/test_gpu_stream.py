@@ -57,6 +57,43 @@ def test_stream_kernel_equals_the_lane_per_waypoint_kernel(hip_lib):
     assert d.max() < 2e-5 and np.median(d) < 1e-7, (d.max(), np.median(d))
 
 
+def test_stream_kernel_carries_the_previous_cycle(hip_lib):
+    """PQP_OPT_CARRY_CYCLES on the device: the same scenarios one planning cycle later start from their slots' previous optima - same paths as the
+    cold solve, fewer sweeps; off by default; a change of shape starts cold."""
+    import torch
+    from path_optimizer_2_amd import capi
+    from path_optimizer_2_amd.synth import jitter_batch, make_batch
+    batch, n = 1000, 80
+    host = make_batch(batch, n, seed=8)
+    dev = torch.device("cuda", 0)
+    hc, hk = _handle(capi, batch, n), _handle(capi, batch, n)
+    hc.set_option(capi.OPT_CARRY_CYCLES, 1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ref = t(host["ref"])
+    for v in range(3):
+        hv = jitter_batch(host, v, seed=8)
+        bounds, scal = t(hv["bounds"]), t(hv["scal"])
+        res = []
+        for h in (hc, hk):
+            out = torch.zeros((batch, n, 7), dtype=torch.float64, device=dev); st = torch.zeros(batch, dtype=torch.int32, device=dev)
+            info = torch.zeros((batch, 8), dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            h.solve_device(batch, n, ref, bounds, scal, out, passes=1, status=st, info=info)
+            h.sync()
+            assert (st.cpu().numpy() == 1).all()
+            res.append((out.cpu().numpy(), info.cpu().numpy()[:, 6].mean()))
+        assert np.abs(res[0][0] - res[1][0]).max() < 5e-7
+        if v == 0:
+            assert res[0][1] == res[1][1]
+        else:
+            assert res[0][1] < 0.75 * res[1][1], (v, res[0][1], res[1][1])
+    b2 = make_batch(batch, 64, seed=9)                           # another shape on the same handle: nothing to carry
+    r2 = hc.solve(b2["ref"], b2["bounds"], b2["scal"], passes=1)
+    k2 = hk.solve(b2["ref"], b2["bounds"], b2["scal"], passes=1)
+    assert np.array_equal(r2["out"], k2["out"])
+    hc.close(); hk.close()
+
+
 def test_stream_kernel_first_solve_only_and_a_given_linearisation_point(hip_lib):
     """passes = 0 is BaseSolver::solve alone; lin != NULL is updateProblemFormulationAndSolve's QP solved cold."""
     import pqp_oracle_c as OC

@@ -159,3 +159,27 @@ def test_fuzzed_scenarios_are_solved_right_or_reported_unsolved():
             assert r["iters"][q] <= 260                         # (two passes of at most 100 + the retry: nobody iterates for ever)
     assert wrong == 0 and missed == 0, (wrong, missed)
     assert solved > 150
+
+
+def test_carrying_the_previous_cycle_s_optimum_changes_the_iterations_not_the_result():
+    """PQP_OPT_CARRY_CYCLES: the first pass of QP k starts from what QP k's slot held after the previous solve (the same scenario one planning
+    cycle earlier, synth.jitter_batch).  Same optimum (to the KKT test's 1e-7), a third fewer sweeps; a slot whose new QP has nothing to do with
+    its old one is still solved."""
+    from path_optimizer_2_amd.synth import jitter_batch
+    B, n = 256, 80
+    host = make_batch(B, n)
+    c = E.Carried(B, n)
+    sweeps = []
+    for v in range(3):
+        hv = jitter_batch(host, v)
+        r = c.solve(host["ref"], hv["bounds"], hv["scal"])
+        cold = E.solve(host["ref"], hv["bounds"], hv["scal"])
+        assert (r["status"] == 1).all()
+        assert np.abs(r["out"] - cold["out"]).max() < 5e-7
+        sweeps.append((r["info"][:, 6].mean(), cold["info"][:, 6].mean()))
+    assert sweeps[0][0] == sweeps[0][1]                       # nothing to carry in the first cycle
+    assert sweeps[1][0] < 0.75 * sweeps[1][1] and sweeps[2][0] < 0.75 * sweeps[2][1]
+    other = make_batch(B, n, "varied", seed=99)               # unrelated scenarios in the same slots
+    r = c.solve(other["ref"], other["bounds"], other["scal"])
+    cold = E.solve(other["ref"], other["bounds"], other["scal"])
+    assert (r["status"] == 1).all() and np.abs(r["out"] - cold["out"]).max() < 5e-7
