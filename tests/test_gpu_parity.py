@@ -128,6 +128,27 @@ def test_assemble_rough_constraints(hip_lib):
     h.close()
 
 
+def test_carrying_a_cycle_through_the_warm_state(hip_lib):
+    """warm == 1 with lin = NULL on the lane-per-waypoint kernel: the first solve of a planning cycle starts from the final iterate and
+    active set the handle kept from the previous cycle (PQP_OPT_STORE_WARM).  On scenarios that moved by 5 % (synth.jitter_batch): the
+    same paths as the cold solve - the optimum is unique - with fewer reduced solves and factorisations (bench.py: secondary.carry_cycles)."""
+    from path_optimizer_2_amd.synth import jitter_batch
+    batch, n = 512, 80
+    host = make_batch(batch, n, seed=6)
+    hw = capi.Handle(capi.production_params(), max_batch=batch, max_n=n)
+    hc = capi.Handle(capi.production_params(), max_batch=batch, max_n=n)
+    work = []
+    for v in range(4):
+        hv = jitter_batch(host, v, seed=6)
+        rw = hw.solve(host["ref"], hv["bounds"], hv["scal"], passes=1, warm=v > 0)
+        rc = hc.solve(host["ref"], hv["bounds"], hv["scal"], passes=1)
+        assert (rw["status"] == 1).all() and (rc["status"] == 1).all()
+        assert np.abs(rw["out"] - rc["out"]).max() < 1e-6, v
+        work.append((rw["info"][:, 5].mean() + 2 * rw["info"][:, 6].mean(), rc["info"][:, 5].mean() + 2 * rc["info"][:, 6].mean()))
+    assert all(w < 0.85 * c for w, c in work[1:]), work          # (a factorisation costs two reduced solves)
+    hw.close(); hc.close()
+
+
 def test_solve_in_rough_constraints_mode(hip_lib):
     """base_solver.cpp:25-34,201-205 SOLVED on the GPU (the lane-per-waypoint kernel, production setting and the reference's ADMM setting):
     beyond precise_planning_length one collision row per waypoint on the centre circle's box, P < N."""
