@@ -304,6 +304,8 @@ int pqp_multi_create(pqp_multi** m, const pqp_params* params, int n_shards, cons
 int pqp_multi_destroy(pqp_multi* m);
 int pqp_multi_shards(const pqp_multi* m);
 pqp_handle* pqp_multi_handle(pqp_multi* m, int shard);       /* a shard's own handle (device-resident use, options, timing) */
+/* every shard's handle gets the option; PQP_OPT_CARRY_CYCLES additionally makes the driver keep the lane-per-waypoint kernel's warm state and start a call
+ * whose batch and n equal the previous call's (no n_of, no lin) from it: the same scenarios one planning cycle later, shard by shard */
 int pqp_multi_set_option(pqp_multi* m, int option, int value);
 int pqp_multi_path_solve(pqp_multi* m, int batch, int n, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
                          const double* scal, int passes, double* out, int32_t* status, int32_t* iters, double* info);

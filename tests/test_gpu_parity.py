@@ -328,8 +328,10 @@ def test_error_paths(hip_lib):
     with pytest.raises(capi.PqpError):
         h.pattern(1)
     big = make_batch(1, 513)
+    rb = h.solve(big["ref"], big["bounds"], big["scal"], passes=0)          # more than 512 waypoints: the lane-per-QP kernel (round 2: PQP_ERR_CAPACITY)
+    assert rb["status"][0] == 1
     with pytest.raises(capi.PqpError):
-        h.solve(big["ref"], big["bounds"], big["scal"], passes=0)           # more than 512 waypoints
+        h.solve(big["ref"], big["bounds"], big["scal"], passes=0, warm=True)   # ... which keeps no warm state: warm == 1 there needs `lin`
     h.close()
 
 

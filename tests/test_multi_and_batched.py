@@ -136,6 +136,29 @@ def test_multi_driver_overlaps_its_shards_and_keeps_its_threads(hip_lib):
 
 
 @pytest.mark.gpu
+def test_multi_driver_carries_a_planning_cycle(hip_lib):
+    """pqp_multi_set_option(PQP_OPT_CARRY_CYCLES): a call of the shape of the previous one starts every shard's first solve from what its handle
+    kept - same paths as a driver without the option, on scenarios that moved by 5 %; a call of another shape starts cold."""
+    from path_optimizer_2_amd.synth import jitter_batch
+    host = make_batch(600, 80, seed=3)
+    prm = capi.production_params()
+    a = capi.MultiHandle(prm, devices=(0, 0), max_batch_per_shard=300, max_n=80)
+    b = capi.MultiHandle(prm, devices=(0, 0), max_batch_per_shard=300, max_n=80)
+    assert a.lib.pqp_multi_set_option(a._m, capi.OPT_CARRY_CYCLES, 1) == 0
+    for v in range(3):
+        hv = jitter_batch(host, v, seed=3)
+        ra = a.solve(host["ref"], hv["bounds"], hv["scal"], passes=1)
+        rb = b.solve(host["ref"], hv["bounds"], hv["scal"], passes=1)
+        assert (ra["status"] == 1).all()
+        assert np.abs(ra["out"] - rb["out"]).max() < 1e-6
+        if v > 0:
+            assert ra["info"][:, 6].mean() < 0.9 * rb["info"][:, 6].mean()        # fewer factorisations: the carried start
+    other = make_batch(200, 64, seed=4)
+    np.testing.assert_array_equal(a.solve(other["ref"], other["bounds"], other["scal"], passes=1)["out"], b.solve(other["ref"], other["bounds"], other["scal"], passes=1)["out"])
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
 def test_batched_cpp_solver_against_the_c_abi(batched_exe, hip_lib):
     """BatchedPathSolver (production setting) on three scenarios of different length, one and two shards: the paths the C++ vectors
     carry are the C ABI's solve_var result digit for digit."""
