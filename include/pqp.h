@@ -210,7 +210,9 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      nearly the same scenarios cycle after cycle; the reference constructs a fresh BaseSolver every cycle
  *                                      (path_optimizer.cpp:138).  The optimum returned is the same (unique; it agrees with the cold solve to the
  *                                      1e-7 of the KKT test); interior-point iterations per path fall from 14 to 9 on scenarios that moved by 5 %.
- *                                      A QP that differs wildly from its slot's previous one is still solved (the start is then merely poor). */
+ *                                      A QP that differs wildly from its slot's previous one is still solved (the start is then merely poor).
+ *                                      The exact TensionSmoother / postSmooth kernels (polish == 1) honour it too: a line's active-set rounds start from
+ *                                      the set its slot ended with in the previous solve of the shape (16-31 rounds from the cold start, 2-3 from there). */
 typedef enum pqp_option { PQP_OPT_STORE_WARM = 1, PQP_OPT_ORDER_BY_COST = 2, PQP_OPT_RESERVE_CUS = 3, PQP_OPT_STREAM_BATCH = 4, PQP_OPT_CARRY_CYCLES = 5 } pqp_option;
 int pqp_set_option(pqp_handle* h, int option, int value);
 int pqp_get_stream(pqp_handle* h, void** hip_stream);   /* hipStream_t */

@@ -535,13 +535,27 @@ class Handle:
                                                  _ptr(os_), _ptr(st), _ptr(it)))
         return dict(x=ox, y=oy, s=os_, status=st, iters=it)
 
-    def smooth_tension(self, x, y, angle, clearance):
+    def smooth_tension(self, x, y, angle, clearance, info=False):
         B, n = x.shape
         ox = np.zeros((B, n)); oy = np.zeros((B, n)); os_ = np.zeros((B, n)); st = np.zeros(B, dtype=np.int32); it = np.zeros(B, dtype=np.int32)
         c = np.ascontiguousarray
-        self._check(self.lib.pqp_smooth_tension(self._h, B, n, _ptr(c(x)), _ptr(c(y)), _ptr(c(angle)), _ptr(c(clearance)), _ptr(ox), _ptr(oy),
-                                                _ptr(os_), _ptr(st), _ptr(it)))
-        return dict(x=ox, y=oy, s=os_, status=st, iters=it)
+        if not info:
+            self._check(self.lib.pqp_smooth_tension(self._h, B, n, _ptr(c(x)), _ptr(c(y)), _ptr(c(angle)), _ptr(c(clearance)), _ptr(ox), _ptr(oy),
+                                                    _ptr(os_), _ptr(st), _ptr(it)))
+            return dict(x=ox, y=oy, s=os_, status=st, iters=it)
+        # with the info rows (factorisations in [5]): the device entry point, torch as the memory plumbing
+        import torch
+        dev = torch.device("cuda", self.device)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        d = [t(a) for a in (x, y, angle, clearance)]
+        o = [torch.zeros((B, n), dtype=torch.float64, device=dev) for _ in range(3)]
+        dst, dit = (torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2))
+        dinf = torch.zeros((B, 8), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        p = lambda a: C.c_void_p(a.data_ptr())
+        self._check(self.lib.pqp_smooth_tension_device(self._h, B, n, p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(o[0]), p(o[1]), p(o[2]), p(dst), p(dit), p(dinf)))
+        self.sync()
+        return dict(x=o[0].cpu().numpy(), y=o[1].cpu().numpy(), s=o[2].cpu().numpy(), status=dst.cpu().numpy(), iters=dit.cpu().numpy(), info=dinf.cpu().numpy())
 
     def smooth_tension2_var(self, x, y, angle, k, s, n_of):
         """pqp_smooth_tension2_var_device (torch as the memory plumbing): lists [B][n_max], n_of [B] points per scenario."""

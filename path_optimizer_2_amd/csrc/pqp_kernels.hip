@@ -700,6 +700,8 @@ struct pqp_handle {
     int hist_batch = 0, hist_n = 0;             // shape of the solve whose costs cost_key / cost_hist hold (0: none)
     int opt_store_warm = 1, opt_order_by_cost = 0, opt_reserve_cus = 0, opt_stream_batch = 24576, opt_carry = 0;
     int stream_last_batch = 0, stream_last_n = 0;      // shape of the last path_stream_kernel launch (what its workspace still holds)
+    DevBuf sm_act[2];                                  // final active sets of the exact TensionSmoother / postSmooth kernels (PQP_OPT_CARRY_CYCLES)
+    int sm_act_batch[2] = {0, 0}, sm_act_n[2] = {0, 0};
     DevBuf stream_ws;                           // workspace of path_stream_kernel
     int num_cu = 0;
     int blocks_per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // occupancy of the solve kernel variants [log2(nw)][cert]
@@ -756,7 +758,7 @@ int pqp_destroy(pqp_handle* h) {
     if (!h) return PQP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (DevBuf* b : {&h->stream_ws, &h->chain_d, &h->chain_i, &h->wscale, &h->ticket, &h->cost_key, &h->cost_hist, &h->order, &h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
+    for (DevBuf* b : {&h->sm_act[0], &h->sm_act[1], &h->stream_ws, &h->chain_d, &h->chain_i, &h->wscale, &h->ticket, &h->cost_key, &h->cost_hist, &h->order, &h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
                       &h->s_status, &h->s_iters, &h->s_info, &h->s_a, &h->s_p, &h->s_l, &h->s_u, &h->s_idx, &h->b_pband, &h->b_q, &h->b_aval,
                       &h->b_lo, &h->b_up, &h->b_x, &h->b_y, &h->b_acol, &h->b_trow, &h->b_tslot, &h->b_in[0], &h->b_in[1], &h->b_in[2],
                       &h->b_in[3], &h->b_in[4], &h->b_out[0], &h->b_out[1], &h->b_out[2], &h->c_buf[0], &h->c_buf[1], &h->c_buf[2],
@@ -783,7 +785,7 @@ int pqp_set_option(pqp_handle* h, int option, int value) {
         case PQP_OPT_ORDER_BY_COST: h->opt_order_by_cost = value ? 1 : 0; h->hist_batch = 0; return PQP_OK;
         case PQP_OPT_RESERVE_CUS: h->opt_reserve_cus = value < 0 ? 0 : value; return PQP_OK;
         case PQP_OPT_STREAM_BATCH: h->opt_stream_batch = value < 0 ? 0 : value; return PQP_OK;
-        case PQP_OPT_CARRY_CYCLES: h->opt_carry = value ? 1 : 0; h->stream_last_batch = 0; return PQP_OK;
+        case PQP_OPT_CARRY_CYCLES: h->opt_carry = value ? 1 : 0; h->stream_last_batch = 0; h->sm_act_batch[0] = h->sm_act_batch[1] = 0; return PQP_OK;
         default: return fail(PQP_ERR_INVALID, "pqp_set_option: unknown option");
     }
 }
@@ -1356,10 +1358,20 @@ static int smooth_tension_impl(pqp_handle* h, int batch, int n, const int32_t* n
         h->next_event_pair();
         PQP_HIP(hipEventRecord(h->ev0, h->stream));
         const double wk = h->prm.cartesian_curvature_weight, wdk = h->prm.cartesian_curvature_rate_weight, wdev = h->prm.cartesian_deviation_weight, tol = h->prm.polish_tol;
-        if (n <= 64) hipLaunchKernelGGL(pqp::tension_exact_kernel<1>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info);
-        else if (n <= 128) hipLaunchKernelGGL(pqp::tension_exact_kernel<2>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info);
-        else if (n <= 256) hipLaunchKernelGGL(pqp::tension_exact_kernel<4>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info);
-        else hipLaunchKernelGGL(pqp::tension_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info);
+        // PQP_OPT_CARRY_CYCLES: the active set every line ended with is kept on the handle; a solve of the shape of the previous one starts from it
+        signed char* act_io = nullptr;
+        int carry = 0;
+        if (h->opt_carry) {
+            const void* before = h->sm_act[0].p;
+            if ((rc = h->sm_act[0].ensure((size_t)batch * n))) return rc;
+            act_io = h->sm_act[0].as<signed char>();
+            carry = (h->sm_act_batch[0] == batch && h->sm_act_n[0] == n && before == h->sm_act[0].p) ? 1 : 0;
+            h->sm_act_batch[0] = batch; h->sm_act_n[0] = n;
+        }
+        if (n <= 64) hipLaunchKernelGGL(pqp::tension_exact_kernel<1>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
+        else if (n <= 128) hipLaunchKernelGGL(pqp::tension_exact_kernel<2>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
+        else if (n <= 256) hipLaunchKernelGGL(pqp::tension_exact_kernel<4>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
+        else hipLaunchKernelGGL(pqp::tension_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
         PQP_HIP(hipGetLastError());
         PQP_HIP(hipEventRecord(h->ev1, h->stream));
         h->timed = true;
@@ -1400,10 +1412,20 @@ static int post_smooth_impl(pqp_handle* h, int batch, int m, const int32_t* m_of
         h->next_event_pair();
         PQP_HIP(hipEventRecord(h->ev0, h->stream));
         const double tol = h->prm.polish_tol;
-        if (m <= 64) hipLaunchKernelGGL(pqp::post_exact_kernel<1>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info);
-        else if (m <= 128) hipLaunchKernelGGL(pqp::post_exact_kernel<2>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info);
-        else if (m <= 256) hipLaunchKernelGGL(pqp::post_exact_kernel<4>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info);
-        else hipLaunchKernelGGL(pqp::post_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info);
+        signed char* act_io = nullptr;          // PQP_OPT_CARRY_CYCLES, as in smooth_tension_impl
+        int carry = 0;
+        if (h->opt_carry) {
+            const void* before = h->sm_act[1].p;
+            int rc_a;
+            if ((rc_a = h->sm_act[1].ensure((size_t)batch * m))) return rc_a;
+            act_io = h->sm_act[1].as<signed char>();
+            carry = (h->sm_act_batch[1] == batch && h->sm_act_n[1] == m && before == h->sm_act[1].p) ? 1 : 0;
+            h->sm_act_batch[1] = batch; h->sm_act_n[1] = m;
+        }
+        if (m <= 64) hipLaunchKernelGGL(pqp::post_exact_kernel<1>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
+        else if (m <= 128) hipLaunchKernelGGL(pqp::post_exact_kernel<2>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
+        else if (m <= 256) hipLaunchKernelGGL(pqp::post_exact_kernel<4>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
+        else hipLaunchKernelGGL(pqp::post_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
         PQP_HIP(hipGetLastError());
         PQP_HIP(hipEventRecord(h->ev1, h->stream));
         h->timed = true;

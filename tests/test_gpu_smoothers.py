@@ -117,6 +117,32 @@ def test_tension_sizes_beyond_the_9x9_formulation(hip_lib):
     assert bad > 1e-3
 
 
+def test_exact_smoother_kernels_carry_the_previous_cycle_s_active_set(hip_lib):
+    """PQP_OPT_CARRY_CYCLES on the exact TensionSmoother / postSmooth kernels: a line that moved a little since the previous solve starts its
+    active-set rounds from the set its slot ended with.  The same optimum (the KKT certificate of the oracle's matrices; equal to the cold solve's),
+    a fraction of the factorisations; another shape on the handle starts cold."""
+    n = 80
+    cases = [tension_inputs(n, seed=40 + b) for b in range(8)]
+    x, y, ang, cl = (np.stack([c[k] for c in cases]) for k in (0, 1, 2, 5))
+    hc = capi.Handle(_polished(), max_batch=8, max_n=n); hk = capi.Handle(_polished(), max_batch=8, max_n=n)
+    hc.set_option(capi.OPT_CARRY_CYCLES, 1)
+    rng = np.random.default_rng(3)
+    for v in range(3):
+        sh = rng.uniform(-0.03, 0.03, x.shape) if v else 0.0
+        xv, yv, clv = x + sh * np.cos(ang + np.pi / 2), y + sh * np.sin(ang + np.pi / 2), cl * (1 + (rng.uniform(-0.05, 0.05, (8, 1)) if v else 0.0))
+        rc, rk = hc.smooth_tension(xv, yv, ang, clv, info=True), hk.smooth_tension(xv, yv, ang, clv, info=True)
+        assert (rc["status"] == 1).all() and (rk["status"] == 1).all()
+        for b in range(8):
+            assert _tension_kkt_certificate(xv[b], yv[b], ang[b], clv[b], rc["x"][b], rc["y"][b]) < 1e-6, (v, b)
+        assert np.abs(rc["x"] - rk["x"]).max() < 1e-7 and np.abs(rc["y"] - rk["y"]).max() < 1e-7
+        if v:
+            assert rc["info"][:, 5].mean() < 0.5 * rk["info"][:, 5].mean(), (v, rc["info"][:, 5].mean(), rk["info"][:, 5].mean())
+    c2 = [tension_inputs(48, seed=60 + b) for b in range(8)]
+    a2 = [np.stack([c[k] for c in c2]) for k in (0, 1, 2, 5)]
+    np.testing.assert_array_equal(hc.smooth_tension(*a2)["x"], hk.smooth_tension(*a2)["x"])
+    hc.close(); hk.close()
+
+
 @pytest.mark.parametrize("m,batch", [(18, 4), (60, 2), (150, 1)])
 def test_post_smooth(hip_lib, m, batch):
     cases = [post_inputs(m, seed=30 + b) for b in range(batch)]
