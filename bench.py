@@ -385,16 +385,13 @@ def main():
                     ln[0].set_params(p); ln[0].set_option(capi.OPT_ORDER_BY_COST, 1 if order else 0)
             for ln in lns:
                 ln[0].set_option(capi.OPT_CARRY_CYCLES, 1 if carry else 0)
-                if carry and not stream:            # the lane-per-waypoint kernel carries a cycle through its warm state (warm == 1 with lin = NULL)
-                    ln[0].set_option(capi.OPT_STORE_WARM, 1)
             k = [0]
 
             def one():
                 hh, o, st, it, inf = lns[k[0] % len(lns)]
                 bv, sv = variants[k[0] % len(variants)]
-                from_previous = carry and not stream and k[0] >= len(lns)        # (every handle's first call is cold)
                 k[0] += 1
-                hh.solve_device(batch, n, ref, bv, sv, o, passes=1, warm=from_previous, status=st, iters=it, info=inf)
+                hh.solve_device(batch, n, ref, bv, sv, o, passes=1, status=st, iters=it, info=inf)
 
             def wait():
                 for ln in lns:
@@ -410,8 +407,8 @@ def main():
             hh, o, st, it, inf = lns[0]
             if carry and not stream:
                 kkt_carry = (float(inf.cpu().numpy()[:, 5].mean()), float(inf.cpu().numpy()[:, 6].mean()))
-                for ln in lns:
-                    ln[0].set_option(capi.OPT_STORE_WARM, 0)
+            for ln in lns:
+                ln[0].set_option(capi.OPT_CARRY_CYCLES, 0)                  # (the checksum's step below is a cold one)
             hh.solve_device(batch, n, ref, variants[0][0], variants[0][1], o, passes=1, status=st, iters=it, info=inf)      # the checksum's step
             hh.sync()
             itn, stn = it.cpu().numpy(), st.cpu().numpy()
@@ -449,7 +446,7 @@ def main():
                                                setting="what base_solver.cpp:61-62 runs: eps 2e-3, OSQP defaults, no polish; paths 2e-4..2e-2 from the optimum"),
         }
         if not stream and n_var > 1:
-            txt = ("PQP_OPT_STORE_WARM + warm == 1 with lin = NULL: the first solve of a cycle starts from the final iterate and active set the handle kept from the "
+            txt = ("PQP_OPT_CARRY_CYCLES: the first solve of a cycle starts from the final iterate and active set the handle kept from the "
                    "previous cycle (the jittered variant {} step(s) earlier) instead of cold - what a planner that re-solves its scenarios every cycle would switch "
                    "on (same paths: the optimum is unique); the reference constructs a fresh solver per cycle, so `value` is measured without it")
             secondary["carry_cycles"] = dict(timed(prm, cost_order, args.steps, inflight=nfl, carry=True), setting="the headline setting with " + txt.format(nfl))

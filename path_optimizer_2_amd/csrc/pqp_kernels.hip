@@ -958,6 +958,9 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     //  gets the exact optimum: zero residuals meet OSQP's termination test at any eps)
     if ((n > 512 && (!warm || lin)) || (h->prm.polish != 0 && !warm && !h->opt_store_warm && h->opt_stream_batch > 0 && batch >= h->opt_stream_batch))
         return path_stream_impl(h, batch, n, n_of, ref, lin, bounds, scal, passes, out, status, iters, info);
+    // PQP_OPT_CARRY_CYCLES on this kernel: a cold call (warm == 0, lin == NULL, no counts) of the shape of the handle's previous solve starts from
+    // the final iterate, equilibration and active set that solve left in the warm state - the same scenarios one planning cycle later
+    if (h->opt_carry && !warm && !lin && !n_of && h->warm_stored && h->warm_batch == batch && h->warm_n == n) warm = 1;
     if (n > 512) return fail(PQP_ERR_CAPACITY, "pqp_path_solve: warm == 1 beyond 512 waypoints needs the linearisation point (`lin`): the lane-per-QP kernel keeps no warm state");
     if (warm && (h->warm_batch != batch || h->warm_n != n || !h->warm_stored))
         return fail(PQP_ERR_INVALID, "pqp_path_solve: warm == 1 needs a previous solve with the same batch and n (with PQP_OPT_STORE_WARM on)");
@@ -1005,7 +1008,7 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     }
     a.wsave = h->wsave.as<double>();
     a.wscale = h->wscale.as<double>();
-    a.store_warm = h->opt_store_warm;
+    a.store_warm = (h->opt_store_warm || h->opt_carry) ? 1 : 0;
     a.ticket = h->ticket.as<unsigned long long>();
     a.ticket_base = h->ticket_next;
     // Host-side bookkeeping of the launch (ticket base of the next launch, launch parity, shape of the cost histogram) is committed
@@ -1039,7 +1042,7 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     h->warm_batch = batch; h->warm_n = n;
-    h->warm_stored = h->opt_store_warm != 0;
+    h->warm_stored = h->opt_store_warm != 0 || h->opt_carry != 0;
     return PQP_OK;
 }
 

@@ -71,9 +71,6 @@ struct Shard {
     int rc = PQP_OK;
     std::string err;
     Staged ref, lin, bounds, scal, counts, out, status, iters, info;
-    // PQP_OPT_CARRY_CYCLES: the first solve of a call starts from what the shard's handle kept of the previous call of the same shape
-    bool carry = false;
-    int last_count = 0, last_n = 0;
 
     int hip(hipError_t e, const char* what) {
         if (e == hipSuccess) return PQP_OK;
@@ -109,17 +106,13 @@ struct Shard {
         if (j.n_of && (rc_ = hip(hipMemsetAsync(out.dev, 0, bn * PQP_OUT_STRIDE * 8, stream), "hipMemsetAsync"))) return rc_;      // rows beyond a QP's own count
         const double* d_lin = j.lin ? (const double*)lin.dev : nullptr;
         int rc_solve;
-        // (the lane-per-waypoint kernel carries a cycle through its warm state: warm == 1 with lin = NULL; the lane-per-QP kernel through its
-        //  workspace: the handle's own PQP_OPT_CARRY_CYCLES, set with the driver's)
-        const int warm = (carry && !j.lin && !j.n_of && last_count == j.count && last_n == j.n && j.n <= 512) ? 1 : 0;
         if (j.n_of)
             rc_solve = pqp_path_solve_var_device(h, j.count, j.n, (const int32_t*)counts.dev, (const double*)ref.dev, d_lin, (const double*)bounds.dev,
                                                  (const double*)scal.dev, j.passes, 0, (double*)out.dev, (int32_t*)status.dev, (int32_t*)iters.dev, (double*)info.dev);
         else
-            rc_solve = pqp_path_solve_device(h, j.count, j.n, (const double*)ref.dev, d_lin, (const double*)bounds.dev, (const double*)scal.dev, j.passes, warm,
+            rc_solve = pqp_path_solve_device(h, j.count, j.n, (const double*)ref.dev, d_lin, (const double*)bounds.dev, (const double*)scal.dev, j.passes, 0,
                                              (double*)out.dev, (int32_t*)status.dev, (int32_t*)iters.dev, (double*)info.dev);
-        if (rc_solve != PQP_OK) { err = pqp_last_error(); (void)hipStreamSynchronize(stream); last_count = 0; return rc_solve; }
-        last_count = j.n_of ? 0 : j.count; last_n = j.n;
+        if (rc_solve != PQP_OK) { err = pqp_last_error(); (void)hipStreamSynchronize(stream); return rc_solve; }
         if ((rc_ = hip(hipMemcpyAsync(out.pin, out.dev, bn * PQP_OUT_STRIDE * 8, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"))) return rc_;
         if (j.status && (rc_ = hip(hipMemcpyAsync(status.pin, status.dev, b * 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"))) return rc_;
         if (j.iters && (rc_ = hip(hipMemcpyAsync(iters.pin, iters.dev, b * 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"))) return rc_;
@@ -239,12 +232,7 @@ pqp_handle* pqp_multi_handle(pqp_multi* m, int shard) {
 int pqp_multi_set_option(pqp_multi* m, int option, int value) {
     if (!m) return mfail(PQP_ERR_INVALID, "pqp_multi_set_option: null handle");
     for (Shard* s : m->shards) {
-        int rc = pqp_set_option(s->h, option, value);
-        if (rc == PQP_OK && option == PQP_OPT_CARRY_CYCLES) {
-            // the driver's own part: keep the warm state of the lane-per-waypoint kernel and start the next call of the same shape from it
-            s->carry = value != 0; s->last_count = 0;
-            rc = pqp_set_option(s->h, PQP_OPT_STORE_WARM, value ? 1 : 0);
-        }
+        const int rc = pqp_set_option(s->h, option, value);      // (PQP_OPT_CARRY_CYCLES: every shard's handle carries its own slice)
         if (rc != PQP_OK) return rc;
     }
     return PQP_OK;

@@ -137,16 +137,20 @@ def test_carrying_a_cycle_through_the_warm_state(hip_lib):
     host = make_batch(batch, n, seed=6)
     hw = capi.Handle(capi.production_params(), max_batch=batch, max_n=n)
     hc = capi.Handle(capi.production_params(), max_batch=batch, max_n=n)
+    ho = capi.Handle(capi.production_params(), max_batch=batch, max_n=n)
+    ho.set_option(capi.OPT_STORE_WARM, 0); ho.set_option(capi.OPT_CARRY_CYCLES, 1)      # the option does the same by itself (and keeps the warm state it needs)
     work = []
     for v in range(4):
         hv = jitter_batch(host, v, seed=6)
         rw = hw.solve(host["ref"], hv["bounds"], hv["scal"], passes=1, warm=v > 0)
+        ro = ho.solve(host["ref"], hv["bounds"], hv["scal"], passes=1)
+        assert np.array_equal(ro["out"], rw["out"]) and np.array_equal(ro["info"][:, 5:7], rw["info"][:, 5:7]), v
         rc = hc.solve(host["ref"], hv["bounds"], hv["scal"], passes=1)
         assert (rw["status"] == 1).all() and (rc["status"] == 1).all()
         assert np.abs(rw["out"] - rc["out"]).max() < 1e-6, v
         work.append((rw["info"][:, 5].mean() + 2 * rw["info"][:, 6].mean(), rc["info"][:, 5].mean() + 2 * rc["info"][:, 6].mean()))
     assert all(w < 0.85 * c for w, c in work[1:]), work          # (a factorisation costs two reduced solves)
-    hw.close(); hc.close()
+    hw.close(); hc.close(); ho.close()
 
 
 def test_solve_in_rough_constraints_mode(hip_lib):
