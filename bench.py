@@ -208,14 +208,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # PQP_BENCH_SHARED_GPU=1 (tests only): every rank on GPU 0, collectives over gloo on host copies - the multi-rank code path of this file on a
+    # one-GPU box (RCCL refuses two ranks on one device).  Its numbers mean nothing; the line says so.
+    shared_gpu = world > 1 and os.environ.get("PQP_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but this node shows {torch.cuda.device_count()} device(s)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
+    coll = (lambda t: t.cpu()) if shared_gpu else (lambda t: t)          # where a collective's tensors live
 
     cfg_id = args.config if args.config is not None else (1 if max(world, args.gpus) == 1 else 3)
     cfg = CONFIGS[cfg_id]
@@ -313,12 +322,22 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     gathered_ok = None
+    gather_info = None
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = coll(torch.tensor([dt], dtype=torch.float64, device=dev))
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        full = gather_paths(out, total)              # untimed: what a caller that wants every path on every rank would do
-        gathered_ok = bool(full.shape[0] == total and torch.equal(full[rank * batch:(rank + 1) * batch], out))
+        full = gather_paths(coll(out), total)        # untimed: what a caller that wants every path on every rank would do
+        gathered_ok = bool(full.shape[0] == total and torch.equal(full[rank * batch:(rank + 1) * batch], coll(out)))
+        # ... and what that RCCL all-gather over xGMI costs (outside the timed region; second call: communicators are warm)
+        torch.cuda.synchronize(); dist.barrier()
+        tg = time.perf_counter()
+        full = gather_paths(coll(out), total)
+        torch.cuda.synchronize(); dist.barrier()
+        gather_s = time.perf_counter() - tg
+        gather_info = {"ms": gather_s * 1e3, "bytes_per_rank_received": int(full.numel() * 8), "what": "torch.distributed all_gather (RCCL) of every rank's [batch][n][7] result slab "
+                       "to every rank, outside the timed region: the only collective of the path (SURVEY.md 8e)"}
+        del full
 
     # per-launch duration of the dominant kernel over the timed region: HIP events the handle recorded around every launch on the
     # stream it launched on, read back now (nothing was synchronised between the launches)
@@ -345,7 +364,7 @@ def main():
             dist.barrier()
         dt_long = time.perf_counter() - t1
         if dist is not None:
-            tl = torch.tensor([dt_long], dtype=torch.float64, device=dev)
+            tl = coll(torch.tensor([dt_long], dtype=torch.float64, device=dev))
             dist.all_reduce(tl, op=dist.ReduceOp.MAX)
             dt_long = float(tl.item())
         sustained = {"value": total * k_long / dt_long, "unit": "paths/s", "steps": k_long, "seconds": dt_long}
@@ -618,12 +637,13 @@ def main():
                        "polish_refine_iter": args.polish_refine, "polish_max_rounds": args.polish_max_rounds, "polish_warm_set": args.polish_warm_set,
                        "passes": "cold solve + 1 re-linearised warm re-solve (PathOptimizer::optimizePath)",
                        "qp_start_order": "most expensive first by the previous step's cost (PQP_OPT_ORDER_BY_COST)" if cost_order else "index order",
-                       "parallelism": f"{world} independent shard(s), no collective in the timed region", "batches_in_flight": max(args.inflight, 1),
+                       "parallelism": f"{world} independent shard(s), no collective in the timed region" + (" - TEST MODE: all ranks share GPU 0 (PQP_BENCH_SHARED_GPU), numbers meaningless" if shared_gpu else ""),
+                       "batches_in_flight": max(args.inflight, 1),
                        **({"smoother": "TensionSmoother2 QP (equality rows only) " + ("as the reference runs it: ADMM to eps 1e-3" if args.reference_setting else
                                        "solved exactly by one Riccati sweep per scenario (pqp_params.polish = 2: tension2_exact_kernel, no ADMM iterations)")} if pipe is not None else {})},
             "admm_iters": {"min": int(it_np.min()), "median": float(np.median(it_np)), "p99": float(np.percentile(it_np, 99)),
                            "max": int(it_np.max()), "mean": float(it_np.mean())},
-            "out_sha1": out_sha, "gather_check": gathered_ok, "solved": int((st_np == 1).sum()), "batch": batch,
+            "out_sha1": out_sha, "gather_check": gathered_ok, "gather": gather_info, "solved": int((st_np == 1).sum()), "batch": batch,
             "sustained": sustained, "secondary": secondary, "roofline": roofline, "roofline_issue": roofline_issue,
         }
         if info_np is not None and stream:

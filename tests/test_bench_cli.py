@@ -1,9 +1,11 @@
 """bench.py's own plumbing, without a GPU: the byte models of its roofline objects and the `--gpus N` entry path without a launcher."""
+import json
 import os
 import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -54,3 +56,21 @@ def test_a_launcher_that_disagrees_with_gpus_is_refused():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE = 2" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
+def test_two_ranks_through_the_launcher_path_on_one_gpu():
+    """`bench.py --gpus 2` end to end on a one-GPU box: bench.py starts the two ranks itself, both use GPU 0 (PQP_BENCH_SHARED_GPU: gloo collectives
+    on host copies, RCCL refuses two ranks per device), each solves its own shard of configs[3], barriers, MAX of the times, the gather and its
+    check, ONE JSON line from rank 0 with n_gpus = 2 and the whole-job value."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PQP_BENCH_SHARED_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "2048", "--sustain", "0.05"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["config_id"] == 3 and d["config"]["batch_per_gpu"] == 2048
+    assert d["solved"] == 2048 and d["gather_check"] is True and d["gather"]["bytes_per_rank_received"] == 2 * 2048 * 80 * 7 * 8
+    assert abs(d["value"] - 2 * 2048 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]          # whole-job paths / the slowest rank's time

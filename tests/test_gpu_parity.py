@@ -150,6 +150,10 @@ def test_carrying_a_cycle_through_the_warm_state(hip_lib):
         assert np.abs(rw["out"] - rc["out"]).max() < 1e-6, v
         work.append((rw["info"][:, 5].mean() + 2 * rw["info"][:, 6].mean(), rc["info"][:, 5].mean() + 2 * rc["info"][:, 6].mean()))
     assert all(w < 0.85 * c for w, c in work[1:]), work          # (a factorisation costs two reduced solves)
+    # scenarios that have nothing to do with what the slots held (another seed, the other profile): a poor start, the same optima
+    other = make_batch(batch, n, "varied", seed=77)
+    ro, rc = ho.solve(other["ref"], other["bounds"], other["scal"], passes=1), hc.solve(other["ref"], other["bounds"], other["scal"], passes=1)
+    assert (ro["status"] == 1).all() and np.abs(ro["out"] - rc["out"]).max() < 1e-5
     hw.close(); hc.close(); ho.close()
 
 
