@@ -424,6 +424,8 @@ def main():
             wait()
             tb = time.perf_counter() - ta
             hh, o, st, it, inf = lns[0]
+            info_rows = stream and p.polish != 0
+            sweeps_mean = float(inf.cpu().numpy()[:, 6].mean()) if info_rows else None          # (of the last timed step on this handle)
             if carry and not stream:
                 kkt_carry = (float(inf.cpu().numpy()[:, 5].mean()), float(inf.cpu().numpy()[:, 6].mean()))
             for ln in lns:
@@ -431,7 +433,6 @@ def main():
             hh.solve_device(batch, n, ref, variants[0][0], variants[0][1], o, passes=1, status=st, iters=it, info=inf)      # the checksum's step
             hh.sync()
             itn, stn = it.cpu().numpy(), st.cpu().numpy()
-            info_rows = stream and p.polish != 0
             r = {"value": batch * steps / tb, "unit": "paths/s", "steps": steps, "ms_per_step": tb / steps * 1e3, "batches_in_flight": inflight,
                  "kernel_ms": float(np.mean(np.concatenate([ln[0].kernel_ms_history(min(max(steps // inflight, 1), 256)) for ln in lns]))),
                  "solved": int((stn == 1).sum()),
@@ -443,8 +444,7 @@ def main():
                 else:
                     ln[0].set_params(prm); ln[0].set_option(capi.OPT_ORDER_BY_COST, 1 if cost_order else 0); ln[0].set_option(capi.OPT_CARRY_CYCLES, 0)
             if info_rows:
-                inf_np = inf.cpu().numpy()
-                r["riccati_sweeps_mean"] = float(inf_np[:, 6].mean())
+                r["riccati_sweeps_mean"] = sweeps_mean
             if carry and not stream:
                 r["kkt_solves_mean"], r["factorisations_mean"] = kkt_carry
             return r
