@@ -183,3 +183,18 @@ def test_carrying_the_previous_cycle_s_optimum_changes_the_iterations_not_the_re
     r = c.solve(other["ref"], other["bounds"], other["scal"])
     cold = E.solve(other["ref"], other["bounds"], other["scal"])
     assert (r["status"] == 1).all() and np.abs(r["out"] - cold["out"]).max() < 5e-7
+
+
+def test_golden_fixtures_by_a_route_without_admm():
+    """tests/golden/path_n8, path_n80: `out_star` = the converged optimum of the QP linearised around `lin` (first solve only), `path_out` =
+    the whole optimizePath.  The fixtures were generated by the oracle's ADMM; the lane-per-QP solver reaches the same points by interior-point
+    + Riccati + active-set rounds - no iteration, factorisation or scaling in common with it."""
+    import os
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name in ("path_n8", "path_n80"):
+        g = np.load(os.path.join(root, name + ".npz"))
+        r0 = E.solve(g["ref"], g["bounds"], g["scal"], passes=0, lin=g["lin"])
+        r1 = E.solve(g["ref"], g["bounds"], g["scal"], passes=1)
+        assert (r0["status"] == 1).all() and (r1["status"] == 1).all()
+        assert np.abs(r0["out"] - g["out_star"]).max() < 1e-6, name
+        assert np.abs(r1["out"][:, :, 3:5] - g["path_out"][:, :, 3:5]).max() < 1e-6, name
