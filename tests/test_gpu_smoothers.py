@@ -117,6 +117,23 @@ def test_tension_sizes_beyond_the_9x9_formulation(hip_lib):
     assert bad > 1e-3
 
 
+def test_exact_tension_kernel_is_bounded_from_the_cold_start(hip_lib):
+    """The first active set comes from interior-point iterations on the box QP (round 3): a launch lasts as long as its slowest line, and no line
+    of these batches needs more than 18 factorisations (round 2's rounds from OSQP's cold-start rule: up to 39 / 67 / 52 at 48 / 80 / 200 points).
+    The counts are those of the numpy restatement (tools/active_set_sweep.py); the optimum is checked by the KKT certificate of the oracle's matrices."""
+    for n in (48, 80, 200):
+        cases = [tension_inputs(n, seed=1000 + b) for b in range(32)]
+        x, y, ang, cl = (np.stack([c[k] for c in cases]) for k in (0, 1, 2, 5))
+        h = capi.Handle(_polished(), max_batch=len(cases), max_n=n)
+        r = h.smooth_tension(x, y, ang, cl, info=True)
+        h.close()
+        assert (r["status"] == 1).all()
+        fac, ipm = r["info"][:, 5], r["info"][:, 3]
+        assert fac.max() <= 18 and ipm.max() <= 15 and (fac - ipm).max() <= 4, (n, fac.max(), ipm.max())
+        for b in (0, 7, 31):
+            assert _tension_kkt_certificate(x[b], y[b], ang[b], cl[b], r["x"][b], r["y"][b]) < 1e-6, (n, b)
+
+
 def test_exact_smoother_kernels_carry_the_previous_cycle_s_active_set(hip_lib):
     """PQP_OPT_CARRY_CYCLES on the exact TensionSmoother / postSmooth kernels: a line that moved a little since the previous solve starts its
     active-set rounds from the set its slot ended with.  The same optimum (the KKT certificate of the oracle's matrices; equal to the cold solve's),

@@ -32,6 +32,24 @@ def test_tension_box_qp_in_the_lateral_shifts_has_the_oracle_s_optimum():
         assert tension_kkt_certificate(x, y, ang, cl, ref["x"][:n], ref["x"][n:2 * n]) < 2e-5, n      # (the ADMM oracle's own accuracy on this QP)
 
 
+def test_interior_start_of_the_exact_tension_kernel_bounds_the_factorisations():
+    """tension_exact_kernel's first active set (round 3): interior-point iterations on the box QP in the lateral shifts, restated in numpy by
+    tools/active_set_sweep.py.  From the split 'multiplier > slack' the exact rounds need 1-3 factorisations where OSQP's cold-start rule needs 10-35,
+    and they end at the same KKT point (the rounds' own acceptance test IS the box QP's KKT test)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import active_set_sweep as A
+    cold, warm = [], []
+    for seed in range(1000, 1012):
+        qp = A.tension_box_qp(48, seed)
+        act, its = A.interior_start(*qp)
+        rounds = A.active_set(*qp, cautious=0.5, act=act)
+        assert 0 < rounds <= 3 and its <= 14, (seed, its, rounds)
+        # the set the interior start predicts is the optimal one up to a box or two: the cold rule's first set is not
+        cold.append(A.active_set(*qp, cautious=0.5)); warm.append(its + rounds)
+    assert max(warm) <= 16 and np.mean(cold) > 1.3 * np.mean(warm) and max(cold) > max(warm)
+
+
 def riccati_tension2(X, Y, phi, kl, s, w_dev=0.005, w_k=1.0, w_dk=10.0):
     """The sweep of tension2_exact_kernel in numpy: state (x, y, theta, previous k), control k; returns x, y."""
     n = len(X)

@@ -1,7 +1,9 @@
-"""The active-set iteration of the exact TensionSmoother / postSmooth kernels (csrc/pqp_smoother_kernels.inc: tension_exact_kernel,
-post_exact_kernel) restated in numpy - same first active set, same acceptance test, same cautious rule - and swept over many random lines
-on the CPU: rounds needed, failures.  The kernel's round counts (tools/smoother_rounds.py, info[5]) reproduce these to the decimal.
-Usage: python tools/active_set_sweep.py [cases=200]        (CPU only; inputs from tests/smoother_cases.py, no oracle involved)"""
+"""The iterations of the exact TensionSmoother / postSmooth kernels (csrc/pqp_smoother_kernels.inc: tension_exact_kernel, post_exact_kernel)
+restated in numpy - same first active set (TensionSmoother, round 3: from interior-point iterations; postSmooth: OSQP's cold-start rule), same
+acceptance test, same cautious rule - and swept over many random lines on the CPU: factorisations needed, failures.  The kernel's counts
+(tools/smoother_rounds.py, info[5]) reproduce these.
+Usage: python tools/active_set_sweep.py [cases=200] [cold]       (CPU only; inputs from tests/smoother_cases.py, no oracle involved;
+       `cold`: the TensionSmoother rounds from the cold-start rule, as round 2 ran them)"""
 import os, sys
 from concurrent.futures import ProcessPoolExecutor
 import numpy as np
@@ -43,9 +45,39 @@ def post_box_qp(m, seed):
     return Hd, np.zeros(m), lo, up
 
 
-def active_set(Hd, lin, lo, up, cautious, tol=1e-7):
+def interior_start(Hd, lin, lo, up, gam=1.0):
+    """Primal-dual interior-point iterations on the box QP (centring 0.2 twice, then 0.05; 0.995 of the way to the boundary; complementarity from
+    0.01 gam to 1e-8 gam); returns the active set 'multiplier > gam * slack' and the iterations.  gam: the cost's scale relative to the reference's weights."""
+    n = len(lin); pinned = lo == up; fr = ~pinned; nf = int(fr.sum())
+    w = up - lo
+    d = np.where(pinned, lo, np.minimum(np.maximum(0.0, lo + 0.1 * w), up - 0.1 * w))
+    tl, tu = np.where(fr, d - lo, 1.0), np.where(fr, up - d, 1.0)
+    zl, zu = np.where(fr, 0.01 * gam / tl, 0.0), np.where(fr, 0.01 * gam / tu, 0.0)
+    its = 0
+    for it in range(40 if nf else 0):
+        g = Hd @ d + lin
+        mu = (tl[fr] @ zl[fr] + tu[fr] @ zu[fr]) / (2 * nf)
+        if mu < 1e-8 * gam and np.abs((g - zl + zu)[fr]).max() < 1e-6 * (gam + np.abs(g).max()):
+            break
+        smu = (0.2 if it < 2 else 0.05) * mu
+        A = Hd + np.diag(zl / tl + zu / tu)
+        dd = np.zeros(n)
+        dd[fr] = np.linalg.solve(A[np.ix_(fr, fr)], (-g + smu / tl - smu / tu)[fr])
+        its += 1
+        dzl = np.where(fr, (smu - tl * zl - zl * dd) / tl, 0.0); dzu = np.where(fr, (smu - tu * zu + zu * dd) / tu, 0.0)
+        a = np.inf
+        for v, dv in ((tl, dd), (tu, -dd), (zl, dzl), (zu, dzu)):
+            m = (dv < 0) & fr
+            if m.any(): a = min(a, (-v[m] / dv[m]).min())
+        a = min(1.0, 0.995 * a)
+        d = d + a * dd; tl = np.where(fr, tl + a * dd, 1.0); tu = np.where(fr, tu - a * dd, 1.0); zl = zl + a * dzl; zu = zu + a * dzu
+    return np.where(pinned, -1, np.where(zl > gam * tl, -1, np.where(zu > gam * tu, 1, 0))), its
+
+
+def active_set(Hd, lin, lo, up, cautious, tol=1e-7, act=None):
     n = len(lin); pinned = lo == up
-    act = np.where(pinned, -1, np.where(lo > 0, -1, np.where(up < 0, 1, 0)))
+    if act is None:
+        act = np.where(pinned, -1, np.where(lo > 0, -1, np.where(up < 0, 1, 0)))
     best, stall, cons = 1e300, 0, False
     for rnd in range(6 * n + 40):
         fix = np.where(act < 0, lo, np.where(act > 0, up, 0.0)); fr = act == 0
@@ -68,17 +100,23 @@ def active_set(Hd, lin, lo, up, cautious, tol=1e-7):
 
 
 def job(a):
-    kind, n, seed = a
+    kind, n, seed, cold = a
     if kind == "tension":
-        return active_set(*tension_box_qp(n, seed), cautious=0.5)
+        qp = tension_box_qp(n, seed)
+        if cold:
+            return active_set(*qp, cautious=0.5)
+        act, its = interior_start(*qp)
+        r = active_set(*qp, cautious=0.5, act=act)
+        return r + its if r > 0 else r
     return active_set(*post_box_qp(n, seed), cautious=0.9)
 
 
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    cold = "cold" in sys.argv[2:]
     with ProcessPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
         for kind, sizes in (("tension", (24, 48, 80, 130, 200, 300)), ("post", (8, 18, 28, 60, 150, 341))):
             for n in sizes:
-                r = np.array(list(ex.map(job, [(kind, n, 1000 + s) for s in range(cases)])))
+                r = np.array(list(ex.map(job, [(kind, n, 1000 + s, cold) for s in range(cases)])))
                 ok = r[r > 0]
-                print(f"{kind:8s} n {n:4d}: {cases} lines, failed {int((r < 0).sum())}, rounds mean {ok.mean():5.1f} p90 {np.percentile(ok, 90):4.0f} max {ok.max():4d}", flush=True)
+                print(f"{kind:8s} n {n:4d}: {cases} lines, failed {int((r < 0).sum())}, factorisations mean {ok.mean():5.1f} p90 {np.percentile(ok, 90):4.0f} max {ok.max():4d}", flush=True)
