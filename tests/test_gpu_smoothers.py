@@ -134,6 +134,32 @@ def test_exact_tension_kernel_is_bounded_from_the_cold_start(hip_lib):
             assert _tension_kkt_certificate(x[b], y[b], ang[b], cl[b], r["x"][b], r["y"][b]) < 1e-6, (n, b)
 
 
+def test_exact_tension_kernel_on_hostile_clearances_and_rough_lines(hip_lib):
+    """The interior start on inputs it was not tuned on: every box a tenth of a micrometre wide, widths spread over six decades, a third of them
+    narrower than a millimetre, clearances far beyond the 2 m cap, raw lines with half a metre of noise.  Every line ends at the KKT point of the
+    oracle's matrices; none needs more than 45 factorisations (the numpy restatement: at most 36 over these patterns)."""
+    n = 80
+    for pat in ("tiny", "log", "mixed", "huge", "noisy"):
+        cases = []
+        for b in range(16):
+            x, y, ang, _, _, cl = tension_inputs(n, seed=2000 + b)
+            rng = np.random.default_rng(2007 + b)
+            if pat == "tiny": cl = np.full(n, 1e-7)
+            elif pat == "log": cl = 10 ** rng.uniform(-6, 0.3, n)
+            elif pat == "mixed": cl = np.where(rng.uniform(size=n) < 0.3, 10 ** rng.uniform(-9, -3, n), rng.uniform(0.3, 3, n))
+            elif pat == "huge": cl = np.full(n, 50.0)
+            else: x = x + rng.normal(scale=0.5, size=n); y = y + rng.normal(scale=0.5, size=n)
+            cases.append((x, y, ang, cl))
+        x, y, ang, cl = (np.stack([c[k] for c in cases]) for k in range(4))
+        h = capi.Handle(_polished(), max_batch=len(cases), max_n=n)
+        r = h.smooth_tension(x, y, ang, cl, info=True)
+        h.close()
+        assert (r["status"] == 1).all(), pat
+        assert r["info"][:, 5].max() <= 45, (pat, r["info"][:, 5].max())
+        for b in range(len(cases)):
+            assert _tension_kkt_certificate(x[b], y[b], ang[b], cl[b], r["x"][b], r["y"][b]) < 1e-6, (pat, b)
+
+
 def test_exact_smoother_kernels_carry_the_previous_cycle_s_active_set(hip_lib):
     """PQP_OPT_CARRY_CYCLES on the exact TensionSmoother / postSmooth kernels: a line that moved a little since the previous solve starts its
     active-set rounds from the set its slot ended with.  The same optimum (the KKT certificate of the oracle's matrices; equal to the cold solve's),

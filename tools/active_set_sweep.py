@@ -47,12 +47,17 @@ def post_box_qp(m, seed):
 
 def interior_start(Hd, lin, lo, up, gam=1.0):
     """Primal-dual interior-point iterations on the box QP (centring 0.2 twice, then 0.05; 0.995 of the way to the boundary; complementarity from
-    0.01 gam to 1e-8 gam); returns the active set 'multiplier > gam * slack' and the iterations.  gam: the cost's scale relative to the reference's weights."""
-    n = len(lin); pinned = lo == up; fr = ~pinned; nf = int(fr.sum())
+    max(0.01 gam, 3e-4 |g| t) to 1e-8 gam; boxes narrower than 1 mm take no part); returns the active set 'multiplier > gam * slack' and the iterations.  gam: the cost's scale relative to the reference's weights."""
+    n = len(lin); pinned = lo == up
     w = up - lo
-    d = np.where(pinned, lo, np.minimum(np.maximum(0.0, lo + 0.1 * w), up - 0.1 * w))
+    narrow = ~pinned & (w < 1e-3)                   # stay at their centre, set by the gradient's sign afterwards
+    fr = ~pinned & ~narrow; nf = int(fr.sum())
+    d = np.where(fr, np.minimum(np.maximum(0.0, lo + 0.1 * w), up - 0.1 * w), 0.5 * (lo + up))
     tl, tu = np.where(fr, d - lo, 1.0), np.where(fr, up - d, 1.0)
-    zl, zu = np.where(fr, 0.01 * gam / tl, 0.0), np.where(fr, 0.01 * gam / tu, 0.0)
+    mu0 = 0.01 * gam
+    if nf:
+        mu0 = max(mu0, 3e-4 * np.abs((Hd @ d + lin)[fr]).max() * np.minimum(tl, tu)[fr].mean())
+    zl, zu = np.where(fr, mu0 / tl, 0.0), np.where(fr, mu0 / tu, 0.0)
     its = 0
     for it in range(40 if nf else 0):
         g = Hd @ d + lin
@@ -71,7 +76,8 @@ def interior_start(Hd, lin, lo, up, gam=1.0):
             if m.any(): a = min(a, (-v[m] / dv[m]).min())
         a = min(1.0, 0.995 * a)
         d = d + a * dd; tl = np.where(fr, tl + a * dd, 1.0); tu = np.where(fr, tu - a * dd, 1.0); zl = zl + a * dzl; zu = zu + a * dzu
-    return np.where(pinned, -1, np.where(zl > gam * tl, -1, np.where(zu > gam * tu, 1, 0))), its
+    g = Hd @ d + lin
+    return np.where(pinned, -1, np.where(narrow, np.where(g > 0, -1, 1), np.where(zl > gam * tl, -1, np.where(zu > gam * tu, 1, 0)))), its
 
 
 def active_set(Hd, lin, lo, up, cautious, tol=1e-7, act=None):
