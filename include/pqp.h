@@ -207,7 +207,7 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      rounds of the first pass, Riccati sweeps, active-set rounds}.  (PQP_OPT_ORDER_BY_COST has no effect on it.)
  *   PQP_OPT_CARRY_CYCLES (default 0)   a cold call (warm == 0, lin == NULL) starts the FIRST pass of QP k from the optimum QP k had in the handle's
  *                                      previous solve of the same batch and n instead of cold (lane-per-waypoint kernel: from the warm state it then keeps
- *                                      - final iterate, equilibration, active set; no n_of; lane-per-QP kernel: from its workspace) - a planner re-solves
+ *                                      - final iterate, equilibration, active set, kept per waypoint: counts per QP may change between the calls; lane-per-QP kernel: from its workspace) - a planner re-solves
  *                                      nearly the same scenarios cycle after cycle; the reference constructs a fresh BaseSolver every cycle
  *                                      (path_optimizer.cpp:138).  The optimum returned is the same (unique; it agrees with the cold solve to the
  *                                      1e-7 of the KKT test); on scenarios that moved by 5 %: configs[1] 4.0 M instead of 3.1 M paths/s and no stragglers
@@ -308,7 +308,7 @@ int pqp_multi_create(pqp_multi** m, const pqp_params* params, int n_shards, cons
 int pqp_multi_destroy(pqp_multi* m);
 int pqp_multi_shards(const pqp_multi* m);
 pqp_handle* pqp_multi_handle(pqp_multi* m, int shard);       /* a shard's own handle (device-resident use, options, timing) */
-/* every shard's handle gets the option (PQP_OPT_CARRY_CYCLES: a call whose batch and n equal the previous call's - no n_of, no lin - starts shard by shard
+/* every shard's handle gets the option (PQP_OPT_CARRY_CYCLES: a call whose batch and n equal the previous call's - no lin - starts shard by shard
  * from what the shard's handle kept: the same scenarios one planning cycle later) */
 int pqp_multi_set_option(pqp_multi* m, int option, int value);
 int pqp_multi_path_solve(pqp_multi* m, int batch, int n, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,

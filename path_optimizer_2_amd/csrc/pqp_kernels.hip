@@ -958,9 +958,11 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     //  gets the exact optimum: zero residuals meet OSQP's termination test at any eps)
     if ((n > 512 && (!warm || lin)) || (h->prm.polish != 0 && !warm && !h->opt_store_warm && h->opt_stream_batch > 0 && batch >= h->opt_stream_batch))
         return path_stream_impl(h, batch, n, n_of, ref, lin, bounds, scal, passes, out, status, iters, info);
-    // PQP_OPT_CARRY_CYCLES on this kernel: a cold call (warm == 0, lin == NULL, no counts) of the shape of the handle's previous solve starts from
-    // the final iterate, equilibration and active set that solve left in the warm state - the same scenarios one planning cycle later
-    if (h->opt_carry && !warm && !lin && !n_of && h->warm_stored && h->warm_batch == batch && h->warm_n == n) warm = 1;
+    // PQP_OPT_CARRY_CYCLES on this kernel: a cold call (warm == 0, lin == NULL) of the shape of the handle's previous solve starts from
+    // the final iterate, equilibration and active set that solve left in the warm state - the same scenarios one planning cycle later.
+    // (With waypoint counts per QP the state is kept per waypoint: a path that grew or shrank by a few waypoints since the previous cycle
+    //  starts its common waypoints from where they were and the new ones from whatever the slot last held there - zero at first.)
+    if (h->opt_carry && !warm && !lin && h->warm_stored && h->warm_batch == batch && h->warm_n == n) warm = 1;
     if (n > 512) return fail(PQP_ERR_CAPACITY, "pqp_path_solve: warm == 1 beyond 512 waypoints needs the linearisation point (`lin`): the lane-per-QP kernel keeps no warm state");
     if (warm && (h->warm_batch != batch || h->warm_n != n || !h->warm_stored))
         return fail(PQP_ERR_INVALID, "pqp_path_solve: warm == 1 needs a previous solve with the same batch and n (with PQP_OPT_STORE_WARM on)");

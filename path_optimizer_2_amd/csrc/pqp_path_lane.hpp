@@ -1644,14 +1644,17 @@ struct PathQp {
         });
     }
 
+    // (A warm state is a starting point, not data: with PQP_OPT_CARRY_CYCLES it is whatever the slot's previous QP left - possibly a QP with another
+    //  waypoint count, or one that ended non-finite.  Entries that are not finite start from 0, so that one bad cycle does not poison the slot for good.)
     PQP_HD void load_warm() {
+        auto fin = [](double v) { return fabs(v) <= 1e300 ? v : 0.0; };
         ctx.phase([&](int t, Lane& ln) {
             Slot& S = ln.s;
             const bool real = S.flags & F_REAL;
             const size_t o = ((size_t)qp * stride + (real ? t : n - 1)) * 6;
-            _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = real ? A.wx[o + k] : 0.0;
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) { S.yT[k] = real ? A.wy[o + k] : 0.0; S.yI[k] = real ? A.wy[o + 3 + k] : 0.0; }
-            if (S.flags & F_LAST) { end_rows()->y[0] = A.wye[2 * (size_t)qp]; end_rows()->y[1] = A.wye[2 * (size_t)qp + 1]; }
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = real ? fin(A.wx[o + k]) : 0.0;
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { S.yT[k] = real ? fin(A.wy[o + k]) : 0.0; S.yI[k] = real ? fin(A.wy[o + 3 + k]) : 0.0; }
+            if (S.flags & F_LAST) { end_rows()->y[0] = fin(A.wye[2 * (size_t)qp]); end_rows()->y[1] = fin(A.wye[2 * (size_t)qp + 1]); }
         });
     }
 
@@ -1723,6 +1726,7 @@ struct PathQp {
                 if (A.warm) {
                     load_warm();
                     rho = ctx.uni(A.wrho[qp]);       // (a vector load: told to be the same in every lane, see DevCtx::uni)
+                    if (!(rho >= kRhoMin && rho <= kRhoMax)) rho = prm.rho;
                 } else {
                     ctx.phase([&](int, Lane& ln) {
                         if (ln.s.flags & F_LAST) { end_rows()->y[0] = 0.0; end_rows()->y[1] = 0.0; }

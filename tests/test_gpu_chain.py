@@ -148,6 +148,40 @@ def test_the_tension_smoothing_method(hip_lib):
     h.close(); hs.close()
 
 
+def test_chain_carries_the_previous_planning_cycle(hip_lib):
+    """PQP_OPT_CARRY_CYCLES through the whole device-resident chain: the vehicle advances a little every cycle (start pose and input points move), so
+    the raw line, the layer and waypoint counts of a scenario change from call to call - the path QP's warm state is kept per waypoint, the exact
+    smoother kernels start from their slot's previous active set.  Every cycle's paths equal those of handles that start cold (what the carried
+    start saves is time: tools/bench_full_chain.py --carry, 656 k -> 958 k scenarios/s)."""
+    B = 24
+    sc = _scenarios(B, seed=21)
+    pair = lambda: (capi.Handle(capi.production_params(), max_batch=B, max_n=256), capi.Handle(_smoother_params(), max_batch=B, max_n=128))
+    h, hs = pair(); hc, hsc = pair()
+    for x in (hc, hsc):
+        x.set_option(capi.OPT_CARRY_CYCLES, 1)
+    rng = np.random.default_rng(3)
+    counts = []
+    for cycle in range(4):
+        pts = sc["pts"].copy(); start = sc["start"].copy()
+        if cycle:
+            pts[:, :, 1] += rng.normal(scale=0.02, size=pts.shape[:2]) * (pts[:, :, 0] != 0)
+            start[:, :2] += rng.normal(scale=0.05, size=(B, 2)); start[:, 2] += rng.normal(scale=0.01, size=B)
+        a = (pts, sc["n_pts"], start, sc["target"], sc["dist"], sc["geom"])
+        cold = h.optimize_path(*a, map_of=sc["map_of"], smoother=hs)
+        got = hc.optimize_path(*a, map_of=sc["map_of"], smoother=hsc)
+        np.testing.assert_array_equal(got["stage"], cold["stage"]); np.testing.assert_array_equal(got["n_out"], cold["n_out"])
+        np.testing.assert_array_equal(got["status"], cold["status"])
+        ok = np.flatnonzero(cold["stage"] == 0)
+        assert len(ok) >= B - 4
+        for b in ok:
+            nv = cold["n_out"][b]
+            assert np.abs(got["out"][b, :nv] - cold["out"][b, :nv]).max() < 2e-5, (cycle, b, np.abs(got["out"][b, :nv] - cold["out"][b, :nv]).max())
+        counts.append(cold["n_out"].copy())
+    assert any((counts[k] != counts[0]).any() for k in range(1, 4))          # the waypoint counts did move between the cycles
+    for x in (h, hs, hc, hsc):
+        x.close()
+
+
 def test_stages_are_the_reference_s_return_false_sites(hip_lib):
     sc = _scenarios(6, seed=9)
     sc["n_pts"][1] = 3                                               # "Few reference points" (reference_path_smoother.cpp:33-36)

@@ -1,7 +1,7 @@
 """The whole of PathOptimizer::solve, input points -> optimised path, as ONE device-resident call (pqp_optimize_path_device): ragged
 scenarios (polygons of 7..13 input points over 8 obstacle maps: every intermediate count differs per scenario), nothing copied to the
 host between the twelve steps.  Prints scenarios/s (host clock around enqueue + sync over several repetitions) and the stage census.
-Usage: python tools/bench_full_chain.py [batch=1024] [n_maps=8] [reps=10]   (run on the GPU box)"""
+Usage: python tools/bench_full_chain.py [batch=1024] [n_maps=8] [reps=10] [--exact-smoothers] [--tension] [--inflight-2] [--moving] [--carry]   (run on the GPU box)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -50,6 +50,8 @@ for _ in range(inflight):
     hs = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3, adaptive_rho_interval=100 if "--rho-interval-100" in sys.argv else 25,
                                          polish=pol, polish_every=25 if pol == 1 else 0, polish_refine_iter=2 if pol else 4), device=0, max_batch=batch, max_n=128)
     h.set_option(capi.OPT_STORE_WARM, 0); h.set_option(capi.OPT_ORDER_BY_COST, 1)
+    if "--carry" in sys.argv:            # PQP_OPT_CARRY_CYCLES on both handles: every QP of the chain starts from its slot's previous planning cycle
+        h.set_option(capi.OPT_CARRY_CYCLES, 1); hs.set_option(capi.OPT_CARRY_CYCLES, 1)
     h.set_option(capi.OPT_RESERVE_CUS, int(os.environ.get("PQP_RESERVE_CUS", "0")))     # (experiments: CUs the path QP leaves to the other kernels in flight)
     # capacities sized to the workload (lines of 18..36 m): every smoother QP of the batch runs at the padded maximum size
     cfg = h.chain_config(raw_max=64, sample_max=48, layer_max=32, n_max=128) if "--default-capacities" not in sys.argv else h.chain_config()
@@ -61,8 +63,21 @@ for _ in range(inflight):
 torch.cuda.synchronize()
 
 
+# --moving (implied by --carry): the scenarios change from call to call as they do between planning cycles - input points shifted by ~2 cm, the start pose by
+# ~5 cm / 0.01 rad - six variants in turn, so that a carried start is the PREVIOUS cycle's solution, not this one's
+moving = "--moving" in sys.argv or "--carry" in sys.argv
+variants = [(d_pts, d_st)]
+if moving:
+    rv = np.random.default_rng(9)
+    for v in range(5):
+        pv = pts.copy(); pv[:, :, 1] += rv.normal(scale=0.02, size=pts.shape[:2]) * (pts[:, :, 0] != 0)
+        sv = start.copy(); sv[:, :2] += rv.normal(scale=0.05, size=(batch, 2)); sv[:, 2] += rv.normal(scale=0.01, size=batch)
+        variants.append((t(pv, np.float64), t(sv, np.float64)))
+
+
 def run(k):
     h, hs, cfg, out, n_out, status, stage, iters = lanes[k % inflight]
+    d_pts, d_st = variants[(k // inflight) % len(variants)]
     h._check(h.lib.pqp_optimize_path_device(h._h, hs._h, capi.C.byref(cfg), batch, p_max, p(d_pts), p(d_np), p(d_st), p(d_tg), p(d_dist), p(d_map),
                                             capi.C.byref(geom), None, p(out), p(n_out), p(status), p(stage), p(iters)))
 
@@ -85,7 +100,8 @@ sg, no = stage.cpu().numpy(), n_out.cpu().numpy()
 names = ["ok", "few points", "smoother failed", "search failed", "short reference", "post smooth failed", "heading", "blocked", "path QP failed", "capacity"]
 print(f"pqp_optimize_path_device: {batch} ragged scenarios over {n_maps} maps ({int(n_pts.min())}..{int(n_pts.max())} input points): "
       f"{dt * 1e3:.3f} ms per batch = {batch / dt:.0f} scenarios/s, input points -> optimised path, device resident"
-      + (f", {inflight} batches in flight" if inflight > 1 else ""))
+      + (f", {inflight} batches in flight" if inflight > 1 else "") + (", scenarios moving from call to call" if moving else "")
+      + (", PQP_OPT_CARRY_CYCLES" if "--carry" in sys.argv else ""))
 print("  stages: " + ", ".join(f"{names[k]} {int((sg == k).sum())}" for k in range(10) if (sg == k).any()))
 ok = sg == 0
 print(f"  paths: {int(ok.sum())} solved, waypoints {int(no[ok].min())}..{int(no[ok].max())} (mean {no[ok].mean():.0f}); "
