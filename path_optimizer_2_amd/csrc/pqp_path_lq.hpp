@@ -36,6 +36,15 @@
 #include <cstdio>
 #endif
 
+#ifndef PQP_LQ_MU0
+#define PQP_LQ_MU0 0.1
+#endif
+#ifndef PQP_LQ_SIGMA_HI
+#define PQP_LQ_SIGMA_HI 0.2
+#endif
+#ifndef PQP_LQ_SIGMA_LO
+#define PQP_LQ_SIGMA_LO 0.05
+#endif
 namespace pqp {
 namespace lq {
 
@@ -456,7 +465,7 @@ struct Solver {
     }
     // after the initial solve: the interior-point state of every row, strictly inside its box where the row has a slack
     PQP_SWEEP void forward_init() {
-        const double theta = 0.05, mu0 = 0.1;
+        const double theta = 0.05, mu0 = PQP_LQ_MU0;
         double x[3] = {x0[0], x0[1], x0[2]};
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         auto start = [&](double v, double lo, double up, bool slack) {
@@ -632,7 +641,7 @@ struct Solver {
             //  line - crawls: 2 % of residual per iteration.  Every QP of the bench distributions is feasible within 12 iterations; one that
             //  has not shed 90 % of its initial residual after 30 gives up as PQP_STATUS_MAX_ITER instead of holding its wavefront for 100)
             while (!(mu < mu_stop && res < 1e-6) && it < kIpmMaxIter && stall < 6 && slow < 3 && !(it >= 30 && res > 0.1 * res0 && res > 1e-6)) {
-                const double sigma = (first || alpha <= 0.9) ? 0.2 : 0.05;
+                const double sigma = (first || alpha <= 0.9) ? PQP_LQ_SIGMA_HI : PQP_LQ_SIGMA_LO;
                 const double sm = sigma * mu;
                 backward<MODE_IPM>(sm);
                 forward_ipm(sm);
