@@ -1528,12 +1528,17 @@ void pqp_corridor_default_params(pqp_corridor_params* p) {
     p->projection_window = 5.0;                         // reference_path_impl.cpp:194
 }
 
+// a distance-map layer the kernels can index with 32 bits (pqp_corridor_kernels.inc: obstacle_distance)
+static bool geometry_ok(const pqp_grid_geometry* g) {
+    return g && g->rows >= 2 && g->cols >= 2 && g->resolution > 0.0 && (long long)g->rows * g->cols < (1ll << 30);
+}
+
 int pqp_corridor_bounds_device(pqp_handle* h, int batch, int n, int m, const double* ref, const int32_t* n_of, const double* spline,
                                const double* spline_ext, const float* dist, const int32_t* map_of, const pqp_grid_geometry* geom,
                                const pqp_corridor_params* prm, double* bounds, int32_t* n_valid) {
     if (!h || !ref || !spline || !spline_ext || !dist || !geom || !prm || !bounds || !n_valid || batch < 1 || n < 1 || m < 3 ||
-        geom->rows < 2 || geom->cols < 2 || !(geom->resolution > 0.0) || !(prm->delta_s > 0.0) || !(prm->smaller_ds > 0.0))
-        return fail(PQP_ERR_INVALID, "pqp_corridor_bounds: bad argument (m >= 3 knots: spline.cpp:164)");
+        !geometry_ok(geom) || !(prm->delta_s > 0.0) || !(prm->smaller_ds > 0.0))
+        return fail(PQP_ERR_INVALID, "pqp_corridor_bounds: bad argument (m >= 3 knots: spline.cpp:164; a map layer of 2 x 2 to 2^30 cells)");
     PQP_HIP(hipSetDevice(h->device));
     pqp::CorridorArgs a;
     a.batch = batch; a.n = n; a.m = m; a.ref = ref; a.spl = spline; a.spl_ext = spline_ext; a.dist = dist; a.map_of = map_of; a.n_of = n_of;
@@ -1879,7 +1884,7 @@ int pqp_dp_corridor_device(pqp_handle* h, int batch, int m, int max_layers, cons
                            const pqp_grid_geometry* geom, const pqp_dp_params* prm, double* layers_s, double* lb, double* ub,
                            int32_t* count, double* vehicle_l) {
     if (!h || !spline || !spline_ext || !length || !start || !dist || !geom || !prm || !layers_s || !lb || !ub || !count || !vehicle_l ||
-        batch < 1 || m < 3 || max_layers < 2 || !(prm->lateral_spacing > 0.0) || !(prm->longitudinal_spacing > 0.0) ||
+        batch < 1 || m < 3 || max_layers < 2 || !geometry_ok(geom) || !(prm->lateral_spacing > 0.0) || !(prm->longitudinal_spacing > 0.0) ||
         2.0 * prm->lateral_range / prm->lateral_spacing + 1.0 > 64.0)
         return fail(PQP_ERR_INVALID, "pqp_dp_corridor: bad argument (at most 64 lateral samples per layer)");
     PQP_HIP(hipSetDevice(h->device));
