@@ -82,6 +82,13 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise OSError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # A process that also uses torch must load torch's HIP runtime FIRST: the wheel bundles its own libamdhip64 under the soname this library needs
+    # too, and whichever copy is mapped first serves both - with /opt/rocm's mapped first, torch finds no device ("No HIP GPUs are available").
+    # (The device-resident entry points of this binding use torch as memory plumbing; the library itself does not depend on it.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
     lib.pqp_default_params.argtypes = [C.POINTER(PqpParams)]
