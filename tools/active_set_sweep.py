@@ -81,10 +81,14 @@ def interior_start(Hd, lin, lo, up, gam=1.0):
 
 
 def active_set(Hd, lin, lo, up, cautious, tol=1e-7, act=None):
+    """act: a first active set (the interior start's: the rounds are then cautious from the first one on, threshold 0.9); None: OSQP's cold-start rule."""
     n = len(lin); pinned = lo == up
+    interior = act is not None
     if act is None:
         act = np.where(pinned, -1, np.where(lo > 0, -1, np.where(up < 0, 1, 0)))
-    best, stall, cons = 1e300, 0, False
+    best, stall, cons = 1e300, 0, interior
+    if interior:
+        cautious = 0.9
     for rnd in range(6 * n + 40):
         fix = np.where(act < 0, lo, np.where(act > 0, up, 0.0)); fr = act == 0
         d = fix.copy()
