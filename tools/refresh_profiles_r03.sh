@@ -18,6 +18,11 @@ cp $(find /tmp/rp1 -name "*kernel_stats.csv" | head -1) ${o}_bench_n1_kernel_sta
 cp $(find /tmp/rp2 -name "*kernel_stats.csv" | head -1) ${o}_bench_stream_65536_kernel_stats.csv
 (cd /tmp && rm -rf /tmp/rp3 && rocprofv3 --kernel-trace --stats -f csv -d /tmp/rp3 -- python $root/bench.py --config 3 --batch 65536 --steps 20 --inflight 1 --no-cpu-baseline --no-secondary --pmc off --sustain 0 > ${root}/${o}_bench_stream_65536_one_at_a_time_under_rocprof.json 2> /dev/null)
 cp $(find /tmp/rp3 -name "*kernel_stats.csv" | head -1) ${o}_bench_stream_65536_one_at_a_time_kernel_stats.csv
+# the smoother QPs (cold and carried), the exact TensionSmoother kernel on distinct lines, the device-resident chain on moving scenarios
+{ timeout 200 python tools/bench_smoothers_carry.py; timeout 100 python tools/smoother_rounds.py; for b in 4096 16384; do timeout 100 python tools/bench_smoothers_carry.py $b 80 | grep tension; done; } 2>&1 | grep -v amdgpu.ids > ${o}_smoothers.txt
+timeout 300 python tools/tension_fuzz.py 2048 2>&1 | grep -v amdgpu.ids > ${o}_tension_fuzz.txt
+for f in "--exact-smoothers --moving" "--exact-smoothers --carry" "--exact-smoothers --tension --moving" "--exact-smoothers --tension --carry" "--exact-smoothers --inflight-2 --moving" "--exact-smoothers --inflight-2 --carry" "--exact-smoothers"; do echo "$f"; timeout 120 python tools/bench_full_chain.py 1024 8 20 $f 2>&1 | grep -v amdgpu.ids; done > ${o}_full_chain.txt
+CHAIN_ARGS="--exact-smoothers --carry" timeout 300 bash tools/pmc_chain.sh r03${tag}_chain_carry > /dev/null 2>&1; cp gpurun_out/prof/r03${tag}_chain_carry/chain_pmc.txt ${o}_chain_carry_pmc.txt
 tail -3 ${o}_pytest.log
 python - <<PY
 import json
