@@ -52,6 +52,7 @@ namespace pqp {
 constexpr double kInfty = 1e30;        // OSQP_INFTY
 constexpr double kMinScaling = 1e-4;
 constexpr double kMaxScaling = 1e4;
+constexpr int kCautiousFromRound = 8;        // active-set rounds of a polish attempt: single moves from this round on at the latest (run())
 constexpr double kRhoMin = 1e-6;
 constexpr double kRhoMax = 1e6;
 constexpr double kRhoTol = 1e-4;
@@ -1956,7 +1957,12 @@ struct PathQp {
                         if (viol < 0.7 * best) { best = viol; stall = 0; } else { stall += 1; }
                         // (progress of the cautious rounds is measured from where they start: the full rounds before them may
                         // have passed through a smaller violation on their way out)
-                        if (stall >= 3 && !conservative) { conservative = true; best = viol; stall = 0; }
+                        // (round 3: ... or when the attempt reaches its 8th round - nearly every QP is done by its 5th, one still moving rows
+                        //  wholesale in its 8th is wandering and would do so until three stalls in a row, e.g. through eight turns of a period-7
+                        //  cycle: over 16 scenario seeds the slowest QP of a batch of 1024 went from 46-121 reduced solves to 39-66, the headline of the
+                        //  two straggler seeds from 1.91 / 2.72 M to 2.79 / 3.12 M paths/s, one launch at a time from 1.03-1.96 M to 1.68-2.19 M, the
+                        //  mean cost stayed - profiles/r03x_seed_sweep.txt; 7 and 9-12 instead of 8: seed 6's straggler survives from 9 on, 7 costs 2 %)
+                        if ((stall >= 3 || round + 1 >= kCautiousFromRound) && !conservative) { conservative = true; best = viol; stall = 0; }
                         round += 1;
                         // (the attempts after a pass's first periodic one start from a better ADMM iterate and get half the rounds:
                         // when those are not enough the rounds are usually cycling, and every further one is wasted.  A quarter
