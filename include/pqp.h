@@ -313,6 +313,12 @@ pqp_handle* pqp_multi_handle(pqp_multi* m, int shard);       /* a shard's own ha
 int pqp_multi_set_option(pqp_multi* m, int option, int value);
 int pqp_multi_path_solve(pqp_multi* m, int batch, int n, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
                          const double* scal, int passes, double* out, int32_t* status, int32_t* iters, double* info);
+/* The exchange step of SURVEY.md 8e / north_star ("RCCL over xGMI only to gather results") in the C ABI: after pqp_multi_path_solve every shard's
+ * paths are still in its GPU's memory; this gathers them over RCCL so that full_out[g] - a buffer of [batch][n][PQP_OUT_STRIDE] doubles in the memory
+ * of shard g's GPU - holds the whole batch in the caller's order, for a consumer that lives on the GPUs (the host copy of pqp_multi_path_solve is
+ * unaffected).  batch and n as in the preceding solve.  One device per shard; librccl.so is dlopen'ed by the first call, a caller that never
+ * gathers does not need it.  The reference has no counterpart (one path per call). */
+int pqp_multi_gather_paths(pqp_multi* m, int batch, int n, double* const* full_out);
 
 /* ---- reference-line smoothing QPs; the solver settings of the handle apply (the reference runs
  *      them at OSQP's default eps 1e-3: tension_smoother_2.cpp:32-36, tension_smoother.cpp:61-65, reference_path_smoother.cpp:533-537).

@@ -62,7 +62,7 @@ EXPORTS = [
     "pqp_default_params", "pqp_production_params", "pqp_last_error", "pqp_version", "pqp_create", "pqp_destroy", "pqp_set_params", "pqp_set_option",
     "pqp_constrain_angle_device", "pqp_stream_wait", "pqp_mark", "pqp_wait_mark", "pqp_get_stream",
     "pqp_chain_default_config", "pqp_optimize_path_device", "pqp_clearance_device", "pqp_smooth_tension2_var_device", "pqp_smooth_tension_var_device", "pqp_post_smooth_var_device", "pqp_spline_fit_var_device",
-    "pqp_shard_range", "pqp_multi_create", "pqp_multi_destroy", "pqp_multi_shards", "pqp_multi_handle", "pqp_multi_set_option", "pqp_multi_path_solve", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
+    "pqp_shard_range", "pqp_multi_create", "pqp_multi_destroy", "pqp_multi_shards", "pqp_multi_handle", "pqp_multi_set_option", "pqp_multi_path_solve", "pqp_multi_gather_paths", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
     "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_solve_var_device", "pqp_path_solve_var", "pqp_path_get_solution",
     "pqp_last_kernel_ms", "pqp_kernel_ms_history", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
     "pqp_post_smooth", "pqp_post_smooth_device", "pqp_corridor_default_params", "pqp_corridor_bounds", "pqp_corridor_bounds_device",
@@ -124,6 +124,7 @@ def load_library(path=None):
     lib.pqp_multi_handle.restype = vp
     lib.pqp_multi_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.pqp_multi_path_solve.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
+    lib.pqp_multi_gather_paths.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.pqp_sync.argtypes = [vp]
     lib.pqp_path_sizes.argtypes = [C.POINTER(PqpParams), C.c_int, vp, C.POINTER(PqpSizes)]
     lib.pqp_path_pattern.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
@@ -241,7 +242,22 @@ class MultiHandle:
                                            _ptr(status), _ptr(iters), _ptr(info))
         if rc != 0:
             raise PqpError(f"pqp error {rc}: {self.lib.pqp_last_error().decode()}")
+        self._last = (batch, n)
         return dict(out=out, status=status, iters=iters, info=info)
+
+    def gather_paths(self, devices):
+        """pqp_multi_gather_paths after solve(): one torch tensor [batch][n][7] per shard, on the shard's GPU (`devices`: the list given at creation),
+        every one holding the whole batch - gathered over RCCL, nothing through the host."""
+        import torch
+        batch, n = self._last
+        outs = [torch.zeros((batch, n, 7), dtype=torch.float64, device=torch.device("cuda", int(d))) for d in devices]
+        for d in devices:
+            torch.cuda.synchronize(int(d))
+        ptrs = (C.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
+        rc = self.lib.pqp_multi_gather_paths(self._m, batch, n, ptrs)
+        if rc != 0:
+            raise PqpError(f"pqp error {rc}: {self.lib.pqp_last_error().decode()}")
+        return outs
 
 
 class PqpError(RuntimeError):

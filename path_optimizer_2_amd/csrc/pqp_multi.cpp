@@ -3,12 +3,16 @@
 // (created in pqp_multi_create, parked on a condition variable between calls), pinned staging buffers and device buffers.  A call
 // hands every worker its slice of the caller's host arrays; the worker stages it into pinned memory, enqueues H2D copies, the
 // device-resident solve and the D2H copies on its handle's stream - true asynchronous DMA, so the copies of one shard run beside the
-// solves of the others also when two shards share a GPU - waits for its stream and writes the caller's output slice.  No collective:
-// with the consumer on the host per-GPU copies beat a device-side gather; the device-resident RCCL all-gather of the
-// result slabs is path_optimizer_2_amd/shard.py (torch.distributed, one process per GPU).
+// solves of the others also when two shards share a GPU - waits for its stream and writes the caller's output slice.  No collective in
+// that call: with the consumer on the host per-GPU copies beat a device-side gather.  For a consumer ON the GPUs there is
+// pqp_multi_gather_paths below: the result slabs the shards keep in device memory, gathered over RCCL (xGMI) so that every GPU holds every
+// path - the one exchange step north_star names, and the only place this library touches RCCL (dlopen'ed on first use: a caller that never
+// gathers needs no librccl).  The one-process-per-GPU counterpart is path_optimizer_2_amd/shard.py (torch.distributed).
 // Plain host C++ over the entry points of pqp_kernels.hip + the HIP runtime's memory API; part of libpqp_hip.so.
 // The reference has no counterpart (one path per call, single-threaded: base_solver.cpp:56-95).
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is dlopen'ed on first use (Rccl below)
 
 #include <chrono>
 #include <condition_variable>
@@ -71,6 +75,7 @@ struct Shard {
     int rc = PQP_OK;
     std::string err;
     Staged ref, lin, bounds, scal, counts, out, status, iters, info;
+    int last_count = -1, last_n = 0;        // shape of the slab out.dev holds (pqp_multi_gather_paths)
 
     int hip(hipError_t e, const char* what) {
         if (e == hipSuccess) return PQP_OK;
@@ -124,6 +129,7 @@ struct Shard {
         if (j.status) std::memcpy(j.status, status.pin, b * 4);
         if (j.iters) std::memcpy(j.iters, iters.pin, b * 4);
         if (j.info) std::memcpy(j.info, info.pin, b * PQP_INFO_STRIDE * 8);
+        last_count = j.count; last_n = j.n;
         if (trace) std::fprintf(stderr, "[pqp_multi] device %d, %d QPs: staged + H2D enqueued %ld us, solve + D2H enqueued %ld us, stream done %ld us, copied out %ld us\n",
                                 device, j.count, t_stage, t_enq, t_sync, us());
         return PQP_OK;
@@ -140,6 +146,7 @@ struct Shard {
                 has_job = false;
             }
             err.clear();
+            if (j.count <= 0) { last_count = 0; last_n = j.n; }
             const int r = j.count > 0 ? run(j) : PQP_OK;
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -170,10 +177,42 @@ struct Shard {
         for (Staged* s : {&ref, &lin, &bounds, &scal, &counts, &out, &status, &iters, &info}) s->release();
     }
 };
+
+// RCCL, resolved at run time.  One communicator per shard (single process, one rank per device), created by the first gather.
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) comm_init_all = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclBroadcast) broadcast = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    std::string why;
+    bool load() {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { const char* e = dlerror(); why = std::string("librccl.so not found (") + (e ? e : "?") + ")"; return false; }
+        auto sym = [&](const char* n) { void* f = dlsym(lib, n); if (!f) why = std::string("librccl.so lacks ") + n; return f; };
+        comm_init_all = (decltype(comm_init_all))sym("ncclCommInitAll");
+        comm_destroy = (decltype(comm_destroy))sym("ncclCommDestroy");
+        group_start = (decltype(group_start))sym("ncclGroupStart");
+        group_end = (decltype(group_end))sym("ncclGroupEnd");
+        broadcast = (decltype(broadcast))sym("ncclBroadcast");
+        error_string = (decltype(error_string))sym("ncclGetErrorString");
+        if (!comm_init_all || !comm_destroy || !group_start || !group_end || !broadcast || !error_string) { lib = nullptr; return false; }
+        return true;
+    }
+};
+Rccl& rccl() { static Rccl r; return r; }
 }  // namespace
 
 struct pqp_multi {
     std::vector<Shard*> shards;
+    std::vector<ncclComm_t> comms;          // empty until the first pqp_multi_gather_paths
+    std::mutex gather_mu;
 };
 
 extern "C" {
@@ -214,6 +253,7 @@ int pqp_multi_create(pqp_multi** out, const pqp_params* params, int n_shards, co
 
 int pqp_multi_destroy(pqp_multi* m) {
     if (!m) return PQP_OK;
+    for (ncclComm_t c : m->comms) (void)rccl().comm_destroy(c);
     for (Shard* s : m->shards) {
         s->stop();
         (void)pqp_destroy(s->h);
@@ -280,6 +320,64 @@ int pqp_multi_path_solve(pqp_multi* m, int batch, int n, const int32_t* n_of, co
     if (!counts.empty() && status)
         for (int q = 0; q < batch; ++q)
             if (counts[q] < 0) status[q] = PQP_STATUS_PRIMAL_INFEASIBLE;
+    return PQP_OK;
+}
+
+// After pqp_multi_path_solve: every shard's result slab is still in its GPU's memory.  Gathers the slabs so that full_out[g] - device memory
+// of shard g's GPU, [batch][n][PQP_OUT_STRIDE] doubles - holds the paths of the whole batch in the caller's order, over RCCL: shard r broadcasts
+// its contiguous slab (pqp_shard_range) to everyone, all broadcasts of all shards in one group on the shards' own streams, which the call waits
+// for.  (Broadcasts rather than one all-gather: the slabs of a batch that does not divide by the shard count differ by one QP.)
+// Needs one device per shard (RCCL refuses two ranks on one device) and librccl.so at run time.
+int pqp_multi_gather_paths(pqp_multi* m, int batch, int n, double* const* full_out) {
+    if (!m || !full_out || batch < 1 || n < 2) return mfail(PQP_ERR_INVALID, "pqp_multi_gather_paths: bad argument");
+    const int world = (int)m->shards.size();
+    std::lock_guard<std::mutex> lk(m->gather_mu);
+    std::vector<int> first(world), count(world);
+    for (int g = 0; g < world; ++g) {
+        pqp_shard_range(batch, world, g, &first[g], &count[g]);
+        if (!full_out[g]) return mfail(PQP_ERR_INVALID, "pqp_multi_gather_paths: null output buffer");
+        if (m->shards[g]->last_count != count[g] || m->shards[g]->last_n != n)
+            return mfail(PQP_ERR_INVALID, "pqp_multi_gather_paths: batch and n are not those of the preceding pqp_multi_path_solve");
+        for (int r = 0; r < g; ++r)
+            if (m->shards[r]->device == m->shards[g]->device)
+                return mfail(PQP_ERR_INVALID, "pqp_multi_gather_paths: two shards share device " + std::to_string(m->shards[g]->device) + " (RCCL takes one rank per device)");
+    }
+    Rccl& R = rccl();
+    if (!R.load()) return mfail(PQP_ERR_HIP, "pqp_multi_gather_paths: " + R.why);
+    auto nfail = [&](ncclResult_t e, const char* what) { return mfail(PQP_ERR_HIP, std::string("pqp_multi_gather_paths: ") + what + ": " + R.error_string(e)); };
+    if (m->comms.empty()) {
+        std::vector<int> devs(world);
+        for (int g = 0; g < world; ++g) devs[g] = m->shards[g]->device;
+        std::vector<ncclComm_t> comms(world);
+        const ncclResult_t e = R.comm_init_all(comms.data(), world, devs.data());
+        if (e != ncclSuccess) return nfail(e, "ncclCommInitAll");
+        m->comms = comms;
+    }
+    std::vector<hipStream_t> streams(world);
+    for (int g = 0; g < world; ++g) {
+        void* sv = nullptr;
+        if (pqp_get_stream(m->shards[g]->h, &sv) != PQP_OK) return PQP_ERR_INVALID;
+        streams[g] = (hipStream_t)sv;
+    }
+    ncclResult_t e = R.group_start();
+    if (e != ncclSuccess) return nfail(e, "ncclGroupStart");
+    ncclResult_t bad = ncclSuccess;
+    for (int g = 0; g < world && bad == ncclSuccess; ++g) {
+        if (hipSetDevice(m->shards[g]->device) != hipSuccess) { (void)R.group_end(); return mfail(PQP_ERR_HIP, "pqp_multi_gather_paths: hipSetDevice"); }
+        for (int r = 0; r < world && bad == ncclSuccess; ++r) {
+            if (count[r] == 0) continue;
+            double* dst = full_out[g] + (size_t)first[r] * n * PQP_OUT_STRIDE;
+            const void* src = r == g ? m->shards[g]->out.dev : (const void*)dst;        // (read on the root only)
+            bad = R.broadcast(src, dst, (size_t)count[r] * n * PQP_OUT_STRIDE, ncclDouble, r, m->comms[g], streams[g]);
+        }
+    }
+    e = R.group_end();
+    if (bad != ncclSuccess) return nfail(bad, "ncclBroadcast");
+    if (e != ncclSuccess) return nfail(e, "ncclGroupEnd");
+    for (int g = 0; g < world; ++g) {
+        if (hipSetDevice(m->shards[g]->device) != hipSuccess || hipStreamSynchronize(streams[g]) != hipSuccess)
+            return mfail(PQP_ERR_HIP, "pqp_multi_gather_paths: hipStreamSynchronize after the gather");
+    }
     return PQP_OK;
 }
 

@@ -136,6 +136,56 @@ def test_multi_driver_overlaps_its_shards_and_keeps_its_threads(hip_lib):
 
 
 @pytest.mark.gpu
+def test_gather_over_rccl_in_the_c_abi(hip_lib):
+    """pqp_multi_gather_paths: the result slabs the shards keep in device memory, gathered over RCCL so that every shard's GPU holds the whole
+    batch (north_star: "RCCL over xGMI only to gather results").  On this one-GPU box: a single shard through the full RCCL path - dlopen,
+    communicator, grouped broadcasts on the shard's stream - must hand back exactly the paths the host copy returned; two shards on ONE device
+    are refused (RCCL takes one rank per device), as is a shape that is not the preceding solve's.  With one device per shard the same code
+    broadcasts every shard's slab to the others (slabs of a batch that does not divide evenly differ by one QP, hence broadcasts, not one all-gather)."""
+    import torch
+    b = make_batch(96, 80)
+    prm = capi.production_params()
+    one = capi.MultiHandle(prm, devices=(0,), max_batch_per_shard=96, max_n=80)
+    got = one.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    assert (got["status"] == 1).all()
+    full = one.gather_paths((0,))
+    np.testing.assert_array_equal(full[0].cpu().numpy(), got["out"])
+    # a second call reuses the communicator; another batch through the same driver
+    b2 = make_batch(64, 80, seed=77)
+    got2 = one.solve(b2["ref"], b2["bounds"], b2["scal"], passes=1)
+    np.testing.assert_array_equal(one.gather_paths((0,))[0].cpu().numpy(), got2["out"])
+    one._last = (96, 80)
+    with pytest.raises(capi.PqpError, match="not those of the preceding"):
+        one.gather_paths((0,))
+    one.close()
+    two = capi.MultiHandle(prm, devices=(0, 0), max_batch_per_shard=48, max_n=80)
+    two.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    with pytest.raises(capi.PqpError, match="one rank per device"):
+        two.gather_paths((0, 0))
+    two.close()
+
+
+@pytest.mark.gpu
+def test_gather_from_a_torch_free_process(hip_lib, tmp_path):
+    """The same gather from a C++ caller that has never heard of torch (tests/cpp/gather_demo.cpp: plain HIP runtime + the C ABI): librccl.so is
+    found by dlopen, every GPU's gathered copy equals the host copy.  Runs with as many shards as the box has GPUs (one here; on an 8-GPU node the
+    same program checks all eight copies: `tests/cpp/gather_demo <file> 8`)."""
+    import torch
+    exe = os.path.join(ROOT, "tests", "cpp", "gather_demo")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", exe, os.path.join(ROOT, "tests", "cpp", "gather_demo.cpp"),
+                    "-L" + CSRC, "-lpqp_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    b = make_batch(70, 80, seed=5)
+    path = str(tmp_path / "batch.bin")
+    with open(path, "wb") as f:
+        f.write(np.array([70, 80], dtype=np.int32).tobytes())
+        for k in ("ref", "bounds", "scal"):
+            f.write(np.ascontiguousarray(b[k], dtype=np.float64).tobytes())
+    shards = torch.cuda.device_count()
+    r = subprocess.run([exe, path, str(shards)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and f"gather ok {shards} 70 solved 70" in r.stdout, (r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
 def test_multi_driver_carries_a_planning_cycle(hip_lib):
     """pqp_multi_set_option(PQP_OPT_CARRY_CYCLES): a call of the shape of the previous one starts every shard's first solve from what its handle
     kept - same paths as a driver without the option, on scenarios that moved by 5 %; a call of another shape starts cold."""
