@@ -211,7 +211,7 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      nearly the same scenarios cycle after cycle; the reference constructs a fresh BaseSolver every cycle
  *                                      (path_optimizer.cpp:138).  The optimum returned is the same (unique; it agrees with the cold solve to the
  *                                      1e-7 of the KKT test); on scenarios that moved by 5 %: configs[1] 4.0 M instead of 3.1 M paths/s and no stragglers
- *                                      (profiles/r03n_seed_sweep.txt, r03x_seed_sweep.txt); lane-per-QP kernel 14 -> 9 interior-point iterations per path.
+ *                                      (profiles/r03n_seed_sweep.txt, r03y_seed_sweep.txt); lane-per-QP kernel 14 -> 9 interior-point iterations per path.
  *                                      A QP that differs wildly from its slot's previous one is still solved (the start is then merely poor).
  *                                      The exact TensionSmoother / postSmooth kernels (polish == 1) honour it too: a line's active-set rounds start from
  *                                      the set its slot ended with in the previous solve of the shape (16-31 rounds from the cold start, 2-3 from there). */

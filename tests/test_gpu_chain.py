@@ -152,7 +152,7 @@ def test_chain_carries_the_previous_planning_cycle(hip_lib):
     """PQP_OPT_CARRY_CYCLES through the whole device-resident chain: the vehicle advances a little every cycle (start pose and input points move), so
     the raw line, the layer and waypoint counts of a scenario change from call to call - the path QP's warm state is kept per waypoint, the exact
     smoother kernels start from their slot's previous active set.  Every cycle's paths equal those of handles that start cold (what the carried
-    start saves is time: tools/bench_full_chain.py --carry, 877 k -> 992 k scenarios/s)."""
+    start saves is time: tools/bench_full_chain.py --carry, 892 k -> 989 k scenarios/s)."""
     B = 24
     sc = _scenarios(B, seed=21)
     pair = lambda: (capi.Handle(capi.production_params(), max_batch=B, max_n=256), capi.Handle(_smoother_params(), max_batch=B, max_n=128))
