@@ -55,8 +55,17 @@ constexpr double kMaxScaling = 1e4;
 // ... and a full round moves the rows whose violation is at least this share of the largest one: the ones a hundred times smaller mostly vanish once the
 // large ones have moved, and moving them along is what sends rounds wandering (round 3, tools/ab_cons.sh: 0.01 - one launch at a time +8 %, the headline
 // of 15 of 16 scenario seeds within 2.5 % of each other; 0.003: no effect, 0.02-0.03: the same, 0.05-0.1: a straggler is back, 0.3: +13 % work)
-constexpr double kFullMoveShare = 0.01;
-constexpr int kCautiousFromRound = 8;        // active-set rounds of a polish attempt: single moves from this round on at the latest (run())
+#ifndef PQP_FULL_MOVE_SHARE
+#define PQP_FULL_MOVE_SHARE 0.01
+#endif
+#ifndef PQP_CAUTIOUS_PER_N
+#define PQP_CAUTIOUS_PER_N 16
+#endif
+#ifndef PQP_CAUTIOUS_FROM_ROUND
+#define PQP_CAUTIOUS_FROM_ROUND 8
+#endif
+constexpr double kFullMoveShare = PQP_FULL_MOVE_SHARE;        // (the macros: tools/build_variants.py experiments)
+constexpr int kCautiousFromRound = PQP_CAUTIOUS_FROM_ROUND;        // active-set rounds of a polish attempt: single moves from this round on at the latest (run())
 constexpr double kRhoMin = 1e-6;
 constexpr double kRhoMax = 1e6;
 constexpr double kRhoTol = 1e-4;
@@ -1789,6 +1798,10 @@ struct PathQp {
         // active-set rounds per polish attempt; <= 0: sized to the path (long paths need more rounds, short ones pay for them)
         const int auto_rounds = n / 5 - 8;
         const int max_rounds = prm.polish_max_rounds > 0 ? prm.polish_max_rounds : (auto_rounds > 24 ? auto_rounds : 24);
+        // (the cautious switch: at the 8th round for paths of up to 128 waypoints, at round n / 16 for longer ones - a long path with contact segments
+        //  legitimately needs more full rounds, and at 8 one QP in ~16 000 of 200-300 waypoints lost its polish altogether: 368 / 868 reduced solves;
+        //  with n / 16 the slowest of 12 288 such QPs needs 70-80, with n / 10 or n / 13 233 - tools/ab_hard_cases.sh, profiles/r03y_seed_sweep.txt)
+        const int cautious_from = (PQP_CAUTIOUS_PER_N > 0 && n / PQP_CAUTIOUS_PER_N > kCautiousFromRound) ? n / PQP_CAUTIOUS_PER_N : kCautiousFromRound;
         double res[6] = {0, 0, 0, 0, 0, 0};
         int pass = 0;
         // per-pass state of the hot loop
@@ -1966,7 +1979,7 @@ struct PathQp {
                         //  cycle: over 16 scenario seeds the slowest QP of a batch of 1024 went from 46-121 reduced solves to 39-66, the headline of the
                         //  two straggler seeds from 1.91 / 2.72 M to 2.79 / 3.12 M paths/s, one launch at a time from 1.03-1.96 M to 1.68-2.19 M, the
                         //  mean cost stayed - profiles/r03x_seed_sweep.txt; 7 and 9-12 instead of 8: seed 6's straggler survives from 9 on, 7 costs 2 %)
-                        if ((stall >= 3 || round + 1 >= kCautiousFromRound) && !conservative) { conservative = true; best = viol; stall = 0; }
+                        if ((stall >= 3 || round + 1 >= cautious_from) && !conservative) { conservative = true; best = viol; stall = 0; }
                         round += 1;
                         // (the attempts after a pass's first periodic one start from a better ADMM iterate and get half the rounds:
                         // when those are not enough the rounds are usually cycling, and every further one is wasted.  A quarter
