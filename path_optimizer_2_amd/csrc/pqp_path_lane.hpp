@@ -58,8 +58,11 @@ constexpr double kMaxScaling = 1e4;
 #ifndef PQP_FULL_MOVE_SHARE
 #define PQP_FULL_MOVE_SHARE 0.01
 #endif
+#ifndef PQP_FIRST_ATTEMPT_ONLY
+#define PQP_FIRST_ATTEMPT_ONLY 1
+#endif
 #ifndef PQP_CAUTIOUS_PER_N
-#define PQP_CAUTIOUS_PER_N 16
+#define PQP_CAUTIOUS_PER_N 0
 #endif
 #ifndef PQP_CAUTIOUS_FROM_ROUND
 #define PQP_CAUTIOUS_FROM_ROUND 8
@@ -1798,9 +1801,10 @@ struct PathQp {
         // active-set rounds per polish attempt; <= 0: sized to the path (long paths need more rounds, short ones pay for them)
         const int auto_rounds = n / 5 - 8;
         const int max_rounds = prm.polish_max_rounds > 0 ? prm.polish_max_rounds : (auto_rounds > 24 ? auto_rounds : 24);
-        // (the cautious switch: at the 8th round for paths of up to 128 waypoints, at round n / 16 for longer ones - a long path with contact segments
-        //  legitimately needs more full rounds, and at 8 one QP in ~16 000 of 200-300 waypoints lost its polish altogether: 368 / 868 reduced solves;
-        //  with n / 16 the slowest of 12 288 such QPs needs 70-80, with n / 10 or n / 13 233 - tools/ab_hard_cases.sh, profiles/r03y_seed_sweep.txt)
+        // (the cautious switch by round count applies to the FIRST attempt of a pass only: later attempts get half the rounds, and switched at 8 they spend
+        //  them on single moves - one QP in ~16 000 of 300 waypoints then never completed a polish, 868 reduced solves; first attempt only: 83.
+        //  PQP_CAUTIOUS_PER_N = 16 - the switch at round n / 16 on long paths - cures that QP and a 368-solve one at 200 waypoints too, but BASELINE
+        //  configs[4]'s batch holds a QP that then wanders: 551 k instead of 690 k scenarios/s; tools/ab_hard_cases.sh, tools/ab_config4.sh)
         const int cautious_from = (PQP_CAUTIOUS_PER_N > 0 && n / PQP_CAUTIOUS_PER_N > kCautiousFromRound) ? n / PQP_CAUTIOUS_PER_N : kCautiousFromRound;
         double res[6] = {0, 0, 0, 0, 0, 0};
         int pass = 0;
@@ -1979,7 +1983,7 @@ struct PathQp {
                         //  cycle: over 16 scenario seeds the slowest QP of a batch of 1024 went from 46-121 reduced solves to 39-66, the headline of the
                         //  two straggler seeds from 1.91 / 2.72 M to 2.79 / 3.12 M paths/s, one launch at a time from 1.03-1.96 M to 1.68-2.19 M, the
                         //  mean cost stayed - profiles/r03x_seed_sweep.txt; 7 and 9-12 instead of 8: seed 6's straggler survives from 9 on, 7 costs 2 %)
-                        if ((stall >= 3 || round + 1 >= cautious_from) && !conservative) { conservative = true; best = viol; stall = 0; }
+                        if ((stall >= 3 || (round + 1 >= cautious_from && !(PQP_FIRST_ATTEMPT_ONLY && prm.polish_every > 0 && it > prm.polish_every))) && !conservative) { conservative = true; best = viol; stall = 0; }
                         round += 1;
                         // (the attempts after a pass's first periodic one start from a better ADMM iterate and get half the rounds:
                         // when those are not enough the rounds are usually cycling, and every further one is wasted.  A quarter
