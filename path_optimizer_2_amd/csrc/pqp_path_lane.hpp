@@ -1805,7 +1805,7 @@ struct PathQp {
         //  them on single moves - one QP in ~16 000 of 300 waypoints then never completed a polish, 868 reduced solves; first attempt only: 83.
         //  PQP_CAUTIOUS_PER_N = 16 - the switch at round n / 16 on long paths - cures that QP and a 368-solve one at 200 waypoints too, but BASELINE
         //  configs[4]'s batch holds a QP that then wanders: 551 k instead of 690 k scenarios/s; tools/ab_hard_cases.sh, tools/ab_config4.sh)
-        const int cautious_from = (PQP_CAUTIOUS_PER_N > 0 && n / PQP_CAUTIOUS_PER_N > kCautiousFromRound) ? n / PQP_CAUTIOUS_PER_N : kCautiousFromRound;
+        const int cautious_from = (PQP_CAUTIOUS_PER_N > 0 && n / (PQP_CAUTIOUS_PER_N > 0 ? PQP_CAUTIOUS_PER_N : 1) > kCautiousFromRound) ? n / (PQP_CAUTIOUS_PER_N > 0 ? PQP_CAUTIOUS_PER_N : 1) : kCautiousFromRound;
         double res[6] = {0, 0, 0, 0, 0, 0};
         int pass = 0;
         // per-pass state of the hot loop
