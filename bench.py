@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--scaling", type=int, default=None, help="Ruiz equilibration passes (default: the production setting's)")
     ap.add_argument("--seed", type=int, default=None, help="seed of the synthetic scenarios (default: synth.BASE_SEED)")
     ap.add_argument("--rho-tolerance", type=float, default=2.0, help="adaptive_rho_tolerance")
+    ap.add_argument("--rho", type=float, default=None, help="initial ADMM step size rho (default: the production setting's 0.1)")
     ap.add_argument("--polish-warm-set", type=int, default=2, help="1: pass 2 starts with a polish on pass 1's active set; 2: and keeps its equilibration")
     ap.add_argument("--check-termination", type=int, default=None, help="residual check interval (iterations; default 8)")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight: consecutive steps (independent batches) go round-robin to k handles / HIP "
@@ -242,7 +243,7 @@ def main():
         kw = dict(eps_abs=args.eps, eps_rel=args.eps, polish=1 if polish else 0, polish_warm_set=args.polish_warm_set if polish else 0,
                   polish_refine_iter=args.polish_refine, polish_max_rounds=args.polish_max_rounds, adaptive_rho_tolerance=args.rho_tolerance)
         for key, val in (("scaling", args.scaling), ("adaptive_rho_interval", args.rho_interval), ("polish_every", args.polish_every),
-                         ("check_termination", args.check_termination), ("polish_lazy", args.polish_lazy)):
+                         ("check_termination", args.check_termination), ("polish_lazy", args.polish_lazy), ("rho", args.rho)):
             if val is not None:
                 kw[key] = val
         if not polish:
