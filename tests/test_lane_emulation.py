@@ -133,6 +133,10 @@ STRAGGLERS = [
     (0, 907, 80, "uniform", "eight-round attempts failing at iterations 25 / 75 / 175", 404),
     (1011, 1720, 300, "varied", "two refinement solves from a distant ADMM iterate left the polished point too inaccurate for the KKT test", 4028),
     (1015, 5821, 37, "varied", "the same, at every attempt until ADMM itself had converged", 3381),
+    # round 3's rules of the rounds (full rounds move the rows above 1 % of the largest violation; a pass's first attempt is cautious from its 8th round on):
+    (1003, 7852, 80, "uniform", "full rounds wandering: 88 reduced solves under round 2's rules, 25 now", 88),
+    (1003, 4600, 120, "varied", "the same: 123, now 31", 123),
+    (1004, 1751, 300, "varied", "with the round-count switch in EVERY attempt of a pass this QP never completed a polish (868): first attempt only", 868),
 ]
 
 
