@@ -202,7 +202,8 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      active-set rounds whose last round is the KKT test, i.e. the same exact optimum as the lane-per-
  *                                      waypoint kernel's verified polish.  It wins where the batch fills the chip's 65 536 lanes (65 536
  *                                      QPs of 80 waypoints: 1.8-2.0x, measured crossover ~20 000); it keeps no warm state
- *                                      (hence the PQP_OPT_STORE_WARM condition), iters[] counts its interior-point iterations and info[] =
+ *                                      (hence the PQP_OPT_STORE_WARM condition; a start curvature outside its box by no more than eps_abs + eps_rel * bound is projected
+ *                                      onto the box - OSQP at that eps calls such a QP solved -, by more: PQP_STATUS_PRIMAL_INFEASIBLE), iters[] counts its interior-point iterations and info[] =
  *                                      {row residual, complementarity, iterations of the first pass, iterations, solved passes, active-set
  *                                      rounds of the first pass, Riccati sweeps, active-set rounds}.  (PQP_OPT_ORDER_BY_COST has no effect on it.)
  *   PQP_OPT_CARRY_CYCLES (default 0)   a cold call (warm == 0, lin == NULL) starts the FIRST pass of QP k from the optimum QP k had in the handle's
