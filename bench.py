@@ -96,6 +96,47 @@ def stream_algorithmic_bytes(n, info):
     return float(np.sum(per_wp) * n)
 
 
+def fetch_calibration():
+    """Factors that turn rocprofv3's FETCH_SIZE / WRITE_SIZE (KiB) into bytes for THIS library's access patterns, measured by
+    tools/fetch_calib.py on a known byte count (tools/probes/fetch_calib.hip; committed record profiles/fetch_calib.json).  Without a
+    record: the MI355X guide's x2 for reads (its figure for 16 B/lane streaming reads) and x1 for writes, labelled as such."""
+    path = os.path.join(ROOT, "profiles", "fetch_calib.json")
+    try:
+        f = json.load(open(path))["factors"]
+        stream_rd, stream_wr = f.get("sweep_like_read") or f["read_8B_per_lane"], f.get("sweep_like_write") or f["write_8B_per_lane"]
+        return {"source": "profiles/fetch_calib.json (tools/fetch_calib.py: known bytes / reported bytes, 4 GiB footprint)",
+                "stream_read": float(stream_rd), "stream_write": float(stream_wr),          # path_stream_kernel: mixed 8 B / 4 B per lane lines
+                "lane_read": float(f["read_8B_per_lane"]), "lane_write": float(f["write_8B_per_lane"]), "all": f}      # path_solve_kernel: 8 B per lane
+    except Exception:
+        return {"source": "uncalibrated: MI355X_MICROARCH.md's x2 for wide streaming reads, x1 for writes (no profiles/fetch_calib.json)",
+                "stream_read": 2.0, "stream_write": 1.0, "lane_read": 2.0, "lane_write": 1.0, "all": None}
+
+
+def shim_batch1(n_list=(60, 80), cycles=40):
+    """The reference's own call pattern timed through the C++ drop-in (tests/cpp/shim_latency.cpp over csrc/base_solver_shim.cpp): one
+    BaseSolver per planning cycle at batch 1 - construct -> solve() -> updateProblemFormulationAndSolve() -> destruct
+    (src/path_optimizer.cpp:138-153).  Microseconds per cycle with the shim's handle pool on and off, reference setting and production
+    setting.  Never raises."""
+    try:
+        from path_optimizer_2_amd.synth import make_batch
+        csrc = os.path.join(ROOT, "path_optimizer_2_amd", "csrc")
+        exe = os.path.join(tempfile.gettempdir(), "pqp_shim_latency")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "shim_latency.cpp"), os.path.join(csrc, "base_solver_shim.cpp"),
+                        "-L" + csrc, "-lpqp_hip", "-Wl,-rpath," + csrc], check=True, capture_output=True, timeout=300)
+        res = {"what": "one BaseSolver per planning cycle at batch 1 (path_optimizer.cpp:138-153): construct -> solve -> updateProblemFormulationAndSolve -> destruct, "
+                       "host-pointer entry points (PCIe copies included), microseconds per cycle; first_cycle_us pays pqp_create"}
+        for n in n_list:
+            b = make_batch(1, n)
+            lines = [str(n)] + [" ".join(repr(float(v)) for v in list(b["ref"][0, i]) + list(b["bounds"][0, i])) for i in range(n)] + [" ".join(repr(float(v)) for v in b["scal"][0])]
+            text = "\n".join(lines) + "\n"
+            for key, cache, polish in ((f"n{n}_reference_setting", 1, 0), (f"n{n}_reference_setting_no_handle_pool", 0, 0), (f"n{n}_production_setting", 1, 1)):
+                r = subprocess.run([exe, str(cycles), str(cache), str(polish)], input=text, capture_output=True, text=True, timeout=300)
+                res[key] = json.loads(r.stdout) if r.returncode == 0 else {"error": r.stderr[-300:]}
+        return res
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def cpu_baseline(make_sample, n, eps, budget_s):
     """The oracle (C restatement of the OSQP-paper algorithm, oracle/pqp_oracle.c) timed on this box's host cores over
     a bounded sample of the same workload.  kind = "port": OSQP itself is not in this image.  Beside it, as a second CPU line, the
@@ -113,12 +154,12 @@ def cpu_baseline(make_sample, n, eps, budget_s):
     return base
 
 
-def pmc_child(argv_core, kernel_substr, timeout_s, steps=6):
+def pmc_child(argv_core, kernel_substr, timeout_s, steps=6, passes=None):
     """Hardware counters of THIS command's dominant kernel, measured now: three rocprofv3 --pmc passes (SQ counters; the TCC byte counters
     FETCH_SIZE / WRITE_SIZE in a pass each: they do not fit one) of a short child run of bench.py, --kernel-trace only
     beside --pmc (MI355X_MICROARCH.md, rocprofv3 PMC section).  Returns per-launch averages or None (never raises)."""
-    passes = ["SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU",
-              "FETCH_SIZE GRBM_GUI_ACTIVE", "WRITE_SIZE SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU"]
+    passes = passes or ["SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU",
+                        "FETCH_SIZE GRBM_GUI_ACTIVE", "WRITE_SIZE SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU"]
     acc, cnt = {}, {}
     try:
         for pmc in passes:
@@ -339,6 +380,53 @@ def main():
         gather_info = {"ms": gather_s * 1e3, "bytes_per_rank_received": int(full.numel() * 8), "what": "torch.distributed all_gather (RCCL) of every rank's [batch][n][7] result slab "
                        "to every rank, outside the timed region: the only collective of the path (SURVEY.md 8e)"}
         del full
+        # the communicator's size as the collective library itself reports it: an all-reduce of ones over RCCL (gloo in the shared-GPU test mode)
+        ones = coll(torch.ones(1, dtype=torch.float64, device=dev))
+        dist.all_reduce(ones)
+        gather_info["rccl_ranks"] = int(round(float(ones.item())))
+        gather_info["backend"] = dist.get_backend()
+
+    # The scaling curve's own references, measured in THIS run on rank 0's GPU while the other ranks wait at a barrier: (i) the per-GPU shard
+    # alone (weak scaling: N GPUs should do N times that), (ii) the WHOLE job's batch on one GPU (strong scaling: what sharding buys over
+    # keeping the batch on one device - a large batch runs on the lane-per-QP kernel there, PQP_OPT_STREAM_BATCH).
+    scaling_ref = None
+    if dist is not None and pipe is None:
+        torch.cuda.synchronize(); dist.barrier()
+        if rank == 0:
+            try:
+                for _ in range(args.warmup):
+                    step()
+                sync_all(); torch.cuda.synchronize()
+                ta = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                sync_all(); torch.cuda.synchronize()
+                shard_alone = batch * args.steps / (time.perf_counter() - ta)
+                hw = make_batch(total, n, profile, seed=args.seed)
+                w_in = [torch.from_numpy(hw[k]).to(dev) for k in ("ref", "bounds", "scal")]
+                h_w = capi.Handle(prm, device=local_rank, max_batch=total, max_n=n)
+                h_w.set_option(capi.OPT_STORE_WARM, 0); h_w.set_option(capi.OPT_ORDER_BY_COST, 1 if cost_order else 0)
+                o_w = torch.zeros((total, n, 7), dtype=torch.float64, device=dev); st_w = torch.zeros(total, dtype=torch.int32, device=dev)
+                torch.cuda.synchronize()
+                for _ in range(2):
+                    h_w.solve_device(total, n, *w_in, o_w, passes=1, status=st_w)
+                h_w.sync()
+                kw = max(2, min(args.steps, 8))
+                ta = time.perf_counter()
+                for _ in range(kw):
+                    h_w.solve_device(total, n, *w_in, o_w, passes=1, status=st_w)
+                h_w.sync()
+                whole = total * kw / (time.perf_counter() - ta)
+                whole_kernel = {1: "path_solve_kernel (lane per waypoint)", 2: "path_stream_kernel (lane per QP)"}.get(h_w.last_path_kernel(), "?")
+                scaling_ref = {"shard_alone_on_one_gpu": {"value": shard_alone, "unit": "paths/s", "batch": batch, "steps": args.steps, "batches_in_flight": len(main_handles)},
+                               "whole_batch_on_one_gpu": {"value": whole, "unit": "paths/s", "batch": total, "launches": kw, "kernel": whole_kernel,
+                                                          "solved": int((st_w == 1).sum().item()), "setting": "one launch after the other"},
+                               "note": "measured on rank 0's GPU after the timed region, the other ranks idle at a barrier"}
+                h_w.close()
+                del w_in, o_w, st_w
+            except Exception as e:          # (the headline does not depend on it)
+                scaling_ref = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.synchronize(); dist.barrier()
 
     # per-launch duration of the dominant kernel over the timed region: HIP events the handle recorded around every launch on the
     # stream it launched on, read back now (nothing was synchronised between the launches)
@@ -465,6 +553,8 @@ def main():
             "reference_setting_eps_2e-3": dict(timed(capi.default_params(), False, max(3, args.steps // 4)),
                                                setting="what base_solver.cpp:61-62 runs: eps 2e-3, OSQP defaults, no polish; paths 2e-4..2e-2 from the optimum"),
         }
+        if cfg_id == 1 and preset_shape:
+            secondary["base_solver_shim_batch1"] = shim_batch1()
         if not stream and n_var > 1:
             txt = ("PQP_OPT_CARRY_CYCLES: the first solve of a cycle starts from the final iterate and active set the handle kept from the "
                    "previous cycle (the jittered variant {} step(s) earlier) instead of cold - what a planner that re-solves its scenarios every cycle would switch "
@@ -537,6 +627,22 @@ def main():
                 secondary["configs3_whole_batch_one_gpu"] = dict(res_w, workload="configs[3]: batch = 65 536 QPs, N = 80, the whole batch on ONE GPU, one launch after the other",
                                                                  speedup_stream_over_lane_per_waypoint=res_w["lane_per_qp_stream_kernel"]["value"] / res_w["lane_per_waypoint_kernel"]["value"])
                 del t_ref, t_b, t_s
+                torch.cuda.empty_cache()
+                if args.pmc == "auto":
+                    # measured HBM traffic of THIS kernel in this run too (the two TCC byte counters, a child pass each; the SQ counters are
+                    # `python bench.py --config 3 --batch 65536`'s)
+                    core3 = ["--config", "3", "--batch", str(bb), "--n", "80", "--profile", "uniform", "--eps", str(args.eps), "--seed", str(args.seed), "--variants", "1"]
+                    pmc3 = pmc_child(core3, "path_stream_kernel", args.pmc_timeout, steps=3, passes=["FETCH_SIZE GRBM_GUI_ACTIVE", "WRITE_SIZE SQ_WAVES"])
+                    rf = res_w["lane_per_qp_stream_kernel"]["roofline"]
+                    if pmc3 and "FETCH_SIZE" in pmc3 and "WRITE_SIZE" in pmc3:
+                        cal = fetch_calibration()
+                        tr = (cal["stream_read"] * pmc3["FETCH_SIZE"] + cal["stream_write"] * pmc3["WRITE_SIZE"]) * 1024.0
+                        kms3 = res_w["lane_per_qp_stream_kernel"]["kernel_ms"]
+                        rf.update(traffic=tr, fetch_size_kib=pmc3["FETCH_SIZE"], write_size_kib=pmc3["WRITE_SIZE"], fetch_size_factor=cal["stream_read"],
+                                  write_size_factor=cal["stream_write"], traffic_over_algorithmic=tr / rf["algorithmic_bytes_per_launch"],
+                                  hbm_measured_frac=tr / (kms3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  traffic_source=f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of `bench.py --config 3 --batch {bb}` (one launch at a time), "
+                                                 f"{pmc3['_launches']} launches averaged; factors: {cal['source']}")
             except Exception as e:          # (out of memory on a shared box, ...: the headline does not depend on it)
                 secondary["configs3_whole_batch_one_gpu"] = {"error": f"{type(e).__name__}: {e}"}
 
@@ -561,16 +667,20 @@ def main():
             core += ["--reference-setting"] if args.reference_setting else []
             pmc = pmc_child(core, kernel_name, args.pmc_timeout, steps=3 if stream else 6)
         traffic = None
+        calib = fetch_calibration()
+        f_rd, f_wr = (calib["stream_read"], calib["stream_write"]) if stream else (calib["lane_read"], calib["lane_write"])
         if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-            # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 tallies a wide read at half its bytes (MICROARCH guide, HBM): x2 on the reads
-            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+            # FETCH_SIZE / WRITE_SIZE are in KiB; what a KiB of them is worth in bytes for this kernel's access pattern was measured
+            # (fetch_calibration(): gfx950 tallies a wide read at half its bytes - MICROARCH guide, HBM - but 8 B / 4 B per lane lines differ)
+            traffic = (f_rd * pmc["FETCH_SIZE"] + f_wr * pmc["WRITE_SIZE"]) * 1024.0
         # launches of different handles overlap: mean number of solve kernels running at a time over the timed region
         concurrency = max(1.0, args.steps * avg_kernel_s / dt) if len(main_handles) > 1 else 1.0
         per_launch = lambda b: b / avg_kernel_s / 1e9 / HBM_PEAK_GBS
         common = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": kernel_name, "kernel_ms": avg_kernel_s * 1e3,
                   "launches_in_flight": len(main_handles), "kernels_running_at_a_time": concurrency, "traffic": traffic,
                   "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command (one launch at a time, the identical batch), after the "
-                                     f"timed region, {pmc['_launches']} launches averaged; FETCH_SIZE x 2 (gfx950 wide-read tally, MI355X_MICROARCH.md)") if traffic else None,
+                                     f"timed region, {pmc['_launches']} launches averaged; bytes = {f_rd:.3f} x FETCH_SIZE + {f_wr:.3f} x WRITE_SIZE, factors: {calib['source']}") if traffic else None,
+                  "fetch_size_factor": f_rd, "write_size_factor": f_wr,
                   "fetch_size_kib": pmc.get("FETCH_SIZE") if pmc else None, "write_size_kib": pmc.get("WRITE_SIZE") if pmc else None,
                   # what HBM really moved per second of ONE launch's own duration, as a fraction of the 8 TB/s peak
                   "hbm_measured_frac": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
@@ -644,9 +754,15 @@ def main():
                                        "solved exactly by one Riccati sweep per scenario (pqp_params.polish = 2: tension2_exact_kernel, no ADMM iterations)")} if pipe is not None else {})},
             "admm_iters": {"min": int(it_np.min()), "median": float(np.median(it_np)), "p99": float(np.percentile(it_np, 99)),
                            "max": int(it_np.max()), "mean": float(it_np.mean())},
-            "out_sha1": out_sha, "gather_check": gathered_ok, "gather": gather_info, "solved": int((st_np == 1).sum()), "batch": batch,
+            "out_sha1": out_sha, "gather_check": gathered_ok, "gather": gather_info, "rccl_ranks": gather_info["rccl_ranks"] if gather_info else None,
+            "solved": int((st_np == 1).sum()), "batch": batch,
             "sustained": sustained, "secondary": secondary, "roofline": roofline, "roofline_issue": roofline_issue,
         }
+        if scaling_ref is not None and "error" not in scaling_ref:
+            line["weak_scaling_efficiency"] = line["value"] / (world * scaling_ref["shard_alone_on_one_gpu"]["value"])
+            line["strong_scaling_vs_one_gpu_whole_batch"] = line["value"] / scaling_ref["whole_batch_on_one_gpu"]["value"]
+        if scaling_ref is not None:
+            line["scaling_reference"] = scaling_ref
         if info_np is not None and stream:
             line["riccati_sweeps"] = {"mean": float(fac_np.mean()), "p99": float(np.percentile(fac_np, 99)), "max": float(fac_np.max())}
             line["active_set_rounds"] = {"mean": float(info_np[:, 7].mean()), "max": float(info_np[:, 7].max())}

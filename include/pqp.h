@@ -264,8 +264,11 @@ int pqp_path_assemble_device(pqp_handle* h, int batch, int n, int precise, const
  *   any eps) and keeps no warm state: beyond 512 waypoints warm == 1 solves the QP around `lin` cold - same optimum - and
  *   pqp_path_get_solution is not available.  Which solver runs is decided
  *   by the handle's pqp_params: pqp_default_params = the reference's OSQP setting (eps 2e-3, no polish, infeasibility certificate),
- *   pqp_production_params = eps 1e-4 + KKT-verified polish.  out[q] holds the last iterate also when status[q] != SOLVED (the
- *   reference's solve() returns false there and leaves its output vector untouched).
+ *   pqp_production_params = eps 1e-4 + KKT-verified polish.  When status[q] != SOLVED (the reference's solve() returns false there and
+ *   leaves its output vector untouched) out[q] is defined but kernel-specific: the lane-per-waypoint kernel leaves its last iterate there;
+ *   the lane-per-QP kernel the optimum of the last pass that WAS solved, or - when none was - the reference line itself (l = dpsi = 0).
+ *   iters[] and info[] differ between the two kernels as well (above; PQP_OPT_STREAM_BATCH): pqp_last_path_kernel says which one served
+ *   the handle's last solve, so that a caller can tell what it received.
  *   A QP with a collision box whose lower bound exceeds its upper bound is refused as OSQP refuses it at setup: the host-pointer
  *   entry points do not launch it and report PQP_STATUS_PRIMAL_INFEASIBLE (out[q] = 0); the *_device entry points do not
  *   validate their inputs (there such a row is pinned to its upper bound). */
@@ -320,6 +323,8 @@ int pqp_multi_path_solve(pqp_multi* m, int batch, int n, const int32_t* n_of, co
  * unaffected).  batch and n as in the preceding solve.  One device per shard; librccl.so is dlopen'ed by the first call, a caller that never
  * gathers does not need it.  The reference has no counterpart (one path per call). */
 int pqp_multi_gather_paths(pqp_multi* m, int batch, int n, double* const* full_out);
+/* ranks of that gather's communicator as RCCL counts them (ncclCommCount); 0 before the first gather, < 0: error */
+int pqp_multi_gather_ranks(pqp_multi* m);
 
 /* ---- reference-line smoothing QPs; the solver settings of the handle apply (the reference runs
  *      them at OSQP's default eps 1e-3: tension_smoother_2.cpp:32-36, tension_smoother.cpp:61-65, reference_path_smoother.cpp:533-537).
@@ -348,6 +353,10 @@ int pqp_post_smooth(pqp_handle* h, int batch, int m, const double* layers_s, con
 int pqp_post_smooth_device(pqp_handle* h, int batch, int m, const double* layers_s, const double* lb, const double* ub,
                            const double* vehicle_l, double* out_l, int32_t* status, int32_t* iters, double* info);
 
+/* Which kernel served the handle's last pqp_path_solve* call (the dispatch depends on batch size, n, warm and the options above): a
+ * pqp_path_kernel, 0 before the first solve; < 0: error. */
+typedef enum pqp_path_kernel { PQP_KERNEL_NONE = 0, PQP_KERNEL_LANE_PER_WAYPOINT = 1, PQP_KERNEL_LANE_PER_QP = 2 } pqp_path_kernel;
+int pqp_last_path_kernel(pqp_handle* h);
 /* GPU time (ms, hipEvent) of the handle's last solve / assemble launch. */
 int pqp_last_kernel_ms(pqp_handle* h, float* ms);
 /* the same for the last `count` launches of this handle (oldest first; at most 256): the events are recorded on the handle's stream

@@ -10,7 +10,8 @@
 //   bool updateProblemFormulationAndSolve(const std::vector<SlState>&, std::vector<SlState>*)   base_solver.cpp:97
 //                                                                 pqp_path_solve(warm = 1, lin = input, passes = 0)
 // In/out may alias in updateProblemFormulationAndSolve (path_optimizer.cpp:153): the input is copied first, as
-// base_solver.cpp:100 does.  Not copyable, not thread-safe (like the reference); one GPU handle per instance.
+// base_solver.cpp:100 does.  Not copyable, not thread-safe (like the reference); one GPU handle per instance, taken from / parked in a
+// process-wide pool (setHandleCaching) so that the reference's one-solver-per-cycle pattern does not pay pqp_create every cycle.
 #pragma once
 #include <vector>
 
@@ -35,6 +36,12 @@ class BaseSolver {
     // extras the reference does not have
     void setParams(const pqp_params& p);          // the gflags the path reads + solver settings (defaults = reference)
     void setMaxSteeringAngle(double rad) { max_steering_angle_ = rad; }   // FLAGS_max_steering_angle (planning_flags.cpp:22)
+    void setDevice(int device);                   // GPU of this instance (default: environment PQP_DEVICE, else 0); before the first solve
+    int device() const { return device_; }
+    // Handles (stream + device workspaces) are parked when an instance dies and taken over by the next instance on the same device: the
+    // reference builds a BaseSolver per planning cycle (path_optimizer.cpp:138), and creating a handle costs more than a batch-1 solve.
+    void setHandleCaching(bool on) { cache_handles_ = on; }
+    static void releaseCachedHandles();           // destroys the parked handles (e.g. before hipDeviceReset)
     const pqp_params& params() const { return params_; }
     int lastStatus() const { return status_; }    // pqp_status of the last solve
     int lastIterations() const { return iters_; }
@@ -51,6 +58,9 @@ class BaseSolver {
     std::vector<SlState> input_path_;
     pqp_params params_;
     pqp_handle* handle_{nullptr};
+    int device_{0};
+    bool cache_handles_{true};
+    bool solved_once_{false};
     double max_steering_angle_{35.0 * 3.14159265358979323846 / 180.0};
     int status_{0}, iters_{0};
 };

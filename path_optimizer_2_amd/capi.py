@@ -62,9 +62,9 @@ EXPORTS = [
     "pqp_default_params", "pqp_production_params", "pqp_last_error", "pqp_version", "pqp_create", "pqp_destroy", "pqp_set_params", "pqp_set_option",
     "pqp_constrain_angle_device", "pqp_stream_wait", "pqp_mark", "pqp_wait_mark", "pqp_get_stream",
     "pqp_chain_default_config", "pqp_optimize_path_device", "pqp_clearance_device", "pqp_smooth_tension2_var_device", "pqp_smooth_tension_var_device", "pqp_post_smooth_var_device", "pqp_spline_fit_var_device",
-    "pqp_shard_range", "pqp_multi_create", "pqp_multi_destroy", "pqp_multi_shards", "pqp_multi_handle", "pqp_multi_set_option", "pqp_multi_path_solve", "pqp_multi_gather_paths", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
+    "pqp_shard_range", "pqp_multi_create", "pqp_multi_destroy", "pqp_multi_shards", "pqp_multi_handle", "pqp_multi_set_option", "pqp_multi_path_solve", "pqp_multi_gather_paths", "pqp_multi_gather_ranks", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
     "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_solve_var_device", "pqp_path_solve_var", "pqp_path_get_solution",
-    "pqp_last_kernel_ms", "pqp_kernel_ms_history", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
+    "pqp_last_kernel_ms", "pqp_last_path_kernel", "pqp_kernel_ms_history", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
     "pqp_post_smooth", "pqp_post_smooth_device", "pqp_corridor_default_params", "pqp_corridor_bounds", "pqp_corridor_bounds_device",
     "pqp_reference_states", "pqp_reference_states_device", "pqp_spline_fit", "pqp_spline_fit_device", "pqp_dp_default_params",
     "pqp_dp_corridor", "pqp_dp_corridor_device", "pqp_segment_raw_reference", "pqp_segment_raw_reference_device", "pqp_bspline_resample", "pqp_bspline_resample_device", "pqp_reference_length", "pqp_reference_length_device", "pqp_offsets_to_points", "pqp_offsets_to_points_device",
@@ -73,8 +73,10 @@ EXPORTS = [
 _lib = None
 
 
-def load_library(path=None):
-    """dlopen libpqp_hip.so and declare the prototypes.  Raises OSError if it was not built."""
+def load_library(path=None, with_torch=None):
+    """dlopen libpqp_hip.so and declare the prototypes.  Raises OSError if it was not built.
+    with_torch: import torch BEFORE the library is mapped (see below).  None = yes unless PQP_CAPI_TORCH=0: the safe default for a process that
+    may use torch later; a torch-free user of the C ABI passes False (or sets PQP_CAPI_TORCH=0) and skips torch's multi-second import."""
     global _lib
     if _lib is not None and path is None:
         return _lib
@@ -85,10 +87,14 @@ def load_library(path=None):
     # A process that also uses torch must load torch's HIP runtime FIRST: the wheel bundles its own libamdhip64 under the soname this library needs
     # too, and whichever copy is mapped first serves both - with /opt/rocm's mapped first, torch finds no device ("No HIP GPUs are available").
     # (The device-resident entry points of this binding use torch as memory plumbing; the library itself does not depend on it.)
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    import sys
+    if with_torch is None:
+        with_torch = os.environ.get("PQP_CAPI_TORCH", "1") != "0"
+    if with_torch or "torch" in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(path)
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
     lib.pqp_default_params.argtypes = [C.POINTER(PqpParams)]
@@ -125,6 +131,7 @@ def load_library(path=None):
     lib.pqp_multi_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.pqp_multi_path_solve.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
     lib.pqp_multi_gather_paths.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.pqp_multi_gather_ranks.argtypes = [vp]
     lib.pqp_sync.argtypes = [vp]
     lib.pqp_path_sizes.argtypes = [C.POINTER(PqpParams), C.c_int, vp, C.POINTER(PqpSizes)]
     lib.pqp_path_pattern.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
@@ -134,6 +141,7 @@ def load_library(path=None):
         getattr(lib, name).argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.pqp_path_get_solution.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.pqp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.pqp_last_path_kernel.argtypes = [vp]
     lib.pqp_kernel_ms_history.argtypes = [vp, vp, C.c_int]
     lib.pqp_smooth_tension2.argtypes = [vp, C.c_int, C.c_int] + [vp] * 10
     lib.pqp_smooth_tension2_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 11
@@ -208,7 +216,7 @@ class MultiHandle:
     """pqp_multi: one handle + one host thread per shard of the batch (several GPUs of one node; devices may repeat)."""
 
     def __init__(self, params=None, devices=(0,), max_batch_per_shard=1024, max_n=128):
-        self.lib = load_library()
+        self.lib = load_library(with_torch=True)
         self.params = params or default_params(self.lib)
         self._m = C.c_void_p()
         devs = (C.c_int32 * len(devices))(*devices)
@@ -259,6 +267,10 @@ class MultiHandle:
             raise PqpError(f"pqp error {rc}: {self.lib.pqp_last_error().decode()}")
         return outs
 
+    def gather_ranks(self):
+        """ncclCommCount of the gather's communicator (0 before the first gather_paths)."""
+        return int(self.lib.pqp_multi_gather_ranks(self._m))
+
 
 class PqpError(RuntimeError):
     pass
@@ -268,7 +280,7 @@ class Handle:
     """Thin RAII wrapper over pqp_handle (one per GPU)."""
 
     def __init__(self, params=None, device=0, max_batch=1024, max_n=128):
-        self.lib = load_library()
+        self.lib = load_library(with_torch=True)
         self.params = params or default_params(self.lib)
         self._h = C.c_void_p()
         self.device = int(device)          # the torch helpers below allocate and synchronise on the handle's own GPU
@@ -649,3 +661,7 @@ class Handle:
         ms = C.c_float()
         self._check(self.lib.pqp_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def last_path_kernel(self):
+        """pqp_last_path_kernel: 1 = lane-per-waypoint kernel, 2 = lane-per-QP kernel served the last solve (0: none yet)."""
+        return int(self.lib.pqp_last_path_kernel(self._h))

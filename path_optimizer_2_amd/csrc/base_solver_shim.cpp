@@ -5,11 +5,55 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
 
 namespace PathOptimizationNS {
 
+namespace {
+// The reference constructs one BaseSolver per planning cycle (src/path_optimizer.cpp:138) and lets it die at the end of optimizePath.  A
+// pqp_handle owns a HIP stream, 2 x 256 events and its device workspaces: creating one costs a few hundred microseconds to milliseconds
+// (bench.py: secondary.base_solver_shim_batch1), several times the batch-1 solve itself.  So handles outlive the instances: a destructor
+// parks its handle here, the next instance on the same device takes it (workspaces grow on demand; parameters are set at every take).
+// Parked handles live until the process ends (BaseSolver::releaseCachedHandles() for a caller that wants them gone earlier: they are
+// never destroyed from a static destructor, where the HIP runtime may already be down).
+struct HandlePool {
+    std::mutex mu;
+    std::vector<std::pair<int, pqp_handle*>> idle;      // (device, handle)
+    pqp_handle* take(int device) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t k = 0; k < idle.size(); ++k)
+            if (idle[k].first == device) { pqp_handle* h = idle[k].second; idle.erase(idle.begin() + (long)k); return h; }
+        return nullptr;
+    }
+    void park(int device, pqp_handle* h) {
+        std::lock_guard<std::mutex> lk(mu);
+        idle.emplace_back(device, h);
+    }
+    void clear() {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& e : idle) (void)pqp_destroy(e.second);
+        idle.clear();
+    }
+};
+HandlePool& pool() { static HandlePool* p = new HandlePool(); return *p; }       // (leaked on purpose: see above)
+
+// FLAGS-like process default of the device ordinal: PQP_DEVICE (the reference has no notion of a device; one per process is the
+// common case: one planner process per GPU)
+int default_device() {
+    const char* e = std::getenv("PQP_DEVICE");
+    if (!e || !*e) return 0;
+    char* end = nullptr;
+    const long v = std::strtol(e, &end, 10);
+    return (end && *end == 0 && v >= 0 && v < 1024) ? (int)v : 0;
+}
+}  // namespace
+
+void BaseSolver::releaseCachedHandles() { pool().clear(); }
+
 BaseSolver::BaseSolver(const ReferencePath& reference_path, const VehicleState& vehicle_state, const std::vector<SlState>& input_path)
-    : n_(input_path.size()), reference_path_(reference_path), vehicle_state_(vehicle_state), input_path_(input_path) {
+    : n_(input_path.size()), reference_path_(reference_path), vehicle_state_(vehicle_state), input_path_(input_path), device_(default_device()) {
     pqp_default_params(&params_);
     // base_solver.cpp:22-37 through the library's own size function
     std::vector<double> s(n_);
@@ -22,7 +66,16 @@ BaseSolver::BaseSolver(const ReferencePath& reference_path, const VehicleState& 
 }
 
 BaseSolver::~BaseSolver() {
-    if (handle_) pqp_destroy(handle_);
+    if (handle_) {
+        if (cache_handles_) pool().park(device_, handle_);
+        else pqp_destroy(handle_);
+    }
+}
+
+void BaseSolver::setDevice(int device) {
+    if (device == device_ || device < 0) return;
+    if (handle_) { if (cache_handles_) pool().park(device_, handle_); else pqp_destroy(handle_); handle_ = nullptr; }
+    device_ = device;
 }
 
 void BaseSolver::setParams(const pqp_params& p) {
@@ -32,11 +85,17 @@ void BaseSolver::setParams(const pqp_params& p) {
 
 bool BaseSolver::run(const std::vector<SlState>& lin, bool warm, std::vector<SlState>* out) {
     if (!out || n_ < 2) return false;
+    // (a pooled handle may still hold another instance's warm state: a warm solve needs THIS instance's own cold solve first - the reference's
+    //  updateBounds() on a solver that was never initialised fails the same way, base_solver.cpp:106)
+    if (warm && !solved_once_) return false;
     const auto& ref_states = reference_path_.getReferenceStates();
     const auto& bounds = reference_path_.getBounds();
     if (ref_states.size() < n_ || bounds.size() < n_ || lin.size() != n_) return false;
     if (!handle_) {
-        if (pqp_create(&handle_, &params_, 0, 1, (int)n_) != PQP_OK) {
+        if (cache_handles_ && (handle_ = pool().take(device_)) != nullptr) {
+            pqp_set_params(handle_, &params_);
+        } else if (pqp_create(&handle_, &params_, device_, 1, (int)n_) != PQP_OK) {
+            handle_ = nullptr;
             std::fprintf(stderr, "BaseSolver: %s\n", pqp_last_error());
             return false;      // no CPU fallback: without the GPU engine solve() fails, as a failed initSolver() does
         }
@@ -63,6 +122,7 @@ bool BaseSolver::run(const std::vector<SlState>& lin, bool warm, std::vector<SlS
         return false;
     }
     if (status != PQP_STATUS_SOLVED) return false;                           // osqp-eigen: solve() true only for "solved"
+    solved_once_ = true;
     out->clear();                                                            // base_solver.cpp:266
     out->reserve(n_);
     for (size_t i = 0; i < n_; ++i) {                                        // base_solver.cpp:269-287: s, v, a stay 0

@@ -700,6 +700,7 @@ struct pqp_handle {
     int hist_batch = 0, hist_n = 0;             // shape of the solve whose costs cost_key / cost_hist hold (0: none)
     int opt_store_warm = 1, opt_order_by_cost = 0, opt_reserve_cus = 0, opt_stream_batch = 24576, opt_carry = 0;
     int stream_last_batch = 0, stream_last_n = 0;      // shape of the last path_stream_kernel launch (what its workspace still holds)
+    int last_path_kernel = 0;                          // pqp_path_kernel of the last pqp_path_solve* launch (pqp_last_path_kernel)
     DevBuf sm_act[2];                                  // final active sets of the exact TensionSmoother / postSmooth kernels (PQP_OPT_CARRY_CYCLES)
     int sm_act_batch[2] = {0, 0}, sm_act_n[2] = {0, 0};
     DevBuf stream_ws;                           // workspace of path_stream_kernel
@@ -933,7 +934,7 @@ static int path_stream_impl(pqp_handle* h, int batch, int n, const int32_t* n_of
     a.batch = batch; a.n = n; a.passes = passes; a.n_of = n_of; a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
     a.status = status; a.iters = iters; a.info = info; a.ws = h->stream_ws.as<double>(); a.prm = h->prm;
     // PQP_OPT_CARRY_CYCLES: the workspace still holds, slot by slot, the optimum of the previous launch of this very shape
-    a.carry = (h->opt_carry && h->stream_last_batch == batch && h->stream_last_n == n && h->stream_ws.p == ws_before) ? 1 : 0;
+    a.carry = (h->opt_carry && !lin && h->stream_last_batch == batch && h->stream_last_n == n && h->stream_ws.p == ws_before) ? 1 : 0;       // (lin == NULL: pqp.h)
     h->next_event_pair();
     PQP_HIP(hipEventRecord(h->ev0, h->stream));
     PQP_HIP(pqp_stream_launch(&a, waves, (void*)h->stream));      // path_stream_kernel lives in its own translation unit (pqp_path_stream.hip)
@@ -942,6 +943,7 @@ static int path_stream_impl(pqp_handle* h, int batch, int n, const int32_t* n_of
     h->stream_last_batch = batch; h->stream_last_n = n;
     h->warm_batch = batch; h->warm_n = n;
     h->warm_stored = false;
+    h->last_path_kernel = PQP_KERNEL_LANE_PER_QP;
     return PQP_OK;
 }
 
@@ -962,7 +964,9 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     // the final iterate, equilibration and active set that solve left in the warm state - the same scenarios one planning cycle later.
     // (With waypoint counts per QP the state is kept per waypoint: a path that grew or shrank by a few waypoints since the previous cycle
     //  starts its common waypoints from where they were and the new ones from whatever the slot last held there - zero at first.)
-    if (h->opt_carry && !warm && !lin && h->warm_stored && h->warm_batch == batch && h->warm_n == n) warm = 1;
+    // (only on a handle whose polish returns the exact optimum: with polish == 0 - the reference's ADMM setting - a promoted call would end at an
+    //  eps-accurate point that depends on the slot's previous QP, and pqp.h promises the cold solve's optimum to the 1e-7 of the KKT test)
+    if (h->opt_carry && h->prm.polish != 0 && !warm && !lin && h->warm_stored && h->warm_batch == batch && h->warm_n == n) warm = 1;
     if (n > 512) return fail(PQP_ERR_CAPACITY, "pqp_path_solve: warm == 1 beyond 512 waypoints needs the linearisation point (`lin`): the lane-per-QP kernel keeps no warm state");
     if (warm && (h->warm_batch != batch || h->warm_n != n || !h->warm_stored))
         return fail(PQP_ERR_INVALID, "pqp_path_solve: warm == 1 needs a previous solve with the same batch and n (with PQP_OPT_STORE_WARM on)");
@@ -1045,6 +1049,7 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     h->timed = true;
     h->warm_batch = batch; h->warm_n = n;
     h->warm_stored = h->opt_store_warm != 0 || h->opt_carry != 0;
+    h->last_path_kernel = PQP_KERNEL_LANE_PER_WAYPOINT;
     return PQP_OK;
 }
 
@@ -1167,6 +1172,11 @@ int pqp_constrain_angle_device(pqp_handle* h, int count, const double* in, doubl
     hipLaunchKernelGGL(pqp::constrain_angle_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, count, in, out);
     PQP_HIP(hipGetLastError());
     return PQP_OK;
+}
+
+int pqp_last_path_kernel(pqp_handle* h) {
+    if (!h) return fail(PQP_ERR_INVALID, "pqp_last_path_kernel: null handle");
+    return h->last_path_kernel;
 }
 
 int pqp_last_kernel_ms(pqp_handle* h, float* ms) {

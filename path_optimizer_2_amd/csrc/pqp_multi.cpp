@@ -12,7 +12,6 @@
 // The reference has no counterpart (one path per call, single-threaded: base_solver.cpp:56-95).
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>      // types and prototypes only: the library is dlopen'ed on first use (Rccl below)
 
 #include <chrono>
 #include <condition_variable>
@@ -84,7 +83,20 @@ struct Shard {
     }
 
     // one shard's slice: host -> pinned -> device, solve, device -> pinned -> host
+    // (every error return goes through here: the stream is drained before the pinned staging buffers can be reused - a copy still in
+    //  flight would race with the next call's memcpy into them - and the slab shape is invalidated, so that a later
+    //  pqp_multi_gather_paths cannot broadcast a slab this failed call left half written)
     int run(const Job& j) {
+        last_count = -1;
+        const int r = run_body(j);
+        if (r != PQP_OK) {
+            void* sv = nullptr;
+            if (pqp_get_stream(h, &sv) == PQP_OK && sv) (void)hipStreamSynchronize((hipStream_t)sv);
+            last_count = -1;
+        }
+        return r;
+    }
+    int run_body(const Job& j) {
         int rc_;
         static const bool trace = std::getenv("PQP_MULTI_TRACE") != nullptr;         // phase times of every call on stderr (debugging aid)
         const auto t0 = std::chrono::steady_clock::now();
@@ -117,7 +129,7 @@ struct Shard {
         else
             rc_solve = pqp_path_solve_device(h, j.count, j.n, (const double*)ref.dev, d_lin, (const double*)bounds.dev, (const double*)scal.dev, j.passes, 0,
                                              (double*)out.dev, (int32_t*)status.dev, (int32_t*)iters.dev, (double*)info.dev);
-        if (rc_solve != PQP_OK) { err = pqp_last_error(); (void)hipStreamSynchronize(stream); return rc_solve; }
+        if (rc_solve != PQP_OK) { err = pqp_last_error(); return rc_solve; }
         if ((rc_ = hip(hipMemcpyAsync(out.pin, out.dev, bn * PQP_OUT_STRIDE * 8, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"))) return rc_;
         if (j.status && (rc_ = hip(hipMemcpyAsync(status.pin, status.dev, b * 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"))) return rc_;
         if (j.iters && (rc_ = hip(hipMemcpyAsync(iters.pin, iters.dev, b * 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync D2H"))) return rc_;
@@ -146,7 +158,7 @@ struct Shard {
                 has_job = false;
             }
             err.clear();
-            if (j.count <= 0) { last_count = 0; last_n = j.n; }
+            if (j.count <= 0) { last_count = j.count == 0 ? 0 : -1; last_n = j.n; }
             const int r = j.count > 0 ? run(j) : PQP_OK;
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -179,16 +191,27 @@ struct Shard {
 };
 
 // RCCL, resolved at run time.  One communicator per shard (single process, one rank per device), created by the first gather.
+// The handful of types and prototypes the gather uses are declared here (NCCL's stable C ABI: rccl.h's ncclComm_t, ncclResult_t with
+// ncclSuccess = 0, ncclDataType_t with ncclDouble = 8), so that the library builds on a ROCm install without the RCCL development headers.
+struct ncclComm;
+typedef ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr int ncclDouble = 8;
 struct Rccl {
     void* lib = nullptr;
-    decltype(&ncclCommInitAll) comm_init_all = nullptr;
-    decltype(&ncclCommDestroy) comm_destroy = nullptr;
-    decltype(&ncclGroupStart) group_start = nullptr;
-    decltype(&ncclGroupEnd) group_end = nullptr;
-    decltype(&ncclBroadcast) broadcast = nullptr;
-    decltype(&ncclGetErrorString) error_string = nullptr;
+    ncclResult_t (*comm_init_all)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*comm_count)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*group_start)() = nullptr;
+    ncclResult_t (*group_end)() = nullptr;
+    ncclResult_t (*broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*error_string)(ncclResult_t) = nullptr;
     std::string why;
+    std::mutex mu;
+    // (callers of two drivers may gather at once: the load is serialised; a library that lacks a symbol is closed again)
     bool load() {
+        std::lock_guard<std::mutex> lk(mu);
         if (lib) return true;
         for (const char* name : {"librccl.so.1", "librccl.so"}) {
             lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -196,13 +219,14 @@ struct Rccl {
         }
         if (!lib) { const char* e = dlerror(); why = std::string("librccl.so not found (") + (e ? e : "?") + ")"; return false; }
         auto sym = [&](const char* n) { void* f = dlsym(lib, n); if (!f) why = std::string("librccl.so lacks ") + n; return f; };
+        comm_count = (decltype(comm_count))sym("ncclCommCount");
         comm_init_all = (decltype(comm_init_all))sym("ncclCommInitAll");
         comm_destroy = (decltype(comm_destroy))sym("ncclCommDestroy");
         group_start = (decltype(group_start))sym("ncclGroupStart");
         group_end = (decltype(group_end))sym("ncclGroupEnd");
         broadcast = (decltype(broadcast))sym("ncclBroadcast");
         error_string = (decltype(error_string))sym("ncclGetErrorString");
-        if (!comm_init_all || !comm_destroy || !group_start || !group_end || !broadcast || !error_string) { lib = nullptr; return false; }
+        if (!comm_init_all || !comm_destroy || !comm_count || !group_start || !group_end || !broadcast || !error_string) { (void)dlclose(lib); lib = nullptr; return false; }
         return true;
     }
 };
@@ -379,6 +403,18 @@ int pqp_multi_gather_paths(pqp_multi* m, int batch, int n, double* const* full_o
             return mfail(PQP_ERR_HIP, "pqp_multi_gather_paths: hipStreamSynchronize after the gather");
     }
     return PQP_OK;
+}
+
+// Ranks of the gather's communicator as RCCL itself counts them (ncclCommCount of shard 0's communicator); 0 before the first
+// pqp_multi_gather_paths, < 0 on error.  What a scaling report should quote beside its own shard count.
+int pqp_multi_gather_ranks(pqp_multi* m) {
+    if (!m) return mfail(PQP_ERR_INVALID, "pqp_multi_gather_ranks: null driver");
+    std::lock_guard<std::mutex> lk(m->gather_mu);
+    if (m->comms.empty()) return 0;
+    int ranks = 0;
+    const ncclResult_t e = rccl().comm_count(m->comms[0], &ranks);
+    if (e != ncclSuccess) return mfail(PQP_ERR_HIP, std::string("pqp_multi_gather_ranks: ncclCommCount: ") + rccl().error_string(e));
+    return ranks;
 }
 
 }  // extern "C"

@@ -74,3 +74,9 @@ def test_two_ranks_through_the_launcher_path_on_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["config_id"] == 3 and d["config"]["batch_per_gpu"] == 2048
     assert d["solved"] == 2048 and d["gather_check"] is True and d["gather"]["bytes_per_rank_received"] == 2 * 2048 * 80 * 7 * 8
     assert abs(d["value"] - 2 * 2048 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]          # whole-job paths / the slowest rank's time
+    # the curve carries its own references: the shard alone and the whole batch on one GPU, both timed in this run on rank 0's GPU
+    assert d["rccl_ranks"] == 2
+    ref = d["scaling_reference"]
+    assert ref["shard_alone_on_one_gpu"]["batch"] == 2048 and ref["whole_batch_on_one_gpu"]["batch"] == 4096 and ref["whole_batch_on_one_gpu"]["solved"] == 4096
+    assert abs(d["weak_scaling_efficiency"] - d["value"] / (2 * ref["shard_alone_on_one_gpu"]["value"])) < 1e-9
+    assert abs(d["strong_scaling_vs_one_gpu_whole_batch"] - d["value"] / ref["whole_batch_on_one_gpu"]["value"]) < 1e-9

@@ -22,6 +22,31 @@ def shim_exe(hip_lib):
     return EXE
 
 
+@pytest.fixture(scope="module")
+def latency_exe(hip_lib):
+    exe = os.path.join(ROOT, "tests", "cpp", "shim_latency")
+    src = [os.path.join(ROOT, "tests", "cpp", "shim_latency.cpp"), os.path.join(CSRC, "base_solver_shim.cpp")]
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe] + src + ["-L" + CSRC, "-lpqp_hip", "-Wl,-rpath," + CSRC], check=True)
+    return exe
+
+
+REF_INCLUDE = "/root/reference/include"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_INCLUDE), reason="the reference tree is not on this box")
+@pytest.mark.parametrize("unit", ["path_optimizer_2_amd/csrc/base_solver_shim.cpp", "include/pqp_batched_solver.hpp"])
+def test_drop_in_mode_compiles_against_the_reference_headers(unit):
+    """with PQP_USE_REFERENCE_TYPES the shim and the batched solver use the reference's OWN ReferencePath /
+    VehicleState / SlState (include/data_struct/*.hpp, std-only) instead of include/pqp_types.hpp.  Pinned here as a compile check of
+    exactly that configuration (syntax + types; the link step needs the reference's objects)."""
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", "-DPQP_USE_REFERENCE_TYPES", "-I" + REF_INCLUDE, "-I" + os.path.join(ROOT, "include"),
+           "-include", "data_struct/data_struct.hpp", "-include", "data_struct/reference_path.hpp", "-include", "data_struct/vehicle_state_frenet.hpp",
+           os.path.join(ROOT, unit)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "error" not in r.stderr
+
+
 def _scenario_text(b, q):
     n = b["ref"].shape[1]
     lines = [str(n)]
@@ -56,3 +81,30 @@ def test_shim_reproduces_optimize_path(shim_exe, mode):
         else:
             ref = O.solve_path(b["ref"][q], b["bounds"][q], b["scal"][q], st=O.OsqpSettings(eps_abs=1e-9, eps_rel=1e-9, max_iter=40000))
             assert np.abs(got[:, 3:5] - ref[-1]["out"][:, 3:5]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_device_ordinal_comes_from_the_environment(shim_exe):
+    """PQP_DEVICE selects the GPU of a BaseSolver (the reference has no notion of a device); an ordinal this box does not have makes
+    solve() return false, like any failed set-up."""
+    import torch
+    b = make_batch(1, 40)
+    ok = subprocess.run([shim_exe], input=_scenario_text(b, 0), capture_output=True, text=True, env=dict(os.environ, PQP_DEVICE="0"))
+    assert ok.returncode == 0, ok.stderr
+    bad = subprocess.run([shim_exe], input=_scenario_text(b, 0), capture_output=True, text=True, env=dict(os.environ, PQP_DEVICE=str(torch.cuda.device_count())))
+    assert bad.returncode == 1 and "bad device ordinal" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_one_solver_per_planning_cycle_reuses_its_handle(latency_exe):
+    """The reference's pattern - a BaseSolver per cycle (path_optimizer.cpp:138) - on the pooled handle: later cycles do not pay pqp_create."""
+    import json
+    b = make_batch(1, 60)
+    runs = {}
+    for cache in (1, 0):
+        r = subprocess.run([latency_exe, "12", str(cache), "0"], input=_scenario_text(b, 0), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        runs[cache] = json.loads(r.stdout)
+    assert runs[1]["n"] == 60 and runs[1]["admm_iters"][0] > 0
+    assert runs[1]["cycle_us_median"] < runs[1]["first_cycle_us"]
+    assert runs[1]["cycle_us_median"] < runs[0]["cycle_us_median"]          # (uncached: every cycle creates stream, events and workspaces)
