@@ -215,8 +215,12 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      (profiles/r03n_seed_sweep.txt, r03y_seed_sweep.txt); lane-per-QP kernel 14 -> 9 interior-point iterations per path.
  *                                      A QP that differs wildly from its slot's previous one is still solved (the start is then merely poor).
  *                                      The exact TensionSmoother / postSmooth kernels (polish == 1) honour it too: a line's active-set rounds start from
- *                                      the set its slot ended with in the previous solve of the shape (16-31 rounds from the cold start, 2-3 from there). */
-typedef enum pqp_option { PQP_OPT_STORE_WARM = 1, PQP_OPT_ORDER_BY_COST = 2, PQP_OPT_RESERVE_CUS = 3, PQP_OPT_STREAM_BATCH = 4, PQP_OPT_CARRY_CYCLES = 5 } pqp_option;
+ *                                      the set its slot ended with in the previous solve of the shape (16-31 rounds from the cold start, 2-3 from there).
+ *   PQP_OPT_CHAIN_GRAPH (default 0)    pqp_optimize_path_device replays a captured hipGraph: the third call with the same arguments (pointers, sizes, configuration,
+ *                                      parameters of both handles) captures its ~25 launches on the handles' streams, later calls with those arguments are ONE
+ *                                      hipGraphLaunch - the gaps between the launches were 13 % of the chain.  Results are bit-identical; any (re)allocation inside
+ *                                      the library, or other arguments, falls back to plain launches (and a new capture).  Set it on the path handle. */
+typedef enum pqp_option { PQP_OPT_STORE_WARM = 1, PQP_OPT_ORDER_BY_COST = 2, PQP_OPT_RESERVE_CUS = 3, PQP_OPT_STREAM_BATCH = 4, PQP_OPT_CARRY_CYCLES = 5, PQP_OPT_CHAIN_GRAPH = 6 } pqp_option;
 int pqp_set_option(pqp_handle* h, int option, int value);
 int pqp_get_stream(pqp_handle* h, void** hip_stream);   /* hipStream_t */
 /* The handle's stream is created non-blocking: work the caller enqueued on ANOTHER stream (the inputs of a *_device call produced by

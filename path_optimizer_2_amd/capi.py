@@ -208,7 +208,7 @@ def _ptr(a):
     return C.c_void_p(int(a))      # raw device pointer (e.g. torch.Tensor.data_ptr())
 
 
-OPT_STORE_WARM, OPT_ORDER_BY_COST, OPT_RESERVE_CUS, OPT_STREAM_BATCH, OPT_CARRY_CYCLES = 1, 2, 3, 4, 5
+OPT_STORE_WARM, OPT_ORDER_BY_COST, OPT_RESERVE_CUS, OPT_STREAM_BATCH, OPT_CARRY_CYCLES, OPT_CHAIN_GRAPH = 1, 2, 3, 4, 5, 6
 SMOOTHING_TENSION2, SMOOTHING_TENSION = 0, 1
 
 

@@ -19,6 +19,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <new>
 #include <string>
 
@@ -651,11 +652,16 @@ int fail(int code, const std::string& msg) {
         if (e_ != hipSuccess) return fail(PQP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// every (re)allocation of a device buffer of the library: captured hipGraphs of the chain hold device pointers and are only replayed
+// while this has not moved (pqp_chain.inc)
+std::atomic<unsigned long long> g_alloc_generation{0};
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
     int ensure(size_t need) {
         if (need <= bytes) return PQP_OK;
+        g_alloc_generation.fetch_add(1, std::memory_order_relaxed);
         if (p) (void)hipFree(p);
         p = nullptr; bytes = 0;
         PQP_HIP(hipMalloc(&p, need));
@@ -687,7 +693,13 @@ struct pqp_handle {
     static constexpr int kMarks = 8;
     static constexpr int kChainMarks = 2;      // + two events of pqp_optimize_path_device's own
     hipEvent_t marks[kMarks + kChainMarks] = {};   // pqp_mark / pqp_wait_mark: ordering between the streams of two handles
-    void next_event_pair() { ev0 = evs0[ev_count % kEvRing]; ev1 = evs1[ev_count % kEvRing]; ev_count += 1; }
+    void next_event_pair() { if (capturing) return; ev0 = evs0[ev_count % kEvRing]; ev1 = evs1[ev_count % kEvRing]; ev_count += 1; }
+    // PQP_OPT_CHAIN_GRAPH: pqp_optimize_path_device captured as hipGraphs (pqp_chain.inc).  capturing: the handle's stream is in capture
+    // mode - no timing events, the path solve resets its ticket counter inside the graph
+    bool capturing = false;
+    int opt_chain_graph = 0;
+    struct ChainGraph { std::vector<unsigned char> key; hipGraphExec_t exec = nullptr; int seen = 0; bool failed = false; unsigned long long ticket_after = 0; };
+    std::vector<ChainGraph> chain_graphs;
     int warm_batch = 0, warm_n = 0;
     bool warm_stored = false;                   // the last solve wrote its final iterate to wx / wy / wye
     DevBuf wx, wy, wye, wrho, wsave, wscale;    // warm state (lane layout) + polish save area, parked Ruiz vectors (per workgroup slot)
@@ -759,6 +771,8 @@ int pqp_destroy(pqp_handle* h) {
     if (!h) return PQP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& g : h->chain_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->chain_graphs.clear();
     for (DevBuf* b : {&h->sm_act[0], &h->sm_act[1], &h->stream_ws, &h->chain_d, &h->chain_i, &h->wscale, &h->ticket, &h->cost_key, &h->cost_hist, &h->order, &h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
                       &h->s_status, &h->s_iters, &h->s_info, &h->s_a, &h->s_p, &h->s_l, &h->s_u, &h->s_idx, &h->b_pband, &h->b_q, &h->b_aval,
                       &h->b_lo, &h->b_up, &h->b_x, &h->b_y, &h->b_acol, &h->b_trow, &h->b_tslot, &h->b_in[0], &h->b_in[1], &h->b_in[2],
@@ -787,6 +801,7 @@ int pqp_set_option(pqp_handle* h, int option, int value) {
         case PQP_OPT_RESERVE_CUS: h->opt_reserve_cus = value < 0 ? 0 : value; return PQP_OK;
         case PQP_OPT_STREAM_BATCH: h->opt_stream_batch = value < 0 ? 0 : value; return PQP_OK;
         case PQP_OPT_CARRY_CYCLES: h->opt_carry = value ? 1 : 0; h->stream_last_batch = 0; h->sm_act_batch[0] = h->sm_act_batch[1] = 0; return PQP_OK;
+        case PQP_OPT_CHAIN_GRAPH: h->opt_chain_graph = value ? 1 : 0; return PQP_OK;
         default: return fail(PQP_ERR_INVALID, "pqp_set_option: unknown option");
     }
 }
@@ -881,11 +896,11 @@ int pqp_path_assemble_device(pqp_handle* h, int batch, int n, int precise, const
         PQP_HIP(hipFuncSetAttribute((const void*)pqp::path_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = batch < 4096 ? batch : 4096;
     h->next_event_pair();
-    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(pqp::path_assemble_kernel, dim3(grid), dim3(256), stage ? lds : 0, h->stream, R, batch, ref, lin, bounds,
                        scal, h->prm, a_val, p_val, lower, upper, stage);
     PQP_HIP(hipGetLastError());
-    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return PQP_OK;
 }
@@ -936,9 +951,9 @@ static int path_stream_impl(pqp_handle* h, int batch, int n, const int32_t* n_of
     // PQP_OPT_CARRY_CYCLES: the workspace still holds, slot by slot, the optimum of the previous launch of this very shape
     a.carry = (h->opt_carry && !lin && h->stream_last_batch == batch && h->stream_last_n == n && h->stream_ws.p == ws_before) ? 1 : 0;       // (lin == NULL: pqp.h)
     h->next_event_pair();
-    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
     PQP_HIP(pqp_stream_launch(&a, waves, (void*)h->stream));      // path_stream_kernel lives in its own translation unit (pqp_path_stream.hip)
-    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     h->stream_last_batch = batch; h->stream_last_n = n;
     h->warm_batch = batch; h->warm_n = n;
@@ -1017,6 +1032,9 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     a.store_warm = (h->opt_store_warm || h->opt_carry) ? 1 : 0;
     a.ticket = h->ticket.as<unsigned long long>();
     a.ticket_base = h->ticket_next;
+    // inside a captured graph the launch cannot take its ticket base from a host counter that moves between replays: the graph resets the
+    // device counter itself and every replay starts at 0 (pqp_chain.inc puts the host counter where the replay leaves the device one)
+    if (h->capturing) { PQP_HIP(hipMemsetAsync(h->ticket.p, 0, 8, h->stream)); a.ticket_base = 0; }
     // Host-side bookkeeping of the launch (ticket base of the next launch, launch parity, shape of the cost histogram) is committed
     // only after the launch has been accepted: a failing step below (allocation, memset, event, launch) leaves the device ticket
     // counter and the host's idea of it in step.
@@ -1034,7 +1052,7 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
         a.order_next = order_write;
     }
     h->next_event_pair();
-    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
     void* kargs[] = {(void*)&a};
     hipError_t le = hipLaunchKernel(fn, dim3(grid), dim3(64 * nw), kargs, lds, h->stream);
     if (le == hipSuccess) le = hipGetLastError();
@@ -1042,10 +1060,10 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
         h->hist_batch = 0; h->hist_n = 0;          // (the histogram may have been cleared for a launch that never ran)
         return fail(PQP_ERR_HIP, std::string("hipLaunchKernel(path_solve_kernel): ") + hipGetErrorString(le));
     }
-    h->ticket_next += (unsigned long long)batch + (unsigned long long)grid;
+    h->ticket_next = a.ticket_base + (unsigned long long)batch + (unsigned long long)grid;
     if (h->opt_order_by_cost) { h->hist_batch = batch; h->hist_n = n; }
     h->solves += 1;
-    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     h->warm_batch = batch; h->warm_n = n;
     h->warm_stored = h->opt_store_warm != 0 || h->opt_carry != 0;
@@ -1281,11 +1299,11 @@ int sm_solve(pqp_handle* h, int type, int batch, int n, int32_t* status, int32_t
 #undef PQP_BQ_PICK
     if (lds > 64 * 1024) PQP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     h->next_event_pair();
-    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
     void* kargs[] = {(void*)&a};
     PQP_HIP(hipLaunchKernel(fn, dim3(batch), dim3(threads), kargs, lds, h->stream));
     PQP_HIP(hipGetLastError());
-    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return PQP_OK;
 }
@@ -1317,12 +1335,12 @@ static int smooth_tension2_impl(pqp_handle* h, int batch, int n, const int32_t* 
                            s_list, h->b_aval.as<double>());
         PQP_HIP(hipGetLastError());
         h->next_event_pair();
-        PQP_HIP(hipEventRecord(h->ev0, h->stream));
+        if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
         hipLaunchKernelGGL(pqp::tension2_exact_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list,
                            h->prm.tension2_deviation_weight, h->prm.tension2_curvature_weight, h->prm.tension2_curvature_rate_weight, h->b_aval.as<double>(),
                            h->b_pband.as<double>(), out_x, out_y, out_s, status, iters, info);
         PQP_HIP(hipGetLastError());
-        PQP_HIP(hipEventRecord(h->ev1, h->stream));
+        if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
         h->timed = true;
         return PQP_OK;
     }
@@ -1371,7 +1389,7 @@ static int smooth_tension_impl(pqp_handle* h, int batch, int n, const int32_t* n
         // exact optima asked for (or the only kernel that holds the QP): the box QP in the lateral shifts alone, one wavefront per scenario (tension_exact_kernel)
         if (!status) return fail(PQP_ERR_INVALID, "pqp_smooth_tension: status is null");
         h->next_event_pair();
-        PQP_HIP(hipEventRecord(h->ev0, h->stream));
+        if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
         const double wk = h->prm.cartesian_curvature_weight, wdk = h->prm.cartesian_curvature_rate_weight, wdev = h->prm.cartesian_deviation_weight, tol = h->prm.polish_tol;
         // PQP_OPT_CARRY_CYCLES: the active set every line ended with is kept on the handle; a solve of the shape of the previous one starts from it
         signed char* act_io = nullptr;
@@ -1388,7 +1406,7 @@ static int smooth_tension_impl(pqp_handle* h, int batch, int n, const int32_t* n
         else if (n <= 256) hipLaunchKernelGGL(pqp::tension_exact_kernel<4>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
         else hipLaunchKernelGGL(pqp::tension_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
         PQP_HIP(hipGetLastError());
-        PQP_HIP(hipEventRecord(h->ev1, h->stream));
+        if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
         h->timed = true;
         return PQP_OK;
     }
@@ -1425,7 +1443,7 @@ static int post_smooth_impl(pqp_handle* h, int batch, int m, const int32_t* m_of
         // exact optima asked for: the box QP in the offsets alone, one wavefront per scenario (post_exact_kernel)
         if (!status) return fail(PQP_ERR_INVALID, "pqp_post_smooth: status is null");
         h->next_event_pair();
-        PQP_HIP(hipEventRecord(h->ev0, h->stream));
+        if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
         const double tol = h->prm.polish_tol;
         signed char* act_io = nullptr;          // PQP_OPT_CARRY_CYCLES, as in smooth_tension_impl
         int carry = 0;
@@ -1442,7 +1460,7 @@ static int post_smooth_impl(pqp_handle* h, int batch, int m, const int32_t* m_of
         else if (m <= 256) hipLaunchKernelGGL(pqp::post_exact_kernel<4>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
         else hipLaunchKernelGGL(pqp::post_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
         PQP_HIP(hipGetLastError());
-        PQP_HIP(hipEventRecord(h->ev1, h->stream));
+        if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
         h->timed = true;
         return PQP_OK;
     }
@@ -1556,7 +1574,7 @@ int pqp_corridor_bounds_device(pqp_handle* h, int batch, int n, int m, const dou
     int threads = 64 * ((3 * n + 63) / 64);
     if (threads > 1024) threads = 1024;
     h->next_event_pair();
-    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
     const size_t lds = pqp::CorridorLds{m, n}.total_bytes();
     if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_corridor_bounds: scenario too large for one CU's LDS (about 9 m + 31 n doubles)");
     if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::corridor_bounds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1564,7 +1582,7 @@ int pqp_corridor_bounds_device(pqp_handle* h, int batch, int n, int m, const dou
                                      // 1024 x n = 80: 1024 lanes 142 us - two scenarios per CU -, 512: 121, 256: 120, 128: 146)
     hipLaunchKernelGGL(pqp::corridor_bounds_kernel, dim3(batch), dim3(threads), lds, h->stream, a);
     PQP_HIP(hipGetLastError());
-    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return PQP_OK;
 }
@@ -1611,13 +1629,13 @@ int pqp_reference_states_device(pqp_handle* h, int batch, int n_max, int m, cons
     a.ds_small = ds_small; a.ds_large = ds_large; a.dynamic = dynamic ? 1 : 0; a.ref = ref; a.count = count; a.init_err = init_err;
     a.lx = a.ly = a.ls = a.langle = a.lk = nullptr;
     h->next_event_pair();
-    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
     const size_t lds = ((size_t)9 * m + n_max) * 8;
     if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_reference_states: 9 m + n_max doubles exceed one CU's LDS");
     if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::reference_states_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(pqp::reference_states_kernel, dim3(batch), dim3(64), lds, h->stream, a);
     PQP_HIP(hipGetLastError());
-    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return PQP_OK;
 }
@@ -1634,13 +1652,13 @@ int pqp_segment_raw_reference_device(pqp_handle* h, int batch, int n_max, int m,
     a.ds_small = delta_s; a.ds_large = delta_s; a.dynamic = 2; a.ref = nullptr; a.count = count; a.init_err = nullptr;
     a.lx = x; a.ly = y; a.ls = s; a.langle = angle; a.lk = k;
     h->next_event_pair();
-    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
     const size_t lds = ((size_t)9 * m + n_max) * 8;
     if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_segment_raw_reference: 9 m + n_max doubles exceed one CU's LDS");
     if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::reference_states_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(pqp::reference_states_kernel, dim3(batch), dim3(64), lds, h->stream, a);
     PQP_HIP(hipGetLastError());
-    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return PQP_OK;
 }
@@ -1711,10 +1729,10 @@ int pqp_offsets_to_points_device(pqp_handle* h, int batch, int m_spline, int m, 
     if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_offsets_to_points: 9 m_spline + 2 m doubles exceed one CU's LDS");
     if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::offsets_to_points_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     h->next_event_pair();
-    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(pqp::offsets_to_points_kernel, dim3(batch), dim3(64), lds, h->stream, a);
     PQP_HIP(hipGetLastError());
-    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return PQP_OK;
 }
@@ -1758,10 +1776,10 @@ int pqp_reference_length_device(pqp_handle* h, int batch, int m, const double* s
     if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_reference_length: 9 m doubles exceed one CU's LDS");
     if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::reference_length_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     h->next_event_pair();
-    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(pqp::reference_length_kernel, dim3(batch), dim3(64), lds, h->stream, a);
     PQP_HIP(hipGetLastError());
-    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return PQP_OK;
 }
@@ -1799,10 +1817,10 @@ int pqp_bspline_resample_device(pqp_handle* h, int batch, int p_max, int n_max, 
     if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_bspline_resample: 3 p_max + 3 n_max doubles exceed one CU's LDS");
     if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::bspline_resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     h->next_event_pair();
-    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(pqp::bspline_resample_kernel, dim3(batch), dim3(64), lds, h->stream, a);
     PQP_HIP(hipGetLastError());
-    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return PQP_OK;
 }
@@ -1845,10 +1863,10 @@ static int spline_fit_impl(pqp_handle* h, int batch, int m, const int32_t* m_of,
     if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_spline_fit: 7 m doubles exceed one CU's LDS");
     if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::spline_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     h->next_event_pair();
-    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(pqp::spline_fit_kernel, dim3(2 * batch), dim3(64), lds, h->stream, a);
     PQP_HIP(hipGetLastError());
-    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return PQP_OK;
 }
@@ -1905,10 +1923,10 @@ int pqp_dp_corridor_device(pqp_handle* h, int batch, int m, int max_layers, cons
     if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_dp_corridor: 9 m + 17 max_layers doubles (+ the edge table) exceed one CU's LDS");
     if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::dp_corridor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     h->next_event_pair();
-    PQP_HIP(hipEventRecord(h->ev0, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(pqp::dp_corridor_kernel, dim3(batch), dim3(pqp::kDpThreads), lds, h->stream, a);
     PQP_HIP(hipGetLastError());
-    PQP_HIP(hipEventRecord(h->ev1, h->stream));
+    if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return PQP_OK;
 }

@@ -228,3 +228,59 @@ def test_clearance_lookup_on_the_device(hip_lib):
     r = h.smooth_tension(np.cumsum(np.ones((3, n)), axis=1), np.zeros((3, n)), np.zeros((3, n)), got)
     assert (r["status"] == 1).all()
     h.close()
+
+
+def test_chain_replayed_as_a_hip_graph_is_bit_identical(hip_lib):
+    """PQP_OPT_CHAIN_GRAPH: the chain's ~25 launches on two streams captured once per argument set and replayed (csrc/pqp_chain.inc).  Same
+    device buffers call after call, their CONTENTS moving like planning cycles: every call's result equals the plainly launched chain's bit for bit -
+    through the plain first calls, the two captures (one per parity of the cost-order double buffer) and the replays - and other arguments fall
+    back to plain launches."""
+    import torch
+    B = 40
+    sc = _scenarios(B, seed=11)
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    p = lambda x: capi.C.c_void_p(x.data_ptr())
+    d_np, d_tg, d_map = t(sc["n_pts"], np.int32), t(sc["target"], np.float64), t(sc["map_of"], np.int32)
+    d_dist = t(np.transpose(sc["dist"], (0, 2, 1)), np.float32)
+    rng = np.random.default_rng(3)
+    cycles = []
+    for _ in range(9):
+        pv = sc["pts"].copy(); pv[:, :, 1] += rng.normal(scale=0.02, size=pv.shape[:2]) * (pv[:, :, 0] != 0)
+        sv = sc["start"].copy(); sv[:, :2] += rng.normal(scale=0.05, size=(B, 2))
+        cycles.append((pv, sv))
+    results = {}
+    for graph in (0, 1):
+        h = capi.Handle(capi.production_params(), device=0, max_batch=B, max_n=256)
+        hs = capi.Handle(_smoother_params(), device=0, max_batch=B, max_n=128)
+        h.set_option(capi.OPT_STORE_WARM, 0); h.set_option(capi.OPT_ORDER_BY_COST, 1); h.set_option(capi.OPT_CHAIN_GRAPH, graph)
+        cfg = h.chain_config(raw_max=64, sample_max=48, layer_max=32, n_max=128)
+        d_pts, d_st = t(cycles[0][0], np.float64), t(cycles[0][1], np.float64)
+        out = torch.zeros((B, cfg.n_max, 7), dtype=torch.float64, device=dev)
+        n_out, status, stage, iters = (torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(4))
+        got = []
+        for pv, sv in cycles:
+            d_pts.copy_(torch.from_numpy(pv)); d_st.copy_(torch.from_numpy(sv))
+            torch.cuda.synchronize()
+            h._check(h.lib.pqp_optimize_path_device(h._h, hs._h, capi.C.byref(cfg), B, sc["pts"].shape[1], p(d_pts), p(d_np), p(d_st), p(d_tg), p(d_dist), p(d_map),
+                                                    capi.C.byref(sc["geom"]), None, p(out), p(n_out), p(status), p(stage), p(iters)))
+            h.sync(); hs.sync()
+            got.append((out.cpu().numpy().copy(), n_out.cpu().numpy().copy(), status.cpu().numpy().copy(), stage.cpu().numpy().copy()))
+        if graph:
+            # other arguments (another output buffer): not the captured graph's - plain launches, same result as the last cycle's
+            out2 = torch.zeros_like(out)
+            h._check(h.lib.pqp_optimize_path_device(h._h, hs._h, capi.C.byref(cfg), B, sc["pts"].shape[1], p(d_pts), p(d_np), p(d_st), p(d_tg), p(d_dist), p(d_map),
+                                                    capi.C.byref(sc["geom"]), None, p(out2), p(n_out), p(status), p(stage), p(iters)))
+            h.sync(); hs.sync()
+            np.testing.assert_array_equal(out2.cpu().numpy(), got[-1][0])
+            # and the handle still solves plain batches afterwards (the ticket counter of the path kernel was reset inside the graph)
+            from path_optimizer_2_amd.synth import make_batch
+            b = make_batch(16, 80)
+            r = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+            assert (r["status"] == 1).all()
+        results[graph] = got
+        h.close(); hs.close()
+    assert (results[0][0][3] == 0).sum() >= B // 2          # most scenarios give a path
+    for k in range(len(cycles)):
+        for a, b_ in zip(results[0][k], results[1][k]):
+            np.testing.assert_array_equal(a, b_)
