@@ -128,7 +128,7 @@ typedef struct pqp_params {
                                          with iters = 0 where the QP's structure allows: TensionSmoother2's (equality rows only: a linear-
                                          quadratic control problem) by one Riccati sweep per scenario; with polish == 1 postSmooth's (a box
                                          QP in the offsets) and TensionSmoother's (a box QP in the lateral shifts) by a KKT-verified
-                                         active-set solve, one wavefront per scenario (up to 384 layers / points; beyond: the generic
+                                         active-set solve, one wavefront per scenario (up to 512 layers / points; beyond: the generic
                                          core's active-set solve from the cold start, with ADMM + KKT-verified polish attempts as the
                                          fallback).  With polish == 2 QPs with inequality rows run the plain ADMM.  The path QP treats 2
                                          like 1 */
@@ -342,7 +342,7 @@ int pqp_smooth_tension2_device(pqp_handle* h, int batch, int n, const double* x_
                                int32_t* status, int32_t* iters, double* info);
 /* TensionSmoother::osqpSmooth    src/reference_path_smoother/tension_smoother.cpp:49-100; clearance = Map::getObstacleDistance
  * at each input point (the distance-map lookup itself, tension_smoother.cpp:168, stays on the caller's side; pqp_clearance_device does it).
- * 4 <= n <= 384 points.  Up to ~166 points a handle in the reference's ADMM setting (polish == 0) runs OSQP's iteration on the 9 x 9-block
+ * 4 <= n <= 512 points.  Up to ~166 points a handle in the reference's ADMM setting (polish == 0) runs OSQP's iteration on the 9 x 9-block
  * core; beyond that core's LDS capacity - and for polish == 1 at any size - the QP is solved exactly (iters = 0), which meets OSQP's
  * termination test at any eps. */
 int pqp_smooth_tension(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list,

@@ -1385,7 +1385,7 @@ static int smooth_tension_impl(pqp_handle* h, int batch, int n, const int32_t* n
     const SmShape sh9 = sm_shape(SM_TENSION, n);
     const pqp::BqLayout lay9{sh9.nv, sh9.nc, sh9.bw};
     const bool generic_fits = (size_t)lay9.total(false) * 8 <= 160 * 1024 && 64 * ((lay9.nbb() + 63) / 64) <= 1024;
-    if ((h->prm.polish == 1 || !generic_fits) && n <= 384) {
+    if ((h->prm.polish == 1 || !generic_fits) && n <= 512) {
         // exact optima asked for (or the only kernel that holds the QP): the box QP in the lateral shifts alone, one wavefront per scenario (tension_exact_kernel)
         if (!status) return fail(PQP_ERR_INVALID, "pqp_smooth_tension: status is null");
         h->next_event_pair();
@@ -1404,7 +1404,8 @@ static int smooth_tension_impl(pqp_handle* h, int batch, int n, const int32_t* n
         if (n <= 64) hipLaunchKernelGGL(pqp::tension_exact_kernel<1>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
         else if (n <= 128) hipLaunchKernelGGL(pqp::tension_exact_kernel<2>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
         else if (n <= 256) hipLaunchKernelGGL(pqp::tension_exact_kernel<4>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
-        else hipLaunchKernelGGL(pqp::tension_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
+        else if (n <= 384) hipLaunchKernelGGL(pqp::tension_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
+        else hipLaunchKernelGGL(pqp::tension_exact_kernel<8>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
         PQP_HIP(hipGetLastError());
         if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
         h->timed = true;
@@ -1439,7 +1440,7 @@ static int post_smooth_impl(pqp_handle* h, int batch, int m, const int32_t* m_of
                             const double* vehicle_l, double* out_l, int32_t* status, int32_t* iters, double* info) {
     if (!h || !layers_s || !lb || !ub || !vehicle_l || !out_l || batch < 1 || m < 4) return fail(PQP_ERR_INVALID, "pqp_post_smooth: bad argument (m >= 4, reference_path_smoother.cpp:528)");
     PQP_HIP(hipSetDevice(h->device));
-    if (h->prm.polish == 1 && m <= 384) {
+    if (h->prm.polish == 1 && m <= 512) {
         // exact optima asked for: the box QP in the offsets alone, one wavefront per scenario (post_exact_kernel)
         if (!status) return fail(PQP_ERR_INVALID, "pqp_post_smooth: status is null");
         h->next_event_pair();
@@ -1458,7 +1459,8 @@ static int post_smooth_impl(pqp_handle* h, int batch, int m, const int32_t* m_of
         if (m <= 64) hipLaunchKernelGGL(pqp::post_exact_kernel<1>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
         else if (m <= 128) hipLaunchKernelGGL(pqp::post_exact_kernel<2>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
         else if (m <= 256) hipLaunchKernelGGL(pqp::post_exact_kernel<4>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
-        else hipLaunchKernelGGL(pqp::post_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
+        else if (m <= 384) hipLaunchKernelGGL(pqp::post_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
+        else hipLaunchKernelGGL(pqp::post_exact_kernel<8>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
         PQP_HIP(hipGetLastError());
         if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
         h->timed = true;

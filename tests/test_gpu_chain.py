@@ -272,7 +272,9 @@ def test_chain_replayed_as_a_hip_graph_is_bit_identical(hip_lib):
             h._check(h.lib.pqp_optimize_path_device(h._h, hs._h, capi.C.byref(cfg), B, sc["pts"].shape[1], p(d_pts), p(d_np), p(d_st), p(d_tg), p(d_dist), p(d_map),
                                                     capi.C.byref(sc["geom"]), None, p(out2), p(n_out), p(status), p(stage), p(iters)))
             h.sync(); hs.sync()
-            np.testing.assert_array_equal(out2.cpu().numpy(), got[-1][0])
+            o2, no = out2.cpu().numpy(), got[-1][1]
+            for b in range(B):          # (rows beyond a scenario's waypoint count are not written: the long-lived buffer keeps older cycles' rows there)
+                np.testing.assert_array_equal(o2[b, :no[b]], got[-1][0][b, :no[b]])
             # and the handle still solves plain batches afterwards (the ticket counter of the path kernel was reset inside the graph)
             from path_optimizer_2_amd.synth import make_batch
             b = make_batch(16, 80)
