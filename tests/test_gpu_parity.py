@@ -424,6 +424,30 @@ def test_the_bench_workload_itself_against_the_c_oracle(hip_lib, n, profile, bat
     assert np.abs(r["out"][:, :, 0:2] - ref["out"][:, :, 0:2]).max() < 1e-4          # x, y of the optimised path
 
 
+def test_long_paths_both_kernels_against_the_c_oracle(hip_lib):
+    """N = 300 (a 60-90 m reference line at 0.15-0.3 m spacing): 64 QPs through BOTH product kernels - lane per waypoint (NW = 8) and lane per QP -
+    against the C oracle run to eps 1e-9, and against each other.  The margin to the 1e-4 bar is smallest here (ill-conditioned long paths: the
+    ADMM oracle itself is only good to ~1e-5 on their weakly determined ends); the two kernels share no iteration, factorisation or scaling."""
+    import pqp_oracle_c as OC
+    n, batch = 300, 64
+    b = make_batch(batch, n, "varied", seed=8)
+    h = capi.Handle(_polished(), max_batch=batch, max_n=n)
+    lane = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    assert h.last_path_kernel() == 1
+    h.set_option(capi.OPT_STORE_WARM, 0); h.set_option(capi.OPT_STREAM_BATCH, 1)
+    qp = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    assert h.last_path_kernel() == 2
+    h.close()
+    ref = OC.solve_batch(OC.params(eps_abs=1e-9, eps_rel=1e-9, max_iter=400000), b["ref"], b["bounds"], b["scal"], passes=1)
+    assert ref["solved"] == batch and (lane["status"] == 1).all() and (qp["status"] == 1).all()
+    worst = lambda a, c: np.abs(a[:, :, 3:5] - c[:, :, 3:5]).reshape(batch, -1).max(axis=1)
+    e_lane, e_qp, e_both = worst(lane["out"], ref["out"]), worst(qp["out"], ref["out"]), worst(lane["out"], qp["out"])
+    print(f"N = 300, 64 QPs: lane-per-waypoint vs oracle median {np.median(e_lane):.1e} max {e_lane.max():.1e}; lane-per-QP vs oracle median {np.median(e_qp):.1e} "
+          f"max {e_qp.max():.1e}; between the kernels median {np.median(e_both):.1e} max {e_both.max():.1e}")
+    assert e_lane.max() < 1e-4 and e_qp.max() < 1e-4 and e_both.max() < 1e-4
+    assert np.median(e_lane) < 2e-6 and np.median(e_qp) < 2e-6 and np.median(e_both) < 1e-6
+
+
 def test_inverted_box_is_refused_by_the_host_entry_points(hip_lib):
     """lower > upper bound on a collision row: OSQP refuses the data at setup and the reference's solve() returns false
     (base_solver.cpp:76-80).  pqp_path_solve does not launch that QP and reports it primal infeasible; its neighbours solve."""
