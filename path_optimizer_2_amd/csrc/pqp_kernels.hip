@@ -93,7 +93,7 @@ __device__ __forceinline__ double wave_sum(double x) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
 }
 
-template <int NW, int K, bool MAX>
+template <int NW, int K, bool MAX, int TL = 64 * NW>       // TL: lanes of the LDS layout (128 * NW for the two-waypoints-per-lane contexts)
 __device__ __forceinline__ void wg_reduce(double (&v)[K], double* shp) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -101,7 +101,7 @@ __device__ __forceinline__ void wg_reduce(double (&v)[K], double* shp) {
         v[k] = MAX ? wave_max(x) : wave_sum(x);
     }
     if (NW > 1) {
-        double* red = shp + ShLayout{64 * NW}.red();
+        double* red = shp + ShLayout{TL}.red();
         const int w = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 0)
             for (int k = 0; k < K; ++k) red[k * 16 + w] = v[k];
@@ -148,6 +148,11 @@ __device__ __noinline__ bool dev_certificate(double* sh, double fl, double rl, d
 #ifndef PQP_DPP
 #define PQP_DPP 1      // +x %: profiles/r02j
 #endif
+// PQP_SAVE_LDS_MAX_NW: up to this many wavefronts per QP the polish save area lives in LDS (beyond: in the workgroup slot's global memory).
+// 4 is what fits (256 lanes: 157 KB); experiments with two QPs' worth of wavefronts per SIMD set it to 1 (40 KB per QP at 128 lanes)
+#ifndef PQP_SAVE_LDS_MAX_NW
+#define PQP_SAVE_LDS_MAX_NW 4
+#endif
 #ifndef PQP_CST_LDS
 #define PQP_CST_LDS 0
 #endif
@@ -166,7 +171,7 @@ __device__ __noinline__ bool dev_late_certificate(double* sh, int t, double* sna
 // barriers (for a one-wave workgroup the barrier is only a wait on outstanding LDS traffic).
 template <int NW>
 struct RegCtx {
-    static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0, kSaveLds = NW <= 4;
+    static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0, kSaveLds = NW <= PQP_SAVE_LDS_MAX_NW;
     // DPP moves (PQP_DPP): the value of the lane H below / above in the same row of 16 lanes, of the previous row's last lane; 0 where
     // there is no such lane.  Must run with every lane enabled (a disabled source lane reads as "no lane").
     static constexpr bool kDpp = PQP_DPP != 0;
@@ -239,7 +244,7 @@ __device__ __noinline__ Uni cold_entry(const PathSolveArgs* args, int qp, double
 template <int NW>
 struct DevCtx {
     // kSaveLds: up to 256 lanes the polish save area fits beside the exchange buffers (72 KB per QP at T = 128, two QPs per CU)
-    static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0, kSaveLds = NW <= 4;
+    static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0, kSaveLds = NW <= PQP_SAVE_LDS_MAX_NW;
     // DPP moves (PQP_DPP): the value of the lane H below / above in the same row of 16 lanes, of the previous row's last lane; 0 where
     // there is no such lane.  Must run with every lane enabled (a disabled source lane reads as "no lane").
     static constexpr bool kDpp = PQP_DPP != 0;
@@ -314,6 +319,105 @@ struct DevCtx {
         dst.s = src.s;
     }
 };
+
+#ifdef PQP_WITH_PAIR
+// ---------------------------------------------------------------------------------------------------------------------------
+// TWO WAYPOINTS PER LANE (round 4; EXPERIMENT, compiled only with -DPQP_WITH_PAIR and selected by PQP_PAIR=1: it is correct - the parity
+// tests pass on it - and 2-2.7x slower, because two lane states need ~466 fp64 of registers where a lane has 256: 1389 spills, profiles/r04g_*).
+// The same solver source on half the wavefronts: lane j of the workgroup owns waypoints 2j and
+// 2j + 1, a phase runs the solver's per-waypoint code for both (all neighbour traffic through the LDS exchange buffers, which are indexed by
+// waypoint: the formulation the host emulation runs), T = 128 NW.  N <= 128 is ONE wavefront per QP (no workgroup barrier is ever a wait, four
+// QPs per CU instead of two); the first cyclic-reduction level eliminates every lane's even waypoint, all further levels run on the odd
+// ones, so with the waypoint index known to the compiler as 2 j + k the dead half of every level folds away: a solve issues one level
+// sequence instead of two, only the per-waypoint phases run twice.  The price is two lane states in one register file (the save area and the
+// parked scaling vectors therefore live in the workgroup slot's global memory) and LDS exchanges where the one-waypoint-per-lane contexts
+// use DPP moves.
+template <int NW>
+struct PairLaneLessCtx {
+    double* shp;
+    __device__ __forceinline__ int T() const { return 128 * NW; }
+    template <class F>
+    __device__ __forceinline__ void phase(F f) {
+        f(2 * (int)threadIdx.x); f(2 * (int)threadIdx.x + 1);
+        __syncthreads();
+    }
+    template <int K, bool MAX, class F>
+    __device__ __forceinline__ void reduce(double (&out)[K], F f) {
+        double b[K];
+        f(2 * (int)threadIdx.x, out); f(2 * (int)threadIdx.x + 1, b);
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[k] = MAX ? fmax(out[k], b[k]) : out[k] + b[k];
+        wg_reduce<NW, K, MAX, 128 * NW>(out, shp);
+    }
+    template <int K, class F> __device__ __forceinline__ void reduce_max(double (&out)[K], F f) { reduce<K, true>(out, f); }
+    template <int K, class F> __device__ __forceinline__ void reduce_sum(double (&out)[K], F f) { reduce<K, false>(out, f); }
+};
+template <int NW>
+__device__ __noinline__ bool dev_certificate_pair(double* sh, double fl, double rl, double kap, double eps, double cscale) {
+    PairLaneLessCtx<NW> c{sh};
+    return primal_certificate(c, sh, 128 * NW, fl, rl, kap, eps, cscale);
+}
+// staging half of late_certificate() for one waypoint (no synchronisation, no evaluation)
+struct StageOnlyCtx {
+    int T_;
+    __device__ __forceinline__ int T() const { return T_; }
+    template <class F> __device__ __forceinline__ void phase(F) {}
+    template <int K, class F> __device__ __forceinline__ void reduce_max(double (&out)[K], F) { for (int k = 0; k < K; ++k) out[k] = 0.0; }
+    template <int K, class F> __device__ __forceinline__ void reduce_sum(double (&out)[K], F) { for (int k = 0; k < K; ++k) out[k] = 0.0; }
+};
+template <int NW>
+__device__ __noinline__ void dev_late_stage_pair(double* sh, int t, double* snap, LateCertIn in, double fl, double rl, double kap, double eps, double cscale) {
+    StageOnlyCtx st{128 * NW};
+    (void)late_certificate(st, sh, 128 * NW, t, snap, false, in, fl, rl, kap, eps, cscale);
+}
+
+template <int NW>
+struct PairCtx {
+    static constexpr bool kCstLds = false, kParkScale = true, kSaveLds = false, kDpp = false;
+    __device__ __forceinline__ static double uni(double x) { return uniform(x); }
+    Lane lane[2];
+    double* shp;
+    __device__ __forceinline__ long long clock() const { return (long long)wall_clock64(); }
+    __device__ __forceinline__ int T() const { return 128 * NW; }
+    __device__ __forceinline__ double* sh() { return shp; }
+    template <class F>
+    __device__ __forceinline__ void phase(F f) {
+        f(2 * (int)threadIdx.x, lane[0]); f(2 * (int)threadIdx.x + 1, lane[1]);
+        __syncthreads();
+    }
+    template <class F>
+    __device__ __forceinline__ void phase_w(F f) {
+        f(2 * (int)threadIdx.x, lane[0]); f(2 * (int)threadIdx.x + 1, lane[1]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    template <int K, bool MAX, class F>
+    __device__ __forceinline__ void reduce(double (&out)[K], F f) {
+        double b[K];
+        f(2 * (int)threadIdx.x, lane[0], out); f(2 * (int)threadIdx.x + 1, lane[1], b);
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[k] = MAX ? fmax(out[k], b[k]) : out[k] + b[k];
+        wg_reduce<NW, K, MAX, 128 * NW>(out, shp);
+    }
+    template <int K, class F> __device__ __forceinline__ void reduce_max(double (&out)[K], F f) { reduce<K, true>(out, f); }
+    template <int K, class F> __device__ __forceinline__ void reduce_sum(double (&out)[K], F f) { reduce<K, false>(out, f); }
+    __device__ __forceinline__ bool certificate(double* sh, int, double fl, double rl, double kap, double eps, double cscale) {
+        return uniform(dev_certificate_pair<NW>(sh, fl, rl, kap, eps, cscale));
+    }
+    // called once per waypoint (twice per lane, inside one phase): every call stages its waypoint, the lane's second call - the data of all
+    // waypoints are then staged - synchronises and evaluates
+    __device__ __forceinline__ bool late_certificate(double* sh, int t, double* snap, bool have, const LateCertIn& in, double fl, double rl, double kap,
+                                                     double eps, double cscale) {
+        dev_late_stage_pair<NW>(sh, t, snap, in, fl, rl, kap, eps, cscale);
+        if ((t & 1) == 0) return false;
+        __syncthreads();
+        return have ? uniform(dev_certificate_pair<NW>(sh, fl, rl, kap, eps, cscale)) : false;
+    }
+    template <class PQ>
+    __device__ __forceinline__ void cold(PQ& pq, int op, int i0, int i1, double d0) { pq.do_cold(op, i0, i1, d0); }
+};
+
+#endif  // PQP_WITH_PAIR
 
 // ticket -> QP of the NEXT launch, most expensive first: cost bins in descending order, within a bin in whatever order this workgroup's
 // lanes draw their ranks (results do not depend on the order).  Run by the last workgroup of a launch to leave its ticket loop (every workgroup counts itself out on hist[kCostBins]):
@@ -416,6 +520,46 @@ __global__ void __launch_bounds__(64 * NW, (NW <= 2) ? PQP_SOLVE_OCC : 1) path_s
     }
     if (args.cost_key) order_next_launch(args);
 }
+
+#ifdef PQP_WITH_PAIR
+// the same persistent-workgroup kernel over the two-waypoints-per-lane context: 64 NW threads per QP of up to 128 NW waypoints
+template <int NW, bool CERT>
+__global__ void __launch_bounds__(64 * NW, 1) path_solve_pair_kernel(const PathSolveArgs args) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int s_ticket;
+    for (;;) {
+        if (threadIdx.x == 0) s_ticket = (int)(atomicAdd(args.ticket, 1ull) - args.ticket_base);
+        __syncthreads();
+        const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+        __syncthreads();
+        if ((unsigned)ticket >= (unsigned)args.batch) break;
+        const int qp = args.order ? args.order[ticket] : ticket;
+        if ((args.n_of ? args.n_of[qp] : args.n) < 2) {
+            if (threadIdx.x == 0) {
+                if (args.status) args.status[qp] = PQP_STATUS_UNSOLVED;
+                if (args.iters) args.iters[qp] = 0;
+                if (args.info) for (int k = 0; k < PQP_INFO_STRIDE; ++k) args.info[(size_t)qp * PQP_INFO_STRIDE + k] = 0.0;
+                args.wrho[qp] = args.prm.rho;
+                args.wye[2 * (size_t)qp] = 0.0; args.wye[2 * (size_t)qp + 1] = 0.0;
+                if (args.cost_key) record_cost(args, qp, 0);
+            }
+            if (args.store_warm)
+                for (int k = threadIdx.x; k < args.n * 6; k += blockDim.x) {
+                    args.wx[(size_t)qp * args.n * 6 + k] = 0.0;
+                    args.wy[(size_t)qp * args.n * 6 + k] = 0.0;
+                }
+            continue;
+        }
+        PairCtx<NW> ctx;
+        ctx.shp = smem;
+        PathQp<PairCtx<NW>, CERT> solver(ctx, args, qp, (int)blockIdx.x);
+        solver.run();
+        __syncthreads();
+    }
+    if (args.cost_key) order_next_launch(args);
+}
+
+#endif  // PQP_WITH_PAIR
 
 // -------------------------------------------------------------------------------------------------------
 // reference numbering helpers (base_solver.cpp:22-37,154-158)
@@ -717,7 +861,7 @@ struct pqp_handle {
     int sm_act_batch[2] = {0, 0}, sm_act_n[2] = {0, 0};
     DevBuf stream_ws;                           // workspace of path_stream_kernel
     int num_cu = 0;
-    int blocks_per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // occupancy of the solve kernel variants [log2(nw)][cert]
+    int blocks_per_cu[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};    // occupancy of the solve kernel variants [pair][log2(nw)][cert]
     DevBuf s_ref, s_lin, s_bounds, s_scal;      // staging for the host-pointer entry points
     DevBuf s_out, s_status, s_iters, s_info, s_a, s_p, s_l, s_u, s_idx;
     // smoother QPs: banded problem data + shared sparsity (cached per type and size) + staging
@@ -1001,11 +1145,29 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     a.prm = h->prm;
     int nw = 1, lg = 0;
     while (64 * nw < n) { nw *= 2; lg += 1; }           // one waypoint per lane: T = 64 * nw >= n threads per QP
-    const bool save_lds = nw <= 4;
-    const size_t lds = (size_t)pqp::ShLayout{64 * nw}.total(save_lds) * 8;
+    // PQP_PAIR (experiment switch, round 4): two waypoints per lane - half the wavefronts per QP (PairCtx)
+#ifdef PQP_WITH_PAIR
+    static const int pair_env = [] { const char* e = std::getenv("PQP_PAIR"); return e ? std::atoi(e) : 0; }();
+    const bool pair = pair_env != 0 && n > 2;
+#else
+    const bool pair = false;
+#endif
+    if (pair) { nw = 1; lg = 0; while (128 * nw < n) { nw *= 2; lg += 1; } }
+    const int T_lanes = pair ? 128 * nw : 64 * nw;      // waypoints the LDS layout holds
+    const bool save_lds = !pair && nw <= PQP_SAVE_LDS_MAX_NW;
+    const size_t lds = (size_t)pqp::ShLayout{T_lanes}.total(save_lds, save_lds || PQP_CST_LDS != 0) * 8;
     // two variants of every kernel: with and without OSQP's primal infeasibility certificate (prm.eps_prim_inf > 0)
     const bool cert = h->prm.eps_prim_inf > 0.0 && h->prm.prim_inf_after <= 0;
     const void* fn = nullptr;
+#ifdef PQP_WITH_PAIR
+    if (pair) {
+        switch (nw) {
+            case 1: fn = cert ? (const void*)pqp::path_solve_pair_kernel<1, true> : (const void*)pqp::path_solve_pair_kernel<1, false>; break;
+            case 2: fn = cert ? (const void*)pqp::path_solve_pair_kernel<2, true> : (const void*)pqp::path_solve_pair_kernel<2, false>; break;
+            default: fn = cert ? (const void*)pqp::path_solve_pair_kernel<4, true> : (const void*)pqp::path_solve_pair_kernel<4, false>; break;
+        }
+    } else
+#endif
     switch (nw) {
         case 1: fn = cert ? (const void*)pqp::path_solve_kernel<1, true> : (const void*)pqp::path_solve_kernel<1, false>; break;
         case 2: fn = cert ? (const void*)pqp::path_solve_kernel<2, true> : (const void*)pqp::path_solve_kernel<2, false>; break;
@@ -1015,7 +1177,7 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     if (lds > 64 * 1024) PQP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent workgroups: as many as the chip holds at once (a surplus one would only wait for a free slot), each with its own
     // save area; they draw the QPs from the ticket counter
-    int& per_cu = h->blocks_per_cu[2 * lg + (cert ? 1 : 0)];
+    int& per_cu = h->blocks_per_cu[(pair ? 8 : 0) + 2 * lg + (cert ? 1 : 0)];
     if (per_cu == 0) {
         PQP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * nw, lds));
         if (per_cu < 1) per_cu = 1;
@@ -1024,8 +1186,8 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     const long long resident = (long long)per_cu * cus;
     const int grid = (int)(batch < resident ? batch : resident);
     if (!save_lds) {          // more than 256 lanes per QP: the save area and the parked Ruiz vectors live in the workgroup slot's global memory
-        if ((rc = h->wsave.ensure((size_t)grid * 64 * nw * PQP_SAVE_STRIDE * 8))) return rc;
-        if ((rc = h->wscale.ensure((size_t)grid * 64 * nw * 18 * 8))) return rc;
+        if ((rc = h->wsave.ensure((size_t)grid * T_lanes * PQP_SAVE_STRIDE * 8))) return rc;
+        if ((rc = h->wscale.ensure((size_t)grid * T_lanes * 18 * 8))) return rc;
     }
     a.wsave = h->wsave.as<double>();
     a.wscale = h->wscale.as<double>();
@@ -1054,7 +1216,7 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     h->next_event_pair();
     if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
     void* kargs[] = {(void*)&a};
-    hipError_t le = hipLaunchKernel(fn, dim3(grid), dim3(64 * nw), kargs, lds, h->stream);
+    hipError_t le = hipLaunchKernel(fn, dim3(grid), dim3(64 * nw), kargs, lds, h->stream);          // (pair: 64 nw threads hold 128 nw waypoints)
     if (le == hipSuccess) le = hipGetLastError();
     if (le != hipSuccess) {
         h->hist_batch = 0; h->hist_n = 0;          // (the histogram may have been cleared for a launch that never ran)

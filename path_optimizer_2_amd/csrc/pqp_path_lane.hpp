@@ -336,7 +336,9 @@ struct ShLayout {
     PQP_HD int save() const { return 38 * T + 32 + 128 + 24; }
     // ... and the dual iterate of the previous late infeasibility check, [T][6] (prim_inf_after)
     PQP_HD int ysnap() const { return (38 + PQP_SAVE_STRIDE) * T + 32 + 128 + 24; }
-    PQP_HD int total(bool save_in_lds = false) const { return (save_in_lds ? 44 + PQP_SAVE_STRIDE : 38) * T + 32 + 128 + 24; }
+    // (contexts whose save area lives in global memory park their scaling vectors there too: without pass constants in LDS the constants
+    //  region is then unused and not allocated - 26 T doubles = 27 KB per QP at 128 waypoints)
+    PQP_HD int total(bool save_in_lds = false, bool cst_in_lds = true) const { return (save_in_lds ? 44 + PQP_SAVE_STRIDE : (cst_in_lds ? 38 : 26)) * T + 32 + 128 + 24; }
     // y_k - y_{k-1} of the last iteration, [T][6] (infeasibility certificate): lives in the part of the factor-time buffer
     // the iteration does not use; every iteration rewrites it, and a check never follows a factorisation directly
     PQP_HD int yprev() const { return 12 * T; }
