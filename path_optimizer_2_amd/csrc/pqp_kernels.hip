@@ -16,6 +16,9 @@
 //
 // No CPU fallback: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
+#if defined(PQP_NO_MONOLITH) && defined(PQP_MONOLITH)
+#undef PQP_MONOLITH      // experiment builds: the cold operations out of line (cold_entry), the lane state crossing through memory
+#endif
 
 #include <cstdio>
 #include <cstring>
