@@ -148,8 +148,10 @@ def test_gather_over_rccl_in_the_c_abi(hip_lib):
     one = capi.MultiHandle(prm, devices=(0,), max_batch_per_shard=96, max_n=80)
     got = one.solve(b["ref"], b["bounds"], b["scal"], passes=1)
     assert (got["status"] == 1).all()
+    assert one.gather_ranks() == 0                                  # no communicator before the first gather
     full = one.gather_paths((0,))
     np.testing.assert_array_equal(full[0].cpu().numpy(), got["out"])
+    assert one.gather_ranks() == 1                                  # ncclCommCount of the gather's communicator: one shard, one rank
     # a second call reuses the communicator; another batch through the same driver
     b2 = make_batch(64, 80, seed=77)
     got2 = one.solve(b2["ref"], b2["bounds"], b2["scal"], passes=1)
