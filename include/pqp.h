@@ -114,7 +114,9 @@ typedef struct pqp_params {
     double sigma;                     /* 1e-6  */
     double alpha;                     /* 1.6   */
     int32_t max_iter;                 /* 4000  */
-    int32_t scaling;                  /* 10 Ruiz passes */
+    int32_t scaling;                  /* 10 Ruiz passes (production: 4).  0: no equilibration - such a handle (in the lean-kernel setting: prim_inf_after > 0 or
+                                         eps_prim_inf == 0) runs the kernel variant with wave-uniform penalty metrics: +4 % paths/s, longer tails of the
+                                         active-set rounds */
     int32_t adaptive_rho;             /* 1     */
     int32_t adaptive_rho_interval;    /* 100 (OSQP's "auto" value without wall-clock profiling) */
     double adaptive_rho_tolerance;    /* 5     */

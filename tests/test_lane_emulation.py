@@ -180,3 +180,29 @@ def test_lazy_refinement_changes_the_cost_not_the_answer(n, profile):
     assert np.abs(eager["out"][:, :, 3:5] - lazy["out"][:, :, 3:5]).max() < 2e-6        # two KKT-verified (1e-7) points of one QP
     assert lazy["info"][:, 5].mean() < 0.92 * eager["info"][:, 5].mean()                # KKT solves
     assert lazy["info"][:, 5].max() <= 1.5 * eager["info"][:, 5].max()                  # and no new stragglers
+
+
+def test_lean_context_is_bit_identical_to_the_general_one_without_equilibration(tmp_path):
+    """Ctx::kLean (csrc/pqp_path_lane.hpp): with scaling == 0 the modified Ruiz equilibration is the identity (D = E = c = 1), so Sigma and the
+    penalty of the transition rows are the same number in every lane; the lean contexts keep them as two uniform scalars instead of nine lane
+    fields.  Same arithmetic in the same order: the host emulation of both gives identical bits - outputs, iteration counts, solve counts."""
+    import ctypes as C
+    import subprocess
+    libs = {}
+    for lean in (0, 1):
+        lib = str(tmp_path / f"liblane_emu_lean{lean}.so")
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-DPQP_EMU_DIET=0", f"-DPQP_EMU_LEAN={lean}", "-o", lib, E.SRC], check=True)
+        libs[lean] = C.CDLL(lib)
+    saved = E._lib
+    try:
+        for B, n, prof, seed in ((24, 80, "uniform", 1), (12, 120, "varied", 2), (6, 200, "uniform", 4), (8, 35, "varied", 7)):
+            b = make_batch(B, n, prof, seed=seed)
+            got = []
+            for lean in (0, 1):
+                E._lib = libs[lean]
+                got.append(E.solve(E.production(scaling=0), b["ref"], b["bounds"], b["scal"], passes=1))
+            assert (got[0]["status"] == 1).all()
+            for key in ("out", "iters", "info", "wx", "wy"):
+                np.testing.assert_array_equal(got[0][key], got[1][key])
+    finally:
+        E._lib = saved

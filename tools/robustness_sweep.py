@@ -1,5 +1,5 @@
 """Solve many seeded batches with the production setting and report what did not end in an accepted polish, and the slowest QPs.
-Usage: python tools/robustness_sweep.py [seeds=16] [batch=8192] [first_seed=1000]   (run on the GPU box)"""
+Usage: python tools/robustness_sweep.py [seeds=16] [batch=8192] [first_seed=1000] [scaling=<production's>]   (run on the GPU box)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,9 +8,11 @@ from path_optimizer_2_amd.synth import make_batch
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 base = int(sys.argv[3]) if len(sys.argv) > 3 else 1000          # first seed
+over = {"scaling": int(sys.argv[4])} if len(sys.argv) > 4 else {}   # Ruiz passes (0: the lean kernel variant)
+print("production setting" + (f" with {over}" if over else ""))
 for n, profile in ((80, "uniform"), (80, "varied"), (120, "varied"), (200, "uniform"), (37, "varied"), (300, "varied")):
     b = batch if n <= 120 else batch // 4
-    h = capi.Handle(capi.production_params(), device=0, max_batch=b, max_n=n)
+    h = capi.Handle(capi.production_params(**over), device=0, max_batch=b, max_n=n)
     tot = bad = 0
     worst = []
     kk = []
