@@ -114,9 +114,10 @@ typedef struct pqp_params {
     double sigma;                     /* 1e-6  */
     double alpha;                     /* 1.6   */
     int32_t max_iter;                 /* 4000  */
-    int32_t scaling;                  /* 10 Ruiz passes (production: 4).  0: no equilibration - such a handle (in the lean-kernel setting: prim_inf_after > 0 or
-                                         eps_prim_inf == 0) runs the kernel variant with wave-uniform penalty metrics: +4 % paths/s, longer tails of the
-                                         active-set rounds */
+    int32_t scaling;                  /* 10 Ruiz passes (OSQP's default).  k < 0 (path QP only; production: -4): |k| passes of the same equilibration
+                                         evaluated on ONE interior waypoint's blocks and taken by every waypoint - the path QP's matrix repeats
+                                         from waypoint to waypoint, and for a pass linearised around the reference line the result is bit for
+                                         bit what |k| full passes give (no exchange, no reduction: ~1 us instead of ~2 us per pass) */
     int32_t adaptive_rho;             /* 1     */
     int32_t adaptive_rho_interval;    /* 100 (OSQP's "auto" value without wall-clock profiling) */
     double adaptive_rho_tolerance;    /* 5     */

@@ -186,7 +186,8 @@ struct BandedQp {
         double* E = sh + L.esc();
         double* dn = sh + L.rhs();     // scratch: new D
         double* en = sh + L.zt();      // scratch: new E
-        for (int pass = 0; pass < prm.scaling; ++pass) {
+        // (scaling < 0 is the path QP's one-waypoint shortcut: the smoother QPs run |scaling| ordinary passes)
+        for (int pass = 0; pass < (prm.scaling < 0 ? -prm.scaling : prm.scaling); ++pass) {
             const double c_now = cscale;
             cols([&](int j) {
                 const double* pb = pband();
@@ -609,7 +610,7 @@ struct BandedQp {
             //  fall back to equilibration + ADMM + periodic polish attempts when that first attempt is rejected)
             direct = ineq[0] == 0.0 || prm.polish == 1;
         }
-        if (prm.scaling > 0 && !direct) ruiz();
+        if (prm.scaling != 0 && !direct) ruiz();
         else {
             cols([&](int j) { sh[L.sig() + j] = prm.sigma; });
             rows([&](int r) {
@@ -699,7 +700,7 @@ struct BandedQp {
                 polish_end(ok);
                 if (ok) { status = PQP_STATUS_SOLVED; polished = 1; break; }
                 if (was_converged) eps_scale *= 0.1;     // rejected: ADMM resumes one decade tighter
-                if (it == 0 && prm.scaling > 0) ruiz();  // (the direct attempt ran without equilibration)
+                if (it == 0 && prm.scaling != 0) ruiz();  // (the direct attempt ran without equilibration)
                 factor();
                 continue;
             }

@@ -174,7 +174,7 @@ __device__ __noinline__ bool dev_late_certificate(double* sh, int t, double* sna
 // barriers (for a one-wave workgroup the barrier is only a wait on outstanding LDS traffic).
 template <int NW>
 struct RegCtx {
-    static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0, kSaveLds = NW <= PQP_SAVE_LDS_MAX_NW, kLean = false;
+    static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0, kSaveLds = NW <= PQP_SAVE_LDS_MAX_NW;
     // DPP moves (PQP_DPP): the value of the lane H below / above in the same row of 16 lanes, of the previous row's last lane; 0 where
     // there is no such lane.  Must run with every lane enabled (a disabled source lane reads as "no lane").
     static constexpr bool kDpp = PQP_DPP != 0;
@@ -244,11 +244,10 @@ __device__ __noinline__ Uni cold_entry(const PathSolveArgs* args, int qp, double
 
 // Hot context: the lane state is a local struct that SROA turns into registers; a phase is the code between two
 // workgroup barriers (for a one-wave workgroup the barrier is only a wait on outstanding LDS traffic).
-template <int NW, bool LEAN = false>
+template <int NW>
 struct DevCtx {
     // kSaveLds: up to 256 lanes the polish save area fits beside the exchange buffers (72 KB per QP at T = 128, two QPs per CU)
-    // kLean: handles with scaling == 0 - uniform Sigma / transition-row penalty instead of nine lane fields (pqp_path_lane.hpp)
-    static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0, kSaveLds = NW <= PQP_SAVE_LDS_MAX_NW, kLean = LEAN;
+    static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0, kSaveLds = NW <= PQP_SAVE_LDS_MAX_NW;
     // DPP moves (PQP_DPP): the value of the lane H below / above in the same row of 16 lanes, of the previous row's last lane; 0 where
     // there is no such lane.  Must run with every lane enabled (a disabled source lane reads as "no lane").
     static constexpr bool kDpp = PQP_DPP != 0;
@@ -377,7 +376,7 @@ __device__ __noinline__ void dev_late_stage_pair(double* sh, int t, double* snap
 
 template <int NW>
 struct PairCtx {
-    static constexpr bool kCstLds = false, kParkScale = true, kSaveLds = false, kDpp = false, kLean = false;
+    static constexpr bool kCstLds = false, kParkScale = true, kSaveLds = false, kDpp = false;
     __device__ __forceinline__ static double uni(double x) { return uniform(x); }
     Lane lane[2];
     double* shp;
@@ -460,7 +459,7 @@ __device__ void order_next_launch(const PathSolveArgs& args) {
 #ifndef PQP_SOLVE_OCC
 #define PQP_SOLVE_OCC 1
 #endif
-template <int NW, bool CERT, bool LEAN = false>
+template <int NW, bool CERT>
 __global__ void __launch_bounds__(64 * NW, (NW <= 2) ? PQP_SOLVE_OCC : 1) path_solve_kernel(const PathSolveArgs args) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_ticket;
@@ -500,7 +499,7 @@ __global__ void __launch_bounds__(64 * NW, (NW <= 2) ? PQP_SOLVE_OCC : 1) path_s
                 }
             continue;
         }
-        DevCtx<NW, LEAN> ctx;
+        DevCtx<NW> ctx;
 #ifndef PQP_MONOLITH
         ctx.mem = &memlane;
 #else
@@ -508,7 +507,7 @@ __global__ void __launch_bounds__(64 * NW, (NW <= 2) ? PQP_SOLVE_OCC : 1) path_s
 #endif
         ctx.shp = smem;
         ctx.args = &args;
-        PathQp<DevCtx<NW, LEAN>, CERT> solver(ctx, args, qp, (int)blockIdx.x);
+        PathQp<DevCtx<NW>, CERT> solver(ctx, args, qp, (int)blockIdx.x);
 #ifdef PQP_TIMING
         const long long t_ticket1 = (long long)wall_clock64();
 #endif
@@ -865,7 +864,7 @@ struct pqp_handle {
     int sm_act_batch[2] = {0, 0}, sm_act_n[2] = {0, 0};
     DevBuf stream_ws;                           // workspace of path_stream_kernel
     int num_cu = 0;
-    int blocks_per_cu[32] = {};    // occupancy of the solve kernel variants [lean][pair][log2(nw)][cert]
+    int blocks_per_cu[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};    // occupancy of the solve kernel variants [pair][log2(nw)][cert]
     DevBuf s_ref, s_lin, s_bounds, s_scal;      // staging for the host-pointer entry points
     DevBuf s_out, s_status, s_iters, s_info, s_a, s_p, s_l, s_u, s_idx;
     // smoother QPs: banded problem data + shared sparsity (cached per type and size) + staging
@@ -1172,17 +1171,6 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
         }
     } else
 #endif
-    // a handle without equilibration (scaling == 0) in the lean-kernel setting runs the variant whose penalty metrics are wave-uniform
-    static const int no_lean_env = [] { const char* e = std::getenv("PQP_NO_LEAN"); return e ? std::atoi(e) : 0; }();      // (tests: the general kernel at scaling == 0)
-    const bool lean = !cert && h->prm.scaling == 0 && !pair && !no_lean_env;
-    if (lean) {
-        switch (nw) {
-            case 1: fn = (const void*)pqp::path_solve_kernel<1, false, true>; break;
-            case 2: fn = (const void*)pqp::path_solve_kernel<2, false, true>; break;
-            case 4: fn = (const void*)pqp::path_solve_kernel<4, false, true>; break;
-            default: fn = (const void*)pqp::path_solve_kernel<8, false, true>; break;
-        }
-    } else
     switch (nw) {
         case 1: fn = cert ? (const void*)pqp::path_solve_kernel<1, true> : (const void*)pqp::path_solve_kernel<1, false>; break;
         case 2: fn = cert ? (const void*)pqp::path_solve_kernel<2, true> : (const void*)pqp::path_solve_kernel<2, false>; break;
@@ -1192,7 +1180,7 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     if (lds > 64 * 1024) PQP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent workgroups: as many as the chip holds at once (a surplus one would only wait for a free slot), each with its own
     // save area; they draw the QPs from the ticket counter
-    int& per_cu = h->blocks_per_cu[(pair ? 8 : 0) + (lean ? 16 : 0) + 2 * lg + (cert ? 1 : 0)];
+    int& per_cu = h->blocks_per_cu[(pair ? 8 : 0) + 2 * lg + (cert ? 1 : 0)];
     if (per_cu == 0) {
         PQP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * nw, lds));
         if (per_cu < 1) per_cu = 1;

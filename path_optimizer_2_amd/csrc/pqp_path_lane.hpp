@@ -661,14 +661,8 @@ struct PathQp {
     enum : int { C_SIG = 0, C_LO = 6, C_UP = 8, C_IDSF = 10, C_IDSR = 11 };
     PQP_HD double cst_get(int t, int c) const { return sh[L.cst() + c * T + t]; }
     PQP_HD void cst_set(int t, int c, double v) const { sh[L.cst() + c * T + t] = v; }
-    // Ctx::kLean (handles with scaling == 0, no equilibration): D = E = c = 1, so Sigma and the penalty of the transition rows are the
-    // same in every lane - two wave-uniform scalars instead of nine lane fields (and no D / E at set-up time).  Bit-identical to the
-    // general code run with scaling = 0.
-    static constexpr bool kLean = Ctx::kLean;
-    double sig_u_ = 0.0, rhoT_u_ = 0.0;
-    PQP_HD double sig_of(const Slot& S, int t, int k) const { if constexpr (kLean) return sig_u_; else if constexpr (kCst) return cst_get(t, C_SIG + k); else return S.sig[k]; }
-    PQP_HD void set_sig(Slot& S, int t, int k, double v) const { if constexpr (kLean) { (void)S; (void)t; (void)k; (void)v; } else if constexpr (kCst) cst_set(t, C_SIG + k, v); else S.sig[k] = v; }
-    PQP_HD double rhoT_of(const Slot& S, int k) const { if constexpr (kLean) return (S.flags & F_REAL) ? rhoT_u_ : 0.0; else return S.rhoT[k]; }
+    PQP_HD double sig_of(const Slot& S, int t, int k) const { if constexpr (kCst) return cst_get(t, C_SIG + k); else return S.sig[k]; }
+    PQP_HD void set_sig(Slot& S, int t, int k, double v) const { if constexpr (kCst) cst_set(t, C_SIG + k, v); else S.sig[k] = v; }
     PQP_HD double idsf_of(const Slot& S, int t) const { if constexpr (kCst) return cst_get(t, C_IDSF); else return S.idsf; }
     PQP_HD double idsr_of(const Slot& S, int t) const { if constexpr (kCst) return cst_get(t, C_IDSR); else return S.idsr; }
     PQP_HD double lo_of(const Slot& S, int t, int j) const { if constexpr (kCst) return cst_get(t, C_LO + j); else return S.lo[j]; }
@@ -701,12 +695,6 @@ struct PathQp {
     // reuse = true keeps D, E, c of the previous pass of this QP (whose matrix differs only by the re-linearisation) and
     // only rebuilds the metrics; any positive diagonal scaling is a valid metric, OSQP's own update path re-equilibrates
     PQP_HD void ruiz(bool reuse = false) {
-        if constexpr (kLean) {
-            cscale = 1.0;
-            ctx.phase([&](int, Lane& ln) { if (ln.s.flags & F_LAST) { end_rows()->E[0] = 1.0; end_rows()->E[1] = 1.0; } });
-            ruiz_metrics();
-            return;
-        }
         if (!reuse) ruiz_equilibrate();
         // kParkScale: D, E are only read here, once per pass - between the passes they live in the workgroup slot's memory instead
         // of in 24 registers of the ADMM loop
@@ -722,8 +710,72 @@ struct PathQp {
         }
         ruiz_metrics();
     }
+    // scaling < 0: |scaling| passes of the same equilibration on ONE interior waypoint's blocks as if every waypoint carried them (the path
+    // QP's matrix repeats from waypoint to waypoint up to the transition's curvature terms): every lane computes the same twelve numbers in
+    // registers - no exchange, no reduction, ~1 us instead of 2.1 us per pass - and takes them as its D, E.  Any positive diagonal scaling is a
+    // valid metric; this one keeps what the equilibration buys the ADMM iterations before a polish.  (The reference's setting keeps OSQP's own.)
+    // the recurrence itself: `passes` passes on the blocks a[6] (absolute values of the transition into one waypoint) -> D[6], E[6], the two end rows' E, c
+    PQP_HD static void nominal_scaling(const pqp_params& prm, const double* a, int passes, double* D, double* E, double* Ee, double& c) {
+        const double acf = fabs(prm.front_length), acr = fabs(prm.rear_length);
+        const double pk[6] = {prm.weight_l, 0.0, prm.weight_kappa, prm.weight_dkappa, prm.weight_slack, prm.weight_slack};
+        _Pragma("unroll") for (int k = 0; k < 6; ++k) { D[k] = 1.0; E[k] = 1.0; }
+        Ee[0] = 1.0; Ee[1] = 1.0; c = 1.0;
+        for (int pass = 0; pass < passes; ++pass) {
+            const double m0 = fmax(E[0] * a[0], E[1] * a[2]), m1 = fmax(E[0] * a[1], E[1] * a[3]), m2 = fmax(E[1] * a[4], E[2]);
+            double cn[6], rn[6];
+            cn[0] = fmax(fmax3(E[0], m0, E[4]), E[5]);
+            cn[1] = fmax(fmax3(E[1], m1, E[4] * acf), E[5] * acr);
+            cn[2] = fmax3(E[2], m2, E[3]);
+            cn[3] = E[2] * a[5];
+            cn[4] = E[4];
+            cn[5] = E[5];
+            rn[0] = fmax3(D[0], D[0] * a[0], D[1] * a[1]);
+            rn[1] = fmax(fmax3(D[1], D[0] * a[2], D[1] * a[3]), D[2] * a[4]);
+            rn[2] = fmax3(D[2], D[2], D[3] * a[5]);
+            rn[3] = D[2];
+            rn[4] = fmax3(D[0], D[1] * acf, D[4]);
+            rn[5] = fmax3(D[0], D[1] * acr, D[5]);
+            const double ren0 = D[0] * Ee[0], ren1 = D[1] * Ee[1];
+            double acc = 0.0;
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) {
+                const double cnk = fmax(cn[k] * D[k], c * D[k] * D[k] * pk[k]);
+                const double rnk = rn[k] * E[k];
+                D[k] = D[k] * rsq(limit_scaling(cnk));
+                E[k] = E[k] * rsq(limit_scaling(rnk));
+                acc += fabs(c * D[k] * D[k] * pk[k]);
+            }
+            Ee[0] = Ee[0] * rsq(limit_scaling(ren0));
+            Ee[1] = Ee[1] * rsq(limit_scaling(ren1));
+            double ct = acc * (1.0 / 6.0);
+            ct = fmax(ct, 1.0);
+            ct = limit_scaling(ct);
+            c = c / ct;
+        }
+    }
+    PQP_HD void ruiz_equilibrate_nominal() {
+        const pqp_params& prm = A.prm;
+        const int m = n / 2 > 0 ? n / 2 : 0;
+        ctx.phase([&](int t, Lane& ln) {
+            if (t == m) { _Pragma("unroll") for (int k = 0; k < 6; ++k) sh[L.xbuf() + k] = ln.s.a[k]; }
+        });
+        double c_out = 1.0;
+        ctx.phase([&](int, Lane& ln) {
+            double a[6], D[6], E[6], Ee[2], c;
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) a[k] = fabs(sh[L.xbuf() + k]);
+            nominal_scaling(prm, a, -prm.scaling, D, E, Ee, c);
+            const int f = ln.s.flags;
+            const bool real = f & F_REAL, prev = f & F_PREV, precise = f & F_PRECISE;
+            const bool colreal[6] = {real, real, real, prev, real, real && precise};
+            const bool rowreal[6] = {real, real, real, real, real, real && precise};
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) { ln.w.D[k] = colreal[k] ? D[k] : 1.0; ln.w.E[k] = rowreal[k] ? E[k] : 1.0; }
+            if (f & F_LAST) { end_rows()->E[0] = Ee[0]; end_rows()->E[1] = Ee[1]; }
+            c_out = c;
+        });
+        cscale = ctx.uni(c_out);
+    }
     PQP_HD void ruiz_equilibrate() {
         const pqp_params& prm = A.prm;
+        if (prm.scaling < 0) { ruiz_equilibrate_nominal(); return; }
         cscale = 1.0;
         ctx.phase([&](int, Lane& ln) {
             _Pragma("unroll") for (int k = 0; k < 6; ++k) { ln.w.D[k] = 1.0; ln.w.E[k] = 1.0; }
@@ -803,21 +855,16 @@ struct PathQp {
         const pqp_params& prm = A.prm;
         const double c = cscale, rho_now = rho;
         const double ic = 1.0 / c;
-        if constexpr (kLean) { sig_u_ = prm.sigma * rcp(c * 1.0 * 1.0); rhoT_u_ = rho_now * kRhoEqFactor * 1.0 * 1.0 * ic; }
         ctx.phase([&](int t, Lane& ln) {
             Slot& S = ln.s;
             const SlotSetup& W = ln.w;
             const bool real = S.flags & F_REAL, precise = S.flags & F_PRECISE;
-            if constexpr (!kLean) {
-                _Pragma("unroll") for (int k = 0; k < 6; ++k) set_sig(S, t, k, prm.sigma * rcp(c * W.D[k] * W.D[k]));
-                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] = real ? rho_now * kRhoEqFactor * W.E[k] * W.E[k] * ic : 0.0;
-            }
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) set_sig(S, t, k, prm.sigma * rcp(c * W.D[k] * W.D[k]));
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] = real ? rho_now * kRhoEqFactor * W.E[k] * W.E[k] * ic : 0.0;
             int fl = S.flags & ~((7 * F_FREE0) | (7 * F_EQ0));      // the active-set bits of a previous polish survive
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                 const bool rowreal = real && (k < 2 || precise);
-                double e = 1.0;
-                if constexpr (!kLean) e = W.E[3 + k];
-                const double e2 = e * e * ic;
+                const double e = W.E[3 + k], e2 = e * e * ic;
                 const double sl = e * raw_lo(S, t, k), su = e * raw_up(S, t, k);
                 const bool free_row = sl < -kInfty * kMinScaling && su > kInfty * kMinScaling;
                 const bool eq_row = !free_row && (su - sl < kRhoTol);
@@ -848,10 +895,9 @@ struct PathQp {
     // rho changed by `ratio`: rescale every penalty that is proportional to rho
     PQP_HD void rescale_rho(double ratio) {
         const double rho_now = rho;
-        if constexpr (kLean) rhoT_u_ *= ratio;
         ctx.phase([&](int, Lane& ln) {
             Slot& S = ln.s;
-            if constexpr (!kLean) { _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] *= ratio; }
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] *= ratio;
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                 const bool fr = S.flags & (F_FREE0 << k);
                 const double r = fr ? S.rhoI[k] : S.rhoI[k] * ratio;
@@ -927,7 +973,7 @@ struct PathQp {
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) { w[6 + k] = S.yT[k]; w[9 + k] = S.yI[k]; w[12 + k] = S.zI[k]; w[15 + k] = S.rhoI[k]; }
             }
             int fl = S.flags & ~((7 * F_ACTLO0) | (7 * F_ACTUP0));
-            if constexpr (!kLean) { _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] *= tgain; }
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) S.rhoT[k] *= tgain;
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                 const bool fr = S.flags & (F_FREE0 << k), eq = S.flags & (F_EQ0 << k);
                 const double e2 = S.rhoI[k] * (eq ? irho_eq : irho);     // E^2 / c of the row
@@ -938,7 +984,7 @@ struct PathQp {
                 if (act_up) fl |= (F_ACTUP0 << k);
             }
             S.flags = keep_set ? S.flags : fl;      // keep_set: start from the active set of the previous pass
-            if constexpr (!kLean) { _Pragma("unroll") for (int k = 0; k < 6; ++k) set_sig(S, t, k, sig_of(S, t, k) * sgain); }
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) set_sig(S, t, k, sig_of(S, t, k) * sgain);
             if (S.flags & F_LAST) {
                 EndRows* er = end_rows();
                 for (int k = 0; k < 2; ++k) {
@@ -951,7 +997,6 @@ struct PathQp {
                 }
             }
         });
-        if constexpr (kLean) { rhoT_u_ *= tgain; sig_u_ *= sgain; }
     }
 
     // --- polish piece 2: penalties, multipliers and z of the current active set
@@ -1110,9 +1155,9 @@ struct PathQp {
                 const double r = real ? w[15 + k] : 0.0;
                 S.rhoI[k] = r;
                 S.rinvI[k] = r > 0.0 ? rcp(r) : 0.0;
-                if constexpr (!kLean) S.rhoT[k] *= itgain;
+                S.rhoT[k] *= itgain;
             }
-            if constexpr (!kLean) { _Pragma("unroll") for (int k = 0; k < 6; ++k) set_sig(S, t, k, sig_of(S, t, k) * isgain); }
+            _Pragma("unroll") for (int k = 0; k < 6; ++k) set_sig(S, t, k, sig_of(S, t, k) * isgain);
             if (S.flags & F_LAST) {
                 EndRows* er = end_rows();
                 for (int k = 0; k < 2; ++k) {
@@ -1124,7 +1169,6 @@ struct PathQp {
             }
             _Pragma("unroll") for (int k = 0; k < 3; ++k) sh[L.xbuf() + 3 * t + k] = S.x[k];
         });
-        if constexpr (kLean) { rhoT_u_ *= itgain; sig_u_ *= isgain; }
         if (!ok && reseed) {
             ctx.phase([&](int t, Lane& ln) {
                 Slot& S = ln.s;
@@ -1163,19 +1207,19 @@ struct PathQp {
             S.cF = rF * idsf; S.cR = rR * idsr;
             const double gf = rF - rF * S.cF, gr = rR - rR * S.cR;
             const double ds = S.a[5];
-            S.tu = rhoT_of(S, 2) * ds;
+            S.tu = S.rhoT[2] * ds;
             const double du = cost_diag(prm, S.flags, 3) + sig_of(S, t, 3) + S.tu * ds;
             S.idu = rcp(du);
             S.tudc = S.tu * S.idu;
-            const double gu = rhoT_of(S, 2) - S.tu * S.tudc;
+            const double gu = S.rhoT[2] - S.tu * S.tudc;
             const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
-            W.Dg[0] = cost_diag(prm, S.flags, 0) + sig_of(S, t, 0) + rhoT_of(S, 0) + gf + gr + re0;
+            W.Dg[0] = cost_diag(prm, S.flags, 0) + sig_of(S, t, 0) + S.rhoT[0] + gf + gr + re0;
             W.Dg[1] = gf * cf + gr * cr;
             W.Dg[2] = 0.0;
-            W.Dg[3] = cost_diag(prm, S.flags, 1) + sig_of(S, t, 1) + rhoT_of(S, 1) + gf * cf * cf + gr * cr * cr + re1;
+            W.Dg[3] = cost_diag(prm, S.flags, 1) + sig_of(S, t, 1) + S.rhoT[1] + gf * cf * cf + gr * cr * cr + re1;
             W.Dg[4] = 0.0;
             W.Dg[5] = cost_diag(prm, S.flags, 2) + sig_of(S, t, 2) + gu + rK;
-            const double r0 = rhoT_of(S, 0), r1 = rhoT_of(S, 1);
+            const double r0 = S.rhoT[0], r1 = S.rhoT[1];
             const double a00 = S.a[0], a01 = S.a[1], a10 = S.a[2], a11 = S.a[3], a12 = S.a[4];
             const double gup = (S.flags & F_PREV) ? gu : 0.0;
             // coupling block: rows = previous waypoint's (l,psi,k), cols = own.  The factorisation carries the NEGATED couplings C' = -C:
@@ -1317,7 +1361,7 @@ struct PathQp {
             Slot& S = ln.s;
             const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
             double wT[3], wI[3];
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) wT[k] = rhoT_of(S, k) * S.bT[k] - S.yT[k];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) wT[k] = S.rhoT[k] * S.bT[k] - S.yT[k];
             _Pragma("unroll") for (int k = 0; k < 3; ++k) wI[k] = S.rhoI[k] * S.zI[k] - S.yI[k];
             double we0 = 0.0, we1 = 0.0;
             if (S.flags & F_LAST) {
@@ -1503,7 +1547,7 @@ struct PathQp {
             _Pragma("unroll") for (int k = 0; k < 6; ++k) S.x[k] = alpha * xt[k] + (1.0 - alpha) * S.x[k];
             double* dyp = sh + L.yprev() + 6 * t;       // y_k - y_{k-1} of this iteration, for the infeasibility certificate
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
-                const double d = rhoT_of(S, k) * alpha * (zT[k] - S.bT[k]);
+                const double d = S.rhoT[k] * alpha * (zT[k] - S.bT[k]);
                 S.yT[k] += d;
                 if (CERT) dyp[k] = d;
             }
@@ -1666,7 +1710,7 @@ struct PathQp {
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                 const double dz = real ? (have_warm ? aT[k] : 0.0) - S.bT[k] : 0.0;
                 sh[L.lin() + 3 * t + k] = dz;
-                S.yT[k] -= rhoT_of(S, k) * dz;
+                S.yT[k] -= S.rhoT[k] * dz;
                 S.zI[k] = (real && have_warm) ? aI[k] : 0.0;
             }
             if (S.flags & F_LAST) {
@@ -1679,7 +1723,7 @@ struct PathQp {
         const double f = 2.0 - A.prm.alpha;
         ctx.phase([&](int t, Lane& ln) {
             Slot& S = ln.s;
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) S.yT[k] += rhoT_of(S, k) * f * sh[L.lin() + 3 * t + k];
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) S.yT[k] += S.rhoT[k] * f * sh[L.lin() + 3 * t + k];
         });
     }
 

@@ -33,10 +33,7 @@ namespace {
 struct HostCtx {
     // default: the device contexts' setting (Ruiz vectors parked, save area in the shared array up to 256 lanes); PQP_EMU_DIET: pass
     // constants in the shared array too, everything parked in global memory
-#ifndef PQP_EMU_LEAN
-#define PQP_EMU_LEAN 0
-#endif
-    static constexpr bool kCstLds = PQP_EMU_DIET != 0, kParkScale = true, kSaveLds = PQP_EMU_DIET == 0, kDpp = false, kLean = PQP_EMU_LEAN != 0;
+    static constexpr bool kCstLds = PQP_EMU_DIET != 0, kParkScale = true, kSaveLds = PQP_EMU_DIET == 0, kDpp = false;
     int T_;
     std::vector<pqp::Lane> lanes;
     std::vector<double> shm;

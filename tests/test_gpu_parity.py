@@ -3,8 +3,6 @@
 Parity rule: integer index maps bit-exact; assembled values to a few ulp; the solution
 against the CONVERGED, KKT-certified oracle optimum: max |l|, |d_heading| error <= 1e-4 (we assert 1e-6
 where both sides run to eps 1e-9/1e-7)."""
-import os
-
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -12,8 +10,6 @@ import scipy.sparse as sp
 import pqp_oracle as O
 from path_optimizer_2_amd import capi
 from path_optimizer_2_amd.synth import make_batch
-
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -426,41 +422,6 @@ def test_the_bench_workload_itself_against_the_c_oracle(hip_lib, n, profile, bat
     assert err.max() < 1e-4
     assert np.percentile(err, 99) < 2e-5 and np.median(err) < 1e-6
     assert np.abs(r["out"][:, :, 0:2] - ref["out"][:, :, 0:2]).max() < 1e-4          # x, y of the optimised path
-
-
-def test_lean_kernel_variant_is_the_general_kernel_without_equilibration(hip_lib):
-    """A handle with scaling == 0 (no Ruiz passes) runs the kernel variant whose Sigma / transition-row penalties are wave-uniform scalars
-    instead of nine lane fields (Ctx::kLean: 60 registers fewer, +4 % paths/s).  Same arithmetic: against the general kernel forced onto the same
-    setting (PQP_NO_LEAN=1, a child process: the switch is read once) the outputs agree within the KKT tolerance, with the same iteration and solve counts -
-    on the host emulation the two are bit-identical (tests/test_lane_emulation.py)."""
-    import json, subprocess, sys
-    code = ("import json, sys, numpy as np\n"
-            "sys.path.insert(0, %r)\n"
-            "from path_optimizer_2_amd import capi\n"
-            "from path_optimizer_2_amd.synth import make_batch\n"
-            "res = {}\n"
-            "for n, prof, B in ((80, 'uniform', 256), (120, 'varied', 128), (200, 'uniform', 64), (35, 'varied', 64)):\n"
-            "    b = make_batch(B, n, prof, seed=3)\n"
-            "    h = capi.Handle(capi.production_params(scaling=0), max_batch=B, max_n=n)\n"
-            "    r = h.solve(b['ref'], b['bounds'], b['scal'], passes=1)\n"
-            "    h.close()\n"
-            "    np.save(sys.argv[1] + '_%%d.npy' %% n, r['out'])\n"
-            "    res[n] = [int((r['status'] == 1).sum()), int(r['iters'].sum()), float(r['info'][:, 5].sum()), float(r['info'][:, 6].sum())]\n"
-            "print(json.dumps(res))\n") % ROOT
-    import tempfile
-    outs = {}
-    with tempfile.TemporaryDirectory() as d:
-        for tag, env in (("lean", {}), ("general", {"PQP_NO_LEAN": "1"})):
-            r = subprocess.run([sys.executable, "-c", code, os.path.join(d, tag)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
-            assert r.returncode == 0, r.stderr[-1500:]
-            stats = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-            outs[tag] = (stats, {n: np.load(os.path.join(d, f"{tag}_{n}.npy")) for n in (80, 120, 200, 35)})
-    assert outs["lean"][0] == outs["general"][0]                       # solved, ADMM iterations, reduced solves, factorisations: the same
-    assert outs["lean"][0]["80"][0] == 256
-    # (on the device the two variants are separate compilations: fused-multiply-add contraction differs here and there, so the same sequence of
-    #  iterations, solves and factorisations ends within the KKT tolerance of each other, not on the same bits)
-    for n in (80, 120, 200, 35):
-        assert np.abs(outs["lean"][1][n] - outs["general"][1][n]).max() < 1e-6, n
 
 
 def test_long_paths_both_kernels_against_the_c_oracle(hip_lib):

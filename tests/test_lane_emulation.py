@@ -182,27 +182,23 @@ def test_lazy_refinement_changes_the_cost_not_the_answer(n, profile):
     assert lazy["info"][:, 5].max() <= 1.5 * eager["info"][:, 5].max()                  # and no new stragglers
 
 
-def test_lean_context_is_bit_identical_to_the_general_one_without_equilibration(tmp_path):
-    """Ctx::kLean (csrc/pqp_path_lane.hpp): with scaling == 0 the modified Ruiz equilibration is the identity (D = E = c = 1), so Sigma and the
-    penalty of the transition rows are the same number in every lane; the lean contexts keep them as two uniform scalars instead of nine lane
-    fields.  Same arithmetic in the same order: the host emulation of both gives identical bits - outputs, iteration counts, solve counts."""
-    import ctypes as C
-    import subprocess
-    libs = {}
-    for lean in (0, 1):
-        lib = str(tmp_path / f"liblane_emu_lean{lean}.so")
-        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-DPQP_EMU_DIET=0", f"-DPQP_EMU_LEAN={lean}", "-o", lib, E.SRC], check=True)
-        libs[lean] = C.CDLL(lib)
-    saved = E._lib
-    try:
-        for B, n, prof, seed in ((24, 80, "uniform", 1), (12, 120, "varied", 2), (6, 200, "uniform", 4), (8, 35, "varied", 7)):
-            b = make_batch(B, n, prof, seed=seed)
-            got = []
-            for lean in (0, 1):
-                E._lib = libs[lean]
-                got.append(E.solve(E.production(scaling=0), b["ref"], b["bounds"], b["scal"], passes=1))
-            assert (got[0]["status"] == 1).all()
-            for key in ("out", "iters", "info", "wx", "wy"):
-                np.testing.assert_array_equal(got[0][key], got[1][key])
-    finally:
-        E._lib = saved
+@pytest.mark.parametrize("n,profile,batch,seed", [(80, "uniform", 24, 1), (120, "varied", 12, 2), (200, "uniform", 6, 4), (35, "varied", 12, 7)])
+def test_equilibration_on_one_waypoint_is_the_full_passes_bit_for_bit(n, profile, batch, seed):
+    """pqp_params.scaling < 0 (the production setting: -4): the modified Ruiz passes evaluated on ONE interior waypoint's blocks, every waypoint
+    taking the result.  The path QP's KKT matrix repeats from waypoint to waypoint up to entries that never carry a norm (the curvature term of
+    the transition, the spacing against unit entries), so for passes linearised around the reference line (path_optimizer.cpp:128-137) and their
+    re-linearised re-solves (which keep the scaling) the shortcut gives the SAME D, E, c as the full passes: identical outputs, iteration and
+    solve counts."""
+    b = make_batch(batch, n, profile, seed=seed)
+    full = E.solve(E.production(scaling=4), b["ref"], b["bounds"], b["scal"], passes=1)
+    one = E.solve(E.production(scaling=-4), b["ref"], b["bounds"], b["scal"], passes=1)
+    assert (full["status"] == 1).all()
+    for key in ("out", "iters", "info", "wx", "wy"):
+        np.testing.assert_array_equal(full[key], one[key])
+    # a linearisation point off the reference line: still a valid positive scaling, the same optimum (the values need not be the passes')
+    rng = np.random.default_rng(seed)
+    lin = np.stack([O.first_linearization(b["ref"][q]) for q in range(2)]) + rng.normal(scale=[0.1, 0.02, 0.005], size=(2, n, 3))
+    r4 = E.solve(E.production(scaling=4), b["ref"][:2], b["bounds"][:2], b["scal"][:2], lin=lin, passes=0)
+    rn = E.solve(E.production(scaling=-4), b["ref"][:2], b["bounds"][:2], b["scal"][:2], lin=lin, passes=0)
+    assert (r4["status"] == 1).all() and (rn["status"] == 1).all()
+    assert np.abs(r4["out"] - rn["out"]).max() < 1e-6
