@@ -948,7 +948,7 @@ int pqp_set_option(pqp_handle* h, int option, int value) {
         case PQP_OPT_RESERVE_CUS: h->opt_reserve_cus = value < 0 ? 0 : value; return PQP_OK;
         case PQP_OPT_STREAM_BATCH: h->opt_stream_batch = value < 0 ? 0 : value; return PQP_OK;
         case PQP_OPT_CARRY_CYCLES: h->opt_carry = value ? 1 : 0; h->stream_last_batch = 0; h->sm_act_batch[0] = h->sm_act_batch[1] = 0; return PQP_OK;
-        case PQP_OPT_CHAIN_GRAPH: h->opt_chain_graph = value ? 1 : 0; return PQP_OK;
+        case PQP_OPT_CHAIN_GRAPH: h->opt_chain_graph = value == 2 ? 2 : (value ? 1 : 0); return PQP_OK;
         default: return fail(PQP_ERR_INVALID, "pqp_set_option: unknown option");
     }
 }

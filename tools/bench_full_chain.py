@@ -1,7 +1,7 @@
 """The whole of PathOptimizer::solve, input points -> optimised path, as ONE device-resident call (pqp_optimize_path_device): ragged
 scenarios (polygons of 7..13 input points over 8 obstacle maps: every intermediate count differs per scenario), nothing copied to the
 host between the twelve steps.  Prints scenarios/s (host clock around enqueue + sync over several repetitions) and the stage census.
-Usage: python tools/bench_full_chain.py [batch=1024] [n_maps=8] [reps=10] [--exact-smoothers] [--tension] [--inflight-2] [--moving] [--carry] [--graph]   (run on the GPU box)"""
+Usage: python tools/bench_full_chain.py [batch=1024] [n_maps=8] [reps=10] [--exact-smoothers] [--tension] [--inflight-2] [--moving] [--carry] [--graph | --graph-unfenced]   (run on the GPU box)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -52,7 +52,7 @@ for _ in range(inflight):
     h.set_option(capi.OPT_STORE_WARM, 0); h.set_option(capi.OPT_ORDER_BY_COST, 1)
     if "--carry" in sys.argv:            # PQP_OPT_CARRY_CYCLES on both handles: every QP of the chain starts from its slot's previous planning cycle
         h.set_option(capi.OPT_CARRY_CYCLES, 1); hs.set_option(capi.OPT_CARRY_CYCLES, 1)
-    h.set_option(capi.OPT_CHAIN_GRAPH, 1 if "--graph" in sys.argv else 0)           # PQP_OPT_CHAIN_GRAPH: the chain replayed as a captured hipGraph
+    h.set_option(capi.OPT_CHAIN_GRAPH, 2 if "--graph-unfenced" in sys.argv else (1 if "--graph" in sys.argv else 0))           # PQP_OPT_CHAIN_GRAPH: the chain replayed as a captured hipGraph
     h.set_option(capi.OPT_RESERVE_CUS, int(os.environ.get("PQP_RESERVE_CUS", "0")))     # (experiments: CUs the path QP leaves to the other kernels in flight)
     # capacities sized to the workload (lines of 18..36 m): every smoother QP of the batch runs at the padded maximum size
     cfg = h.chain_config(raw_max=64, sample_max=48, layer_max=32, n_max=128) if "--default-capacities" not in sys.argv else h.chain_config()
@@ -88,7 +88,7 @@ def sync():
         h.sync(); hs.sync()
 
 
-for k in range((3 if "--graph" not in sys.argv else 2 * max(len(variants), 3)) * inflight):          # (--graph: plain call + capture per argument set, before the clock)
+for k in range((3 if not any(a.startswith("--graph") for a in sys.argv) else 2 * max(len(variants), 3)) * inflight):          # (--graph: plain call + capture per argument set, before the clock)
     run(k)
 sync()
 t0 = time.perf_counter()
@@ -102,7 +102,7 @@ names = ["ok", "few points", "smoother failed", "search failed", "short referenc
 print(f"pqp_optimize_path_device: {batch} ragged scenarios over {n_maps} maps ({int(n_pts.min())}..{int(n_pts.max())} input points): "
       f"{dt * 1e3:.3f} ms per batch = {batch / dt:.0f} scenarios/s, input points -> optimised path, device resident"
       + (f", {inflight} batches in flight" if inflight > 1 else "") + (", scenarios moving from call to call" if moving else "")
-      + (", PQP_OPT_CARRY_CYCLES" if "--carry" in sys.argv else "") + (", PQP_OPT_CHAIN_GRAPH" if "--graph" in sys.argv else ""))
+      + (", PQP_OPT_CARRY_CYCLES" if "--carry" in sys.argv else "") + (", PQP_OPT_CHAIN_GRAPH" if "--graph" in sys.argv else (", PQP_OPT_CHAIN_GRAPH = 2 (unfenced)" if "--graph-unfenced" in sys.argv else "")))
 print("  stages: " + ", ".join(f"{names[k]} {int((sg == k).sum())}" for k in range(10) if (sg == k).any()))
 ok = sg == 0
 print(f"  paths: {int(ok.sum())} solved, waypoints {int(no[ok].min())}..{int(no[ok].max())} (mean {no[ok].mean():.0f}); "
