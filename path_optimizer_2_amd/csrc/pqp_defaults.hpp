@@ -64,10 +64,7 @@ inline void production_params(pqp_params* p) {
     default_params(p);
     p->eps_abs = 1e-4;
     p->eps_rel = 1e-4;
-#ifndef PQP_PROD_SCALING
-#define PQP_PROD_SCALING -4
-#endif
-    p->scaling = PQP_PROD_SCALING;                  // 4 Ruiz passes instead of OSQP's 10: the polish returns the exact optimum whatever the
+    p->scaling = -4;                                // 4 Ruiz passes instead of OSQP's 10: the polish returns the exact optimum whatever the
                                                     // metric, the ADMM iterations before it only have to predict the active set (+0.5 % solves,
                                                     // -6 passes of 2.5 us: +4.5 % paths/s, profiles/r02h_policy_sweep.txt).  Negative (round 4):
                                                     // the passes evaluated on one interior waypoint's blocks and taken by every waypoint - bit

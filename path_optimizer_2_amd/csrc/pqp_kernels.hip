@@ -16,9 +16,6 @@
 //
 // No CPU fallback: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
-#if defined(PQP_NO_MONOLITH) && defined(PQP_MONOLITH)
-#undef PQP_MONOLITH      // experiment builds: the cold operations out of line (cold_entry), the lane state crossing through memory
-#endif
 
 #include <cstdio>
 #include <cstring>
@@ -37,25 +34,12 @@ namespace pqp {
 // -------------------------------------------------------------------------------------------------------
 // device execution context for PathQp: a phase is the code between two workgroup barriers
 // -------------------------------------------------------------------------------------------------------
-#ifndef PQP_UNIFORM
-#define PQP_UNIFORM 1     // +4.4 %: profiles/r02l_uniform_control.txt
-#endif
 // A value that is the same in every lane, told to the compiler: what is derived from it - the control state of PathQp::run - then
-// branches with s_cbranch instead of exec-mask bookkeeping (v_cndmask per state variable per branch).
+// branches with s_cbranch instead of exec-mask bookkeeping (v_cndmask per state variable per branch; +4.4 %: profiles/r02l_uniform_control.txt).
 __device__ __forceinline__ double uniform(double x) {
-#if PQP_UNIFORM
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
-#else
-    return x;
-#endif
 }
-__device__ __forceinline__ bool uniform(bool x) {
-#if PQP_UNIFORM
-    return __builtin_amdgcn_readfirstlane((int)x) != 0;
-#else
-    return x;
-#endif
-}
+__device__ __forceinline__ bool uniform(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; }
 
 // wave / workgroup reductions shared by the hot and the cold context
 // One step of a wavefront max-reduction in the VALU (DPP: data-parallel primitives move a value between lanes inside the instruction,
@@ -96,7 +80,7 @@ __device__ __forceinline__ double wave_sum(double x) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
 }
 
-template <int NW, int K, bool MAX, int TL = 64 * NW>       // TL: lanes of the LDS layout (128 * NW for the two-waypoints-per-lane contexts)
+template <int NW, int K, bool MAX>
 __device__ __forceinline__ void wg_reduce(double (&v)[K], double* shp) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -104,7 +88,7 @@ __device__ __forceinline__ void wg_reduce(double (&v)[K], double* shp) {
         v[k] = MAX ? wave_max(x) : wave_sum(x);
     }
     if (NW > 1) {
-        double* red = shp + ShLayout{TL}.red();
+        double* red = shp + ShLayout{64 * NW}.red();
         const int w = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 0)
             for (int k = 0; k < K; ++k) red[k * 16 + w] = v[k];
@@ -146,22 +130,9 @@ __device__ __noinline__ bool dev_certificate(double* sh, double fl, double rl, d
     return primal_certificate(c, sh, 64 * NW, fl, rl, kap, eps, cscale);
 }
 
-// PQP_CST_LDS / PQP_PARK_SCALE: the register diet of pqp_path_lane.hpp (12 pass constants per waypoint in LDS, Ruiz vectors parked in
-// memory between the passes)
-#ifndef PQP_DPP
-#define PQP_DPP 1      // +x %: profiles/r02j
-#endif
-// PQP_SAVE_LDS_MAX_NW: up to this many wavefronts per QP the polish save area lives in LDS (beyond: in the workgroup slot's global memory).
-// 4 is what fits (256 lanes: 157 KB); experiments with two QPs' worth of wavefronts per SIMD set it to 1 (40 KB per QP at 128 lanes)
-#ifndef PQP_SAVE_LDS_MAX_NW
-#define PQP_SAVE_LDS_MAX_NW 4
-#endif
-#ifndef PQP_CST_LDS
-#define PQP_CST_LDS 0
-#endif
-#ifndef PQP_PARK_SCALE
-#define PQP_PARK_SCALE 1       // measured: +2 % (profiles/r02b_variants.txt); PQP_CST_LDS: no gain at one wave per SIMD
-#endif
+// Up to this many wavefronts per QP the polish save area (and the parked Ruiz vectors) live in LDS; beyond, in the workgroup slot's global
+// memory.  4 is what fits (256 lanes: 157 KB).
+constexpr int kSaveLdsMaxNw = 4;
 
 template <int NW>
 __device__ __noinline__ bool dev_late_certificate(double* sh, int t, double* snap, bool have, LateCertIn in, double fl, double rl, double kap, double eps,
@@ -170,87 +141,17 @@ __device__ __noinline__ bool dev_late_certificate(double* sh, int t, double* sna
     return late_certificate(c, sh, 64 * NW, t, snap, have, in, fl, rl, kap, eps, cscale);
 }
 
-// Context whose lane state is a local struct (SROA -> registers).  A phase is the code between two workgroup
-// barriers (for a one-wave workgroup the barrier is only a wait on outstanding LDS traffic).
-template <int NW>
-struct RegCtx {
-    static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0, kSaveLds = NW <= PQP_SAVE_LDS_MAX_NW;
-    // DPP moves (PQP_DPP): the value of the lane H below / above in the same row of 16 lanes, of the previous row's last lane; 0 where
-    // there is no such lane.  Must run with every lane enabled (a disabled source lane reads as "no lane").
-    static constexpr bool kDpp = PQP_DPP != 0;
-    template <int CTRL, int ROW_MASK>
-    __device__ __forceinline__ static double dpp0(double v) {
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
-        return __hiloint2double(hi, lo);
-    }
-    template <int H> __device__ __forceinline__ static double lane_below(double v) { return dpp0<0x110 + H, 0xf>(v); }     // row_shr:H
-    template <int H> __device__ __forceinline__ static double lane_above(double v) { return dpp0<0x100 + H, 0xf>(v); }     // row_shl:H
-    __device__ __forceinline__ static double prev_row_last(double v) { return dpp0<0x142, 0xe>(v); }                      // row_bcast:15
-    __device__ __forceinline__ static double uni(double x) { return uniform(x); }      // a wave-uniform value that reaches control flow
-    Lane lane;
-    double* shp;
-    __device__ __forceinline__ int T() const { return 64 * NW; }
-    __device__ __forceinline__ double* sh() { return shp; }
-    template <class F>
-    __device__ __forceinline__ void phase(F f) {
-        f((int)threadIdx.x, lane);
-        __syncthreads();
-    }
-    __device__ __forceinline__ long long clock() const { return (long long)wall_clock64(); }     // 100 MHz
-    __device__ __forceinline__ bool certificate(double* sh, int, double fl, double rl, double kap, double eps, double cscale) {
-        return uniform(dev_certificate<NW>(sh, fl, rl, kap, eps, cscale));
-    }
-    __device__ __forceinline__ bool late_certificate(double* sh, int t, double* snap, bool have, const LateCertIn& in, double fl, double rl, double kap,
-                                                     double eps, double cscale) {
-        return uniform(dev_late_certificate<NW>(sh, t, snap, have, in, fl, rl, kap, eps, cscale));
-    }
-    // wave-local phase: LDS operations of one wavefront execute in program order, so lanes of the same wavefront see each
-    // other's writes without a workgroup barrier; the fence only stops the compiler from moving LDS accesses across it
-    template <class F>
-    __device__ __forceinline__ void phase_w(F f) {
-        f((int)threadIdx.x, lane);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    template <int K, class F>
-    __device__ __forceinline__ void reduce_max(double (&out)[K], F f) {
-        f((int)threadIdx.x, lane, out);
-        wg_reduce<NW, K, true>(out, shp);
-    }
-    template <int K, class F>
-    __device__ __forceinline__ void reduce_sum(double (&out)[K], F f) {
-        f((int)threadIdx.x, lane, out);
-        wg_reduce<NW, K, false>(out, shp);
-    }
-    template <class PQ>
-    __device__ __forceinline__ void cold(PQ& pq, int op, int i0, int i1, double d0) { pq.do_cold(op, i0, i1, d0); }
-};
-
-// The rare, register-hungry part of the solver (assemble, Ruiz, factorisation, polish bookkeeping, unpack) runs
-// here, out of line, one function per operation: the lane state comes in through memory, lives in registers
-// inside, goes back through memory.  Whatever these functions spill never touches the ADMM loop.
-template <int NW, int OP, bool CERT = true>
-__device__ __noinline__ Uni cold_entry(const PathSolveArgs* args, int qp, double* shp, Lane* mem, Uni u, int i0, int i1, double d0) {
-    RegCtx<NW> cctx;
-    cctx.shp = shp;
-    cctx.lane.s = mem->s;
-    PathQp<RegCtx<NW>, CERT> c(cctx, *args, qp);
-    c.set_uni(u);
-    c.do_cold(OP, i0, i1, d0);
-    mem->s = cctx.lane.s;
-    return c.get_uni();
-}
-
 // Hot context: the lane state is a local struct that SROA turns into registers; a phase is the code between two
 // workgroup barriers (for a one-wave workgroup the barrier is only a wait on outstanding LDS traffic).
 template <int NW>
 struct DevCtx {
     // kSaveLds: up to 256 lanes the polish save area fits beside the exchange buffers (72 KB per QP at T = 128, two QPs per CU)
-    static constexpr bool kCstLds = PQP_CST_LDS != 0, kParkScale = PQP_PARK_SCALE != 0, kSaveLds = NW <= PQP_SAVE_LDS_MAX_NW;
-    // DPP moves (PQP_DPP): the value of the lane H below / above in the same row of 16 lanes, of the previous row's last lane; 0 where
-    // there is no such lane.  Must run with every lane enabled (a disabled source lane reads as "no lane").
-    static constexpr bool kDpp = PQP_DPP != 0;
+    // kCstLds: pass constants in LDS instead of in registers (no gain at one wavefront per SIMD); kParkScale: the Ruiz vectors are parked
+    // between the passes (+2 %, profiles/r02b_variants.txt)
+    static constexpr bool kCstLds = false, kParkScale = true, kSaveLds = NW <= kSaveLdsMaxNw;
+    // DPP moves: the value of the lane H below / above in the same row of 16 lanes, of the previous row's last lane; 0 where
+    // there is no such lane.  Must run with every lane enabled (a disabled source lane reads as "no lane").  (profiles/r02j_dpp_exchanges.txt)
+    static constexpr bool kDpp = true;
     template <int CTRL, int ROW_MASK>
     __device__ __forceinline__ static double dpp0(double v) {
         const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
@@ -262,9 +163,7 @@ struct DevCtx {
     __device__ __forceinline__ static double prev_row_last(double v) { return dpp0<0x142, 0xe>(v); }                      // row_bcast:15
     __device__ __forceinline__ static double uni(double x) { return uniform(x); }      // a wave-uniform value that reaches control flow
     Lane lane;
-    Lane* mem;
     double* shp;
-    const PathSolveArgs* args;
     __device__ __forceinline__ long long clock() const { return (long long)wall_clock64(); }     // 100 MHz
     __device__ __forceinline__ bool certificate(double* sh, int, double fl, double rl, double kap, double eps, double cscale) {
         return uniform(dev_certificate<NW>(sh, fl, rl, kap, eps, cscale));
@@ -298,129 +197,11 @@ struct DevCtx {
         f((int)threadIdx.x, lane, out);
         wg_reduce<NW, K, false>(out, shp);
     }
-    // hot -> cold -> hot: spill the whole lane state once, explicitly, around the out-of-line call
-    template <class PQ>
-    __device__ __forceinline__ void cold(PQ& pq, int op, int i0, int i1, double d0) {
-#ifdef PQP_MONOLITH
-        pq.do_cold(op, i0, i1, d0);
-        return;
-#endif
-        copy_hot(*mem, lane);
-        Uni u;
-        switch (op) {      // `op` is a literal at every call site: one case survives inlining
-            case COLD_BEGIN_PASS: u = cold_entry<NW, COLD_BEGIN_PASS>(args, pq.qp, shp, mem, pq.get_uni(), i0, i1, d0); break;
-            case COLD_REFACTOR: u = cold_entry<NW, COLD_REFACTOR>(args, pq.qp, shp, mem, pq.get_uni(), i0, i1, d0); break;
-            case COLD_END_PASS: u = cold_entry<NW, COLD_END_PASS>(args, pq.qp, shp, mem, pq.get_uni(), i0, i1, d0); break;
-            case COLD_CERT: u = cold_entry<NW, COLD_CERT>(args, pq.qp, shp, mem, pq.get_uni(), i0, i1, d0); break;
-            default: u = cold_entry<NW, COLD_FINISH>(args, pq.qp, shp, mem, pq.get_uni(), i0, i1, d0); break;
-        }
-        copy_hot(lane, *mem);
-        pq.set_uni(u);
-    }
-    // only what the ADMM loop reads: Slot (the SlotSetup part of a Lane is cold-only)
-    __device__ __forceinline__ static void copy_hot(Lane& dst, const Lane& src) {
-        dst.s = src.s;
-    }
-};
-
-#ifdef PQP_WITH_PAIR
-// ---------------------------------------------------------------------------------------------------------------------------
-// TWO WAYPOINTS PER LANE (round 4; EXPERIMENT, compiled only with -DPQP_WITH_PAIR and selected by PQP_PAIR=1: it is correct - the parity
-// tests pass on it - and 2-2.7x slower, because two lane states need ~466 fp64 of registers where a lane has 256: 1389 spills, profiles/r04g_*).
-// The same solver source on half the wavefronts: lane j of the workgroup owns waypoints 2j and
-// 2j + 1, a phase runs the solver's per-waypoint code for both (all neighbour traffic through the LDS exchange buffers, which are indexed by
-// waypoint: the formulation the host emulation runs), T = 128 NW.  N <= 128 is ONE wavefront per QP (no workgroup barrier is ever a wait, four
-// QPs per CU instead of two); the first cyclic-reduction level eliminates every lane's even waypoint, all further levels run on the odd
-// ones, so with the waypoint index known to the compiler as 2 j + k the dead half of every level folds away: a solve issues one level
-// sequence instead of two, only the per-waypoint phases run twice.  The price is two lane states in one register file (the save area and the
-// parked scaling vectors therefore live in the workgroup slot's global memory) and LDS exchanges where the one-waypoint-per-lane contexts
-// use DPP moves.
-template <int NW>
-struct PairLaneLessCtx {
-    double* shp;
-    __device__ __forceinline__ int T() const { return 128 * NW; }
-    template <class F>
-    __device__ __forceinline__ void phase(F f) {
-        f(2 * (int)threadIdx.x); f(2 * (int)threadIdx.x + 1);
-        __syncthreads();
-    }
-    template <int K, bool MAX, class F>
-    __device__ __forceinline__ void reduce(double (&out)[K], F f) {
-        double b[K];
-        f(2 * (int)threadIdx.x, out); f(2 * (int)threadIdx.x + 1, b);
-#pragma unroll
-        for (int k = 0; k < K; ++k) out[k] = MAX ? fmax(out[k], b[k]) : out[k] + b[k];
-        wg_reduce<NW, K, MAX, 128 * NW>(out, shp);
-    }
-    template <int K, class F> __device__ __forceinline__ void reduce_max(double (&out)[K], F f) { reduce<K, true>(out, f); }
-    template <int K, class F> __device__ __forceinline__ void reduce_sum(double (&out)[K], F f) { reduce<K, false>(out, f); }
-};
-template <int NW>
-__device__ __noinline__ bool dev_certificate_pair(double* sh, double fl, double rl, double kap, double eps, double cscale) {
-    PairLaneLessCtx<NW> c{sh};
-    return primal_certificate(c, sh, 128 * NW, fl, rl, kap, eps, cscale);
-}
-// staging half of late_certificate() for one waypoint (no synchronisation, no evaluation)
-struct StageOnlyCtx {
-    int T_;
-    __device__ __forceinline__ int T() const { return T_; }
-    template <class F> __device__ __forceinline__ void phase(F) {}
-    template <int K, class F> __device__ __forceinline__ void reduce_max(double (&out)[K], F) { for (int k = 0; k < K; ++k) out[k] = 0.0; }
-    template <int K, class F> __device__ __forceinline__ void reduce_sum(double (&out)[K], F) { for (int k = 0; k < K; ++k) out[k] = 0.0; }
-};
-template <int NW>
-__device__ __noinline__ void dev_late_stage_pair(double* sh, int t, double* snap, LateCertIn in, double fl, double rl, double kap, double eps, double cscale) {
-    StageOnlyCtx st{128 * NW};
-    (void)late_certificate(st, sh, 128 * NW, t, snap, false, in, fl, rl, kap, eps, cscale);
-}
-
-template <int NW>
-struct PairCtx {
-    static constexpr bool kCstLds = false, kParkScale = true, kSaveLds = false, kDpp = false;
-    __device__ __forceinline__ static double uni(double x) { return uniform(x); }
-    Lane lane[2];
-    double* shp;
-    __device__ __forceinline__ long long clock() const { return (long long)wall_clock64(); }
-    __device__ __forceinline__ int T() const { return 128 * NW; }
-    __device__ __forceinline__ double* sh() { return shp; }
-    template <class F>
-    __device__ __forceinline__ void phase(F f) {
-        f(2 * (int)threadIdx.x, lane[0]); f(2 * (int)threadIdx.x + 1, lane[1]);
-        __syncthreads();
-    }
-    template <class F>
-    __device__ __forceinline__ void phase_w(F f) {
-        f(2 * (int)threadIdx.x, lane[0]); f(2 * (int)threadIdx.x + 1, lane[1]);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    template <int K, bool MAX, class F>
-    __device__ __forceinline__ void reduce(double (&out)[K], F f) {
-        double b[K];
-        f(2 * (int)threadIdx.x, lane[0], out); f(2 * (int)threadIdx.x + 1, lane[1], b);
-#pragma unroll
-        for (int k = 0; k < K; ++k) out[k] = MAX ? fmax(out[k], b[k]) : out[k] + b[k];
-        wg_reduce<NW, K, MAX, 128 * NW>(out, shp);
-    }
-    template <int K, class F> __device__ __forceinline__ void reduce_max(double (&out)[K], F f) { reduce<K, true>(out, f); }
-    template <int K, class F> __device__ __forceinline__ void reduce_sum(double (&out)[K], F f) { reduce<K, false>(out, f); }
-    __device__ __forceinline__ bool certificate(double* sh, int, double fl, double rl, double kap, double eps, double cscale) {
-        return uniform(dev_certificate_pair<NW>(sh, fl, rl, kap, eps, cscale));
-    }
-    // called once per waypoint (twice per lane, inside one phase): every call stages its waypoint, the lane's second call - the data of all
-    // waypoints are then staged - synchronises and evaluates
-    __device__ __forceinline__ bool late_certificate(double* sh, int t, double* snap, bool have, const LateCertIn& in, double fl, double rl, double kap,
-                                                     double eps, double cscale) {
-        dev_late_stage_pair<NW>(sh, t, snap, in, fl, rl, kap, eps, cscale);
-        if ((t & 1) == 0) return false;
-        __syncthreads();
-        return have ? uniform(dev_certificate_pair<NW>(sh, fl, rl, kap, eps, cscale)) : false;
-    }
+    // The cold operations (assemble, Ruiz, factorisation, polish bookkeeping, unpack) run inline on the same lane state: out of line, on a
+    // memory-resident copy, the lane state's round trips cost more than the spills they avoid (0.36x, profiles/r04h_cold_ops_out_of_line_ab.txt)
     template <class PQ>
     __device__ __forceinline__ void cold(PQ& pq, int op, int i0, int i1, double d0) { pq.do_cold(op, i0, i1, d0); }
 };
-
-#endif  // PQP_WITH_PAIR
 
 // ticket -> QP of the NEXT launch, most expensive first: cost bins in descending order, within a bin in whatever order this workgroup's
 // lanes draw their ranks (results do not depend on the order).  Run by the last workgroup of a launch to leave its ticket loop (every workgroup counts itself out on hist[kCostBins]):
@@ -455,17 +236,12 @@ __device__ void order_next_launch(const PathSolveArgs& args) {
     for (int b = threadIdx.x; b <= kCostBins; b += nt) __hip_atomic_store(args.cost_hist + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
 }
 
-// PQP_SOLVE_OCC: wavefronts per SIMD the solve kernel is compiled for (the register budget per lane is 512 / PQP_SOLVE_OCC)
-#ifndef PQP_SOLVE_OCC
-#define PQP_SOLVE_OCC 1
-#endif
+// One wavefront per SIMD: the lane state + the factorisation take the whole 512-register budget (occupancy 2 on 256: 0.41-0.53x,
+// profiles/r04f_occupancy2_ab.txt)
 template <int NW, bool CERT>
-__global__ void __launch_bounds__(64 * NW, (NW <= 2) ? PQP_SOLVE_OCC : 1) path_solve_kernel(const PathSolveArgs args) {
+__global__ void __launch_bounds__(64 * NW, 1) path_solve_kernel(const PathSolveArgs args) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_ticket;
-#ifndef PQP_MONOLITH
-    Lane memlane;
-#endif
     // Persistent workgroups: every workgroup draws tickets until the batch is used up (each workgroup ends on one ticket beyond
     // it, so a launch consumes exactly batch + gridDim.x tickets and the host knows the next launch's base without a reset).
     // (Drawing the next ticket while the current QP is solved - to hide the ~2 us of the returning atomic - was measured and dropped: at
@@ -500,13 +276,7 @@ __global__ void __launch_bounds__(64 * NW, (NW <= 2) ? PQP_SOLVE_OCC : 1) path_s
             continue;
         }
         DevCtx<NW> ctx;
-#ifndef PQP_MONOLITH
-        ctx.mem = &memlane;
-#else
-        ctx.mem = nullptr;
-#endif
         ctx.shp = smem;
-        ctx.args = &args;
         PathQp<DevCtx<NW>, CERT> solver(ctx, args, qp, (int)blockIdx.x);
 #ifdef PQP_TIMING
         const long long t_ticket1 = (long long)wall_clock64();
@@ -524,45 +294,6 @@ __global__ void __launch_bounds__(64 * NW, (NW <= 2) ? PQP_SOLVE_OCC : 1) path_s
     if (args.cost_key) order_next_launch(args);
 }
 
-#ifdef PQP_WITH_PAIR
-// the same persistent-workgroup kernel over the two-waypoints-per-lane context: 64 NW threads per QP of up to 128 NW waypoints
-template <int NW, bool CERT>
-__global__ void __launch_bounds__(64 * NW, 1) path_solve_pair_kernel(const PathSolveArgs args) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ int s_ticket;
-    for (;;) {
-        if (threadIdx.x == 0) s_ticket = (int)(atomicAdd(args.ticket, 1ull) - args.ticket_base);
-        __syncthreads();
-        const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
-        __syncthreads();
-        if ((unsigned)ticket >= (unsigned)args.batch) break;
-        const int qp = args.order ? args.order[ticket] : ticket;
-        if ((args.n_of ? args.n_of[qp] : args.n) < 2) {
-            if (threadIdx.x == 0) {
-                if (args.status) args.status[qp] = PQP_STATUS_UNSOLVED;
-                if (args.iters) args.iters[qp] = 0;
-                if (args.info) for (int k = 0; k < PQP_INFO_STRIDE; ++k) args.info[(size_t)qp * PQP_INFO_STRIDE + k] = 0.0;
-                args.wrho[qp] = args.prm.rho;
-                args.wye[2 * (size_t)qp] = 0.0; args.wye[2 * (size_t)qp + 1] = 0.0;
-                if (args.cost_key) record_cost(args, qp, 0);
-            }
-            if (args.store_warm)
-                for (int k = threadIdx.x; k < args.n * 6; k += blockDim.x) {
-                    args.wx[(size_t)qp * args.n * 6 + k] = 0.0;
-                    args.wy[(size_t)qp * args.n * 6 + k] = 0.0;
-                }
-            continue;
-        }
-        PairCtx<NW> ctx;
-        ctx.shp = smem;
-        PathQp<PairCtx<NW>, CERT> solver(ctx, args, qp, (int)blockIdx.x);
-        solver.run();
-        __syncthreads();
-    }
-    if (args.cost_key) order_next_launch(args);
-}
-
-#endif  // PQP_WITH_PAIR
 
 // -------------------------------------------------------------------------------------------------------
 // reference numbering helpers (base_solver.cpp:22-37,154-158)
@@ -864,7 +595,7 @@ struct pqp_handle {
     int sm_act_batch[2] = {0, 0}, sm_act_n[2] = {0, 0};
     DevBuf stream_ws;                           // workspace of path_stream_kernel
     int num_cu = 0;
-    int blocks_per_cu[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};    // occupancy of the solve kernel variants [pair][log2(nw)][cert]
+    int blocks_per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // occupancy of the solve kernel variants [log2(nw)][cert]
     DevBuf s_ref, s_lin, s_bounds, s_scal;      // staging for the host-pointer entry points
     DevBuf s_out, s_status, s_iters, s_info, s_a, s_p, s_l, s_u, s_idx;
     // smoother QPs: banded problem data + shared sparsity (cached per type and size) + staging
@@ -1148,29 +879,12 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     a.prm = h->prm;
     int nw = 1, lg = 0;
     while (64 * nw < n) { nw *= 2; lg += 1; }           // one waypoint per lane: T = 64 * nw >= n threads per QP
-    // PQP_PAIR (experiment switch, round 4): two waypoints per lane - half the wavefronts per QP (PairCtx)
-#ifdef PQP_WITH_PAIR
-    static const int pair_env = [] { const char* e = std::getenv("PQP_PAIR"); return e ? std::atoi(e) : 0; }();
-    const bool pair = pair_env != 0 && n > 2;
-#else
-    const bool pair = false;
-#endif
-    if (pair) { nw = 1; lg = 0; while (128 * nw < n) { nw *= 2; lg += 1; } }
-    const int T_lanes = pair ? 128 * nw : 64 * nw;      // waypoints the LDS layout holds
-    const bool save_lds = !pair && nw <= PQP_SAVE_LDS_MAX_NW;
-    const size_t lds = (size_t)pqp::ShLayout{T_lanes}.total(save_lds, save_lds || PQP_CST_LDS != 0) * 8;
+    const int T_lanes = 64 * nw;
+    const bool save_lds = nw <= pqp::kSaveLdsMaxNw;
+    const size_t lds = (size_t)pqp::ShLayout{T_lanes}.total(save_lds, save_lds) * 8;
     // two variants of every kernel: with and without OSQP's primal infeasibility certificate (prm.eps_prim_inf > 0)
     const bool cert = h->prm.eps_prim_inf > 0.0 && h->prm.prim_inf_after <= 0;
     const void* fn = nullptr;
-#ifdef PQP_WITH_PAIR
-    if (pair) {
-        switch (nw) {
-            case 1: fn = cert ? (const void*)pqp::path_solve_pair_kernel<1, true> : (const void*)pqp::path_solve_pair_kernel<1, false>; break;
-            case 2: fn = cert ? (const void*)pqp::path_solve_pair_kernel<2, true> : (const void*)pqp::path_solve_pair_kernel<2, false>; break;
-            default: fn = cert ? (const void*)pqp::path_solve_pair_kernel<4, true> : (const void*)pqp::path_solve_pair_kernel<4, false>; break;
-        }
-    } else
-#endif
     switch (nw) {
         case 1: fn = cert ? (const void*)pqp::path_solve_kernel<1, true> : (const void*)pqp::path_solve_kernel<1, false>; break;
         case 2: fn = cert ? (const void*)pqp::path_solve_kernel<2, true> : (const void*)pqp::path_solve_kernel<2, false>; break;
@@ -1180,7 +894,7 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     if (lds > 64 * 1024) PQP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent workgroups: as many as the chip holds at once (a surplus one would only wait for a free slot), each with its own
     // save area; they draw the QPs from the ticket counter
-    int& per_cu = h->blocks_per_cu[(pair ? 8 : 0) + 2 * lg + (cert ? 1 : 0)];
+    int& per_cu = h->blocks_per_cu[2 * lg + (cert ? 1 : 0)];
     if (per_cu == 0) {
         PQP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * nw, lds));
         if (per_cu < 1) per_cu = 1;
@@ -1219,7 +933,7 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     h->next_event_pair();
     if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
     void* kargs[] = {(void*)&a};
-    hipError_t le = hipLaunchKernel(fn, dim3(grid), dim3(64 * nw), kargs, lds, h->stream);          // (pair: 64 nw threads hold 128 nw waypoints)
+    hipError_t le = hipLaunchKernel(fn, dim3(grid), dim3(64 * nw), kargs, lds, h->stream);
     if (le == hipSuccess) le = hipGetLastError();
     if (le != hipSuccess) {
         h->hist_batch = 0; h->hist_n = 0;          // (the histogram may have been cleared for a launch that never ran)

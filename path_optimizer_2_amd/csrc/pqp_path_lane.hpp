@@ -53,22 +53,10 @@ constexpr double kInfty = 1e30;        // OSQP_INFTY
 constexpr double kMinScaling = 1e-4;
 constexpr double kMaxScaling = 1e4;
 // ... and a full round moves the rows whose violation is at least this share of the largest one: the ones a hundred times smaller mostly vanish once the
-// large ones have moved, and moving them along is what sends rounds wandering (round 3, tools/ab_cons.sh: 0.01 - one launch at a time +8 %, the headline
+// large ones have moved, and moving them along is what sends rounds wandering (round 3 sweep: 0.01 - one launch at a time +8 %, the headline
 // of 15 of 16 scenario seeds within 2.5 % of each other; 0.003: no effect, 0.02-0.03: the same, 0.05-0.1: a straggler is back, 0.3: +13 % work)
-#ifndef PQP_FULL_MOVE_SHARE
-#define PQP_FULL_MOVE_SHARE 0.01
-#endif
-#ifndef PQP_FIRST_ATTEMPT_ONLY
-#define PQP_FIRST_ATTEMPT_ONLY 1
-#endif
-#ifndef PQP_CAUTIOUS_PER_N
-#define PQP_CAUTIOUS_PER_N 0
-#endif
-#ifndef PQP_CAUTIOUS_FROM_ROUND
-#define PQP_CAUTIOUS_FROM_ROUND 8
-#endif
-constexpr double kFullMoveShare = PQP_FULL_MOVE_SHARE;        // (the macros: tools/build_variants.py experiments)
-constexpr int kCautiousFromRound = PQP_CAUTIOUS_FROM_ROUND;        // active-set rounds of a polish attempt: single moves from this round on at the latest (run())
+constexpr double kFullMoveShare = 0.01;
+constexpr int kCautiousFromRound = 8;        // active-set rounds of a polish attempt: single moves from this round on at the latest (run())
 constexpr double kRhoMin = 1e-6;
 constexpr double kRhoMax = 1e6;
 constexpr double kRhoTol = 1e-4;
@@ -1868,10 +1856,10 @@ struct PathQp {
         const int auto_rounds = n / 5 - 8;
         const int max_rounds = prm.polish_max_rounds > 0 ? prm.polish_max_rounds : (auto_rounds > 24 ? auto_rounds : 24);
         // (the cautious switch by round count applies to the FIRST attempt of a pass only: later attempts get half the rounds, and switched at 8 they spend
-        //  them on single moves - one QP in ~16 000 of 300 waypoints then never completed a polish, 868 reduced solves; first attempt only: 83.
-        //  PQP_CAUTIOUS_PER_N = 16 - the switch at round n / 16 on long paths - cures that QP and a 368-solve one at 200 waypoints too, but BASELINE
-        //  configs[4]'s batch holds a QP that then wanders: 551 k instead of 690 k scenarios/s; tools/ab_hard_cases.sh, tools/ab_config4.sh)
-        const int cautious_from = (PQP_CAUTIOUS_PER_N > 0 && n / (PQP_CAUTIOUS_PER_N > 0 ? PQP_CAUTIOUS_PER_N : 1) > kCautiousFromRound) ? n / (PQP_CAUTIOUS_PER_N > 0 ? PQP_CAUTIOUS_PER_N : 1) : kCautiousFromRound;
+        //  them on single moves - one QP in ~16 000 of 300 waypoints then never completed a polish, 868 reduced solves; first attempt only: 83.  A switch
+        //  at round n / 16 on long paths cures that QP and a 368-solve one at 200 waypoints too, but BASELINE configs[4]'s batch holds a QP that then
+        //  wanders: 551 k instead of 690 k scenarios/s - round 3 records)
+        const int cautious_from = kCautiousFromRound;
         double res[6] = {0, 0, 0, 0, 0, 0};
         int pass = 0;
         // per-pass state of the hot loop
@@ -2049,7 +2037,7 @@ struct PathQp {
                         //  cycle: over 16 scenario seeds the slowest QP of a batch of 1024 went from 46-121 reduced solves to 39-66, the headline of the
                         //  two straggler seeds from 1.91 / 2.72 M to 2.79 / 3.12 M paths/s, one launch at a time from 1.03-1.96 M to 1.68-2.19 M, the
                         //  mean cost stayed - profiles/r03x_seed_sweep.txt; 7 and 9-12 instead of 8: seed 6's straggler survives from 9 on, 7 costs 2 %)
-                        if ((stall >= 3 || (round + 1 >= cautious_from && !(PQP_FIRST_ATTEMPT_ONLY && prm.polish_every > 0 && it > prm.polish_every))) && !conservative) { conservative = true; best = viol; stall = 0; }
+                        if ((stall >= 3 || (round + 1 >= cautious_from && !(prm.polish_every > 0 && it > prm.polish_every))) && !conservative) { conservative = true; best = viol; stall = 0; }
                         round += 1;
                         // (the attempts after a pass's first periodic one start from a better ADMM iterate and get half the rounds:
                         // when those are not enough the rounds are usually cycling, and every further one is wasted.  A quarter

@@ -36,15 +36,6 @@
 #include <cstdio>
 #endif
 
-#ifndef PQP_LQ_MU0
-#define PQP_LQ_MU0 0.1
-#endif
-#ifndef PQP_LQ_SIGMA_HI
-#define PQP_LQ_SIGMA_HI 0.2
-#endif
-#ifndef PQP_LQ_SIGMA_LO
-#define PQP_LQ_SIGMA_LO 0.05
-#endif
 namespace pqp {
 namespace lq {
 
@@ -60,8 +51,8 @@ constexpr int kIpmMaxIter = 100;
 constexpr int kPolishMaxRounds = 12;
 
 // reciprocal: the hardware seed (4.6e-8, tools/probes/rcp_probe.hip) + ONE Newton step = 2.2e-15 relative - a third fewer instructions than
-// pqp::rcp's two steps in a kernel whose row arithmetic is mostly reciprocals (PQP_STREAM_RCP2: the two-step one, for A/B runs)
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(PQP_STREAM_RCP2)
+// pqp::rcp's two steps in a kernel whose row arithmetic is mostly reciprocals (two steps: -2 %, profiles/r03a_stream_first.txt)
+#if defined(__HIP_DEVICE_COMPILE__)
 PQP_HD double rcpq(double x) {
     const double r = __builtin_amdgcn_rcp(x);
     return fma(fma(-x, r, 1.0), r, r);
@@ -70,13 +61,9 @@ PQP_HD double rcpq(double x) {
 PQP_HD double rcpq(double x) { return rcp(x); }
 #endif
 
-// The sweeps of the solver as functions of their own on the device (PQP_LQ_NOINLINE): the solver object then lives in the lane's private
-// memory between them and every sweep gets a register allocation of its own, instead of one allocation over the whole inlined solve.
-#if defined(__HIP_DEVICE_COMPILE__) && defined(PQP_LQ_NOINLINE)
-#define PQP_SWEEP __device__ __attribute__((noinline))
-#else
+// The sweeps of the solver are inlined into one kernel body (as functions of their own - the solver object then lives in the lane's private
+// memory between them - 280 registers instead of 512 and 1.25x slower: profiles/r03a_stream_first.txt)
 #define PQP_SWEEP PQP_HD
-#endif
 
 // a two-sided row of the interior-point rounds: value, slacks to the two bounds, multipliers of the two bounds
 struct Row { double g, tl, tu, zl, zu; };
@@ -299,10 +286,7 @@ struct Solver {
             }
         }
     }
-#ifndef PQP_STREAM_DEPTH
-#define PQP_STREAM_DEPTH 1
-#endif
-    static constexpr int kDepth = PQP_STREAM_DEPTH;
+    static constexpr int kDepth = 1;         // (2 / 3 / 4 / 6 waypoints ahead: slower at every depth - spills; profiles/r03a_stream_first.txt)
 
     // what a sweep reads per waypoint
     struct Box { double lof, upf, lor, upr; };
@@ -465,7 +449,7 @@ struct Solver {
     }
     // after the initial solve: the interior-point state of every row, strictly inside its box where the row has a slack
     PQP_SWEEP void forward_init() {
-        const double theta = 0.05, mu0 = PQP_LQ_MU0;
+        const double theta = 0.05, mu0 = 0.1;
         double x[3] = {x0[0], x0[1], x0[2]};
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         auto start = [&](double v, double lo, double up, bool slack) {
@@ -641,7 +625,7 @@ struct Solver {
             //  line - crawls: 2 % of residual per iteration.  Every QP of the bench distributions is feasible within 12 iterations; one that
             //  has not shed 90 % of its initial residual after 30 gives up as PQP_STATUS_MAX_ITER instead of holding its wavefront for 100)
             while (!(mu < mu_stop && res < 1e-6) && it < kIpmMaxIter && stall < 6 && slow < 3 && !(it >= 30 && res > 0.1 * res0 && res > 1e-6)) {
-                const double sigma = (first || alpha <= 0.9) ? PQP_LQ_SIGMA_HI : PQP_LQ_SIGMA_LO;
+                const double sigma = (first || alpha <= 0.9) ? 0.2 : 0.05;
                 const double sm = sigma * mu;
                 backward<MODE_IPM>(sm);
                 forward_ipm(sm);

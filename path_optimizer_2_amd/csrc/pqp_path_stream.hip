@@ -10,12 +10,10 @@
 #include "pqp_path_lq.hpp"
 
 namespace pqp {
-#ifndef PQP_STREAM_OCC
-#define PQP_STREAM_OCC 1
-#endif
-__global__ void __launch_bounds__(64, PQP_STREAM_OCC) path_stream_kernel(const lq::Args a) {
-    // (blockDim.x = lanes per wavefront in use: 64, or 32 - half-filled wavefronts, two per SIMD: PQP_STREAM_LANES)
-    const int lanes = (int)blockDim.x;
+// (one wavefront per SIMD: the whole 512-register budget; two / four per SIMD spill and lose, half-filled wavefronts two per SIMD lose 1.5x -
+//  profiles/r03a_stream_first.txt)
+__global__ void __launch_bounds__(64, 1) path_stream_kernel(const lq::Args a) {
+    const int lanes = 64;
     // (Sorting the QPs by the sweeps they took in the previous solve, so that a wavefront's 64 lanes finish together, was built and
     // measured: 11 % less traffic and 14 % fewer instructions, the same 10.7 ms at 65 536 QPs - every wavefront is resident at once and the
     // launch lasts as long as its slowest one - and its ordering kernel waited milliseconds for a free slot behind a second launch in
@@ -29,12 +27,9 @@ __global__ void __launch_bounds__(64, PQP_STREAM_OCC) path_stream_kernel(const l
 
 }  // namespace pqp
 
-#ifndef PQP_STREAM_LANES
-#define PQP_STREAM_LANES 64
-#endif
 extern "C" hipError_t pqp_stream_launch(const pqp::lq::Args* a, int waves, void* stream) {
     (void)waves;
-    const int lanes = PQP_STREAM_LANES;
+    const int lanes = 64;
     hipLaunchKernelGGL(pqp::path_stream_kernel, dim3((a->batch + lanes - 1) / lanes), dim3(lanes), 0, (hipStream_t)stream, *a);
     return hipGetLastError();
 }

@@ -12,8 +12,10 @@ LIB = os.path.join(CSRC, "libpqp_hip_timing.so" if MASK is None else f"libpqp_hi
 
 
 def build():
-    import __graft_entry__ as g
-    g.build_hip(defines=["PQP_TIMING"] + ([] if MASK is None else [f"PQP_TIMING_MASK={MASK}"]), out=LIB)
+    """The library with the device-clock instrumentation of pqp_path_lane.hpp compiled in (a debug build of its own, one hipcc call)."""
+    defs = ["-DPQP_TIMING"] + ([] if MASK is None else [f"-DPQP_TIMING_MASK={MASK}"])
+    srcs = [os.path.join(CSRC, f) for f in ("pqp_kernels.hip", "pqp_path_stream.hip", "pqp_multi.cpp")]
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *defs, "-o", LIB, *srcs, "-lpthread", "-ldl"], cwd=CSRC, check=True)
 
 
 if __name__ == "__main__":
