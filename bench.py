@@ -744,8 +744,8 @@ def main():
                        "kernel": "path_stream_kernel" if stream else "path_solve_kernel",
                        "scenarios_per_step": f"{n_var} variants cycled: the batch and its +-5 % jittered planning cycles (synth.jitter_batch)" if pipe is None and n_var > 1 else "the identical batch every step",
                        "polish_every": prm.polish_every, "adaptive_rho_interval": prm.adaptive_rho_interval, "check_termination": prm.check_termination,
-                       "ruiz_passes": abs(prm.scaling), "ruiz_evaluated_on": "one interior waypoint's blocks, taken by every waypoint (pqp_params.scaling < 0: the same "
-                       "D, E, c bit for bit)" if prm.scaling < 0 else "every waypoint (OSQP's passes)", "polish_lazy": prm.polish_lazy,
+                       "ruiz_passes": abs(prm.scaling), "ruiz_evaluated_on": "one interior waypoint's blocks, taken by every waypoint (pqp_params.scaling < 0: a valid "
+                       "diagonal scaling, equal to the full passes' D, E, c on these scenario families)" if prm.scaling < 0 else "every waypoint (OSQP's passes)", "polish_lazy": prm.polish_lazy,
                        "polish_refine_iter": args.polish_refine, "polish_max_rounds": args.polish_max_rounds, "polish_warm_set": args.polish_warm_set,
                        "passes": "cold solve + 1 re-linearised warm re-solve (PathOptimizer::optimizePath)",
                        "qp_start_order": "most expensive first by the previous step's cost (PQP_OPT_ORDER_BY_COST)" if cost_order else "index order",

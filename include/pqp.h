@@ -115,9 +115,12 @@ typedef struct pqp_params {
     double alpha;                     /* 1.6   */
     int32_t max_iter;                 /* 4000  */
     int32_t scaling;                  /* 10 Ruiz passes (OSQP's default).  k < 0 (path QP only; production: -4): |k| passes of the same equilibration
-                                         evaluated on ONE interior waypoint's blocks and taken by every waypoint - the path QP's matrix repeats
-                                         from waypoint to waypoint, and for a pass linearised around the reference line the result is bit for
-                                         bit what |k| full passes give (no exchange, no reduction: ~1 us instead of ~2 us per pass) */
+                                         evaluated on ONE interior waypoint's blocks and taken by every waypoint (no exchange, no reduction: ~1 us
+                                         instead of ~2 us per pass).  A valid positive diagonal scaling - any is - that equals what |k| full passes
+                                         give on the tested scenario families (uniform spacing, default flags, a pass linearised around the
+                                         reference line); it ignores what only single waypoints carry (first / last waypoint's rows, rough rows,
+                                         varied spacing).  Meant for handles with polish != 0, whose result does not depend on the metric: with
+                                         polish == 0 the eps-accurate iterates then differ from OSQP's.  |k| <= 64 (pqp_set_params). */
     int32_t adaptive_rho;             /* 1     */
     int32_t adaptive_rho_interval;    /* 100 (OSQP's "auto" value without wall-clock profiling) */
     double adaptive_rho_tolerance;    /* 5     */

@@ -209,6 +209,7 @@ def _ptr(a):
 
 
 OPT_STORE_WARM, OPT_ORDER_BY_COST, OPT_RESERVE_CUS, OPT_STREAM_BATCH, OPT_CARRY_CYCLES, OPT_CHAIN_GRAPH = 1, 2, 3, 4, 5, 6
+KERNEL_NONE, KERNEL_LANE_PER_WAYPOINT, KERNEL_LANE_PER_QP = 0, 1, 2      # pqp_last_path_kernel
 SMOOTHING_TENSION2, SMOOTHING_TENSION = 0, 1
 
 

@@ -75,6 +75,7 @@ BaseSolver::~BaseSolver() {
 void BaseSolver::setDevice(int device) {
     if (device == device_ || device < 0) return;
     if (handle_) { if (cache_handles_) pool().park(device_, handle_); else pqp_destroy(handle_); handle_ = nullptr; }
+    solved_once_ = false;          // (the next handle - possibly a pooled one with another instance's warm state - has not seen this instance's cold solve)
     device_ = device;
 }
 
@@ -121,8 +122,10 @@ bool BaseSolver::run(const std::vector<SlState>& lin, bool warm, std::vector<SlS
         std::fprintf(stderr, "BaseSolver: %s\n", pqp_last_error());
         return false;
     }
-    if (status != PQP_STATUS_SOLVED) return false;                           // osqp-eigen: solve() true only for "solved"
+    // the cold solve was launched on this handle: its warm state is this instance's own, whatever the status - the reference's solver stays
+    // initialised after a solve() that ends at max_iter or infeasible, and updateProblemFormulationAndSolve still runs (base_solver.cpp:97-110)
     solved_once_ = true;
+    if (status != PQP_STATUS_SOLVED) return false;                           // osqp-eigen: solve() true only for "solved"
     out->clear();                                                            // base_solver.cpp:266
     out->reserve(n_);
     for (size_t i = 0; i < n_; ++i) {                                        // base_solver.cpp:269-287: s, v, a stay 0

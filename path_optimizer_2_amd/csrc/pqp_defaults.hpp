@@ -67,9 +67,9 @@ inline void production_params(pqp_params* p) {
     p->scaling = -4;                                // 4 Ruiz passes instead of OSQP's 10: the polish returns the exact optimum whatever the
                                                     // metric, the ADMM iterations before it only have to predict the active set (+0.5 % solves,
                                                     // -6 passes of 2.5 us: +4.5 % paths/s, profiles/r02h_policy_sweep.txt).  Negative (round 4):
-                                                    // the passes evaluated on one interior waypoint's blocks and taken by every waypoint - bit
-                                                    // for bit the same D, E, c for a pass linearised around the reference line, without the
-                                                    // passes' exchanges and reductions (+1.2 % paths/s, profiles/r04l_nominal_scaling_ab.txt)
+                                                    // the passes evaluated on one interior waypoint's blocks and taken by every waypoint - on
+                                                    // the tested scenario families the same D, E, c as the full passes, without their
+                                                    // exchanges and reductions; the polish makes the result independent of it (+1.2 % paths/s, profiles/r04l_nominal_scaling_ab.txt)
     p->adaptive_rho_interval = 8;
     p->check_termination = 8;
     p->polish = 1;

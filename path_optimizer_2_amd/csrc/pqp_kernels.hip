@@ -576,7 +576,7 @@ struct pqp_handle {
     // mode - no timing events, the path solve resets its ticket counter inside the graph
     bool capturing = false;
     int opt_chain_graph = 0;
-    struct ChainGraph { std::vector<unsigned char> key; hipGraphExec_t exec = nullptr; int seen = 0; bool failed = false; unsigned long long ticket_after = 0; };
+    struct ChainGraph { std::vector<unsigned char> key; hipGraphExec_t exec = nullptr; bool failed = false; bool lane_launch = false; unsigned long long ticket_after = 0; };
     std::vector<ChainGraph> chain_graphs;
     int warm_batch = 0, warm_n = 0;
     bool warm_stored = false;                   // the last solve wrote its final iterate to wx / wy / wye
@@ -649,6 +649,9 @@ int pqp_destroy(pqp_handle* h) {
     if (!h) return PQP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    // (captured chains of OTHER handles may hold this handle's workspaces and events - the smoother handle of a pair: their keys carry the
+    //  allocation generation, so none of them is replayed after this)
+    g_alloc_generation.fetch_add(1, std::memory_order_relaxed);
     for (auto& g : h->chain_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     h->chain_graphs.clear();
     for (DevBuf* b : {&h->sm_act[0], &h->sm_act[1], &h->stream_ws, &h->chain_d, &h->chain_i, &h->wscale, &h->ticket, &h->cost_key, &h->cost_hist, &h->order, &h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
@@ -667,6 +670,7 @@ int pqp_destroy(pqp_handle* h) {
 
 int pqp_set_params(pqp_handle* h, const pqp_params* params) {
     if (!h || !params) return fail(PQP_ERR_INVALID, "pqp_set_params: null argument");
+    if (params->scaling < -64 || params->scaling > 64) return fail(PQP_ERR_INVALID, "pqp_set_params: |scaling| (equilibration passes) beyond 64");
     h->prm = *params;
     return PQP_OK;
 }
@@ -1114,6 +1118,10 @@ SmShape sm_shape(int type, int n) {
 // shared sparsity of a smoother QP in the interleaved variable order: integer host logic (like pqp_path_sizes)
 int sm_upload_structure(pqp_handle* h, int type, int n) {
     if (h->b_struct_type == type && h->b_struct_n == n) return PQP_OK;
+    // a host -> device copy from vectors that go out of scope + a synchronise: not something a capturing stream may do.  The capture of
+    // pqp_optimize_path_device is abandoned cleanly (the body fails, the call falls back to plain launches and never captures these arguments again:
+    // a chain whose smoothers alternate between two structure types on the generic core uploads on every call)
+    if (h->capturing) return fail(PQP_ERR_INVALID, "smoother structure upload inside a graph capture");
     const SmShape sh = sm_shape(type, n);
     std::vector<int> acol((size_t)sh.nc * pqp::kRMax, -1), trow((size_t)sh.nv * pqp::kCMax, -1), tslot((size_t)sh.nv * pqp::kCMax, 0);
     auto row = [&](int r, int c0, int c1, int c2) { int* a = &acol[(size_t)r * pqp::kRMax]; a[0] = c0; a[1] = c1; a[2] = c2; };

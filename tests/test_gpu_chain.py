@@ -287,3 +287,54 @@ def test_chain_replayed_as_a_hip_graph_is_bit_identical(hip_lib):
         for g in (1, 2):
             for a, b_ in zip(results[0][k], results[g][k]):
                 np.testing.assert_array_equal(a, b_)
+
+
+@pytest.mark.gpu
+def test_chain_graph_on_the_lane_per_qp_kernel_leaves_the_ticket_counter_alone(hip_lib):
+    """A captured chain whose path solve runs on path_stream_kernel (PQP_OPT_STREAM_BATCH reached) never touches the lane-per-waypoint kernel's
+    ticket counter: plain pqp_path_solve calls on the same handle between two replays keep working (round 4's replay rewound the host's
+    ticket base to the value at capture time - the next plain launch then drew only tickets beyond its batch and solved nothing), and the
+    replays stay bit-identical to plain launches."""
+    import torch
+    from path_optimizer_2_amd.synth import make_batch
+    B = 24
+    sc = _scenarios(B, seed=5)
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    p = lambda x: capi.C.c_void_p(x.data_ptr())
+    d_np, d_tg, d_map = t(sc["n_pts"], np.int32), t(sc["target"], np.float64), t(sc["map_of"], np.int32)
+    d_dist = t(np.transpose(sc["dist"], (0, 2, 1)), np.float32)
+    plain = make_batch(16, 80)
+    ref_h = capi.Handle(capi.production_params(), device=0, max_batch=16, max_n=80)
+    want = ref_h.solve(plain["ref"], plain["bounds"], plain["scal"], passes=1)
+    ref_h.close()
+    results = {}
+    for graph in (0, 1):
+        h = capi.Handle(capi.production_params(), device=0, max_batch=B, max_n=256)
+        hs = capi.Handle(_smoother_params(), device=0, max_batch=B, max_n=128)
+        h.set_option(capi.OPT_STORE_WARM, 0); h.set_option(capi.OPT_STREAM_BATCH, 1); h.set_option(capi.OPT_CHAIN_GRAPH, graph)
+        cfg = h.chain_config(raw_max=64, sample_max=48, layer_max=32, n_max=128)
+        d_pts, d_st = t(sc["pts"], np.float64), t(sc["start"], np.float64)
+        out = torch.zeros((B, cfg.n_max, 7), dtype=torch.float64, device=dev)
+        n_out, status, stage, iters = (torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(4))
+        got = []
+        for cycle in range(6):
+            h._check(h.lib.pqp_optimize_path_device(h._h, hs._h, capi.C.byref(cfg), B, sc["pts"].shape[1], p(d_pts), p(d_np), p(d_st), p(d_tg), p(d_dist), p(d_map),
+                                                    capi.C.byref(sc["geom"]), None, p(out), p(n_out), p(status), p(stage), p(iters)))
+            h.sync(); hs.sync()
+            assert h.last_path_kernel() == capi.KERNEL_LANE_PER_QP
+            got.append((out.cpu().numpy().copy(), n_out.cpu().numpy().copy(), status.cpu().numpy().copy()))
+            # plain solves on the lane-per-waypoint kernel in between (the option is put back before the next chain call: same key)
+            h.set_option(capi.OPT_STREAM_BATCH, 0)
+            for _ in range(1 + cycle % 2):
+                r = h.solve(plain["ref"], plain["bounds"], plain["scal"], passes=1)
+                assert h.last_path_kernel() == capi.KERNEL_LANE_PER_WAYPOINT
+                assert (r["status"] == 1).all(), (graph, cycle, r["status"])
+                np.testing.assert_array_equal(r["out"], want["out"])
+            h.set_option(capi.OPT_STREAM_BATCH, 1)
+        results[graph] = got
+        h.close(); hs.close()
+    assert (results[0][0][2] == 0).sum() >= B // 2
+    for k in range(6):
+        for a, b_ in zip(results[0][k], results[1][k]):
+            np.testing.assert_array_equal(a, b_)
