@@ -15,7 +15,7 @@ still one pass over one whole batch, and K steps are timed); --inflight 1 and it
 Consecutive steps solve SIMILAR, not identical, batches (--variants 8: the scenarios one planning cycle later, synth.jitter_batch: corridor
 sides and start state scaled by 1 +- 5 %), so that the most-expensive-first start order (previous step's cost) has no perfect foresight;
 `secondary.identical_batch_every_step` is round 2's headline (the same batch re-solved every step).
-Batches of at least 24 576 QPs (PQP_OPT_STREAM_BATCH) run on the lane-per-QP kernel (path_stream_kernel: HBM-streaming, its roofline is
+Batches of at least 20 480 x max(1, N / 80)^2 QPs (PQP_OPT_STREAM_BATCH, the measured crossover) run on the lane-per-QP kernel (path_stream_kernel: HBM-streaming, its roofline is
 measured traffic): `--config 3 --batch 65536` is configs[3]'s whole batch on one GPU, timed in every default run under
 `secondary.configs3_whole_batch_one_gpu_stream_kernel`.
 Solver setting: the engine's production setting (pqp_production_params: ADMM to eps 1e-4 + KKT-verified polish — every returned path
@@ -277,7 +277,9 @@ def main():
     total = batch * world
     polish = not args.no_polish and not args.reference_setting
     cost_order = not args.no_cost_order
-    STREAM_BATCH = 24576           # the handle's default PQP_OPT_STREAM_BATCH (include/pqp.h): from here on the lane-per-QP kernel runs
+    # the handle's default PQP_OPT_STREAM_BATCH (include/pqp.h: the measured crossover of the two kernels, 20 480 x max(1, n / 80)^2 QPs):
+    # from here on the lane-per-QP kernel runs
+    STREAM_BATCH = int(20480.0 * max(1.0, n / 80.0) ** 2)
     stream = polish and cfg_id != 4 and batch >= STREAM_BATCH
 
     def production(**over):
@@ -704,7 +706,7 @@ def main():
                                  "= x kernels running at a time (two launches in flight share the chip).  A MODEL, not traffic: the iterates of path_solve_kernel are "
                                  "register / LDS resident, it is bound by fp64 VALU issue + LDS latency (roofline_issue); what HBM really moved is `traffic`, "
                                  "hbm_measured_frac = traffic / kernel time / 8 TB/s.  The kernel whose roofline IS measured traffic is path_stream_kernel "
-                                 "(batches >= 24 576: secondary.configs3_whole_batch_one_gpu, `bench.py --config 3 --batch 65536`)")
+                                 "(batches >= 20 480 at N = 80: secondary.configs3_whole_batch_one_gpu, `bench.py --config 3 --batch 65536`)")
         if secondary and secondary.get("plain_admm_eps_1e-4") and not stream:
             # what the model says about the solver the metric names: OSQP's plain ADMM streaming its data from HBM every iteration
             its = secondary["plain_admm_eps_1e-4"]["admm_iters"]["mean"]
@@ -762,6 +764,10 @@ def main():
         if scaling_ref is not None and "error" not in scaling_ref:
             line["weak_scaling_efficiency"] = line["value"] / (world * scaling_ref["shard_alone_on_one_gpu"]["value"])
             line["strong_scaling_vs_one_gpu_whole_batch"] = line["value"] / scaling_ref["whole_batch_on_one_gpu"]["value"]
+            # north_star's "scaling 1 -> N GPUs" read as STRONG scaling: the whole job (N shards on N GPUs) against the same total batch kept
+            # on ONE GPU with the kernel this library picks for that size there - next to "scaling": "weak" (per-GPU work fixed), which
+            # is how the ranks are loaded
+            line["scaling_strong"] = line["strong_scaling_vs_one_gpu_whole_batch"]
         if scaling_ref is not None:
             line["scaling_reference"] = scaling_ref
         if info_np is not None and stream:

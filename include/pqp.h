@@ -201,13 +201,15 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *   PQP_OPT_RESERVE_CUS (default 0)    compute units the path QP's persistent workgroups leave free.  Their wavefronts own a SIMD's whole
  *                                      register file, so kernels of another stream (the smoother chain of the next batch, configs[4]) only
  *                                      get onto the chip when a unit is left to them.
- *   PQP_OPT_STREAM_BATCH (default 24 576; 0: never)  cold solves (warm == 0) of at least this many QPs on a handle with polish != 0 and
+ *   PQP_OPT_STREAM_BATCH (default -1 = by measurement: 20 480 x max(1, n / 80)^2 - the measured crossover of the two kernels on one MI355X,
+ *                                      18.7 k QPs at 80 waypoints, ~45 k at 120, profiles/r05a_crossover_*; 0: never)
+ *                                      cold solves (warm == 0) of at least this many QPs on a handle with polish != 0 and
  *                                      PQP_OPT_STORE_WARM off run on the lane-per-QP kernel (one QP per lane, 64 per wavefront, the
  *                                      per-waypoint state streamed through a batch-interleaved workspace of 240 n bytes per QP in HBM;
  *                                      csrc/pqp_path_lq.hpp): the path QP as a linear-quadratic control problem, interior-point rounds +
  *                                      active-set rounds whose last round is the KKT test, i.e. the same exact optimum as the lane-per-
  *                                      waypoint kernel's verified polish.  It wins where the batch fills the chip's 65 536 lanes (65 536
- *                                      QPs of 80 waypoints: 1.8-2.0x, measured crossover ~20 000); it keeps no warm state
+ *                                      QPs of 80 waypoints: 1.9x); it keeps no warm state
  *                                      (hence the PQP_OPT_STORE_WARM condition; a start curvature outside its box by no more than eps_abs + eps_rel * bound is projected
  *                                      onto the box - OSQP at that eps calls such a QP solved -, by more: PQP_STATUS_PRIMAL_INFEASIBLE), iters[] counts its interior-point iterations and info[] =
  *                                      {row residual, complementarity, iterations of the first pass, iterations, solved passes, active-set

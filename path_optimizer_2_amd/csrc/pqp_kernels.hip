@@ -576,7 +576,7 @@ struct pqp_handle {
     // mode - no timing events, the path solve resets its ticket counter inside the graph
     bool capturing = false;
     int opt_chain_graph = 0;
-    struct ChainGraph { std::vector<unsigned char> key; hipGraphExec_t exec = nullptr; bool failed = false; bool lane_launch = false; unsigned long long ticket_after = 0; };
+    struct ChainGraph { std::vector<unsigned char> key; hipGraphExec_t exec = nullptr; bool failed = false; bool lane_launch = false; int path_kernel = 0; unsigned long long ticket_after = 0; };
     std::vector<ChainGraph> chain_graphs;
     int warm_batch = 0, warm_n = 0;
     bool warm_stored = false;                   // the last solve wrote its final iterate to wx / wy / wye
@@ -588,7 +588,7 @@ struct pqp_handle {
     unsigned long long ticket_next = 0;
     long long solves = 0;                       // solve launches so far (parity selects the cost histogram being filled)
     int hist_batch = 0, hist_n = 0;             // shape of the solve whose costs cost_key / cost_hist hold (0: none)
-    int opt_store_warm = 1, opt_order_by_cost = 0, opt_reserve_cus = 0, opt_stream_batch = 24576, opt_carry = 0;
+    int opt_store_warm = 1, opt_order_by_cost = 0, opt_reserve_cus = 0, opt_stream_batch = -1, opt_carry = 0;      // (opt_stream_batch < 0: stream_batch_auto(n))
     int stream_last_batch = 0, stream_last_n = 0;      // shape of the last path_stream_kernel launch (what its workspace still holds)
     int last_path_kernel = 0;                          // pqp_path_kernel of the last pqp_path_solve* launch (pqp_last_path_kernel)
     DevBuf sm_act[2];                                  // final active sets of the exact TensionSmoother / postSmooth kernels (PQP_OPT_CARRY_CYCLES)
@@ -681,7 +681,7 @@ int pqp_set_option(pqp_handle* h, int option, int value) {
         case PQP_OPT_STORE_WARM: h->opt_store_warm = value ? 1 : 0; return PQP_OK;
         case PQP_OPT_ORDER_BY_COST: h->opt_order_by_cost = value ? 1 : 0; h->hist_batch = 0; return PQP_OK;
         case PQP_OPT_RESERVE_CUS: h->opt_reserve_cus = value < 0 ? 0 : value; return PQP_OK;
-        case PQP_OPT_STREAM_BATCH: h->opt_stream_batch = value < 0 ? 0 : value; return PQP_OK;
+        case PQP_OPT_STREAM_BATCH: h->opt_stream_batch = value < 0 ? -1 : value; return PQP_OK;
         case PQP_OPT_CARRY_CYCLES: h->opt_carry = value ? 1 : 0; h->stream_last_batch = 0; h->sm_act_batch[0] = h->sm_act_batch[1] = 0; return PQP_OK;
         case PQP_OPT_CHAIN_GRAPH: h->opt_chain_graph = value == 2 ? 2 : (value ? 1 : 0); return PQP_OK;
         default: return fail(PQP_ERR_INVALID, "pqp_set_option: unknown option");
@@ -844,6 +844,16 @@ static int path_stream_impl(pqp_handle* h, int batch, int n, const int32_t* n_of
     return PQP_OK;
 }
 
+// PQP_OPT_STREAM_BATCH "auto": the batch size from which the lane-per-QP kernel is the faster one, by measurement on one MI355X
+// (profiles/r05a_crossover_n80.txt, r05a_crossover_n120.txt: 18.7 k QPs at 80 waypoints, ~45 k at 120).  A lone wavefront of that kernel
+// takes sweeps x n waypoint steps whatever the batch (5.5 ms at n = 80, 10.5 ms at n = 120), the lane-per-waypoint kernel's time per QP hardly
+// depends on n: the crossover grows like n^2.
+static int stream_batch_auto(int n) {
+    const double r = n > 80 ? (double)n / 80.0 : 1.0;
+    const double t = 20480.0 * r * r;
+    return t < 1.0e9 ? (int)t : 1000000000;
+}
+
 static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
                            const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters, double* info) {
     if (!h || !ref || !bounds || !scal || !out || batch < 1 || n < 2 || passes < 0)
@@ -855,7 +865,8 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     // (warm == 1 beyond 512 waypoints: the QP around `lin` is solved cold - its optimum is unique, a warm start only saves iterations -
     //  so BaseSolver::solve + updateProblemFormulationAndSolve work at any size; and there also a handle in the reference's ADMM setting
     //  gets the exact optimum: zero residuals meet OSQP's termination test at any eps)
-    if ((n > 512 && (!warm || lin)) || (h->prm.polish != 0 && !warm && !h->opt_store_warm && h->opt_stream_batch > 0 && batch >= h->opt_stream_batch))
+    const int stream_from = h->opt_stream_batch < 0 ? stream_batch_auto(n) : h->opt_stream_batch;
+    if ((n > 512 && (!warm || lin)) || (h->prm.polish != 0 && !warm && !h->opt_store_warm && stream_from > 0 && batch >= stream_from))
         return path_stream_impl(h, batch, n, n_of, ref, lin, bounds, scal, passes, out, status, iters, info);
     // PQP_OPT_CARRY_CYCLES on this kernel: a cold call (warm == 0, lin == NULL) of the shape of the handle's previous solve starts from
     // the final iterate, equilibration and active set that solve left in the warm state - the same scenarios one planning cycle later.

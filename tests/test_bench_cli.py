@@ -80,3 +80,4 @@ def test_two_ranks_through_the_launcher_path_on_one_gpu():
     assert ref["shard_alone_on_one_gpu"]["batch"] == 2048 and ref["whole_batch_on_one_gpu"]["batch"] == 4096 and ref["whole_batch_on_one_gpu"]["solved"] == 4096
     assert abs(d["weak_scaling_efficiency"] - d["value"] / (2 * ref["shard_alone_on_one_gpu"]["value"])) < 1e-9
     assert abs(d["strong_scaling_vs_one_gpu_whole_batch"] - d["value"] / ref["whole_batch_on_one_gpu"]["value"]) < 1e-9
+    assert d["scaling"] == "weak" and d["scaling_strong"] == d["strong_scaling_vs_one_gpu_whole_batch"]

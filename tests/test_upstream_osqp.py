@@ -1,0 +1,106 @@
+"""The one-command upstream pin (task 6): the oracle's optima against REAL OSQP.
+
+The reference solves its QPs with OsqpEigen / OSQP (base_solver.cpp:59-64,80-89), which this image does not hold (no osqp, no
+network): every solver-parity claim of this repo is "against the build's own OSQP-paper restatement" - DESIGN.md says "parity
+unpinned".  Anyone with `pip install osqp` turns that into "pinned" by running
+
+    python -m pytest tests/test_upstream_osqp.py -q
+
+These tests are SKIPPED when `osqp` cannot be imported (as here and on the GPU box).  They need no GPU: they compare what the
+oracle (oracle/pqp_oracle.py: the matrices exactly as BaseSolver assembles them, x* of the committed goldens) says with what OSQP
+returns for the same matrices - settings as base_solver.cpp:59-62 sets them (warm start on, verbosity off, OSQP defaults otherwise),
+eps tightened so that OSQP's answer is the optimum to 1e-7 rather than to its 2e-3."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+osqp = pytest.importorskip("osqp", reason="upstream OSQP is not installed in this image: parity stays 'unpinned' (DESIGN.md section 6)")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import pqp_oracle as O  # noqa: E402
+from path_optimizer_2_amd.synth import make_batch  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+TIGHT = dict(eps_abs=1e-9, eps_rel=1e-9, max_iter=400000)
+
+
+def osqp_solve(Pd, A, lo, up, warm=None, **over):
+    """One OSQP solve of min 1/2 x' diag(Pd) x s.t. lo <= A x <= up with the reference's call pattern (base_solver.cpp:59-64, 80-89:
+    settings -> data -> initSolver -> solve; :106-110: updateBounds / updateLinearConstraintsMatrix -> solve on the warm solver, which is
+    what `warm` = (x, y) of the previous solve stands for).  Written for the Python interface of OSQP 0.6.x and 1.x."""
+    n = len(Pd)
+    P = sp.triu(sp.diags(np.asarray(Pd, dtype=np.float64)), format="csc")
+    A = sp.csc_matrix(A)
+    q = np.zeros(n)
+    settings = dict(TIGHT)
+    settings.update(over)
+    m = osqp.OSQP()
+    lo = np.maximum(np.asarray(lo, dtype=np.float64), -1e30)       # OSQP_INFTY
+    up = np.minimum(np.asarray(up, dtype=np.float64), 1e30)
+    try:                      # 0.6.x names
+        m.setup(P=P, q=q, A=A, l=lo, u=up, verbose=False, warm_start=True, polish=False, **settings)
+    except TypeError:         # 1.x names
+        m.setup(P=P, q=q, A=A, l=lo, u=up, verbose=False, warm_starting=True, polishing=False, **settings)
+    if warm is not None:
+        m.warm_start(x=warm[0], y=warm[1])
+    r = m.solve()
+    status = r.info.status
+    return np.asarray(r.x), np.asarray(r.y), status
+
+
+@pytest.mark.parametrize("name", ["path_n8", "path_n80"])
+def test_golden_optima_are_what_osqp_returns(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    batch = g["ref"].shape[0]
+    worst = 0.0
+    for q in range(batch):
+        Pd, A, lo, up, sz = O.assemble_path_qp(g["ref"][q], g["lin"][q], g["bounds"][q], g["scal"][q])
+        # the committed matrices are these matrices (values at the structural pattern, bounds)
+        np.testing.assert_allclose(np.asarray(sp.csc_matrix(A)[g["rows"], g["cols"]]).ravel(), g["a_val"][q], rtol=0, atol=1e-13)
+        x, y, status = osqp_solve(Pd, A, lo, up)
+        assert str(status).startswith("solved"), status
+        n = g["ref"].shape[1]
+        worst = max(worst, float(np.abs(x[:3 * n] - g["x_star"][q][:3 * n]).max()))
+        c = O.kkt_certificate(sp.diags(Pd), np.zeros(sz["vars"]), A, lo, up, x, y)
+        assert max(c["pri"], c["stat"], c["comp"]) < 1e-6, c
+    assert worst <= 1e-6, worst
+
+
+def test_two_pass_pipeline_on_bench_scenarios_matches_osqp():
+    """PathOptimizer::optimizePath on 64 of bench.py's configs[1] scenarios: cold solve around (0, 0, k_ref), re-linearise, warm
+    re-solve (path_optimizer.cpp:124-161) - OSQP's final (l, d_heading) against the oracle's converged ones."""
+    b = make_batch(64, 80)
+    st = O.OsqpSettings(eps_abs=1e-10, eps_rel=1e-10, max_iter=200000)
+    worst = 0.0
+    for q in range(64):
+        want = O.solve_path(b["ref"][q], b["bounds"][q], b["scal"][q], st=st)[-1]["out"]
+        lin = O.first_linearization(b["ref"][q])
+        warm = None
+        for _ in range(2):
+            Pd, A, lo, up, sz = O.assemble_path_qp(b["ref"][q], lin, b["bounds"][q], b["scal"][q])
+            x, y, status = osqp_solve(Pd, A, lo, up, warm=warm)
+            assert str(status).startswith("solved"), status
+            out = O.unpack_path(x, b["ref"][q])
+            lin = out[:, 3:6].copy()
+            warm = (x, y)
+        worst = max(worst, float(np.abs(out[:, 3:5] - want[:, 3:5]).max()))
+    assert worst <= 1e-6, worst
+
+
+def test_reference_setting_iteration_counts_are_in_the_oracles_range():
+    """At the reference's own eps (2e-3, base_solver.cpp:61-62) OSQP and the restatement stop within a few checks of each other (OSQP's first
+    rho update is wall-clock dependent with profiling on, so the counts need not be equal) and at points 1e-2-close to the optimum."""
+    b = make_batch(16, 80)
+    st = O.OsqpSettings()
+    for q in range(16):
+        lin = O.first_linearization(b["ref"][q])
+        Pd, A, lo, up, sz = O.assemble_path_qp(b["ref"][q], lin, b["bounds"][q], b["scal"][q])
+        mine = O.osqp_admm(sp.diags(Pd), np.zeros(sz["vars"]), A, lo, up, st)
+        x, y, status = osqp_solve(Pd, A, lo, up, eps_abs=2e-3, eps_rel=2e-3, max_iter=4000)
+        assert str(status).startswith("solved"), status
+        assert float(np.abs(x[:240] - mine["x"][:240]).max()) < 5e-2
