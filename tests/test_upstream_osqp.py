@@ -73,7 +73,9 @@ def test_golden_optima_are_what_osqp_returns(name):
 
 def test_two_pass_pipeline_on_bench_scenarios_matches_osqp():
     """PathOptimizer::optimizePath on 64 of bench.py's configs[1] scenarios: cold solve around (0, 0, k_ref), re-linearise, warm
-    re-solve (path_optimizer.cpp:124-161) - OSQP's final (l, d_heading) against the oracle's converged ones."""
+    re-solve (path_optimizer.cpp:124-161) - OSQP's final (l, d_heading) against the oracle's converged ones.  (1e-5, not the single QP's 1e-6:
+    the second QP is built around the first one's solution, and two solvers' 1e-9-accurate first solutions already move its optimum by ~1e-6 on
+    paths with a nearly degenerate contact - measured between two tight runs of the oracle itself.  The parity bar is 1e-4.)"""
     b = make_batch(64, 80)
     st = O.OsqpSettings(eps_abs=1e-10, eps_rel=1e-10, max_iter=200000)
     worst = 0.0
@@ -89,7 +91,7 @@ def test_two_pass_pipeline_on_bench_scenarios_matches_osqp():
             lin = out[:, 3:6].copy()
             warm = (x, y)
         worst = max(worst, float(np.abs(out[:, 3:5] - want[:, 3:5]).max()))
-    assert worst <= 1e-6, worst
+    assert worst <= 1e-5, worst
 
 
 def test_reference_setting_iteration_counts_are_in_the_oracles_range():
