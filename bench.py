@@ -494,7 +494,7 @@ def main():
                 for ln in lns:
                     ln[0].set_params(p); ln[0].set_option(capi.OPT_ORDER_BY_COST, 1 if order else 0)
             for ln in lns:
-                ln[0].set_option(capi.OPT_CARRY_CYCLES, 1 if carry else 0)
+                ln[0].set_option(capi.OPT_CARRY_CYCLES, int(carry))          # (True: every QP, k >= 2: the previous launch's most expensive 1 / k only)
             k = [0]
 
             def one():
@@ -518,7 +518,7 @@ def main():
             info_rows = stream and p.polish != 0
             sweeps_mean = float(inf.cpu().numpy()[:, 6].mean()) if info_rows else None          # (of the last timed step on this handle)
             if carry and not stream:
-                kkt_carry = (float(inf.cpu().numpy()[:, 5].mean()), float(inf.cpu().numpy()[:, 6].mean()))
+                kkt_carry = (float(inf.cpu().numpy()[:, 5].mean()), float(inf.cpu().numpy()[:, 6].mean()), float(inf.cpu().numpy()[:, 5].max()))
             for ln in lns:
                 ln[0].set_option(capi.OPT_CARRY_CYCLES, 0)                  # (the checksum's step below is a cold one)
             hh.solve_device(batch, n, ref, variants[0][0], variants[0][1], o, passes=1, status=st, iters=it, info=inf)      # the checksum's step
@@ -537,7 +537,7 @@ def main():
             if info_rows:
                 r["riccati_sweeps_mean"] = sweeps_mean
             if carry and not stream:
-                r["kkt_solves_mean"], r["factorisations_mean"] = kkt_carry
+                r["kkt_solves_mean"], r["factorisations_mean"], r["kkt_solves_max"] = kkt_carry
             return r
         nfl = len(lanes)
         secondary = {
@@ -563,6 +563,12 @@ def main():
                    "on (same paths: the optimum is unique); the reference constructs a fresh solver per cycle, so `value` is measured without it")
             secondary["carry_cycles"] = dict(timed(prm, cost_order, args.steps, inflight=nfl, carry=True), setting="the headline setting with " + txt.format(nfl))
             secondary["carry_cycles_one_batch_at_a_time"] = dict(timed(prm, cost_order, args.steps, carry=True), setting="one launch after the other with " + txt.format(1))
+            if cost_order:
+                tails = ("PQP_OPT_CARRY_CYCLES = {0}: only the QPs that were among the most expensive 1/{0} of the handle's previous solve (by the cost keys the start order "
+                         "uses) start from their previous cycle's optimum, all others start cold; same paths; not `value` for the same reason")
+                secondary["carry_tails"] = dict(timed(prm, cost_order, args.steps, inflight=nfl, carry=8), setting="the headline setting with " + tails.format(8))
+                secondary["carry_tails_one_batch_at_a_time"] = dict(timed(prm, cost_order, args.steps, carry=8), setting="one launch after the other with " + tails.format(8))
+                secondary["carry_tails_quarter_one_batch_at_a_time"] = dict(timed(prm, cost_order, args.steps, carry=4), setting="one launch after the other with " + tails.format(4))
         if stream and n_var > 1:
             secondary["carry_cycles"] = dict(timed(prm, cost_order, args.steps, inflight=nfl, carry=True),
                                              setting="the headline setting with PQP_OPT_CARRY_CYCLES: the first pass of every QP starts from the optimum its slot had in the handle's "

@@ -134,7 +134,7 @@ typedef struct pqp_params {
                                          with iters = 0 where the QP's structure allows: TensionSmoother2's (equality rows only: a linear-
                                          quadratic control problem) by one Riccati sweep per scenario; with polish == 1 postSmooth's (a box
                                          QP in the offsets) and TensionSmoother's (a box QP in the lateral shifts) by a KKT-verified
-                                         active-set solve, one wavefront per scenario (up to 512 layers / points; beyond: the generic
+                                         active-set solve, one wavefront per scenario (up to 1024 layers / points; beyond: the generic
                                          core's active-set solve from the cold start, with ADMM + KKT-verified polish attempts as the
                                          fallback).  With polish == 2 QPs with inequality rows run the plain ADMM.  The path QP treats 2
                                          like 1 */
@@ -222,6 +222,12 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      1e-7 of the KKT test); on scenarios that moved by 5 %: configs[1] 4.0 M instead of 3.1 M paths/s and no stragglers
  *                                      (profiles/r03n_seed_sweep.txt, r03y_seed_sweep.txt); lane-per-QP kernel 14 -> 9 interior-point iterations per path.
  *                                      A QP that differs wildly from its slot's previous one is still solved (the start is then merely poor).
+ *                                      Value k = 2..64 ("tails", lane-per-waypoint kernel, needs PQP_OPT_ORDER_BY_COST): only the QPs that were among the most
+ *                                      expensive 1 / k of the handle's previous solve of the shape start from their previous optimum, all others start
+ *                                      cold - a launch lasts as long as its slowest QPs, and those are the ones a cold active-set search wanders on
+ *                                      (a carried QP keeps its cold cost key, one bin less per cycle, so that it stays among the carried ones).  configs[1], one
+ *                                      launch at a time: k = 8 2.47 M against 2.01 M paths/s cold, the slowest QP 29 instead of 48 reduced solves
+ *                                      (profiles/r05c_*).
  *                                      The exact TensionSmoother / postSmooth kernels (polish == 1) honour it too: a line's active-set rounds start from
  *                                      the set its slot ended with in the previous solve of the shape (16-31 rounds from the cold start, 2-3 from there).
  *   PQP_OPT_CHAIN_GRAPH (default 0)    pqp_optimize_path_device replays a captured hipGraph: the third call with the same arguments (pointers, sizes, configuration,
@@ -353,7 +359,7 @@ int pqp_smooth_tension2_device(pqp_handle* h, int batch, int n, const double* x_
                                int32_t* status, int32_t* iters, double* info);
 /* TensionSmoother::osqpSmooth    src/reference_path_smoother/tension_smoother.cpp:49-100; clearance = Map::getObstacleDistance
  * at each input point (the distance-map lookup itself, tension_smoother.cpp:168, stays on the caller's side; pqp_clearance_device does it).
- * 4 <= n <= 512 points.  Up to ~166 points a handle in the reference's ADMM setting (polish == 0) runs OSQP's iteration on the 9 x 9-block
+ * 4 <= n <= 1024 points (the reference: unbounded, one point per metre of line).  Up to ~166 points a handle in the reference's ADMM setting (polish == 0) runs OSQP's iteration on the 9 x 9-block
  * core; beyond that core's LDS capacity - and for polish == 1 at any size - the QP is solved exactly (iters = 0), which meets OSQP's
  * termination test at any eps. */
 int pqp_smooth_tension(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list,

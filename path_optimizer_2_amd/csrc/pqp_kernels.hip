@@ -162,6 +162,7 @@ struct DevCtx {
     template <int H> __device__ __forceinline__ static double lane_above(double v) { return dpp0<0x100 + H, 0xf>(v); }     // row_shl:H
     __device__ __forceinline__ static double prev_row_last(double v) { return dpp0<0x142, 0xe>(v); }                      // row_bcast:15
     __device__ __forceinline__ static double uni(double x) { return uniform(x); }      // a wave-uniform value that reaches control flow
+    __device__ __forceinline__ static int uni_int(int x) { return __builtin_amdgcn_readfirstlane(x); }
     Lane lane;
     double* shp;
     __device__ __forceinline__ long long clock() const { return (long long)wall_clock64(); }     // 100 MHz
@@ -223,8 +224,14 @@ __device__ void order_next_launch(const PathSolveArgs& args) {
     for (int b = threadIdx.x; b < kCostBins; b += nt) start[b] = __hip_atomic_load(args.cost_hist + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (threadIdx.x == 0) {                 // exclusive suffix sum over 256 bins: QPs in more expensive bins
-        int acc = 0;
-        for (int b = kCostBins - 1; b >= 0; --b) { const int c = start[b]; start[b] = acc; acc += c; }
+        int acc = 0, thr = kCostBins;
+        for (int b = kCostBins - 1; b >= 0; --b) {
+            const int c = start[b]; start[b] = acc;
+            if ((long long)(args.carry_tails > 1 ? args.carry_tails : 8) * acc < args.batch) thr = b;       // (the cheapest bin above which less than 1 / k of the batch lies)
+            acc += c;
+        }
+        // PQP_OPT_CARRY_CYCLES = k >= 2: the bin from which on a QP counts as one of the launch's expensive ones (read by the next launch's QPs)
+        __hip_atomic_store(args.cost_hist + kCostBins + 1, thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     for (int q = threadIdx.x; q < args.batch; q += nt) {
@@ -682,7 +689,7 @@ int pqp_set_option(pqp_handle* h, int option, int value) {
         case PQP_OPT_ORDER_BY_COST: h->opt_order_by_cost = value ? 1 : 0; h->hist_batch = 0; return PQP_OK;
         case PQP_OPT_RESERVE_CUS: h->opt_reserve_cus = value < 0 ? 0 : value; return PQP_OK;
         case PQP_OPT_STREAM_BATCH: h->opt_stream_batch = value < 0 ? -1 : value; return PQP_OK;
-        case PQP_OPT_CARRY_CYCLES: h->opt_carry = value ? 1 : 0; h->stream_last_batch = 0; h->sm_act_batch[0] = h->sm_act_batch[1] = 0; return PQP_OK;
+        case PQP_OPT_CARRY_CYCLES: h->opt_carry = value < 0 ? 0 : (value > 64 ? 64 : value); h->stream_last_batch = 0; h->sm_act_batch[0] = h->sm_act_batch[1] = 0; return PQP_OK;
         case PQP_OPT_CHAIN_GRAPH: h->opt_chain_graph = value == 2 ? 2 : (value ? 1 : 0); return PQP_OK;
         default: return fail(PQP_ERR_INVALID, "pqp_set_option: unknown option");
     }
@@ -874,7 +881,11 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     //  starts its common waypoints from where they were and the new ones from whatever the slot last held there - zero at first.)
     // (only on a handle whose polish returns the exact optimum: with polish == 0 - the reference's ADMM setting - a promoted call would end at an
     //  eps-accurate point that depends on the slot's previous QP, and pqp.h promises the cold solve's optimum to the 1e-7 of the KKT test)
-    if (h->opt_carry && h->prm.polish != 0 && !warm && !lin && h->warm_stored && h->warm_batch == batch && h->warm_n == n) warm = 1;
+    // (value k >= 2, "tails": only the QPs that were among the most expensive 1 / k of the previous launch - by the cost keys PQP_OPT_ORDER_BY_COST
+    //  keeps - start from there, the others start cold: what bounds a launch is its slowest QPs)
+    int carry_tails = 0;
+    if (h->opt_carry && h->prm.polish != 0 && !warm && !lin && h->warm_stored && h->warm_batch == batch && h->warm_n == n &&
+        (h->opt_carry < 2 || (h->opt_order_by_cost && h->hist_batch == batch && h->hist_n == n))) { warm = 1; carry_tails = h->opt_carry >= 2 ? h->opt_carry : 0; }
     if (n > 512) return fail(PQP_ERR_CAPACITY, "pqp_path_solve: warm == 1 beyond 512 waypoints needs the linearisation point (`lin`): the lane-per-QP kernel keeps no warm state");
     if (warm && (h->warm_batch != batch || h->warm_n != n || !h->warm_stored))
         return fail(PQP_ERR_INVALID, "pqp_path_solve: warm == 1 needs a previous solve with the same batch and n (with PQP_OPT_STORE_WARM on)");
@@ -924,6 +935,7 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     a.wsave = h->wsave.as<double>();
     a.wscale = h->wscale.as<double>();
     a.store_warm = (h->opt_store_warm || h->opt_carry) ? 1 : 0;
+    a.carry_tails = carry_tails;
     a.ticket = h->ticket.as<unsigned long long>();
     a.ticket_base = h->ticket_next;
     // inside a captured graph the launch cannot take its ticket base from a host counter that moves between replays: the graph resets the
@@ -1283,7 +1295,7 @@ static int smooth_tension_impl(pqp_handle* h, int batch, int n, const int32_t* n
     const SmShape sh9 = sm_shape(SM_TENSION, n);
     const pqp::BqLayout lay9{sh9.nv, sh9.nc, sh9.bw};
     const bool generic_fits = (size_t)lay9.total(false) * 8 <= 160 * 1024 && 64 * ((lay9.nbb() + 63) / 64) <= 1024;
-    if ((h->prm.polish == 1 || !generic_fits) && n <= 512) {
+    if ((h->prm.polish == 1 || !generic_fits) && n <= 1024) {
         // exact optima asked for (or the only kernel that holds the QP): the box QP in the lateral shifts alone, one wavefront per scenario (tension_exact_kernel)
         if (!status) return fail(PQP_ERR_INVALID, "pqp_smooth_tension: status is null");
         h->next_event_pair();
@@ -1303,7 +1315,11 @@ static int smooth_tension_impl(pqp_handle* h, int batch, int n, const int32_t* n
         else if (n <= 128) hipLaunchKernelGGL(pqp::tension_exact_kernel<2>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
         else if (n <= 256) hipLaunchKernelGGL(pqp::tension_exact_kernel<4>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
         else if (n <= 384) hipLaunchKernelGGL(pqp::tension_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
-        else hipLaunchKernelGGL(pqp::tension_exact_kernel<8>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
+        else if (n <= 512) hipLaunchKernelGGL(pqp::tension_exact_kernel<8>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
+        // (twelve / sixteen points per lane: the lane state no longer fits the registers - 1.8 / 3.3 KB of scratch per lane - but lines that long are
+        //  rare, a point per metre of reference line, and the recursion down the lanes, not the spills, is what their time goes to)
+        else if (n <= 768) hipLaunchKernelGGL(pqp::tension_exact_kernel<12>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
+        else hipLaunchKernelGGL(pqp::tension_exact_kernel<16>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
         PQP_HIP(hipGetLastError());
         if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
         h->timed = true;
@@ -1338,7 +1354,7 @@ static int post_smooth_impl(pqp_handle* h, int batch, int m, const int32_t* m_of
                             const double* vehicle_l, double* out_l, int32_t* status, int32_t* iters, double* info) {
     if (!h || !layers_s || !lb || !ub || !vehicle_l || !out_l || batch < 1 || m < 4) return fail(PQP_ERR_INVALID, "pqp_post_smooth: bad argument (m >= 4, reference_path_smoother.cpp:528)");
     PQP_HIP(hipSetDevice(h->device));
-    if (h->prm.polish == 1 && m <= 512) {
+    if (h->prm.polish == 1 && m <= 1024) {
         // exact optima asked for: the box QP in the offsets alone, one wavefront per scenario (post_exact_kernel)
         if (!status) return fail(PQP_ERR_INVALID, "pqp_post_smooth: status is null");
         h->next_event_pair();
@@ -1358,7 +1374,9 @@ static int post_smooth_impl(pqp_handle* h, int batch, int m, const int32_t* m_of
         else if (m <= 128) hipLaunchKernelGGL(pqp::post_exact_kernel<2>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
         else if (m <= 256) hipLaunchKernelGGL(pqp::post_exact_kernel<4>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
         else if (m <= 384) hipLaunchKernelGGL(pqp::post_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
-        else hipLaunchKernelGGL(pqp::post_exact_kernel<8>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
+        else if (m <= 512) hipLaunchKernelGGL(pqp::post_exact_kernel<8>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
+        else if (m <= 768) hipLaunchKernelGGL(pqp::post_exact_kernel<12>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
+        else hipLaunchKernelGGL(pqp::post_exact_kernel<16>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
         PQP_HIP(hipGetLastError());
         if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
         h->timed = true;

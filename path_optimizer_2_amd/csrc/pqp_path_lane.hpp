@@ -93,6 +93,8 @@ struct PathSolveArgs {
     int32_t* cost_key;      // [batch] or nullptr: bin << 24 | rank within the bin, written at the end of every QP
     int32_t* cost_hist;     // [256] QPs per cost bin (atomically counted) + [256] = workgroups that have finished this launch
     int32_t* order_next;    // [batch] the ticket -> QP map of the NEXT launch, written by the last workgroup to finish this one
+    int carry_tails;        // PQP_OPT_CARRY_CYCLES = k >= 2 (with warm == 1): only the QPs whose cost in the previous launch reached the bin
+                            // cost_hist[kCostBins + 1] - the most expensive 1 / k - start from their previous optimum, the others start cold
     pqp_params prm;
 };
 enum { kCostBins = 256 };
@@ -465,9 +467,10 @@ PQP_HD bool late_certificate(LC& c, double* sh, int T, int t, double* snap, bool
 // most-expensive-first order: key = bin << 24.  Neither the counter update nor the store returns anything the QP waits for (a returning
 // atomic on device-scope memory is ~2 us of exposed latency at the end of every QP); the rank within a bin is handed out by the
 // workgroup that writes the next launch's order.
-PQP_HD void record_cost(const PathSolveArgs& a, int qp, int cost) {
+PQP_HD void record_cost(const PathSolveArgs& a, int qp, int cost, int at_least_bin = -1) {
     int bin = cost >> 3;
     bin = bin < kCostBins - 1 ? bin : kCostBins - 1;
+    bin = bin > at_least_bin ? bin : at_least_bin;
 #if defined(__HIP_DEVICE_COMPILE__)
     (void)__hip_atomic_fetch_add(a.cost_hist + bin, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // (device-scope store: the last workgroup of the launch, on whatever XCD, reads it with a device-scope load)
@@ -1794,7 +1797,7 @@ struct PathQp {
             if (i0 == 0) {
                 PQP_SUB(0, load());
                 rho = prm.rho;
-                if (A.warm) {
+                if (have_warm) {
                     load_warm();
                     rho = ctx.uni(A.wrho[qp]);       // (a vector load: told to be the same in every lane, see DevCtx::uni)
                     if (!(rho >= kRhoMin && rho <= kRhoMax)) rho = prm.rho;
@@ -1870,7 +1873,18 @@ struct PathQp {
         bool lazy_look = false;          // polish_lazy: the next look at the polished point follows a single solve
         bool direct_polish = false, last_accepted = false;
         // the pending cold operation
-        int op = COLD_BEGIN_PASS, i0 = 0, i1 = A.warm ? 1 : 0;
+        // (carry_tails: the QP's cost bin in the previous launch - its key is rewritten at the end of this solve - against the launch's threshold bin)
+        // A carried QP keeps its cold cost key minus one bin per cycle instead of its (cheap) carried cost: with the carried cost it would drop out of
+        // the expensive eighth at once, start cold - and late, by a key that says "cheap" - in the next cycle, and every hard QP would alternate
+        // between the two (measured: one launch at a time 1.75 M against the cold 1.98 M paths/s, profiles/r05b_*)
+        bool qp_warm = A.warm != 0;
+        int keep_bin = -1;
+        if (A.carry_tails && A.warm) {
+            const int prev_bin = ctx.uni_int(A.cost_key[qp] >> 24);
+            qp_warm = prev_bin >= ctx.uni_int(A.cost_hist[kCostBins + 1]);
+            if (qp_warm) keep_bin = prev_bin - 1;
+        }
+        int op = COLD_BEGIN_PASS, i0 = 0, i1 = qp_warm ? 1 : 0;
         double d0 = 0.0;
 #ifdef PQP_TIMING
         // debug build only (tools/kernel_timeline.py): wall-clock ticks per category, written over the info record
@@ -2064,7 +2078,7 @@ struct PathQp {
         PQP_TIC(0x40);
         ctx.phase([&](int t, Lane&) {
             if (t == 0) {
-                if (A.cost_key) record_cost(A, qp, 4 * kkt_total + 13 * fac_total);
+                if (A.cost_key) record_cost(A, qp, 4 * kkt_total + 13 * fac_total, keep_bin);
                 A.wrho[qp] = rho_final;
                 if (A.status) A.status[qp] = status;
                 if (A.iters) A.iters[qp] = total_iters;

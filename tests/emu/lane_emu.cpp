@@ -53,6 +53,7 @@ struct HostCtx {
         }
     }
     static double uni(double x) { return x; }
+    static int uni_int(int x) { return x; }
     template <class PQ> void cold(PQ& pq, int op, int i0, int i1, double d0) { pq.do_cold(op, i0, i1, d0); }
     // lane-less context of the infeasibility certificate
     struct LaneLess {

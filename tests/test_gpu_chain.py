@@ -334,7 +334,7 @@ def test_chain_graph_on_the_lane_per_qp_kernel_leaves_the_ticket_counter_alone(h
             h.set_option(capi.OPT_STREAM_BATCH, 1)
         results[graph] = got
         h.close(); hs.close()
-    assert (results[0][0][2] == 0).sum() >= B // 2
+    assert (results[0][0][2] == 1).sum() >= B // 2          # most scenarios give a path
     for k in range(6):
         for a, b_ in zip(results[0][k], results[1][k]):
             np.testing.assert_array_equal(a, b_)

@@ -157,6 +157,39 @@ def test_carrying_a_cycle_through_the_warm_state(hip_lib):
     hw.close(); hc.close(); ho.close()
 
 
+def test_carrying_only_the_expensive_tail(hip_lib):
+    """PQP_OPT_CARRY_CYCLES = k >= 2: of a batch re-solved one planning cycle later only the QPs that were among the most expensive 1/k of the
+    previous solve (cost keys of PQP_OPT_ORDER_BY_COST; a carried QP keeps its cold key, one bin less per cycle) start from their previous
+    optimum; everybody else starts cold.  Same paths as the cold solve; most QPs do exactly the cold solve's work, the carried ones less; the
+    slowest QPs of the launch get cheaper."""
+    from path_optimizer_2_amd.synth import jitter_batch
+    batch, n = 1024, 80
+    host = make_batch(batch, n)
+    ht = capi.Handle(capi.production_params(), max_batch=batch, max_n=n)
+    hc = capi.Handle(capi.production_params(), max_batch=batch, max_n=n)
+    for h in (ht, hc):
+        h.set_option(capi.OPT_STORE_WARM, 0); h.set_option(capi.OPT_ORDER_BY_COST, 1)
+    ht.set_option(capi.OPT_CARRY_CYCLES, 8)
+    cost = lambda r: 4 * r["info"][:, 5] + 13 * r["info"][:, 6]
+    worst_t, worst_c = [], []
+    for v in range(6):
+        hv = jitter_batch(host, v)
+        rt = ht.solve(host["ref"], hv["bounds"], hv["scal"], passes=1)
+        rc = hc.solve(host["ref"], hv["bounds"], hv["scal"], passes=1)
+        assert (rt["status"] == 1).all() and (rc["status"] == 1).all()
+        assert np.abs(rt["out"] - rc["out"]).max() < 1e-6, v
+        ct, cc = cost(rt), cost(rc)
+        if v == 0:
+            assert np.array_equal(ct, cc)                      # nothing to carry yet
+        else:
+            other = ct != cc                                   # QPs that did other work than the cold solve: the carried ones
+            assert batch // 32 <= other.sum() <= batch // 2, (v, other.sum())
+            assert ct[other].mean() < 0.85 * cc[other].mean(), (v, ct[other].mean(), cc[other].mean())
+            worst_t.append(np.sort(ct)[-8:].mean()); worst_c.append(np.sort(cc)[-8:].mean())
+    assert np.mean(worst_t[1:]) < 0.9 * np.mean(worst_c[1:]), (worst_t, worst_c)       # the launch's slowest QPs
+    ht.close(); hc.close()
+
+
 def test_solve_in_rough_constraints_mode(hip_lib):
     """base_solver.cpp:25-34,201-205 SOLVED on the GPU (the lane-per-waypoint kernel, production setting and the reference's ADMM setting):
     beyond precise_planning_length one collision row per waypoint on the centre circle's box, P < N."""

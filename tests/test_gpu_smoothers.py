@@ -85,8 +85,8 @@ def test_tension(hip_lib, n, batch):
 def test_tension_sizes_beyond_the_9x9_formulation(hip_lib):
     """750 variables in 9 x 9 blocks need more LDS than a CU has: from there on every handle - the reference's ADMM setting included - gets
     the exact kernel.  A handle that asks for exact optima (polish = 1) solves the same QP as a box QP in the lateral shifts, one wavefront per
-    scenario (tension_exact_kernel), for up to 512 points; checked by the KKT conditions of the oracle's matrices, no solver involved."""
-    for n, seeds in ((250, (1, 2, 3)), (384, (4,)), (500, (7, 8)), (130, (5, 6))):         # (500: eight points per lane, round 4)
+    scenario (tension_exact_kernel), for up to 1024 points; checked by the KKT conditions of the oracle's matrices, no solver involved."""
+    for n, seeds in ((250, (1, 2, 3)), (384, (4,)), (500, (7, 8)), (700, (9,)), (1000, (10, 11)), (130, (5, 6))):         # (500: eight points per lane, round 4; 700 / 1000: twelve / sixteen, round 5)
         cases = [tension_inputs(n, seed=sd) for sd in seeds]
         x, y, ang, cl = (np.stack([c[k] for c in cases]) for k in (0, 1, 2, 5))
         if n >= 250:
@@ -274,9 +274,9 @@ def test_post_smooth_exact_kernel(hip_lib):
     h.close()
 
 
-@pytest.mark.parametrize("m", [100, 200, 341, 500])
+@pytest.mark.parametrize("m", [100, 200, 341, 500, 700, 1000])
 def test_post_smooth_exact_kernel_on_long_corridors(hip_lib, m):
-    """More than 64 layers: two, four, six or eight layers per lane of the same wavefront (post_exact_kernel<K>); ragged counts across the slot
+    """More than 64 layers: two, four, six, eight, twelve or sixteen layers per lane of the same wavefront (post_exact_kernel<K>); ragged counts across the slot
     boundaries (63, 64, 65, 128, 129 ...), the KKT certificate of the oracle's matrices, and the generic core - the reference's
     formulation, ADMM run to 1e-9 on the device - on one of them."""
     rng = np.random.default_rng(m)
