@@ -540,19 +540,21 @@ def main():
                 r["kkt_solves_mean"], r["factorisations_mean"], r["kkt_solves_max"] = kkt_carry
             return r
         nfl = len(lanes)
+        # (the driver times K = 20 steps = 7 ms of configs[1]: the side measurements take at least 400 steps each, so that they mean something there too)
+        sec_steps = max(args.steps, min(400, max(20, int(0.25 / max(dt / args.steps, 1e-6)))))
         secondary = {
-            "one_batch_at_a_time": dict(timed(prm, cost_order, args.steps), setting="the headline setting, one launch strictly after the other (--inflight 1)")
+            "one_batch_at_a_time": dict(timed(prm, cost_order, sec_steps), setting="the headline setting, one launch strictly after the other (--inflight 1)")
             if nfl > 1 else None,
-            "index_order": dict(timed(prm, not cost_order, args.steps), setting="one launch after the other with the QPs started in index order"
+            "index_order": dict(timed(prm, not cost_order, sec_steps), setting="one launch after the other with the QPs started in index order"
                                 if cost_order else "one launch after the other with the QPs started most-expensive-first (previous step's cost)"),
-            "inflight2_index_order": dict(timed(prm, False, args.steps, inflight=2), setting="two batches in flight, QPs started in index order") if nfl >= 2 else None,
-            "identical_batch_every_step": dict(timed(prm, cost_order, args.steps, inflight=nfl, variants=var_in[:1]),
+            "inflight2_index_order": dict(timed(prm, False, sec_steps, inflight=2), setting="two batches in flight, QPs started in index order") if nfl >= 2 else None,
+            "identical_batch_every_step": dict(timed(prm, cost_order, sec_steps, inflight=nfl, variants=var_in[:1]),
                                                setting="the headline setting with the SAME batch re-solved every step (round 2's headline: the start "
                                                        "order then has perfect foresight of every QP's cost)") if n_var > 1 else None,
-            "plain_admm_eps_1e-4": dict(timed(capi.default_params(eps_abs=1e-4, eps_rel=1e-4), False, max(3, args.steps // 8)),
+            "plain_admm_eps_1e-4": dict(timed(capi.default_params(eps_abs=1e-4, eps_rel=1e-4), False, max(3, sec_steps // 8)),
                                         setting="the literal metric: OSQP termination at eps_abs = eps_rel = 1e-4, OSQP defaults, no polish "
                                                 "(pqp_default_params); paths 1e-5..2e-3 from the optimum"),
-            "reference_setting_eps_2e-3": dict(timed(capi.default_params(), False, max(3, args.steps // 4)),
+            "reference_setting_eps_2e-3": dict(timed(capi.default_params(), False, max(3, sec_steps // 4)),
                                                setting="what base_solver.cpp:61-62 runs: eps 2e-3, OSQP defaults, no polish; paths 2e-4..2e-2 from the optimum"),
         }
         if cfg_id == 1 and preset_shape:
@@ -561,16 +563,16 @@ def main():
             txt = ("PQP_OPT_CARRY_CYCLES: the first solve of a cycle starts from the final iterate and active set the handle kept from the "
                    "previous cycle (the jittered variant {} step(s) earlier) instead of cold - what a planner that re-solves its scenarios every cycle would switch "
                    "on (same paths: the optimum is unique); the reference constructs a fresh solver per cycle, so `value` is measured without it")
-            secondary["carry_cycles"] = dict(timed(prm, cost_order, args.steps, inflight=nfl, carry=True), setting="the headline setting with " + txt.format(nfl))
-            secondary["carry_cycles_one_batch_at_a_time"] = dict(timed(prm, cost_order, args.steps, carry=True), setting="one launch after the other with " + txt.format(1))
+            secondary["carry_cycles"] = dict(timed(prm, cost_order, sec_steps, inflight=nfl, carry=True), setting="the headline setting with " + txt.format(nfl))
+            secondary["carry_cycles_one_batch_at_a_time"] = dict(timed(prm, cost_order, sec_steps, carry=True), setting="one launch after the other with " + txt.format(1))
             if cost_order:
                 tails = ("PQP_OPT_CARRY_CYCLES = {0}: only the QPs that were among the most expensive 1/{0} of the handle's previous solve (by the cost keys the start order "
                          "uses) start from their previous cycle's optimum, all others start cold; same paths; not `value` for the same reason")
-                secondary["carry_tails"] = dict(timed(prm, cost_order, args.steps, inflight=nfl, carry=8), setting="the headline setting with " + tails.format(8))
-                secondary["carry_tails_one_batch_at_a_time"] = dict(timed(prm, cost_order, args.steps, carry=8), setting="one launch after the other with " + tails.format(8))
-                secondary["carry_tails_quarter_one_batch_at_a_time"] = dict(timed(prm, cost_order, args.steps, carry=4), setting="one launch after the other with " + tails.format(4))
+                secondary["carry_tails"] = dict(timed(prm, cost_order, sec_steps, inflight=nfl, carry=8), setting="the headline setting with " + tails.format(8))
+                secondary["carry_tails_one_batch_at_a_time"] = dict(timed(prm, cost_order, sec_steps, carry=8), setting="one launch after the other with " + tails.format(8))
+                secondary["carry_tails_quarter_one_batch_at_a_time"] = dict(timed(prm, cost_order, sec_steps, carry=4), setting="one launch after the other with " + tails.format(4))
         if stream and n_var > 1:
-            secondary["carry_cycles"] = dict(timed(prm, cost_order, args.steps, inflight=nfl, carry=True),
+            secondary["carry_cycles"] = dict(timed(prm, cost_order, sec_steps, inflight=nfl, carry=True),
                                              setting="the headline setting with PQP_OPT_CARRY_CYCLES: the first pass of every QP starts from the optimum its slot had in the handle's "
                                                      "previous solve (the jittered variant two steps earlier) instead of cold - what a planner that re-solves its scenarios every "
                                                      "cycle would switch on; the reference constructs a fresh solver per cycle, so `value` is measured without it")
@@ -767,6 +769,17 @@ def main():
             "solved": int((st_np == 1).sum()), "batch": batch,
             "sustained": sustained, "secondary": secondary, "roofline": roofline, "roofline_issue": roofline_issue,
         }
+        if pipe is None:
+            if stream:
+                line["lanes_active_frac"] = {"value": batch / (64.0 * ((batch + 63) // 64)), "what": "QPs per 64-lane wavefront of path_stream_kernel (one lane per QP)"}
+            else:
+                t_lanes = 64
+                while t_lanes < n:
+                    t_lanes *= 2
+                line["lanes_active_frac"] = {"value": n / float(t_lanes), "lanes_per_qp": t_lanes,
+                                             "what": "waypoints per lane of a QP's workgroup (one lane per waypoint, 64 x 2^k lanes per QP): at N = 80 a QP holds 128 lanes - the kernel's time "
+                                                     "per QP follows the lanes (the depth of the reduction tree), not N; filling the idle 37.5 % with a third QP per two workgroups "
+                                                     "runs the three in lock-step: x0.95 ... x1.07 by the trace-driven model of profiles/r05_lockstep_three_qps_per_workgroup.txt"}
         if scaling_ref is not None and "error" not in scaling_ref:
             line["weak_scaling_efficiency"] = line["value"] / (world * scaling_ref["shard_alone_on_one_gpu"]["value"])
             line["strong_scaling_vs_one_gpu_whole_batch"] = line["value"] / scaling_ref["whole_batch_on_one_gpu"]["value"]
