@@ -559,6 +559,41 @@ def main():
         }
         if cfg_id == 1 and preset_shape:
             secondary["base_solver_shim_batch1"] = shim_batch1()
+            # the same batch at the reference's own path length: its demo plans N ~ 60 waypoints (BASELINE configs[0]), which fit ONE wavefront per QP -
+            # four QPs per CU instead of two (64 -> 65 waypoints costs 1.8x)
+            try:
+                n60 = 60
+                h60 = make_batch(batch, n60, profile, seed=args.seed)
+                r60 = torch.from_numpy(h60["ref"]).to(dev)
+                v60 = []
+                for v in range(4):
+                    hv = jitter_batch(h60, v, seed=args.seed)
+                    v60.append((torch.from_numpy(hv["bounds"]).to(dev), torch.from_numpy(hv["scal"]).to(dev)))
+                l60 = []
+                for _ in range(nfl):
+                    hh = capi.Handle(prm, device=local_rank, max_batch=batch, max_n=n60)
+                    hh.set_option(capi.OPT_STORE_WARM, 0); hh.set_option(capi.OPT_ORDER_BY_COST, 1 if cost_order else 0)
+                    l60.append((hh, torch.zeros((batch, n60, 7), dtype=torch.float64, device=dev), torch.zeros(batch, dtype=torch.int32, device=dev)))
+                torch.cuda.synchronize()
+
+                def run60(k):
+                    for i in range(k):
+                        hh, o, st = l60[i % len(l60)]
+                        hh.solve_device(batch, n60, r60, v60[i % 4][0], v60[i % 4][1], o, passes=1, status=st)
+                    for hh, *_ in l60:
+                        hh.sync()
+                run60(8)
+                ta = time.perf_counter()
+                run60(sec_steps)
+                t60 = time.perf_counter() - ta
+                secondary["reference_demo_length_n60"] = {"value": batch * sec_steps / t60, "unit": "paths/s", "steps": sec_steps, "ms_per_step": t60 / sec_steps * 1e3,
+                                                          "batch": batch, "n_waypoints": n60, "batches_in_flight": len(l60), "solved": int((l60[0][2] == 1).sum().item()),
+                                                          "setting": "the headline setting at N = 60 waypoints: one wavefront per QP (64 lanes), four QPs per CU"}
+                for hh, *_ in l60:
+                    hh.close()
+                del l60, v60, r60
+            except Exception as e:          # (the headline does not depend on it)
+                secondary["reference_demo_length_n60"] = {"error": f"{type(e).__name__}: {e}"}
         if not stream and n_var > 1:
             txt = ("PQP_OPT_CARRY_CYCLES: the first solve of a cycle starts from the final iterate and active set the handle kept from the "
                    "previous cycle (the jittered variant {} step(s) earlier) instead of cold - what a planner that re-solves its scenarios every cycle would switch "

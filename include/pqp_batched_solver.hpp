@@ -59,9 +59,15 @@ class BatchedPathSolver {
     // A planner that re-solves the same scenarios (same count, same order, equal waypoint counts) every cycle: the first solve of scenario k starts
     // from the optimum scenario k had in the previous optimizePaths call instead of cold.  Same paths (the optimum is unique), about a quarter less
     // time.  The reference builds a fresh BaseSolver per cycle (path_optimizer.cpp:138): off by default.
-    void setCarryCycles(bool on) {
-        carry_cycles_ = on;
-        if (multi_) pqp_multi_set_option(multi_, PQP_OPT_CARRY_CYCLES, on ? 1 : 0);
+    void setCarryCycles(bool on) { setCarryCycles(on ? 1 : 0); }
+    // ... k >= 2: only the scenarios that were among the most expensive 1 / k of the previous call start from their previous optimum, all others
+    // start cold - the ones a call waits for (PQP_OPT_CARRY_CYCLES = k; switches PQP_OPT_ORDER_BY_COST on, whose cost keys it needs)
+    void setCarryCycles(int k) {
+        carry_cycles_ = k < 0 ? 0 : k;
+        if (multi_) {
+            if (carry_cycles_ >= 2) pqp_multi_set_option(multi_, PQP_OPT_ORDER_BY_COST, 1);
+            pqp_multi_set_option(multi_, PQP_OPT_CARRY_CYCLES, carry_cycles_);
+        }
     }
     size_t size() const { return scenarios_.size(); }
 
@@ -82,7 +88,8 @@ class BatchedPathSolver {
                 return false;                      // no CPU fallback
             }
             pqp_multi_set_option(multi_, PQP_OPT_STORE_WARM, 0);       // every call is a complete optimizePath
-            if (carry_cycles_) pqp_multi_set_option(multi_, PQP_OPT_CARRY_CYCLES, 1);
+            if (carry_cycles_ >= 2) pqp_multi_set_option(multi_, PQP_OPT_ORDER_BY_COST, 1);
+            if (carry_cycles_) pqp_multi_set_option(multi_, PQP_OPT_CARRY_CYCLES, carry_cycles_);
         }
         const size_t bn = (size_t)batch * n_max;
         ref_.assign(bn * PQP_REF_STRIDE, 0.0); bounds_.assign(bn * PQP_BOUNDS_STRIDE, 0.0); scal_.assign((size_t)batch * PQP_SCAL_STRIDE, 0.0);
@@ -136,7 +143,7 @@ class BatchedPathSolver {
     std::vector<Scenario> scenarios_;
     std::vector<double> ref_, bounds_, scal_, out_;
     std::vector<int32_t> n_of_, status_, iters_;
-    bool carry_cycles_ = false;
+    int carry_cycles_ = 0;      // PQP_OPT_CARRY_CYCLES value
 };
 
 // PathOptimizer::optimizePath (path_optimizer.cpp:124-161) for one scenario whose reference states and bounds already exist.
