@@ -405,18 +405,24 @@ def main():
                 sync_all(); torch.cuda.synchronize()
                 shard_alone = batch * args.steps / (time.perf_counter() - ta)
                 hw = make_batch(total, n, profile, seed=args.seed)
-                w_in = [torch.from_numpy(hw[k]).to(dev) for k in ("ref", "bounds", "scal")]
+                w_ref = torch.from_numpy(hw["ref"]).to(dev)
+                # (as the shards: consecutive launches solve the scenarios one planning cycle later, so that a start / wavefront order by the previous solve's
+                #  costs has no perfect foresight)
+                w_var = []
+                for v in range(min(n_var, 4)):
+                    hv = jitter_batch(hw, v, seed=args.seed)
+                    w_var.append((torch.from_numpy(hv["bounds"]).to(dev), torch.from_numpy(hv["scal"]).to(dev)))
                 h_w = capi.Handle(prm, device=local_rank, max_batch=total, max_n=n)
                 h_w.set_option(capi.OPT_STORE_WARM, 0); h_w.set_option(capi.OPT_ORDER_BY_COST, 1 if cost_order else 0)
                 o_w = torch.zeros((total, n, 7), dtype=torch.float64, device=dev); st_w = torch.zeros(total, dtype=torch.int32, device=dev)
                 torch.cuda.synchronize()
-                for _ in range(2):
-                    h_w.solve_device(total, n, *w_in, o_w, passes=1, status=st_w)
+                for i in range(2):
+                    h_w.solve_device(total, n, w_ref, w_var[i % len(w_var)][0], w_var[i % len(w_var)][1], o_w, passes=1, status=st_w)
                 h_w.sync()
                 kw = max(2, min(args.steps, 8))
                 ta = time.perf_counter()
-                for _ in range(kw):
-                    h_w.solve_device(total, n, *w_in, o_w, passes=1, status=st_w)
+                for i in range(kw):
+                    h_w.solve_device(total, n, w_ref, w_var[i % len(w_var)][0], w_var[i % len(w_var)][1], o_w, passes=1, status=st_w)
                 h_w.sync()
                 whole = total * kw / (time.perf_counter() - ta)
                 whole_kernel = {1: "path_solve_kernel (lane per waypoint)", 2: "path_stream_kernel (lane per QP)"}.get(h_w.last_path_kernel(), "?")
@@ -425,7 +431,7 @@ def main():
                                                           "solved": int((st_w == 1).sum().item()), "setting": "one launch after the other"},
                                "note": "measured on rank 0's GPU after the timed region, the other ranks idle at a barrier"}
                 h_w.close()
-                del w_in, o_w, st_w
+                del w_ref, w_var, o_w, st_w
             except Exception as e:          # (the headline does not depend on it)
                 scaling_ref = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.synchronize(); dist.barrier()
@@ -644,6 +650,31 @@ def main():
                         for v in range(4):
                             hv = jitter_batch(hb, v + 1, seed=args.seed)
                             var_b.append((torch.from_numpy(hv["bounds"]).to(dev), torch.from_numpy(hv["scal"]).to(dev)))
+                        # (the launches above re-solve the IDENTICAL batch: the wavefront order - PQP_OPT_ORDER_BY_COST, wavefronts of QPs that ran the same
+                        #  phases in the previous solve - then has perfect foresight.  The scenarios one planning cycle later:)
+                        torch.cuda.synchronize()
+                        for v in range(4):
+                            hh.solve_device(bb, 80, t_ref, var_b[v][0], var_b[v][1], o, passes=1, status=stt, info=inf)
+                        hh.sync()
+                        tj = time.perf_counter()
+                        for v in range(4):
+                            hh.solve_device(bb, 80, t_ref, var_b[v][0], var_b[v][1], o, passes=1, status=stt, info=inf)
+                        hh.sync()
+                        tjd = (time.perf_counter() - tj) / 4
+                        res_w[name]["on_jittered_planning_cycles"] = {"value": bb / tjd, "unit": "paths/s", "ms_per_step": tjd * 1e3, "solved": int((stt == 1).sum().item()),
+                                                                      "setting": "4 jittered variants of the batch cycled: the wavefront order comes from the previous cycle's phase counts"}
+                        hh.set_option(capi.OPT_ORDER_BY_COST, 0)
+                        torch.cuda.synchronize()
+                        for _ in range(2):
+                            hh.solve_device(bb, 80, t_ref, t_b, t_s, o, passes=1, status=stt, info=inf)
+                        hh.sync()
+                        tu = time.perf_counter()
+                        for _ in range(ks):
+                            hh.solve_device(bb, 80, t_ref, t_b, t_s, o, passes=1, status=stt, info=inf)
+                        hh.sync()
+                        tud = (time.perf_counter() - tu) / ks
+                        res_w[name]["index_order"] = {"value": bb / tud, "unit": "paths/s", "ms_per_step": tud * 1e3, "setting": "PQP_OPT_ORDER_BY_COST off: QP k in slot k (round 4's launch)"}
+                        hh.set_option(capi.OPT_ORDER_BY_COST, 1)
                         hh.set_option(capi.OPT_CARRY_CYCLES, 1)
                         torch.cuda.synchronize()
                         for v in range(4):

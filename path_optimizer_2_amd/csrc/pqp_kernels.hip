@@ -601,6 +601,9 @@ struct pqp_handle {
     DevBuf sm_act[2];                                  // final active sets of the exact TensionSmoother / postSmooth kernels (PQP_OPT_CARRY_CYCLES)
     int sm_act_batch[2] = {0, 0}, sm_act_n[2] = {0, 0};
     DevBuf stream_ws;                           // workspace of path_stream_kernel
+    DevBuf stream_key, stream_hist, stream_order;      // PQP_OPT_ORDER_BY_COST on that kernel: phase keys, key histogram, two slot -> QP maps
+    long long stream_solves = 0;                // ordered launches so far (parity selects the map being read)
+    int stream_order_batch = 0, stream_order_n = 0;    // shape the map being read was built for (0: none)
     int num_cu = 0;
     int blocks_per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // occupancy of the solve kernel variants [log2(nw)][cert]
     DevBuf s_ref, s_lin, s_bounds, s_scal;      // staging for the host-pointer entry points
@@ -661,7 +664,7 @@ int pqp_destroy(pqp_handle* h) {
     g_alloc_generation.fetch_add(1, std::memory_order_relaxed);
     for (auto& g : h->chain_graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     h->chain_graphs.clear();
-    for (DevBuf* b : {&h->sm_act[0], &h->sm_act[1], &h->stream_ws, &h->chain_d, &h->chain_i, &h->wscale, &h->ticket, &h->cost_key, &h->cost_hist, &h->order, &h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
+    for (DevBuf* b : {&h->sm_act[0], &h->sm_act[1], &h->stream_ws, &h->stream_key, &h->stream_hist, &h->stream_order, &h->chain_d, &h->chain_i, &h->wscale, &h->ticket, &h->cost_key, &h->cost_hist, &h->order, &h->wx, &h->wy, &h->wye, &h->wrho, &h->wsave, &h->s_ref, &h->s_lin, &h->s_bounds, &h->s_scal, &h->s_out,
                       &h->s_status, &h->s_iters, &h->s_info, &h->s_a, &h->s_p, &h->s_l, &h->s_u, &h->s_idx, &h->b_pband, &h->b_q, &h->b_aval,
                       &h->b_lo, &h->b_up, &h->b_x, &h->b_y, &h->b_acol, &h->b_trow, &h->b_tslot, &h->b_in[0], &h->b_in[1], &h->b_in[2],
                       &h->b_in[3], &h->b_in[4], &h->b_out[0], &h->b_out[1], &h->b_out[2], &h->c_buf[0], &h->c_buf[1], &h->c_buf[2],
@@ -686,7 +689,7 @@ int pqp_set_option(pqp_handle* h, int option, int value) {
     if (!h) return fail(PQP_ERR_INVALID, "pqp_set_option: null handle");
     switch (option) {
         case PQP_OPT_STORE_WARM: h->opt_store_warm = value ? 1 : 0; return PQP_OK;
-        case PQP_OPT_ORDER_BY_COST: h->opt_order_by_cost = value ? 1 : 0; h->hist_batch = 0; return PQP_OK;
+        case PQP_OPT_ORDER_BY_COST: h->opt_order_by_cost = value ? 1 : 0; h->hist_batch = 0; h->stream_order_batch = 0; return PQP_OK;
         case PQP_OPT_RESERVE_CUS: h->opt_reserve_cus = value < 0 ? 0 : value; return PQP_OK;
         case PQP_OPT_STREAM_BATCH: h->opt_stream_batch = value < 0 ? -1 : value; return PQP_OK;
         case PQP_OPT_CARRY_CYCLES: h->opt_carry = value < 0 ? 0 : (value > 64 ? 64 : value); h->stream_last_batch = 0; h->sm_act_batch[0] = h->sm_act_batch[1] = 0; return PQP_OK;
@@ -839,11 +842,30 @@ static int path_stream_impl(pqp_handle* h, int batch, int n, const int32_t* n_of
     a.status = status; a.iters = iters; a.info = info; a.ws = h->stream_ws.as<double>(); a.prm = h->prm;
     // PQP_OPT_CARRY_CYCLES: the workspace still holds, slot by slot, the optimum of the previous launch of this very shape
     a.carry = (h->opt_carry && !lin && h->stream_last_batch == batch && h->stream_last_n == n && h->stream_ws.p == ws_before) ? 1 : 0;       // (lin == NULL: pqp.h)
+    // PQP_OPT_ORDER_BY_COST: wavefronts of QPs that ran the same phases in the handle's previous solve of the shape.  Only where it pays - batches that
+    // put a wavefront on (nearly) every SIMD: below that a launch lasts as long as one wavefront's sweeps whatever its lanes do (profiles/r05g_*) - and
+    // not with PQP_OPT_CARRY_CYCLES (a slot's workspace then holds the previous optimum of the QP that sat there) or inside a graph capture (host-side parity).
+    const bool ordered = h->opt_order_by_cost && !h->opt_carry && !h->capturing && waves >= 3 * h->num_cu;
+    if (ordered) {
+        if ((rc = h->stream_key.ensure((size_t)batch * 4)) || (rc = h->stream_hist.ensure(((size_t)pqp::lq::kOrderBins + 1) * 4)) ||
+            (rc = h->stream_order.ensure((size_t)2 * batch * 4)))
+            return rc;
+        if (h->stream_order_batch != batch || h->stream_order_n != n) {          // a shape change: stale counts, no map yet
+            PQP_HIP(hipMemsetAsync(h->stream_hist.p, 0, ((size_t)pqp::lq::kOrderBins + 1) * 4, h->stream));
+            a.order = nullptr;
+        } else {
+            a.order = h->stream_order.as<int32_t>() + (size_t)(h->stream_solves & 1) * batch;
+        }
+        a.key_out = h->stream_key.as<int32_t>();
+        a.hist = h->stream_hist.as<int32_t>();
+        a.order_next = h->stream_order.as<int32_t>() + (size_t)((h->stream_solves + 1) & 1) * batch;
+    }
     h->next_event_pair();
     if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
     PQP_HIP(pqp_stream_launch(&a, waves, (void*)h->stream));      // path_stream_kernel lives in its own translation unit (pqp_path_stream.hip)
     if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
+    if (ordered) { h->stream_solves += 1; h->stream_order_batch = batch; h->stream_order_n = n; }
     h->stream_last_batch = batch; h->stream_last_n = n;
     h->warm_batch = batch; h->warm_n = n;
     h->warm_stored = false;

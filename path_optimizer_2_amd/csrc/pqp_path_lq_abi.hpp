@@ -31,6 +31,10 @@ enum FieldF {
 constexpr int kBlockDoubles = kFieldsD + kFieldsF / 2;            // 30 doubles = 240 bytes per waypoint and QP
 static_assert(kFieldsF % 2 == 0, "the float fields fill whole doubles");
 
+// phase key of a QP: interior-point iterations of the first pass (5 bits), active-set rounds of the first pass (3), iterations (4) and rounds (3) of the
+// re-linearised pass - what a wavefront runs in lock-step, most significant first
+constexpr int kOrderBins = 1 << 15;
+
 struct Args {
     int batch, n, passes;
     const int32_t* n_of;        // [batch] or nullptr
@@ -43,6 +47,14 @@ struct Args {
     int32_t* iters;             // [batch] or nullptr: interior-point iterations over all passes
     double* info;               // [batch][PQP_INFO_STRIDE] or nullptr
     double* ws;                 // [ceil(batch / 64)][n][kBlockDoubles][64]
+    // PQP_OPT_ORDER_BY_COST on this kernel (batches that fill the chip): slot -> QP map of THIS launch (wavefronts of QPs that ran the same interior-point
+    // iterations / active-set rounds per pass in the previous solve: the 64 lanes of a wavefront run the maxima of their phases in lock-step) or nullptr;
+    // what the launch records for the next one: every QP's phase key, the key histogram (+ [kOrderBins]: wavefronts finished), and the next map -
+    // written by the last wavefront to finish (pqp_path_stream.hip)
+    const int32_t* order;       // [batch] or nullptr
+    int32_t* key_out;           // [batch] or nullptr
+    int32_t* hist;              // [kOrderBins + 1]
+    int32_t* order_next;        // [batch]
     int carry;                  // 1: the workspace still holds what this very launch shape left there last time (PQP_OPT_CARRY_CYCLES): a QP's first pass
                                 // starts its interior-point rounds from its slot's previous optimum - the same scenario one planning cycle earlier
     pqp_params prm;

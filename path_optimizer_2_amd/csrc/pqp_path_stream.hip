@@ -10,19 +10,80 @@
 #include "pqp_path_lq.hpp"
 
 namespace pqp {
+
+// slot -> QP of the NEXT launch, heaviest phase keys first: a counting sort over the 32 768 key bins, run by the last wavefront of the launch to finish (all
+// keys and bin counts are complete then; no separate kernel: with a second launch in flight a tiny ordering kernel waits for a free SIMD behind its 1024
+// resident wavefronts).  64 lanes: an exclusive scan of the bins in descending key order, 64 bins per step, then every QP draws its rank from its bin.
+__device__ void stream_order_next(const lq::Args& a) {
+    const int lane = (int)threadIdx.x;
+    // (every loop below keeps several independent device-scope accesses in flight per lane: one returning atomic at a time is ~1.2 us, and the first
+    //  form of this function - one per iteration - took 1.2 ms of a 10.6 ms launch: exactly what the order had saved)
+    constexpr int US = 8;                                                       // bins per lane and scan step
+    int carry = 0;
+    for (int base = lq::kOrderBins - 64 * US; base >= 0; base -= 64 * US) {
+        // group u = bins [base + 64 (US - 1 - u), + 64): lane 0 of group 0 takes the heaviest bin
+        int c[US];
+#pragma unroll
+        for (int u = 0; u < US; ++u) c[u] = __hip_atomic_load(a.hist + base + 64 * (US - 1 - u) + 63 - lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < US; ++u) {
+            int incl = c[u];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+            __hip_atomic_store(a.hist + base + 64 * (US - 1 - u) + 63 - lane, carry + incl - c[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // QPs in heavier bins
+            carry += __shfl(incl, 63);
+        }
+    }
+    __threadfence();
+    constexpr int UQ = 16;                                                      // QPs per lane and scatter step
+    for (int q0 = 0; q0 < a.batch; q0 += 64 * UQ) {
+        int k[UQ], pos[UQ];
+#pragma unroll
+        for (int u = 0; u < UQ; ++u) { const int q = q0 + 64 * u + lane; k[u] = q < a.batch ? __hip_atomic_load(a.key_out + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1; }
+#pragma unroll
+        for (int u = 0; u < UQ; ++u) pos[u] = k[u] >= 0 ? __hip_atomic_fetch_add(a.hist + (k[u] & (lq::kOrderBins - 1)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.batch;
+#pragma unroll
+        for (int u = 0; u < UQ; ++u) if (pos[u] < a.batch) a.order_next[pos[u]] = q0 + 64 * u + lane;
+    }
+    __threadfence();
+    for (int b = lane; b <= lq::kOrderBins; b += 64) __hip_atomic_store(a.hist + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch
+}
+
 // (one wavefront per SIMD: the whole 512-register budget; two / four per SIMD spill and lose, half-filled wavefronts two per SIMD lose 1.5x -
 //  profiles/r03a_stream_first.txt)
 __global__ void __launch_bounds__(64, 1) path_stream_kernel(const lq::Args a) {
     const int lanes = 64;
-    // (Sorting the QPs by the sweeps they took in the previous solve, so that a wavefront's 64 lanes finish together, was built and
-    // measured: 11 % less traffic and 14 % fewer instructions, the same 10.7 ms at 65 536 QPs - every wavefront is resident at once and the
-    // launch lasts as long as its slowest one - and its ordering kernel waited milliseconds for a free slot behind a second launch in
-    // flight.  Dropped: profiles/r03d_stream_ordered.txt.)
-    const int qp = blockIdx.x * lanes + threadIdx.x;
-    if (qp >= a.batch) return;
-    lq::StridedWs ws{a.ws + (size_t)blockIdx.x * a.n * lq::kBlockDoubles * lanes, (int)threadIdx.x, lanes};
-    lq::Solver<lq::StridedWs> s(a, qp, ws);
-    s.run();
+    // Wavefronts of similar work (a.order, PQP_OPT_ORDER_BY_COST): the 64 lanes of a wavefront run every phase - interior-point iterations and active-set
+    // rounds of each pass - as often as their slowest lane.  Sorting by the TOTAL sweeps of the previous solve changes nothing (round 3: 11 % less
+    // traffic, the same 10.7 ms - profiles/r03d_stream_ordered.txt); sorting by the four phase counts, first pass first, does: 25.4 -> 16.8 lock-step
+    // phases per wavefront for 16.5 per lane, 11.1 -> 9.4 ms at 65 536 QPs with the counts of the identical batch, 10.3 ms with those of the previous
+    // planning cycle (profiles/r05g_stream_sorted_probe.txt).
+    const int slot = blockIdx.x * lanes + threadIdx.x;
+    const bool live = slot < a.batch;
+    if (live) {
+        const int qp = a.order ? a.order[slot] : slot;
+        lq::StridedWs ws{a.ws + (size_t)blockIdx.x * a.n * lq::kBlockDoubles * lanes, (int)threadIdx.x, lanes};
+        lq::Solver<lq::StridedWs> s(a, qp, ws);
+        s.run();
+        if (a.key_out) {
+            const int it1 = s.ipm_iters_first < 31 ? s.ipm_iters_first : 31, s1 = s.set_rounds_first < 7 ? s.set_rounds_first : 7;
+            const int it2r = s.ipm_iters - s.ipm_iters_first, s2r = s.set_rounds - s.set_rounds_first;
+            const int it2 = it2r < 15 ? it2r : 15, s2 = s2r < 7 ? s2r : 7;
+            const int key = (it1 << 10) | (s1 << 7) | (it2 << 3) | s2;
+            // (device-scope: the last wavefront of the launch, on whatever XCD, reads them with device-scope loads)
+            __hip_atomic_store(a.key_out + qp, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(a.hist + key, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (a.key_out) {
+        int last = 0;
+        if (threadIdx.x == 0) {
+            __threadfence();
+            last = atomicAdd(a.hist + lq::kOrderBins, 1) == (int)gridDim.x - 1;
+            __threadfence();
+        }
+        if (__shfl(last, 0)) stream_order_next(a);
+    }
 }
 
 }  // namespace pqp

@@ -190,6 +190,26 @@ def test_stream_kernel_on_the_whole_of_configs_3(hip_lib):
     h.close()
     assert (st.cpu().numpy() == 1).all()
     assert shas[0] == shas[1]
+    # PQP_OPT_ORDER_BY_COST on this kernel (round 5): from the second solve on the wavefronts hold QPs that ran the same phases in the previous one.
+    # The same paths bit for bit (a QP's arithmetic does not depend on its slot) - also on a jittered batch, whose map comes from another batch's
+    # counts - every QP solved exactly once, and the wavefronts' lock-step phase maxima come down from ~25 to ~17 per wavefront
+    from path_optimizer_2_amd.synth import jitter_batch
+    ho = _handle(capi, batch, n)
+    ho.set_option(capi.OPT_ORDER_BY_COST, 1)
+    hv = jitter_batch(b, 1)
+    bounds_v, scal_v = torch.from_numpy(hv["bounds"]).to(dev), torch.from_numpy(hv["scal"]).to(dev)
+
+    def phases(inf):        # what the wavefronts of an index-ordered launch would run for these per-QP counts
+        ph = np.stack([inf[:, 2], inf[:, 5], inf[:, 3] - inf[:, 2], inf[:, 7] - inf[:, 5]], axis=1)
+        return ph
+    for k, (bb, ss) in enumerate(((bounds, scal), (bounds, scal), (bounds_v, scal_v), (bounds, scal))):
+        out.zero_(); st.zero_()
+        ho.solve_device(batch, n, ref, bb, ss, out, passes=1, status=st, info=info)
+        ho.sync()
+        assert (st.cpu().numpy() == 1).all(), k
+        if k in (0, 1, 3):
+            assert hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest() == shas[0], k
+    ho.close()
     # properties of an optimum that need no oracle: start state, curvature box, end box, x / y consistent with l
     assert np.abs(o[:, 0, 3] - b["scal"][:, 0]).max() < 1e-12 and np.abs(o[:, 0, 5] - b["scal"][:, 2]).max() < 1e-12
     assert np.abs(o[:, :, 5]).max() <= np.tan(35 * np.pi / 180) / 2.5 + 1e-8

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from path_optimizer_2_amd import capi
-from path_optimizer_2_amd.synth import make_batch
+from path_optimizer_2_amd.synth import make_batch, jitter_batch
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 80
@@ -22,8 +22,9 @@ st = torch.zeros(batch, dtype=torch.int32, device=dev); it = torch.zeros(batch, 
 info = torch.zeros((batch, 8), dtype=torch.float64, device=dev)
 
 
-def run(perm, label, steps=6):
-    ref, bounds, scal = (torch.from_numpy(np.ascontiguousarray(host[k][perm])).to(dev) for k in ("ref", "bounds", "scal"))
+def run(perm, label, steps=6, src=None):
+    src = src or host
+    ref, bounds, scal = (torch.from_numpy(np.ascontiguousarray(src[k][perm])).to(dev) for k in ("ref", "bounds", "scal"))
     torch.cuda.synchronize()
     for _ in range(2):
         h.solve_device(batch, n, ref, bounds, scal, out, passes=1, status=st, iters=it, info=info)
@@ -55,4 +56,15 @@ tot = key.sum(axis=1)
 order2 = np.lexsort((key[:, 3], key[:, 2], key[:, 1], key[:, 0], tot))[::-1]
 run(order2, "sorted by total, then the phase counts")
 run(order2[::-1].copy(), "... ascending (cheapest wavefronts first)")
+# imperfect foresight: the keys of THIS batch applied to the same scenarios one planning cycle later (synth.jitter_batch, +-5 %), as bench.py cycles them
+for v in (1, 2):
+    hv = jitter_batch(host, v)
+    infv = run(np.arange(batch), f"jittered variant {v}: index order", src=hv)
+    run(order, f"jittered variant {v}: sorted by variant 0's phase counts", src=hv)
+    kv = np.stack([infv[:, 2], infv[:, 5], infv[:, 3] - infv[:, 2], infv[:, 7] - infv[:, 5]], axis=1).astype(np.int64)
+    run(np.lexsort((kv[:, 3], kv[:, 2], kv[:, 1], kv[:, 0]))[::-1], f"jittered variant {v}: sorted by its own phase counts", src=hv)
+    print("   share of QPs whose four counts equal variant 0's: %.2f; first-pass iterations equal: %.2f" % ((kv == key).all(axis=1).mean(), (kv[:, 0] == key[:, 0]).mean()))
+# coarser keys: what a cheap predictor might still know
+for name, kk in (("first-pass interior-point iterations only", key[:, 0]), ("first pass: iterations, then set rounds", key[:, 0] * 16 + key[:, 1])):
+    run(np.argsort(-kk, kind="stable"), "sorted by " + name)
 h.close()
