@@ -64,6 +64,15 @@ for v in (1, 2):
     kv = np.stack([infv[:, 2], infv[:, 5], infv[:, 3] - infv[:, 2], infv[:, 7] - infv[:, 5]], axis=1).astype(np.int64)
     run(np.lexsort((kv[:, 3], kv[:, 2], kv[:, 1], kv[:, 0]))[::-1], f"jittered variant {v}: sorted by its own phase counts", src=hv)
     print("   share of QPs whose four counts equal variant 0's: %.2f; first-pass iterations equal: %.2f" % ((kv == key).all(axis=1).mean(), (kv[:, 0] == key[:, 0]).mean()))
+# which key order survives imperfect foresight best: variant 1 in the order of variant 0's counts
+hv = jitter_batch(host, 1)
+for name, cols in (("it1 s1 it2 s2", (0, 1, 2, 3)), ("it1 it2 s1 s2", (0, 2, 1, 3)), ("it2 it1 s1 s2", (2, 0, 1, 3)), ("s1 it1 s2 it2", (1, 0, 3, 2)), ("it1 it2", (0, 2)),
+                   ("it1+it2, s1+s2", None)):
+    if cols is None:
+        kk = [key[:, 1] + key[:, 3], key[:, 0] + key[:, 2]]
+    else:
+        kk = [key[:, c] for c in reversed(cols)]
+    run(np.lexsort(tuple(kk))[::-1], f"variant 1 by variant 0's keys, order {name}", src=hv)
 # coarser keys: what a cheap predictor might still know
 for name, kk in (("first-pass interior-point iterations only", key[:, 0]), ("first pass: iterations, then set rounds", key[:, 0] * 16 + key[:, 1])):
     run(np.argsort(-kk, kind="stable"), "sorted by " + name)
