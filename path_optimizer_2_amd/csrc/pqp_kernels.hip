@@ -208,8 +208,9 @@ struct DevCtx {
 // lanes draw their ranks (results do not depend on the order).  Run by the last workgroup of a launch to leave its ticket loop (every workgroup counts itself out on hist[kCostBins]):
 // all keys and bin counts of the launch are complete then.  No separate kernel: with two launches in flight a tiny ordering kernel
 // waits for a free CU slot behind the other launch's persistent workgroups (measured: 266 us instead of 3).
-__device__ void order_next_launch(const PathSolveArgs& args) {
-    __shared__ int start[kCostBins];
+// `start`: 256 ints of the workgroup's dynamic LDS (free once its last QP is done).  Not a static array: 1 KB more per workgroup is what kept a FOURTH
+// one-wavefront workgroup (paths of up to 64 waypoints: 40.4 KB each) off a compute unit's 160 KB - three QPs per CU, one SIMD idle (round 5).
+__device__ void order_next_launch(const PathSolveArgs& args, int* start) {
     __shared__ int s_last;
     // release / acquire around the count-out: this workgroup's keys and bin counts (relaxed agent-scope atomics of record_cost) are
     // visible before its count is, and the last workgroup reads the other XCDs' keys only after it has seen every count
@@ -298,7 +299,7 @@ __global__ void __launch_bounds__(64 * NW, 1) path_solve_kernel(const PathSolveA
         }
 #endif
     }
-    if (args.cost_key) order_next_launch(args);
+    if (args.cost_key) order_next_launch(args, reinterpret_cast<int*>(smem));
 }
 
 
