@@ -197,7 +197,8 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *   PQP_OPT_ORDER_BY_COST (default 0)  start the QPs of a batch most-expensive-first, by the reduced-KKT solves and
  *                                      factorisations each QP needed in the handle's previous solve of the same batch and n
  *                                      (a planner re-solves nearly the same scenarios every cycle).  The first solve of a shape
- *                                      runs in index order.
+ *                                      runs in index order.  On the lane-per-QP kernel (batches that put a wavefront on nearly every SIMD) the same option groups
+ *                                      the QPs into wavefronts of similar work - see PQP_OPT_STREAM_BATCH below.
  *   PQP_OPT_RESERVE_CUS (default 0)    compute units the path QP's persistent workgroups leave free.  Their wavefronts own a SIMD's whole
  *                                      register file, so kernels of another stream (the smoother chain of the next batch, configs[4]) only
  *                                      get onto the chip when a unit is left to them.
