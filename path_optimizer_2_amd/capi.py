@@ -27,7 +27,7 @@ class PqpParams(C.Structure):
         ("polish_refine_iter", C.c_int32), ("polish_every", C.c_int32), ("polish_warm_set", C.c_int32), ("polish_max_rounds", C.c_int32),
         ("polish_reseed", C.c_int32), ("polish_diverge", C.c_int32), ("polish_delta", C.c_double), ("polish_tol", C.c_double),
         ("polish_reseed_factor", C.c_double), ("eps_prim_inf", C.c_double), ("polish_patience", C.c_int32), ("prim_inf_after", C.c_int32),
-        ("polish_lazy", C.c_int32), ("reserved1", C.c_int32),
+        ("polish_lazy", C.c_int32), ("polish_final_refine", C.c_int32),
         ("tension2_deviation_weight", C.c_double), ("tension2_curvature_weight", C.c_double),
         ("tension2_curvature_rate_weight", C.c_double), ("cartesian_curvature_weight", C.c_double),
         ("cartesian_curvature_rate_weight", C.c_double), ("cartesian_deviation_weight", C.c_double),

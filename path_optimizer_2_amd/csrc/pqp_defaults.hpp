@@ -43,7 +43,7 @@ inline void default_params(pqp_params* p) {
     p->polish_patience = 0;
     p->prim_inf_after = 0;                          // OSQP: the certificate at every check
     p->polish_lazy = 0;
-    p->reserved1 = 0;
+    p->polish_final_refine = 0;
     p->polish_delta = 1e-6;
     p->polish_tol = 1e-7;
     p->tension2_deviation_weight = 0.005;           // planning_flags.cpp:57

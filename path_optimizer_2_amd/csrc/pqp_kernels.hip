@@ -149,6 +149,7 @@ struct DevCtx {
     // kCstLds: pass constants in LDS instead of in registers (no gain at one wavefront per SIMD); kParkScale: the Ruiz vectors are parked
     // between the passes (+2 %, profiles/r02b_variants.txt)
     static constexpr bool kCstLds = false, kParkScale = true, kSaveLds = NW <= kSaveLdsMaxNw;
+    static constexpr bool kFinalRefine = NW >= 4;      // pqp_params::polish_final_refine is honoured: the contexts of paths beyond 128 waypoints
     // DPP moves: the value of the lane H below / above in the same row of 16 lanes, of the previous row's last lane; 0 where
     // there is no such lane.  Must run with every lane enabled (a disabled source lane reads as "no lane").  (profiles/r02j_dpp_exchanges.txt)
     static constexpr bool kDpp = true;
@@ -926,6 +927,12 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     a.status = status; a.iters = iters; a.info = info;
     a.wx = h->wx.as<double>(); a.wy = h->wy.as<double>(); a.wye = h->wye.as<double>(); a.wrho = h->wrho.as<double>();
     a.prm = h->prm;
+    // Long paths: the polished point's residuals in the transition rows add up along the path - the rows are a discrete double integrator, an error of
+    // 1e-9 per row in (psi, kappa) is 1e-4 in l after 300 waypoints - so an accepted point gets one more refinement solve per pass beyond 128 waypoints, three beyond 256 (each shrinks the error ~10x: 4.6e-3 -> 4.4e-4 -> 4.1e-5 -> 3.3e-6 on
+    // the worst path of 300 waypoints; the kernels of up to 128 waypoints do not compile the feature in: Ctx::kFinalRefine) (a 100x
+    // tighter acceptance test instead leaves a few QPs in 30 000 unverifiable: 350-1000 solves, configs[4] halved).  Measured against the converged C oracle over 32 768 QPs per shape (profiles/r05o_*): before, 7 paths of 200 waypoints
+    // and 117 of 300 were 3e-5 ... 4.6e-3 off (the lane-per-QP kernel, whose roll-out satisfies the rows exactly: 5e-6).
+    { const int k = n > 256 ? 3 : (n > 128 ? 1 : 0); if (a.prm.polish_final_refine < k) a.prm.polish_final_refine = k; }
     int nw = 1, lg = 0;
     while (64 * nw < n) { nw *= 2; lg += 1; }           // one waypoint per lane: T = 64 * nw >= n threads per QP
     const int T_lanes = 64 * nw;

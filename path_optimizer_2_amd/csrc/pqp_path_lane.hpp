@@ -2030,7 +2030,15 @@ struct PathQp {
                     // the refinement solves start from the ADMM iterate; from a distant one the budgeted number of them may leave the
                     // polished point short of the accuracy the KKT test needs: up to 3 more pairs of solves instead of throwing the
                     // attempt away
-                    if (!solve_ok && res[4] == 0.0 && extra_refine < 3) { extra_refine += 1; refine_left = 2; continue; }
+                    // (long paths, pqp_params::polish_final_refine = k: a point that passes is refined k times more - and tested again - before it is returned)
+                    // (only in the contexts of long paths - Ctx::kFinalRefine: more than 128 lanes per QP -, so that the kernels of shorter paths compile
+                    //  to what they were: their register allocation is one source line away from 20 more spilled registers and -1.5 %)
+                    if constexpr (Ctx::kFinalRefine) {
+                        const bool hold = ok && extra_refine < prm.polish_final_refine;
+                        if (((!solve_ok && extra_refine < 3) || hold) && res[4] == 0.0) { extra_refine += 1; refine_left = hold ? 1 : 2; continue; }
+                    } else {
+                        if (!solve_ok && res[4] == 0.0 && extra_refine < 3) { extra_refine += 1; refine_left = 2; continue; }
+                    }
                     extra_refine = 0;
 #ifdef PQP_EMU_DEBUG
                     printf("  polish qp %d it %d round %d: pri %.3e dua %.3e viol %.3e %s -> %s\n", qp, it, round, res[0], res[1], viol, conservative ? "(cons)" : "", ok ? "ACCEPT" : "reject");

@@ -157,6 +157,29 @@ def test_carrying_a_cycle_through_the_warm_state(hip_lib):
     hw.close(); hc.close(); ho.close()
 
 
+def test_long_paths_whole_batches_both_kernels(hip_lib):
+    """Paths of 200 and 300 waypoints, 2048 QPs each, through BOTH path-QP kernels: the batches of tools/robustness_sweep.py that held the lane-per-waypoint
+    kernel's worst points before round 5 (seed 1005 / qp 1659 at 200 waypoints: 2.3e-4 off the converged oracle, seed 1015 / qp 2009 at 300: 2.6e-4 - KKT
+    residuals of 1e-9 in the transition rows add up along a long path; the acceptance test is 100x tighter beyond 128 waypoints now).  The lane-per-QP
+    kernel's roll-out satisfies those rows exactly: agreement of the two over the whole batch + the two named QPs against the C oracle."""
+    import pqp_oracle_c as OC
+    for n, profile, seed, q_bad in ((200, "uniform", 1005, 1659), (300, "varied", 1015, 2009)):
+        host = make_batch(2048, n, profile, seed=seed)
+        h = capi.Handle(capi.production_params(), max_batch=2048, max_n=n)
+        hs = capi.Handle(capi.production_params(), max_batch=2048, max_n=n)
+        hs.set_option(capi.OPT_STORE_WARM, 0); hs.set_option(capi.OPT_STREAM_BATCH, 1)
+        r = h.solve(host["ref"], host["bounds"], host["scal"], passes=1)
+        rs = hs.solve(host["ref"], host["bounds"], host["scal"], passes=1)
+        assert h.last_path_kernel() == capi.KERNEL_LANE_PER_WAYPOINT and hs.last_path_kernel() == capi.KERNEL_LANE_PER_QP
+        assert (r["status"] == 1).all() and (rs["status"] == 1).all()
+        d = np.abs(r["out"][:, :, 3:5] - rs["out"][:, :, 3:5]).max(axis=(1, 2))
+        assert d.max() < 5e-5, (n, d.max(), int(d.argmax()))
+        o = OC.solve_batch(OC.params(eps_abs=1e-10, eps_rel=1e-10, max_iter=400000), host["ref"][q_bad:q_bad + 1], host["bounds"][q_bad:q_bad + 1],
+                           host["scal"][q_bad:q_bad + 1], passes=1)
+        assert np.abs(o["out"][0][:, 3:5] - r["out"][q_bad][:, 3:5]).max() < 2e-5 and np.abs(o["out"][0][:, 3:5] - rs["out"][q_bad][:, 3:5]).max() < 2e-5
+        h.close(); hs.close()
+
+
 def test_carrying_only_the_expensive_tail(hip_lib):
     """PQP_OPT_CARRY_CYCLES = k >= 2: of a batch re-solved one planning cycle later only the QPs that were among the most expensive 1/k of the
     previous solve (cost keys of PQP_OPT_ORDER_BY_COST; a carried QP keeps its cold key, one bin less per cycle) start from their previous
