@@ -10,7 +10,7 @@ from smoother_cases import tension_inputs, tension_kkt_certificate
 
 lines = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 prm = capi.default_params(eps_abs=1e-3, eps_rel=1e-3, polish=1, polish_every=25, adaptive_rho_interval=25, polish_refine_iter=2)
-for n in (24, 48, 80, 130, 200, 300, 384):
+for n in (24, 48, 80, 130, 200, 300, 384, 500, 700, 1000):
     cases = [tension_inputs(n, seed=5000 + b) for b in range(lines)]
     x, y, ang, cl = (np.stack([c[k] for c in cases]) for k in (0, 1, 2, 5))
     h = capi.Handle(prm, max_batch=lines, max_n=n)
