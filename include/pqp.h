@@ -205,7 +205,8 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      register file, so kernels of another stream (the smoother chain of the next batch, configs[4]) only
  *                                      get onto the chip when a unit is left to them.
  *   PQP_OPT_STREAM_BATCH (default -1 = by measurement: 20 480 x max(1, n / 80)^2 - the measured crossover of the two kernels on one MI355X,
- *                                      18.7 k QPs at 80 waypoints, ~45 k at 120, profiles/r05a_crossover_*; 0: never)
+ *                                      18.7 k QPs at 80 waypoints, ~45 k at 120, profiles/r05a_crossover_*; 64 n beyond 256 waypoints,
+ *                                      profiles/r05t_crossover_long_paths.txt; 0: never)
  *                                      cold solves (warm == 0) of at least this many QPs on a handle with polish != 0 and
  *                                      PQP_OPT_STORE_WARM off run on the lane-per-QP kernel (one QP per lane, 64 per wavefront, the
  *                                      per-waypoint state streamed through a batch-interleaved workspace of 240 n bytes per QP in HBM;

@@ -879,7 +879,10 @@ static int path_stream_impl(pqp_handle* h, int batch, int n, const int32_t* n_of
 // (profiles/r05a_crossover_n80.txt, r05a_crossover_n120.txt: 18.7 k QPs at 80 waypoints, ~45 k at 120).  A lone wavefront of that kernel
 // takes sweeps x n waypoint steps whatever the batch (5.5 ms at n = 80, 10.5 ms at n = 120), the lane-per-waypoint kernel's time per QP hardly
 // depends on n: the crossover grows like n^2.
+// Beyond 256 waypoints the lane-per-waypoint kernel runs two wavefronts per SIMD on half the registers and takes 4.1 ... 4.9 us per QP instead
+// of 1.0: the crossover is back at 16.7 k / 22.5 k / 32 k QPs at 300 / 400 / 512 waypoints (profiles/r05t_crossover_long_paths.txt): 64 n.
 static int stream_batch_auto(int n) {
+    if (n > 256) return 64 * n;
     const double r = n > 80 ? (double)n / 80.0 : 1.0;
     const double t = 20480.0 * r * r;
     return t < 1.0e9 ? (int)t : 1000000000;

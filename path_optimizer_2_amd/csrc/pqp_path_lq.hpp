@@ -166,7 +166,7 @@ PQP_HD void add_lpsi_term(Value& v, double w, double L, double t) {
     v.p[0] -= w * t; v.p[1] -= w * t * L;
 }
 
-enum Mode { MODE_INIT = 0, MODE_IPM = 1, MODE_GUESS = 2, MODE_SET = 3 };
+enum Mode { MODE_INIT = 0, MODE_IPM = 1, MODE_GUESS = 2, MODE_SET = 3, MODE_SET_GUARDED = 4 };      // (the last: roll-outs only, forward_set)
 
 // The solver of one QP.  WS: the lane's view of the workspace, ld(field, waypoint) / st(field, waypoint, value).
 template <class WS>
@@ -292,7 +292,7 @@ struct Solver {
     struct Box { double lof, upf, lor, upr; };
     struct IpmRows { float tlf, tuf, zlf, zuf, tlr, tur, zlr, zur, tlk, tuk, zlk, zuk; double gk; };
     struct BackIn { Stage s; Box b; IpmRows r; float dgf, dgr, dgk; double act, lam; };
-    struct FwdIn { Stage s; double K0, K1, K2, kk; Box b; IpmRows r; double act, lam; };     // stage / gains of transition i, rows of waypoint i + 1
+    struct FwdIn { Stage s; double K0, K1, K2, kk; Box b; IpmRows r; double act, lam; double xo[3]; };     // stage / gains of transition i, rows of waypoint i + 1
 
     PQP_HD Box load_box(int i) const { Box b; b.lof = ws.ld(D_LOF, i); b.upf = ws.ld(D_UPF, i); b.lor = ws.ld(D_LOR, i); b.upr = ws.ld(D_UPR, i); return b; }
     PQP_HD IpmRows load_rows(int i) const {
@@ -327,7 +327,8 @@ struct Solver {
         in.K0 = ws.ld(D_K0, i); in.K1 = ws.ld(D_K1, i); in.K2 = ws.ld(D_K2, i); in.kk = ws.ld(D_KK, i);
         in.b = load_box(i + 1);
         if (MODE == MODE_IPM) in.r = load_rows(i + 1);
-        if (MODE == MODE_SET) { in.act = ws.ld(D_ACT, i + 1); in.lam = ws.ld(D_LAM, i + 1); }
+        if (MODE == MODE_SET || MODE == MODE_SET_GUARDED) { in.act = ws.ld(D_ACT, i + 1); in.lam = ws.ld(D_LAM, i + 1); }
+        if (MODE == MODE_SET_GUARDED) { in.xo[0] = ws.ld(D_X0, i + 1); in.xo[1] = ws.ld(D_X1, i + 1); in.xo[2] = ws.ld(D_X2, i + 1); }      // the point the set was taken from
         return in;
     }
 
@@ -560,11 +561,24 @@ struct Solver {
     }
     // roll-out of an active-set round: the point, the set it asks for, the multipliers of its hard rows.  Returns true when the point
     // confirms its set (the KKT test) and holds its hard rows.
+    //
+    // The rounds are Newton steps on a convex, piecewise quadratic function F (a collision row that is out of its box costs w_s / 2 times
+    // the square of what it is out by): the set S is the piece the current point x lies on, the round's point x_N minimises that piece's
+    // quadratic q_S.  Undamped - the next point is x_N - they can cycle on paths of several hundred waypoints, where a handful of rows that
+    // are barely active move the far end of the path by decimetres (1 QP in 16 384 at 512 waypoints: a cycle of 28 sets, the same one
+    // from all three attempts; 5 in 131 072 at 1000).  GUARDED rounds step to x + t (x_N - x) with the largest t of 1, 1/2, 1/4, 1/8, 1/16
+    // at which F still falls along the segment: F' (t) = (t - 1) d^T H_S d + (what the rows that have left their piece at x + t d add),
+    // d^T H_S d and the second term for the candidate steps summed in this roll-out, D_X* keeping x and the step fields of the
+    // interior-point rounds d; settle(t) then moves x and takes the collision rows' sides from where it arrives.  F falls with every
+    // guarded round, so no set comes back.  (Hard rows - curvature, end boxes - change sides by their own test as before: they are
+    // multiplier estimates, not part of F.)  A set is only ever accepted when its own point x_N confirms it.
+    template <bool GUARDED>
     PQP_SWEEP bool forward_set() {
         double x[3] = {x0[0], x0[1], x0[2]};
-        bool changed = false;
+        bool asks = false;          // x_N asks for another set than the one it was computed with
         double pin = 0.0;
-        ws.st(D_X0, 0, x[0]); ws.st(D_X1, 0, x[1]); ws.st(D_X2, 0, x[2]);
+        double dhd = 0.0, slope[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, dk_prev = 0.0, dl = 0.0, dp = 0.0;
+        if (!GUARDED) { ws.st(D_X0, 0, x[0]); ws.st(D_X1, 0, x[1]); ws.st(D_X2, 0, x[2]); }
         auto soft = [&](int act, double v, double lo, double up) {
             // consistent within the tolerance: keep; else what the point asks for
             const bool keep = (act == 1 && v >= up - kSetTol) || (act == -1 && v <= lo + kSetTol) || (act == 0 && v <= up + kSetTol && v >= lo - kSetTol);
@@ -582,27 +596,91 @@ struct Solver {
             lam = 0.0;
             return v > up + kSetTol ? 1 : (v < lo - kSetTol ? -1 : 0);
         };
-        sweep_up<kDepth, FwdIn>(0, n - 1, [&](int i) { return load_fwd<MODE_SET>(i); }, [&](int i, const FwdIn& in) {
+        // a collision row along the segment: its share of d^T H_S d and of the slopes at the candidate steps (v = o + t dv; side a in S)
+        auto along = [&](int a, double o, double dv, double lo, double up) {
+            if (a != 0) dhd += w_s * dv * dv;
+            double t = 1.0;
+#pragma unroll
+            for (int c = 0; c < 5; ++c, t *= 0.5) {
+                const double v = o + t * dv;
+                const double truth = v > up ? v - up : (v < lo ? v - lo : 0.0);
+                const double model = a > 0 ? v - up : (a < 0 ? v - lo : 0.0);
+                slope[c] += w_s * (truth - model) * dv;
+            }
+        };
+        sweep_up<kDepth, FwdIn>(0, n - 1, [&](int i) { return load_fwd<GUARDED ? MODE_SET_GUARDED : MODE_SET>(i); }, [&](int i, const FwdIn& in) {
             advance(in, x);
             const int j = i + 1;
-            ws.st(D_X0, j, x[0]); ws.st(D_X1, j, x[1]); ws.st(D_X2, j, x[2]);
+            if (!GUARDED) { ws.st(D_X0, j, x[0]); ws.st(D_X1, j, x[1]); ws.st(D_X2, j, x[2]); }
             const double lof = in.b.lof, upf = in.b.upf, lor = in.b.lor, upr = in.b.upr;
             const double L0 = lor <= -kBig ? 0.0 : Lf;
             const int code = (int)in.act;
             const int af = code % 3 - 1, ar = (code / 3) % 3 - 1, ak = code / 9 - 1;
-            const int nf = upf - lof > kEqWidth ? soft(af, x[0] + L0 * x[1], lof, upf) : 1;
-            const int nr = upr >= kBig ? 0 : (upr - lor > kEqWidth ? soft(ar, x[0] + Lr * x[1], lor, upr) : 1);
+            const bool live_f = upf - lof > kEqWidth, on_r = upr < kBig, live_r = on_r && upr - lor > kEqWidth;
+            int nf = live_f ? soft(af, x[0] + L0 * x[1], lof, upf) : 1;
+            int nr = !on_r ? 0 : (live_r ? soft(ar, x[0] + Lr * x[1], lor, upr) : 1);
             double lam = in.lam;
             const int nk = hard(ak, lam, x[2], -kl, kl);
-            changed = changed || nf != af || nr != ar || nk != ak;
+            asks = asks || nf != af || nr != ar || nk != ak;
+#if defined(PQP_LQ_DEBUG) && !defined(__HIP_DEVICE_COMPILE__)
+            if (nf != af || nr != ar || nk != ak)
+                std::fprintf(stderr, "    qp %d set round %d waypoint %d: front %d -> %d (%.3e in [%.6f, %.6f]) rear %d -> %d (%.3e in [%.6f, %.6f]) kappa %d -> %d (%.9f, lam %.3e)\n", qp, set_rounds, j,
+                             af, nf, x[0] + L0 * x[1], lof, upf, ar, nr, x[0] + Lr * x[1], lor, upr, ak, nk, x[2], lam);
+#endif
+            if (GUARDED) {
+                dl = x[0] - in.xo[0]; dp = x[1] - in.xo[1];
+                const double dk = x[2] - in.xo[2], du = (dk - dk_prev) * rcpq(in.s.ds);
+                dk_prev = dk;
+                ws.stf(S_DGF, j, dl); ws.stf(S_DGR, j, dp); ws.stf(S_DGK, j, dk);
+                dhd += w_l * dl * dl + (w_k + (ak != 0 ? kInvDelta : 0.0)) * dk * dk + w_u * du * du;
+                if (live_f) along(af, in.xo[0] + L0 * in.xo[1], dl + L0 * dp, lof, upf); else dhd += w_s * (dl + L0 * dp) * (dl + L0 * dp);
+                if (live_r) along(ar, in.xo[0] + Lr * in.xo[1], dl + Lr * dp, lor, upr); else if (on_r) dhd += w_s * (dl + Lr * dp) * (dl + Lr * dp);
+                nf = af; nr = ar;           // (settle() takes the collision rows' sides from where the step arrives)
+            }
             ws.st(D_ACT, j, (double)((nf + 1) + 3 * (nr + 1) + 9 * (nk + 1)));
             ws.st(D_LAM, j, lam);
         });
+        if (GUARDED) dhd += kInvDelta * ((act_el != 0 ? dl * dl : 0.0) + (act_ep != 0 ? dp * dp : 0.0));
         const int ne = hard(act_el, lam_el, x[0], -a.prm.end_l_bound, a.prm.end_l_bound);
-        changed = changed || ne != act_el; act_el = ne;
-        if (psi_hi < kBig) { const int np = hard(act_ep, lam_ep, x[1], psi_lo, psi_hi); changed = changed || np != act_ep; act_ep = np; }
+        asks = asks || ne != act_el; act_el = ne;
+        if (psi_hi < kBig) { const int np = hard(act_ep, lam_ep, x[1], psi_lo, psi_hi); asks = asks || np != act_ep; act_ep = np; }
         set_rounds += 1;
-        return !changed && pin <= kPinTol;
+        if (GUARDED) {
+            step = 1.0 / 16.0;
+            double t = 1.0;
+            for (int c = 0; c < 5; ++c, t *= 0.5) if ((t - 1.0) * dhd + slope[c] <= 0.0) { step = t; break; }
+        }
+#if defined(PQP_LQ_DEBUG) && !defined(__HIP_DEVICE_COMPILE__)
+        std::fprintf(stderr, "  qp %d set round %d: asks %d pin %.3e end rows %d %d", qp, set_rounds, (int)asks, pin, act_el, act_ep);
+        if (GUARDED) std::fprintf(stderr, " | guarded: d^T H d %.3e slopes %.3e %.3e %.3e %.3e %.3e -> step %.4f", dhd, slope[0], (0.5 - 1.0) * dhd + slope[1], (0.25 - 1.0) * dhd + slope[2], (0.125 - 1.0) * dhd + slope[3], (0.0625 - 1.0) * dhd + slope[4], step);
+        std::fprintf(stderr, "\n");
+#endif
+        return !asks && pin <= kPinTol;
+    }
+    double step;          // of the last guarded round
+    // after a guarded round: x <- x + step d, the collision rows on the sides that point asks for
+    struct SettleIn { double x0, x1, x2, act; float d0, d1, d2; Box b; };
+    PQP_SWEEP void settle() {
+        const double t = step;
+        sweep_up<kDepth, SettleIn>(1, n, [&](int j) {
+            SettleIn in;
+            in.x0 = ws.ld(D_X0, j); in.x1 = ws.ld(D_X1, j); in.x2 = ws.ld(D_X2, j); in.act = ws.ld(D_ACT, j);
+            in.d0 = ws.ldf(S_DGF, j); in.d1 = ws.ldf(S_DGR, j); in.d2 = ws.ldf(S_DGK, j);
+            in.b = load_box(j);
+            return in;
+        }, [&](int j, const SettleIn& in) {
+            const double l = in.x0 + t * (double)in.d0, psi = in.x1 + t * (double)in.d1;
+            ws.st(D_X0, j, l); ws.st(D_X1, j, psi); ws.st(D_X2, j, in.x2 + t * (double)in.d2);
+            const double lof = in.b.lof, upf = in.b.upf, lor = in.b.lor, upr = in.b.upr;
+            const double L0 = lor <= -kBig ? 0.0 : Lf;
+            const int code = (int)in.act;
+            const int ak = code / 9 - 1;
+            const double vf = l + L0 * psi, vr = l + Lr * psi;
+            // (no hysteresis here: the side is the piece of F the point lies on)
+            const int nf = upf - lof > kEqWidth ? (vf > upf ? 1 : (vf < lof ? -1 : 0)) : 1;
+            const int nr = upr >= kBig ? 0 : (upr - lor > kEqWidth ? (vr > upr ? 1 : (vr < lor ? -1 : 0)) : 1);
+            ws.st(D_ACT, j, (double)((nf + 1) + 3 * (nr + 1) + 9 * (ak + 1)));
+        });
     }
 
     // Returns PQP_STATUS_SOLVED, or why not.  A QP whose hard rows cannot all hold (an end box out of the controls' reach, say) shows in
@@ -643,8 +721,15 @@ struct Solver {
             else if (!(mu < 1e-3)) verdict = PQP_STATUS_MAX_ITER;      // (short of mu_stop but below 1e-3: the active-set rounds get their chance)
             else {
                 backward<MODE_GUESS>(0.0);
-                for (int r = 0; r < kPolishMaxRounds; ++r) {
-                    if (forward_set()) return PQP_STATUS_SOLVED;
+                // (the last attempt: guarded rounds once the plain ones have had their chance)
+                const int max_rounds = attempt == 2 ? 5 * kPolishMaxRounds : kPolishMaxRounds;
+                for (int r = 0; r < max_rounds; ++r) {
+                    if (r < kPolishMaxRounds) { if (forward_set<false>()) return PQP_STATUS_SOLVED; }
+                    else {
+                        // (x_N confirms its set: one plain roll-out of the same gains puts it into D_X*, which a guarded one leaves at x)
+                        if (forward_set<true>()) { if (forward_set<false>()) return PQP_STATUS_SOLVED; }
+                        else settle();
+                    }
                     backward<MODE_SET>(0.0);
                 }
                 verdict = PQP_STATUS_MAX_ITER;

@@ -248,3 +248,27 @@ def test_paths_of_more_than_512_waypoints(hip_lib):
     rd = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
     h.close()
     assert (rd["status"] == 1).all() and np.array_equal(rd["out"], r["out"])             # exact optima there too: they meet eps 2e-3
+
+
+@pytest.mark.gpu
+def test_long_paths_whose_active_set_rounds_cycle(hip_lib):
+    """The QPs of tests/test_lq_emulation.py::CYCLING on the device: the plain active-set rounds of all three attempts cycle on them; the
+    guarded rounds of the last attempt (pqp_path_lq.hpp forward_set<true>: steps as long as the piecewise quadratic objective falls along
+    them) end at the optimum - SOLVED, and the returned path passes the KKT conditions of the assembled QP of the last pass."""
+    from path_optimizer_2_amd import capi
+    from path_optimizer_2_amd.synth import make_batch
+    from test_lq_emulation import CYCLING, kkt_certificate_of_the_last_pass
+    for n, profile, seed, qp in CYCLING:
+        kw = {} if seed is None else {"seed": seed}
+        # the QP among 63 neighbours: one wavefront, its other lanes on QPs of ordinary cost
+        b = make_batch(64, n, profile, first_qp=qp - 10, **kw)
+        h = capi.Handle(capi.production_params(), device=0, max_batch=64, max_n=n)
+        h.set_option(capi.OPT_STORE_WARM, 0)
+        h.set_option(capi.OPT_STREAM_BATCH, 1)
+        r0 = h.solve(b["ref"], b["bounds"], b["scal"], passes=0)
+        r1 = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+        assert h.last_path_kernel() == capi.KERNEL_LANE_PER_QP
+        h.close()
+        assert (r1["status"] == 1).all() and (r1["info"][:, 4] == 2).all()
+        assert r1["info"][10, 7] > 36, r1["info"][10]
+        kkt_certificate_of_the_last_pass(b["ref"][10], b["bounds"][10], b["scal"][10], r0["out"][10], r1["out"][10])

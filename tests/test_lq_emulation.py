@@ -26,38 +26,60 @@ def test_every_path_is_the_converged_oracle_s(n, profile, batch, seed):
     assert np.abs(r["out"][:k] - want).max() < 1e-4
 
 
-def test_kkt_certificate_of_the_returned_point():
+def kkt_certificate_of_the_last_pass(ref, bounds, scal, first, final):
     """Solver-independent: the returned (l, psi, kappa, kappa') with the slacks and multipliers it implies satisfies the KKT conditions of
-    the assembled QP of the LAST pass (oracle assembly, reference numbering)."""
+    the assembled QP of the LAST pass (oracle assembly around the first pass's optimum, reference numbering)."""
     import scipy.sparse as sp
-    n = 60
-    b = make_batch(6, n, "varied", seed=12)
+    n = ref.shape[0]
+    Pd, A, lo, up, sz = O.assemble_path_qp(ref, first[:, 3:6], bounds, scal)
+    o = final
+    x = np.zeros(sz["vars"])
+    x[0:3 * n:3] = o[:, 3]; x[1:3 * n:3] = o[:, 4]; x[2:3 * n:3] = o[:, 5]; x[3 * n:4 * n - 1] = o[:-1, 6]
+    # slacks: what the collision rows need beyond their box
+    A = sp.csr_matrix(A)
+    rows = A @ x
+    for i in range(n):
+        for j in range(2):
+            r_ = 4 * n + 2 * i + j
+            x[4 * n - 1 + 2 * i + j] = np.clip(rows[r_], lo[r_], up[r_]) - rows[r_]
+    ax = A @ x
+    assert np.maximum(lo - ax, ax - up).max() < 1e-8                      # primal feasibility
+    # multipliers: slack rows y = -w_s s; the rest from stationarity by least squares on the rows active at x
+    g = Pd * x
+    act = (np.abs(ax - lo) < 1e-7) | (np.abs(ax - up) < 1e-7)
+    At = A[act].T.toarray()
+    y_act, *_ = np.linalg.lstsq(At, -g, rcond=None)
+    assert np.abs(At @ y_act + g).max() < 1e-6                            # stationarity
+    y = np.zeros(sz["cons"]); y[act] = y_act
+    ineq = act & (up - lo > 1e-9)
+    assert (y[ineq & (np.abs(ax - up) < 1e-7)] > -1e-6).all() and (y[ineq & (np.abs(ax - lo) < 1e-7)] < 1e-6).all()   # dual signs
+
+
+def test_kkt_certificate_of_the_returned_point():
+    b = make_batch(6, 60, "varied", seed=12)
     r0 = E.solve(b["ref"], b["bounds"], b["scal"], passes=0)
     r1 = E.solve(b["ref"], b["bounds"], b["scal"], passes=1)
     for q in range(6):
-        lin = r0["out"][q][:, 3:6]
-        Pd, A, lo, up, sz = O.assemble_path_qp(b["ref"][q], lin, b["bounds"][q], b["scal"][q])
-        o = r1["out"][q]
-        x = np.zeros(sz["vars"])
-        x[0:3 * n:3] = o[:, 3]; x[1:3 * n:3] = o[:, 4]; x[2:3 * n:3] = o[:, 5]; x[3 * n:4 * n - 1] = o[:-1, 6]
-        # slacks: what the collision rows need beyond their box
-        A = sp.csr_matrix(A)
-        rows = A @ x
-        for i in range(n):
-            for j in range(2):
-                r_ = 4 * n + 2 * i + j
-                x[4 * n - 1 + 2 * i + j] = np.clip(rows[r_], lo[r_], up[r_]) - rows[r_]
-        ax = A @ x
-        assert np.maximum(lo - ax, ax - up).max() < 1e-8                      # primal feasibility
-        # multipliers: slack rows y = -w_s s; the rest from stationarity by least squares on the rows active at x
-        g = Pd * x
-        act = (np.abs(ax - lo) < 1e-7) | (np.abs(ax - up) < 1e-7)
-        At = A[act].T.toarray()
-        y_act, *_ = np.linalg.lstsq(At, -g, rcond=None)
-        assert np.abs(At @ y_act + g).max() < 1e-6                            # stationarity
-        y = np.zeros(sz["cons"]); y[act] = y_act
-        ineq = act & (up - lo > 1e-9)
-        assert (y[ineq & (np.abs(ax - up) < 1e-7)] > -1e-6).all() and (y[ineq & (np.abs(ax - lo) < 1e-7)] < 1e-6).all()   # dual signs
+        kkt_certificate_of_the_last_pass(b["ref"][q], b["bounds"][q], b["scal"][q], r0["out"][q], r1["out"][q])
+
+
+# QPs on which the plain active-set rounds cycle - from the interior point of every attempt - until the rounds run out (found by
+# tools/lq_robustness_sweep.py-style sweeps of 16 384 ... 131 072 QPs per size; none at 300 waypoints or fewer): (n, profile, seed, QP)
+CYCLING = [(512, "varied", None, 5742), (1000, "varied", 3001, 1450), (1000, "uniform", 3007, 3912)]
+
+
+@pytest.mark.parametrize("n,profile,seed,qp", CYCLING)
+def test_guarded_rounds_end_the_cycles_of_long_paths(n, profile, seed, qp):
+    """forward_set<GUARDED>: the last attempt's rounds beyond the usual twelve step only as far as the piecewise quadratic objective
+    falls.  These QPs ended PQP_STATUS_MAX_ITER before (profiles/r05t_crossover_long_paths.txt: 16 383 of 16 384 at 512 waypoints); now
+    SOLVED, and what SOLVED returns passes the KKT conditions of the assembled QP."""
+    kw = {} if seed is None else {"seed": seed}
+    b = make_batch(1, n, profile, first_qp=qp, **kw)
+    r0 = E.solve(b["ref"], b["bounds"], b["scal"], passes=0)
+    r1 = E.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    assert r1["status"][0] == 1 and r1["info"][0, 4] == 2
+    assert r1["info"][0, 7] > 36                      # (it did take the guarded rounds: more than three attempts' worth of plain ones)
+    kkt_certificate_of_the_last_pass(b["ref"][0], b["bounds"][0], b["scal"][0], r0["out"][0], r1["out"][0])
 
 
 def test_first_solve_only_given_linearisation_point_and_two_step_route():
