@@ -214,8 +214,7 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      active-set rounds whose last round is the KKT test, i.e. the same exact optimum as the lane-per-
  *                                      waypoint kernel's verified polish.  It wins where the batch fills the chip's 65 536 lanes (65 536
  *                                      QPs of 80 waypoints: 1.9x); it keeps no warm state
- *                                      (hence the PQP_OPT_STORE_WARM condition; a start curvature outside its box by no more than eps_abs + eps_rel * bound is projected
- *                                      onto the box - OSQP at that eps calls such a QP solved -, by more: PQP_STATUS_PRIMAL_INFEASIBLE), iters[] counts its interior-point iterations and info[] =
+ *                                      (hence the PQP_OPT_STORE_WARM condition), iters[] counts its interior-point iterations and info[] =
  *                                      {row residual, complementarity, iterations of the first pass, iterations, solved passes, active-set
  *                                      rounds of the first pass, Riccati sweeps, active-set rounds}.  PQP_OPT_ORDER_BY_COST on this kernel (round 5; batches of at least
  *                                      768 wavefronts, not with PQP_OPT_CARRY_CYCLES): the wavefronts of a solve hold QPs that ran the same interior-point iterations and
@@ -298,6 +297,9 @@ int pqp_path_assemble_device(pqp_handle* h, int batch, int n, int precise, const
  *   the lane-per-QP kernel the optimum of the last pass that WAS solved, or - when none was - the reference line itself (l = dpsi = 0).
  *   iters[] and info[] differ between the two kernels as well (above; PQP_OPT_STREAM_BATCH): pqp_last_path_kernel says which one served
  *   the handle's last solve, so that a caller can tell what it received.
+ *   A start curvature scal[q][2] outside the curvature box by no more than OSQP's primal tolerance eps_abs + eps_rel * bound is projected onto the
+ *   box by both kernels (strictly such a QP has no feasible point; OSQP at that eps calls it solved with a point that misses the row by that
+ *   little); outside by more: PQP_STATUS_PRIMAL_INFEASIBLE.
  *   A QP with a collision box whose lower bound exceeds its upper bound is refused as OSQP refuses it at setup: the host-pointer
  *   entry points do not launch it and report PQP_STATUS_PRIMAL_INFEASIBLE (out[q] = 0); the *_device entry points do not
  *   validate their inputs (there such a row is pinned to its upper bound). */

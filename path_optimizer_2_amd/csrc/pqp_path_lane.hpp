@@ -607,6 +607,10 @@ struct PathQp {
             sincos_shared(sc[5], &sn, &cn);
             kap = (sn / cn) / prm.wheel_base;
         }
+        // A start curvature outside its box by no more than OSQP's primal tolerance (eps_abs + eps_rel * bound) is a QP the reference calls solved: ADMM
+        // meets eps with a point that misses the row by that little.  Strictly it has no feasible point, so no polish of it could ever be verified (the
+        // scenario of tools/robustness_sweep.py seed 1007, QP 6640: 520 ADMM iterations, 627 reduced solves, a launch that lasts 6 ms instead of 0.66).
+        // The start state is projected onto the box by that little instead, as the lane-per-QP kernel does (pqp_path_lq.hpp run()), and the QP solved exactly.
         ctx.phase([&](int t, Lane& ln) {
             Slot& S = ln.s;
             const int i = t;
@@ -618,6 +622,10 @@ struct PathQp {
             _Pragma("unroll") for (int k = 0; k < 6; ++k) S.a[k] = a6[k];
             // transition right-hand sides: -c (:221-224), or -x0 at the first waypoint (:216-220)
             _Pragma("unroll") for (int k = 0; k < 3; ++k) S.bT[k] = !real ? 0.0 : (prev ? -c3[k] : -sc[k]);
+            if (real && !prev) {
+                const double over = fabs(sc[2]) - kap;
+                if (over > 0.0 && over <= prm.eps_abs + prm.eps_rel * kap) S.bT[2] = sc[2] > 0.0 ? -kap : kap;
+            }
             // collision boxes (:232-248); rough: one row l + s_c on the centre box, the R row and sr are dummies
             const int ic = real ? i : n - 1;
             const double* b = A.bounds + ((size_t)qp * stride + ic) * PQP_BOUNDS_STRIDE;

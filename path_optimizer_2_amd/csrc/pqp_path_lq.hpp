@@ -787,8 +787,8 @@ struct Solver {
         x0[0] = sc[0]; x0[1] = sc[1]; x0[2] = sc[2];                      // base_solver.cpp:216-220
         kl = tan(sc[5]) / p.wheel_base;                                   // :226
         // A start curvature outside its box by no more than OSQP's primal tolerance (eps_abs + eps_rel * bound) is a QP the reference calls solved - ADMM
-        // meets eps with a point that misses the row by that little - and so does the lane-per-waypoint kernel ("a polish that cannot be verified
-        // ends like OSQP").  Here the start state is projected onto the box by that little, and the QP solved exactly; beyond the tolerance the QP is PRIMAL_INFEASIBLE (below).
+        // meets eps with a point that misses the row by that little.  The start state is projected onto the box by that little, and the QP solved exactly (the
+        // lane-per-waypoint kernel does the same in assemble()); beyond the tolerance the QP is PRIMAL_INFEASIBLE (below).
         if (fabs(x0[2]) > kl && fabs(x0[2]) - kl <= p.eps_abs + p.eps_rel * kl) x0[2] = x0[2] > 0.0 ? kl : -kl;
         psi_lo = -kInfty; psi_hi = kInfty;
         if (p.constraint_end_heading && sc[4] == 0.0) {                   // :254-258

@@ -399,6 +399,31 @@ def test_error_paths(hip_lib):
     h.close()
 
 
+def test_a_start_curvature_outside_its_box_by_less_than_the_tolerance_on_the_gpu(hip_lib):
+    """tests/test_lane_emulation.py::test_a_start_curvature_outside_its_box_by_less_than_the_tolerance_is_projected on the device: the scenario
+    whose start curvature lies 3.8e-5 outside the curvature box - once 627 reduced solves, unpolished - among 31 ordinary neighbours: every QP
+    polished in both passes at an ordinary cost, the same paths from both kernels; outside by more than OSQP's tolerance: PRIMAL_INFEASIBLE."""
+    b = make_batch(32, 80, "varied", seed=1007, first_qp=6640 - 7)
+    kap = np.tan(b["scal"][7, 5]) / 2.5
+    assert 0.0 < b["scal"][7, 2] - kap < 1e-4
+    res = {}
+    for stream in (0, 1):
+        h = capi.Handle(capi.production_params(), max_batch=32, max_n=80)
+        h.set_option(capi.OPT_STORE_WARM, 0)
+        h.set_option(capi.OPT_STREAM_BATCH, stream)
+        res[stream] = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+        assert h.last_path_kernel() == (capi.KERNEL_LANE_PER_QP if stream else capi.KERNEL_LANE_PER_WAYPOINT)
+        h.close()
+        assert (res[stream]["status"] == 1).all() and (res[stream]["info"][:, 4] == 2).all()
+    assert res[0]["info"][7, 5] < 60 and res[0]["iters"][7] == 8
+    assert np.abs(res[0]["out"][:, :, 3:5] - res[1]["out"][:, :, 3:5]).max() < 2e-6
+    b["scal"][7, 2] = kap + 1.5e-4
+    h = capi.Handle(capi.production_params(), max_batch=32, max_n=80)
+    r = h.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    h.close()
+    assert r["status"][7] == 4 and (np.delete(r["status"], 7) == 1).all()
+
+
 def test_primal_infeasibility_certificate_on_the_gpu(hip_lib):
     """OSQP's certificate (kernel variant with eps_prim_inf > 0, the default parameters): a start curvature outside the
     curvature box ends with PQP_STATUS_PRIMAL_INFEASIBLE at the same termination check as the restatement; the production

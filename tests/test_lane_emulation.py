@@ -152,19 +152,38 @@ def test_former_stragglers_finish_in_the_first_attempts(seed, qp, n, profile, wh
     assert np.abs(r["out"][0][:, 3:5] - ref[-1]["out"][:, 3:5]).max() < 5e-5
 
 
-def test_a_polish_that_cannot_be_verified_ends_like_osqp():
-    """This scenario's start curvature lies 1.6e-5 outside the curvature box: ADMM meets eps = 1e-4, no tighter test, and no
-    polished point passes the KKT check.  polish_patience = 5: solved, unpolished, after the attempt at iteration 465 of each
-    pass (without it: 4000 iterations and PQP_STATUS_MAX_ITER)."""
+def test_a_start_curvature_outside_its_box_by_less_than_the_tolerance_is_projected():
+    """This scenario's start curvature lies 3.8e-5 outside the curvature box: strictly the QP has no feasible point, OSQP at eps 1e-4 - the
+    reference - calls it solved with a point that misses the row by that little.  The kernel used to end the same way - solved, unpolished,
+    after 520 ADMM iterations and 627 reduced solves, forty times the cost of an ordinary QP: a launch with this QP in it lasted 6 ms instead
+    of 0.66.  Now the start state is projected onto the box when it is outside by no more than OSQP's primal tolerance, as the lane-per-QP
+    solver does, and the QP solved exactly: polished, at an ordinary cost, the same path as that solver's."""
+    import lq_emu_util as LQ
     b = make_batch(1, 80, "varied", seed=1007, first_qp=6640)
+    kap = np.tan(b["scal"][0, 5]) / 2.5
+    assert 0.0 < b["scal"][0, 2] - kap < 1e-4
     r = E.solve(E.production(), b["ref"], b["bounds"], b["scal"], passes=1)
-    assert r["status"][0] == 1 and r["info"][0, 4] == 0 and r["iters"][0] <= 2 * 495
+    assert r["status"][0] == 1 and r["info"][0, 4] == 2 and r["iters"][0] == 8 and r["info"][0, 5] < 40
+    q = LQ.solve(b["ref"], b["bounds"], b["scal"])
+    assert q["status"][0] == 1 and np.abs(r["out"][0][:, 3:5] - q["out"][0][:, 3:5]).max() < 1e-6
     ref = O.solve_path(b["ref"][0], b["bounds"][0], b["scal"][0], st=O.OsqpSettings(eps_abs=1e-4, eps_rel=1e-4))
-    assert [x["status"] for x in ref] == ["solved", "solved"]                  # the plain algorithm calls it solved too
-    assert np.abs(r["out"][0][:, 3:5] - ref[-1]["out"][:, 3:5]).max() < 2e-3   # two eps-1e-4 ADMM points of one QP
-    r0 = E.solve(E.production(polish_patience=0, max_iter=1500), b["ref"], b["bounds"], b["scal"], passes=1)
-    assert r0["status"][0] == 2
+    assert [x["status"] for x in ref] == ["solved", "solved"]                  # the plain algorithm on the unprojected QP: solved too,
+    assert np.abs(r["out"][0][:, 3:5] - ref[-1]["out"][:, 3:5]).max() < 2e-3   # an eps-1e-4 ADMM point of it
+    # outside by more than the tolerance: no point satisfies the rows, and ADMM says so
+    sc = b["scal"].copy()
+    sc[0, 2] = kap + 1.5e-4
+    assert E.solve(E.production(), b["ref"], b["bounds"], sc, passes=1)["status"][0] == 4
 
+
+def test_a_polish_that_cannot_be_verified_ends_like_osqp():
+    """A polish no point of which passes its KKT test (here: a tolerance nothing can meet) must not hold the QP for max_iter iterations:
+    polish_patience = 5 ends it solved - by OSQP's own test, as the reference would - and unpolished after the attempt at iteration 260 of each
+    pass; without it ADMM runs on between attempts for more than twice as long."""
+    b = make_batch(1, 80, "varied", seed=1007, first_qp=6640)
+    r = E.solve(E.production(polish_tol=1e-30), b["ref"], b["bounds"], b["scal"], passes=1)
+    assert r["status"][0] == 1 and r["info"][0, 4] == 0 and r["iters"][0] <= 2 * 495
+    r0 = E.solve(E.production(polish_tol=1e-30, polish_patience=0, max_iter=1500), b["ref"], b["bounds"], b["scal"], passes=1)
+    assert r0["info"][0, 4] == 0 and r0["iters"][0] > 2 * r["iters"][0]
 
 
 @pytest.mark.parametrize("n,profile", [(80, "uniform"), (120, "varied"), (200, "uniform")])
