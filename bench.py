@@ -196,8 +196,8 @@ def main():
     ap.add_argument("--profile", default=None, choices=["uniform", "varied"])
     ap.add_argument("--eps", type=float, default=1e-4, help="eps_abs = eps_rel of the ADMM termination test")
     ap.add_argument("--no-polish", action="store_true", help="plain OSQP termination, no polish")
-    ap.add_argument("--rho-interval", type=int, default=None, help="adaptive_rho_interval (iterations; default: the production setting's 8)")
-    ap.add_argument("--polish-every", type=int, default=None, help="also try the KKT-verified polish every k ADMM iterations (default 8)")
+    ap.add_argument("--rho-interval", type=int, default=None, help="adaptive_rho_interval (iterations; default: the production setting's: 5 up to 90 waypoints, 8 beyond)")
+    ap.add_argument("--polish-every", type=int, default=None, help="also try the KKT-verified polish every k ADMM iterations (default: 5 up to 90 waypoints, 8 beyond)")
     ap.add_argument("--polish-lazy", type=int, default=None, help="rounds of a polish attempt that move rows after one solve (default: the production setting's 5)")
     ap.add_argument("--polish-refine", type=int, default=2, help="refinement solves per active-set round of the polish")
     ap.add_argument("--polish-max-rounds", type=int, default=0, help="active-set rounds before a polish attempt gives up (0: max(24, n/5 - 8))")
@@ -206,7 +206,7 @@ def main():
     ap.add_argument("--rho-tolerance", type=float, default=2.0, help="adaptive_rho_tolerance")
     ap.add_argument("--rho", type=float, default=None, help="initial ADMM step size rho (default: the production setting's 0.1)")
     ap.add_argument("--polish-warm-set", type=int, default=2, help="1: pass 2 starts with a polish on pass 1's active set; 2: and keeps its equilibration")
-    ap.add_argument("--check-termination", type=int, default=None, help="residual check interval (iterations; default 8)")
+    ap.add_argument("--check-termination", type=int, default=None, help="residual check interval (iterations; default: 5 up to 90 waypoints, 8 beyond)")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight: consecutive steps (independent batches) go round-robin to k handles / HIP "
                     "streams, as a planning server keeps independent batches in flight: the next batch's QPs fill the slots the slow tail of "
                     "this one leaves idle.  1 = strictly one launch after the other (reported under secondary.one_batch_at_a_time)")
@@ -820,7 +820,7 @@ def main():
                                   "1e-4; the metric's literal 'ADMM iters to 1e-4' is secondary.plain_admm_eps_1e-4)") if polish else "plain OSQP termination (ADMM to eps)",
                        "kernel": "path_stream_kernel" if stream else "path_solve_kernel",
                        "scenarios_per_step": f"{n_var} variants cycled: the batch and its +-5 % jittered planning cycles (synth.jitter_batch)" if pipe is None and n_var > 1 else "the identical batch every step",
-                       "polish_every": prm.polish_every, "adaptive_rho_interval": prm.adaptive_rho_interval, "check_termination": prm.check_termination,
+                       "polish_every": capi.path_interval(prm.polish_every, n), "adaptive_rho_interval": capi.path_interval(prm.adaptive_rho_interval, n), "check_termination": capi.path_interval(prm.check_termination, n),
                        "ruiz_passes": abs(prm.scaling), "ruiz_evaluated_on": "one interior waypoint's blocks, taken by every waypoint (pqp_params.scaling < 0: a valid "
                        "diagonal scaling, equal to the full passes' D, E, c on these scenario families)" if prm.scaling < 0 else "every waypoint (OSQP's passes)", "polish_lazy": prm.polish_lazy,
                        "polish_refine_iter": args.polish_refine, "polish_max_rounds": args.polish_max_rounds, "polish_warm_set": args.polish_warm_set,

@@ -122,9 +122,11 @@ typedef struct pqp_params {
                                          varied spacing).  Meant for handles with polish != 0, whose result does not depend on the metric: with
                                          polish == 0 the eps-accurate iterates then differ from OSQP's.  |k| <= 64 (pqp_set_params). */
     int32_t adaptive_rho;             /* 1     */
-    int32_t adaptive_rho_interval;    /* 100 (OSQP's "auto" value without wall-clock profiling) */
+    int32_t adaptive_rho_interval;    /* 100 (OSQP's "auto" value without wall-clock profiling).  This field, check_termination and polish_every < 0
+                                         (pqp_production_params: -1): by path length - 5 iterations for paths of up to 90 waypoints, 8 beyond
+                                         (measured: profiles/r05x_polish_every_seeds_configs.txt; the smoother QPs: 8) */
     double adaptive_rho_tolerance;    /* 5     */
-    int32_t check_termination;        /* 25    */
+    int32_t check_termination;        /* 25    (< 0: see adaptive_rho_interval) */
     /* solution polishing (OSQP paper section 4.2; OSQP default and the reference: off).  When on, the active
      * set the ADMM iterate predicts is solved as an equality-constrained QP (regularised KKT + iterative
      * refinement) and ACCEPTED ONLY IF the polished point passes a KKT check (primal feasibility of inactive
@@ -139,7 +141,7 @@ typedef struct pqp_params {
                                          fallback).  With polish == 2 QPs with inequality rows run the plain ADMM.  The path QP treats 2
                                          like 1 */
     int32_t polish_refine_iter;       /* 4     */
-    int32_t polish_every;             /* 0: only when the residual test passes; k: also try every k iterations */
+    int32_t polish_every;             /* 0: only when the residual test passes; k: also try every k iterations; < 0: see adaptive_rho_interval */
     int32_t polish_warm_set;          /* 1: a warm re-linearised re-solve starts with a polish on the previous pass's active set;
                                          2: ... and keeps that pass's equilibration (D, E, c) instead of re-running Ruiz */
     int32_t polish_max_rounds;        /* 40: active-set correction rounds per polish attempt; <= 0: max(24, n/5 - 8) (40 for the smoothers) */

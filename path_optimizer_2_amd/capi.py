@@ -209,6 +209,12 @@ def _ptr(a):
 
 
 OPT_STORE_WARM, OPT_ORDER_BY_COST, OPT_RESERVE_CUS, OPT_STREAM_BATCH, OPT_CARRY_CYCLES, OPT_CHAIN_GRAPH = 1, 2, 3, 4, 5, 6
+def path_interval(value, n):
+    """What pqp_params.adaptive_rho_interval / check_termination / polish_every mean for paths of n waypoints: negative values (the production
+    setting) stand for "by path length" (csrc/pqp_defaults.hpp path_interval: 5 iterations up to 90 waypoints, 8 beyond)."""
+    return value if value >= 0 else (5 if n <= 90 else 8)
+
+
 KERNEL_NONE, KERNEL_LANE_PER_WAYPOINT, KERNEL_LANE_PER_QP = 0, 1, 2      # pqp_last_path_kernel
 SMOOTHING_TENSION2, SMOOTHING_TENSION = 0, 1
 

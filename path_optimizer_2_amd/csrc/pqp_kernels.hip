@@ -935,7 +935,8 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     // the worst path of 300 waypoints; the kernels of up to 128 waypoints do not compile the feature in: Ctx::kFinalRefine) (a 100x
     // tighter acceptance test instead leaves a few QPs in 30 000 unverifiable: 350-1000 solves, configs[4] halved).  Measured against the converged C oracle over 32 768 QPs per shape (profiles/r05o_*): before, 7 paths of 200 waypoints
     // and 117 of 300 were 3e-5 ... 4.6e-3 off (the lane-per-QP kernel, whose roll-out satisfies the rows exactly: 5e-6).
-    { const int k = n > 256 ? 3 : (n > 128 ? 1 : 0); if (a.prm.polish_final_refine < k) a.prm.polish_final_refine = k; }
+    // ... and the production setting's intervals by path length (pqp_defaults.hpp)
+    pqp::resolve_path_params(&a.prm, n);
     int nw = 1, lg = 0;
     while (64 * nw < n) { nw *= 2; lg += 1; }           // one waypoint per lane: T = 64 * nw >= n threads per QP
     const int T_lanes = 64 * nw;
@@ -1222,6 +1223,7 @@ int sm_solve(pqp_handle* h, int type, int batch, int n, int32_t* status, int32_t
     a.pband = h->b_pband.as<double>(); a.q = h->b_q.as<double>(); a.acol = h->b_acol.as<int>(); a.aval = h->b_aval.as<double>();
     a.trow = h->b_trow.as<int>(); a.tslot = h->b_tslot.as<int>(); a.lo = h->b_lo.as<double>(); a.up = h->b_up.as<double>();
     a.x = h->b_x.as<double>(); a.y = h->b_y.as<double>(); a.status = status; a.iters = iters; a.info = info; a.prm = h->prm;
+    pqp::resolve_banded_params(&a.prm);
     // the row data of A, the index lists and q staged in LDS once per QP (256-lane kernels: always - two of them still share a CU's LDS up
     // to 80 KB each; 512-lane kernels: when it fits; 1024-lane kernels: never)
     const size_t lds0 = (size_t)pqp::BqLayout{sh.nv, sh.nc, sh.bw}.total(false) * 8, lds1 = (size_t)pqp::BqLayout{sh.nv, sh.nc, sh.bw}.total(true) * 8;

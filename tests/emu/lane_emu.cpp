@@ -123,6 +123,7 @@ extern "C" int pqp_emu_path_solve(const pqp_params* prm, int batch, int n, const
     a.wscale = wscale.data();
     a.store_warm = 1;
     a.prm = *prm;
+    pqp::resolve_path_params(&a.prm, n);          // (as the launcher does)
     a.n_of = g_n_of;
     for (int q = 0; q < batch; ++q) {
         if (pqp::PathQp<HostCtx, true>::count_of(a, q) < 2) {
@@ -146,6 +147,7 @@ extern "C" int pqp_emu_probe(const pqp_params* prm, int n, const double* ref, co
     pqp::PathSolveArgs a;
     std::memset(&a, 0, sizeof(a));
     a.batch = 1; a.n = n; a.ref = ref; a.bounds = bounds; a.scal = scal; a.prm = *prm;
+    pqp::resolve_path_params(&a.prm, n);
     std::vector<double> wsave((size_t)T * PQP_SAVE_STRIDE, 0.0);
     a.wsave = wsave.data();
     std::vector<double> wscale((size_t)T * 18, 0.0);
@@ -223,6 +225,7 @@ extern "C" int pqp_emu_banded_solve(const pqp_params* prm, int batch, int nv, in
     a.batch = batch; a.nv = nv; a.nc = nc; a.bw = bw; a.pbw = pbw;
     a.pband = pband; a.q = q; a.acol = acol; a.aval = aval; a.trow = trow; a.tslot = tslot; a.lo = lo; a.up = up;
     a.x = x; a.y = y; a.status = status; a.iters = iters; a.info = info; a.prm = *prm;
+    pqp::resolve_banded_params(&a.prm);
     switch (bw) {
         case 3: bq_run<3>(a); break;
         case 4: bq_run<4>(a); break;

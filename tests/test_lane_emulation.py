@@ -163,7 +163,7 @@ def test_a_start_curvature_outside_its_box_by_less_than_the_tolerance_is_project
     kap = np.tan(b["scal"][0, 5]) / 2.5
     assert 0.0 < b["scal"][0, 2] - kap < 1e-4
     r = E.solve(E.production(), b["ref"], b["bounds"], b["scal"], passes=1)
-    assert r["status"][0] == 1 and r["info"][0, 4] == 2 and r["iters"][0] == 8 and r["info"][0, 5] < 40
+    assert r["status"][0] == 1 and r["info"][0, 4] == 2 and r["iters"][0] == 5 and r["info"][0, 5] < 40
     q = LQ.solve(b["ref"], b["bounds"], b["scal"])
     assert q["status"][0] == 1 and np.abs(r["out"][0][:, 3:5] - q["out"][0][:, 3:5]).max() < 1e-6
     ref = O.solve_path(b["ref"][0], b["bounds"][0], b["scal"][0], st=O.OsqpSettings(eps_abs=1e-4, eps_rel=1e-4))
@@ -221,3 +221,20 @@ def test_equilibration_on_one_waypoint_is_the_full_passes_bit_for_bit(n, profile
     rn = E.solve(E.production(scaling=-4), b["ref"][:2], b["bounds"][:2], b["scal"][:2], lin=lin, passes=0)
     assert (r4["status"] == 1).all() and (rn["status"] == 1).all()
     assert np.abs(r4["out"] - rn["out"]).max() < 1e-6
+
+
+def test_the_production_intervals_follow_the_path_length():
+    """pqp_params.adaptive_rho_interval / check_termination / polish_every < 0 (pqp_production_params): 5 iterations for paths of up to 100
+    waypoints, 8 beyond (csrc/pqp_defaults.hpp path_interval, mirrored by capi.path_interval).  A QP whose first polish attempt is accepted
+    has run exactly that many ADMM iterations; explicit values are taken as they are; the optimum does not depend on any of it."""
+    from path_optimizer_2_amd import capi
+    p = E.production()
+    assert p.adaptive_rho_interval < 0 and p.check_termination < 0 and p.polish_every < 0
+    for n in (60, 90, 91, 120):
+        b = make_batch(16, n, "uniform", seed=5)
+        r = E.solve(p, b["ref"], b["bounds"], b["scal"], passes=1)
+        assert (r["status"] == 1).all() and (r["info"][:, 4] == 2).all()
+        k = capi.path_interval(p.polish_every, n)
+        assert k == (5 if n <= 90 else 8) and np.median(r["iters"]) == k and r["iters"].min() == k
+        r8 = E.solve(E.production(adaptive_rho_interval=8, check_termination=8, polish_every=8), b["ref"], b["bounds"], b["scal"], passes=1)
+        assert r8["iters"].min() == 8 and np.abs(r8["out"][:, :, 3:5] - r["out"][:, :, 3:5]).max() < 2e-6
