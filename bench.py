@@ -595,7 +595,7 @@ def main():
                 secondary["reference_demo_length_n60"] = {"value": batch * sec_steps / t60, "unit": "paths/s", "steps": sec_steps, "ms_per_step": t60 / sec_steps * 1e3,
                                                           "batch": batch, "n_waypoints": n60, "batches_in_flight": len(l60), "solved": int((l60[0][2] == 1).sum().item()),
                                                           "setting": "the headline setting at N = 60 waypoints: one wavefront per QP (64 lanes), four QPs per CU = 1024 slots - a batch of 1024 is then ONE QP per slot and a "
-                                                                     "launch lasts as long as its slowest QP; 8192 QPs of N = 60: 5.75 M paths/s (profiles/r05k_n_sweep_batch8192.txt)"}
+                                                                     "launch lasts as long as its slowest QP (handles created after the headline's: their streams may share a hardware queue, so this is a lower bound - on its own, `bench.py --batch 1024 --n 60`: 5.3 M paths/s, profiles/r05ac_interval_rule_ends.txt); 8192 QPs of N = 60: 7.7 M paths/s (profiles/r05ab_n_sweep_batch8192.txt)"}
                 for hh, *_ in l60:
                     hh.close()
                 del l60, v60, r60
