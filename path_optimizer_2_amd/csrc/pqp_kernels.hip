@@ -1,13 +1,7 @@
 // pqp_kernels.hip — gfx950 (MI355X / CDNA4) kernels and the C ABI of include/pqp.h.
 //
-//   path_solve_kernel     persistent workgroups (64*NW lanes, one waypoint per lane) draw QPs from a ticket counter,
-//                         most expensive first when the handle knows the QPs' previous cost: assemble -> Ruiz
-//                         metrics -> block-cyclic-reduction factor -> ADMM loop + KKT-verified polish -> unpack ->
-//                         re-linearise -> warm re-solve, everything in VGPRs + 79 KB of LDS (T = 128: exchange buffers, polish save
-//                         area, parked Ruiz vectors; two QPs per CU); lanes of one row of 16 exchange through DPP operands, the
-//                         solver's control state is wave-uniform (scalar branches); HBM is read once (scenario) and written once
-//                         (path).  Algorithm: pqp_path_lane.hpp.
-//                         The last workgroup to finish a launch writes the ticket -> QP map of the next one (order_next_launch).
+//   path_solve_kernel     the lane-per-waypoint path-QP kernel lives in pqp_path_solve.hip (one translation unit per workgroup width);
+//                         this file holds its launcher, path_solve_impl.
 //   path_assemble_kernel  BaseSolver::setCost/setConstraints in the REFERENCE numbering: CSC values of A,
 //                         diagonal of P, l, u; staged through LDS and written with contiguous, coalesced
 //                         stores (base_solver.cpp:119-261).
@@ -29,280 +23,9 @@
 #include "pqp_path_lq_abi.hpp"
 #include <vector>
 
+#include "pqp_wave.hpp"
+
 namespace pqp {
-
-// -------------------------------------------------------------------------------------------------------
-// device execution context for PathQp: a phase is the code between two workgroup barriers
-// -------------------------------------------------------------------------------------------------------
-// A value that is the same in every lane, told to the compiler: what is derived from it - the control state of PathQp::run - then
-// branches with s_cbranch instead of exec-mask bookkeeping (v_cndmask per state variable per branch; +4.4 %: profiles/r02l_uniform_control.txt).
-__device__ __forceinline__ double uniform(double x) {
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
-}
-__device__ __forceinline__ bool uniform(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; }
-
-// wave / workgroup reductions shared by the hot and the cold context
-// One step of a wavefront max-reduction in the VALU (DPP: data-parallel primitives move a value between lanes inside the instruction,
-// no LDS round trip as with __shfl): x = max(x, x of the lane CTRL selects); lanes without a source keep their value.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_max_step(double x) {
-    const int lo = __double2loint(x), hi = __double2hiint(x);
-    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    return fmax(x, __hiloint2double(ohi, olo));
-}
-// max over the 64 lanes of a wavefront, the same value in every lane (and known to the compiler as wave-uniform)
-__device__ __forceinline__ double wave_max(double x) {
-    x = dpp_max_step<0x111, 0xf>(x);      // row_shr:1
-    x = dpp_max_step<0x112, 0xf>(x);      // row_shr:2
-    x = dpp_max_step<0x114, 0xf>(x);      // row_shr:4
-    x = dpp_max_step<0x118, 0xf>(x);      // row_shr:8      -> lane 15 of every row of 16: the row's max
-    x = dpp_max_step<0x142, 0xa>(x);      // row_bcast:15   -> lanes 31, 63: max of rows 0-1, 2-3
-    x = dpp_max_step<0x143, 0xc>(x);      // row_bcast:31   -> lane 63: max of the wavefront
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
-}
-
-// the same for a sum (lanes without a source add 0)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_sum_step(double x) {
-    const int lo = __double2loint(x), hi = __double2hiint(x);
-    const int olo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
-    const int ohi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
-    return x + __hiloint2double(ohi, olo);
-}
-__device__ __forceinline__ double wave_sum(double x) {
-    x = dpp_sum_step<0x111, 0xf>(x);
-    x = dpp_sum_step<0x112, 0xf>(x);
-    x = dpp_sum_step<0x114, 0xf>(x);
-    x = dpp_sum_step<0x118, 0xf>(x);
-    x = dpp_sum_step<0x142, 0xa>(x);
-    x = dpp_sum_step<0x143, 0xc>(x);
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
-}
-
-template <int NW, int K, bool MAX>
-__device__ __forceinline__ void wg_reduce(double (&v)[K], double* shp) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        double x = v[k];
-        v[k] = MAX ? wave_max(x) : wave_sum(x);
-    }
-    if (NW > 1) {
-        double* red = shp + ShLayout{64 * NW}.red();
-        const int w = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0)
-            for (int k = 0; k < K; ++k) red[k * 16 + w] = v[k];
-        __syncthreads();
-        for (int k = 0; k < K; ++k) {
-            double x = red[k * 16];
-            for (int j = 1; j < NW; ++j) x = MAX ? fmax(x, red[k * 16 + j]) : x + red[k * 16 + j];
-            v[k] = uniform(x);
-        }
-    }
-    __syncthreads();
-}
-
-// Lane-less context + out-of-line evaluation of the infeasibility certificate (all data in LDS): nothing of it lives in the
-// registers of the ADMM loop.
-template <int NW>
-struct LaneLessCtx {
-    double* shp;
-    __device__ __forceinline__ int T() const { return 64 * NW; }
-    template <class F>
-    __device__ __forceinline__ void phase(F f) {
-        f((int)threadIdx.x);
-        __syncthreads();
-    }
-    template <int K, class F>
-    __device__ __forceinline__ void reduce_max(double (&out)[K], F f) {
-        f((int)threadIdx.x, out);
-        wg_reduce<NW, K, true>(out, shp);
-    }
-    template <int K, class F>
-    __device__ __forceinline__ void reduce_sum(double (&out)[K], F f) {
-        f((int)threadIdx.x, out);
-        wg_reduce<NW, K, false>(out, shp);
-    }
-};
-template <int NW>
-__device__ __noinline__ bool dev_certificate(double* sh, double fl, double rl, double kap, double eps, double cscale) {
-    LaneLessCtx<NW> c{sh};
-    return primal_certificate(c, sh, 64 * NW, fl, rl, kap, eps, cscale);
-}
-
-// Up to this many wavefronts per QP the polish save area (and the parked Ruiz vectors) live in LDS; beyond, in the workgroup slot's global
-// memory.  4 is what fits (256 lanes: 157 KB).
-constexpr int kSaveLdsMaxNw = 4;
-
-template <int NW>
-__device__ __noinline__ bool dev_late_certificate(double* sh, int t, double* snap, bool have, LateCertIn in, double fl, double rl, double kap, double eps,
-                                                  double cscale) {
-    LaneLessCtx<NW> c{sh};
-    return late_certificate(c, sh, 64 * NW, t, snap, have, in, fl, rl, kap, eps, cscale);
-}
-
-// Hot context: the lane state is a local struct that SROA turns into registers; a phase is the code between two
-// workgroup barriers (for a one-wave workgroup the barrier is only a wait on outstanding LDS traffic).
-template <int NW>
-struct DevCtx {
-    // kSaveLds: up to 256 lanes the polish save area fits beside the exchange buffers (72 KB per QP at T = 128, two QPs per CU)
-    // kCstLds: pass constants in LDS instead of in registers (no gain at one wavefront per SIMD); kParkScale: the Ruiz vectors are parked
-    // between the passes (+2 %, profiles/r02b_variants.txt)
-    static constexpr bool kCstLds = false, kParkScale = true, kSaveLds = NW <= kSaveLdsMaxNw;
-    static constexpr bool kFinalRefine = NW >= 4;      // pqp_params::polish_final_refine is honoured: the contexts of paths beyond 128 waypoints
-    // DPP moves: the value of the lane H below / above in the same row of 16 lanes, of the previous row's last lane; 0 where
-    // there is no such lane.  Must run with every lane enabled (a disabled source lane reads as "no lane").  (profiles/r02j_dpp_exchanges.txt)
-    static constexpr bool kDpp = true;
-    template <int CTRL, int ROW_MASK>
-    __device__ __forceinline__ static double dpp0(double v) {
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
-        return __hiloint2double(hi, lo);
-    }
-    template <int H> __device__ __forceinline__ static double lane_below(double v) { return dpp0<0x110 + H, 0xf>(v); }     // row_shr:H
-    template <int H> __device__ __forceinline__ static double lane_above(double v) { return dpp0<0x100 + H, 0xf>(v); }     // row_shl:H
-    __device__ __forceinline__ static double prev_row_last(double v) { return dpp0<0x142, 0xe>(v); }                      // row_bcast:15
-    __device__ __forceinline__ static double uni(double x) { return uniform(x); }      // a wave-uniform value that reaches control flow
-    __device__ __forceinline__ static int uni_int(int x) { return __builtin_amdgcn_readfirstlane(x); }
-    Lane lane;
-    double* shp;
-    __device__ __forceinline__ long long clock() const { return (long long)wall_clock64(); }     // 100 MHz
-    __device__ __forceinline__ bool certificate(double* sh, int, double fl, double rl, double kap, double eps, double cscale) {
-        return uniform(dev_certificate<NW>(sh, fl, rl, kap, eps, cscale));
-    }
-    __device__ __forceinline__ bool late_certificate(double* sh, int t, double* snap, bool have, const LateCertIn& in, double fl, double rl, double kap,
-                                                     double eps, double cscale) {
-        return uniform(dev_late_certificate<NW>(sh, t, snap, have, in, fl, rl, kap, eps, cscale));
-    }
-    __device__ __forceinline__ int T() const { return 64 * NW; }
-    __device__ __forceinline__ double* sh() { return shp; }
-    template <class F>
-    __device__ __forceinline__ void phase(F f) {
-        f((int)threadIdx.x, lane);
-        __syncthreads();
-    }
-    // wave-local phase: LDS operations of one wavefront execute in program order, so lanes of the same wavefront see each
-    // other's writes without a workgroup barrier; the fence only stops the compiler from moving LDS accesses across it
-    template <class F>
-    __device__ __forceinline__ void phase_w(F f) {
-        f((int)threadIdx.x, lane);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    template <int K, class F>
-    __device__ __forceinline__ void reduce_max(double (&out)[K], F f) {
-        f((int)threadIdx.x, lane, out);
-        wg_reduce<NW, K, true>(out, shp);
-    }
-    template <int K, class F>
-    __device__ __forceinline__ void reduce_sum(double (&out)[K], F f) {
-        f((int)threadIdx.x, lane, out);
-        wg_reduce<NW, K, false>(out, shp);
-    }
-    // The cold operations (assemble, Ruiz, factorisation, polish bookkeeping, unpack) run inline on the same lane state: out of line, on a
-    // memory-resident copy, the lane state's round trips cost more than the spills they avoid (0.36x, profiles/r04h_cold_ops_out_of_line_ab.txt)
-    template <class PQ>
-    __device__ __forceinline__ void cold(PQ& pq, int op, int i0, int i1, double d0) { pq.do_cold(op, i0, i1, d0); }
-};
-
-// ticket -> QP of the NEXT launch, most expensive first: cost bins in descending order, within a bin in whatever order this workgroup's
-// lanes draw their ranks (results do not depend on the order).  Run by the last workgroup of a launch to leave its ticket loop (every workgroup counts itself out on hist[kCostBins]):
-// all keys and bin counts of the launch are complete then.  No separate kernel: with two launches in flight a tiny ordering kernel
-// waits for a free CU slot behind the other launch's persistent workgroups (measured: 266 us instead of 3).
-// `start`: 256 ints of the workgroup's dynamic LDS (free once its last QP is done).  Not a static array: 1 KB more per workgroup is what kept a FOURTH
-// one-wavefront workgroup (paths of up to 64 waypoints: 40.4 KB each) off a compute unit's 160 KB - three QPs per CU, one SIMD idle (round 5).
-__device__ void order_next_launch(const PathSolveArgs& args, int* start) {
-    __shared__ int s_last;
-    // release / acquire around the count-out: this workgroup's keys and bin counts (relaxed agent-scope atomics of record_cost) are
-    // visible before its count is, and the last workgroup reads the other XCDs' keys only after it has seen every count
-    if (threadIdx.x == 0) {
-        __threadfence();
-        s_last = atomicAdd(args.cost_hist + kCostBins, 1) == (int)gridDim.x - 1;
-        __threadfence();
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const int nt = blockDim.x;
-    for (int b = threadIdx.x; b < kCostBins; b += nt) start[b] = __hip_atomic_load(args.cost_hist + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (threadIdx.x == 0) {                 // exclusive suffix sum over 256 bins: QPs in more expensive bins
-        int acc = 0, thr = kCostBins;
-        for (int b = kCostBins - 1; b >= 0; --b) {
-            const int c = start[b]; start[b] = acc;
-            if ((long long)(args.carry_tails > 1 ? args.carry_tails : 8) * acc < args.batch) thr = b;       // (the cheapest bin above which less than 1 / k of the batch lies)
-            acc += c;
-        }
-        // PQP_OPT_CARRY_CYCLES = k >= 2: the bin from which on a QP counts as one of the launch's expensive ones (read by the next launch's QPs)
-        __hip_atomic_store(args.cost_hist + kCostBins + 1, thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    for (int q = threadIdx.x; q < args.batch; q += nt) {
-        const int k = __hip_atomic_load(args.cost_key + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int pos = atomicAdd(&start[(k >> 24) & 0xff], 1);          // (LDS atomic: the rank of q within its bin)
-        if (pos < args.batch) args.order_next[pos] = q;
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b <= kCostBins; b += nt) __hip_atomic_store(args.cost_hist + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
-}
-
-// One wavefront per SIMD: the lane state + the factorisation take the whole 512-register budget (occupancy 2 on 256: 0.41-0.53x,
-// profiles/r04f_occupancy2_ab.txt)
-template <int NW, bool CERT>
-__global__ void __launch_bounds__(64 * NW, 1) path_solve_kernel(const PathSolveArgs args) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ int s_ticket;
-    // Persistent workgroups: every workgroup draws tickets until the batch is used up (each workgroup ends on one ticket beyond
-    // it, so a launch consumes exactly batch + gridDim.x tickets and the host knows the next launch's base without a reset).
-    // (Drawing the next ticket while the current QP is solved - to hide the ~2 us of the returning atomic - was measured and dropped: at
-    // batch 1024 on 512 slots every workgroup then reserves its second QP the moment it starts its first, the most expensive QPs of the
-    // first round pair up with the most expensive of the rest, and the launch takes 0.69 instead of 0.53 ms.)
-    for (;;) {
-#ifdef PQP_TIMING
-        const long long t_ticket0 = (long long)wall_clock64();
-#endif
-        if (threadIdx.x == 0) s_ticket = (int)(atomicAdd(args.ticket, 1ull) - args.ticket_base);
-        __syncthreads();
-        const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
-        __syncthreads();
-        if ((unsigned)ticket >= (unsigned)args.batch) break;      // (unsigned: a ticket below the base - a host/device counter mismatch - ends the workgroup too)
-        const int qp = args.order ? args.order[ticket] : ticket;
-        // (written out rather than through PathQp::count_of: with the call here the register allocator spills 170 VGPRs of the loop)
-        if ((args.n_of ? args.n_of[qp] : args.n) < 2) {
-            // nothing to optimise: defined outputs for everything a later call may read (status, counters, warm state)
-            if (threadIdx.x == 0) {
-                if (args.status) args.status[qp] = PQP_STATUS_UNSOLVED;
-                if (args.iters) args.iters[qp] = 0;
-                if (args.info) for (int k = 0; k < PQP_INFO_STRIDE; ++k) args.info[(size_t)qp * PQP_INFO_STRIDE + k] = 0.0;
-                args.wrho[qp] = args.prm.rho;
-                args.wye[2 * (size_t)qp] = 0.0; args.wye[2 * (size_t)qp + 1] = 0.0;
-                if (args.cost_key) record_cost(args, qp, 0);
-            }
-            if (args.store_warm)
-                for (int k = threadIdx.x; k < args.n * 6; k += blockDim.x) {
-                    args.wx[(size_t)qp * args.n * 6 + k] = 0.0;
-                    args.wy[(size_t)qp * args.n * 6 + k] = 0.0;
-                }
-            continue;
-        }
-        DevCtx<NW> ctx;
-        ctx.shp = smem;
-        PathQp<DevCtx<NW>, CERT> solver(ctx, args, qp, (int)blockIdx.x);
-#ifdef PQP_TIMING
-        const long long t_ticket1 = (long long)wall_clock64();
-#endif
-        solver.run();
-        __syncthreads();
-#ifdef PQP_TIMING
-        if (threadIdx.x == 0) {                                                                                          // debug build only
-            double* dbg = args.out + (size_t)qp * args.n * PQP_OUT_STRIDE;
-            dbg[8] = (double)(t_ticket1 - t_ticket0);
-            dbg[9] = (double)t_ticket0; dbg[10] = (double)(long long)wall_clock64(); dbg[11] = (double)blockIdx.x;       // the schedule: start, end, slot
-        }
-#endif
-    }
-    if (args.cost_key) order_next_launch(args, reinterpret_cast<int*>(smem));
-}
-
 
 // -------------------------------------------------------------------------------------------------------
 // reference numbering helpers (base_solver.cpp:22-37,154-158)
@@ -881,6 +604,15 @@ static int path_stream_impl(pqp_handle* h, int batch, int n, const int32_t* n_of
 // depends on n: the crossover grows like n^2.
 // Beyond 256 waypoints the lane-per-waypoint kernel runs two wavefronts per SIMD on half the registers and takes 4.1 ... 4.9 us per QP instead
 // of 1.0: the crossover is back at 16.7 k / 22.5 k / 32 k QPs at 300 / 400 / 512 waypoints (profiles/r05t_crossover_long_paths.txt): 64 n.
+// the lane-per-waypoint kernels, by wavefronts per QP (pqp_path_solve.hip compiled with -DPQP_NW=1 / 2 / 4 / 8); cert: with the in-loop
+// infeasibility certificate
+extern "C" {
+const void* pqp_path_solve_fn_nw1(int cert);
+const void* pqp_path_solve_fn_nw2(int cert);
+const void* pqp_path_solve_fn_nw4(int cert);
+const void* pqp_path_solve_fn_nw8(int cert);
+}
+
 static int stream_batch_auto(int n) {
     if (n > 256) return 64 * n;
     const double r = n > 80 ? (double)n / 80.0 : 1.0;
@@ -945,11 +677,11 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     // two variants of every kernel: with and without OSQP's primal infeasibility certificate (prm.eps_prim_inf > 0)
     const bool cert = h->prm.eps_prim_inf > 0.0 && h->prm.prim_inf_after <= 0;
     const void* fn = nullptr;
-    switch (nw) {
-        case 1: fn = cert ? (const void*)pqp::path_solve_kernel<1, true> : (const void*)pqp::path_solve_kernel<1, false>; break;
-        case 2: fn = cert ? (const void*)pqp::path_solve_kernel<2, true> : (const void*)pqp::path_solve_kernel<2, false>; break;
-        case 4: fn = cert ? (const void*)pqp::path_solve_kernel<4, true> : (const void*)pqp::path_solve_kernel<4, false>; break;
-        default: fn = cert ? (const void*)pqp::path_solve_kernel<8, true> : (const void*)pqp::path_solve_kernel<8, false>; break;
+    switch (nw) {       // (pqp_path_solve.hip, one translation unit per width)
+        case 1: fn = pqp_path_solve_fn_nw1(cert); break;
+        case 2: fn = pqp_path_solve_fn_nw2(cert); break;
+        case 4: fn = pqp_path_solve_fn_nw4(cert); break;
+        default: fn = pqp_path_solve_fn_nw8(cert); break;
     }
     if (lds > 64 * 1024) PQP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent workgroups: as many as the chip holds at once (a surplus one would only wait for a free slot), each with its own

@@ -7,15 +7,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "path_optimizer_2_amd", "csrc")
-MASK = os.environ.get("PQP_TIMING_MASK")       # e.g. 0x10: only iterate() is timed (and the total): one category per build perturbs least
+MASK = os.environ.get("PQP_TIMING_MASK") or None       # e.g. 0x10: only iterate() is timed (and the total): one category per build perturbs least
 LIB = os.path.join(CSRC, "libpqp_hip_timing.so" if MASK is None else f"libpqp_hip_timing_{MASK}.so")
 
 
 def build():
-    """The library with the device-clock instrumentation of pqp_path_lane.hpp compiled in (a debug build of its own, one hipcc call)."""
+    """The library with the device-clock instrumentation of pqp_path_lane.hpp compiled into the lane-per-waypoint kernels (a debug build of its own:
+    the four pqp_path_solve.hip objects with -DPQP_TIMING, linked with the shipped objects of the other translation units)."""
+    import __graft_entry__ as G
+    from concurrent.futures import ThreadPoolExecutor
+    G.build_hip()
     defs = ["-DPQP_TIMING"] + ([] if MASK is None else [f"-DPQP_TIMING_MASK={MASK}"])
-    srcs = [os.path.join(CSRC, f) for f in ("pqp_kernels.hip", "pqp_path_stream.hip", "pqp_multi.cpp")]
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *defs, "-o", LIB, *srcs, "-lpthread", "-ldl"], cwd=CSRC, check=True)
+    odir = os.path.join(CSRC, "build", "timing" if MASK is None else f"timing_{MASK}")
+    units = [(s, d + defs, o) for s, d, o in G.HIP_UNITS if s == "pqp_path_solve.hip"]
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = [o for o, _ in ex.map(lambda u: G.compile_unit(*u, odir=odir), units)]
+    objs += [os.path.join(CSRC, "build", "libpqp_hip", o) for s, _, o in G.HIP_UNITS if s != "pqp_path_solve.hip"]
+    G.link_units(objs, LIB)
 
 
 if __name__ == "__main__":
@@ -24,8 +32,7 @@ if __name__ == "__main__":
     import torch
     from path_optimizer_2_amd import capi
     from path_optimizer_2_amd.synth import make_batch
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".inc"))] + [os.path.join(ROOT, "include", "pqp.h")]
-    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+    if not os.path.exists(LIB):         # (built where the objects of the other translation units are: `python tools/kernel_timeline.py build` before the GPU call)
         build()
     capi.LIB_PATH = LIB
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
