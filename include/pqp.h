@@ -496,10 +496,13 @@ int pqp_segment_raw_reference(pqp_handle* h, int batch, int n_max, int m, const 
                               double delta_s, double* x, double* y, double* s, double* angle, double* k, int32_t* count);
 
 /* ---- natural cubic spline through the knots ----------------------------------------------------------
- * tk::spline::set_points  src/tools/spline.cpp:161-249 (+ band_matrix::lu_solve :69-148), as called on the smoothed reference line
+ * tk::spline::set_points  src/tools/spline.cpp:161-249 (behaviour: the natural cubic spline, f'' = 0 at both ends, linear continuation beyond
+ * them), as called on the smoothed reference line
  * (tension_smoother.cpp:36-38, reference_path_smoother.cpp:58-59,574-576, reference_path_impl.cpp:349-350).
  * s, x, y [batch][m] (s strictly increasing, m >= 3)  ->  spline [batch][9][m], spline_ext [batch][4] in the layout
- * pqp_reference_states / pqp_corridor_bounds take.  Coefficients are the reference's bit for bit. */
+ * pqp_reference_states / pqp_corridor_bounds take.  The kernel solves the textbook moment equations by a Thomas recurrence of its own (not
+ * the reference's band-matrix LU): the coefficients agree with the reference's to round-off (< 1e-13 of a row's largest, tested against the
+ * reference's compiled tk::spline); knots and values are copied. */
 int pqp_spline_fit_device(pqp_handle* h, int batch, int m, const double* s, const double* x, const double* y, double* spline,
                           double* spline_ext);
 int pqp_spline_fit(pqp_handle* h, int batch, int m, const double* s, const double* x, const double* y, double* spline, double* spline_ext);

@@ -277,6 +277,8 @@ struct Slot {
     double Dinv[6], GL[9], GR[9];
     // per-iteration scratch that crosses a phase boundary
     double r[3], rv, rsf, rsr, xt[6];
+    // contexts with kCstAcc: the halves of the pass constants that live in the accumulator half of the register file (see PathQp::acc_get)
+    int acc[24];
 };
 // setup-time state (dead inside the ADMM loop)
 struct SlotSetup {
@@ -543,6 +545,15 @@ struct PathQp {
 #else
 #define PQP_SUB(k, stmt) do { stmt; } while (0)
 #endif
+// PQP_TIMING_ITER (with PQP_TIMING): shader-clock ticks of the pieces of iterate(), accumulated per QP -> out[qp][12..19] (tools/kernel_timeline.py)
+#if defined(PQP_TIMING) && defined(PQP_TIMING_ITER)
+    long long tit_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tit_last_ = 0;      // [0..7] iterate(), [8..15] factor()
+#define PQP_IT_BEGIN() do { tit_last_ = ctx.cycles(); } while (0)
+#define PQP_IT(k) do { const long long now_ = ctx.cycles(); tit_[k] += now_ - tit_last_; tit_last_ = now_; } while (0)
+#else
+#define PQP_IT_BEGIN() do { } while (0)
+#define PQP_IT(k) do { } while (0)
+#endif
 
     PQP_HD PathQp(Ctx& c, const PathSolveArgs& a, int q, int slot_ = -1)
         : ctx(c), A(a), qp(q), slot(slot_ < 0 ? q : slot_), stride(a.n), n(count_of(a, q)), T(c.T()), L{c.T()}, sh(c.sh()), rho(a.prm.rho), cscale(1.0), kap(0.0), alpha_(a.prm.alpha), polishing_(false), cert_(false), snap_valid_(false), kkt_solves_(0), factors_(0) {}
@@ -634,7 +645,8 @@ struct PathQp {
             soft_bounds(f_lb, f_ub, prm.expected_safety_margin, prm.min_clearance, flo, fup);
             soft_bounds(b[2], b[3], prm.expected_safety_margin, prm.min_clearance, rlo, rup);
             const double lo0 = real ? flo : 0.0, up0 = real ? fup : 0.0, lo1 = (real && precise) ? rlo : 0.0, up1 = (real && precise) ? rup : 0.0;
-            if constexpr (kCst) { cst_set(t, C_LO, lo0); cst_set(t, C_LO + 1, lo1); cst_set(t, C_UP, up0); cst_set(t, C_UP + 1, up1); }
+            if constexpr (kAcc) { acc_set(S, C_LO, lo0); acc_set(S, C_LO + 1, lo1); acc_set(S, C_UP, up0); acc_set(S, C_UP + 1, up1); }
+            else if constexpr (kCst) { cst_set(t, C_LO, lo0); cst_set(t, C_LO + 1, lo1); cst_set(t, C_UP, up0); cst_set(t, C_UP + 1, up1); }
             else { S.lo[0] = lo0; S.up[0] = up0; S.lo[1] = lo1; S.up[1] = up1; }
             if (S.flags & F_LAST) {                                         // :250-259
                 EndRows* er = end_rows();
@@ -657,15 +669,22 @@ struct PathQp {
     // Pass constants of a waypoint that the iteration reads once: in registers (Slot fields) or, in contexts with kCstLds, in LDS -
     // 24 registers less in the ADMM loop, which is what lets two wavefronts share a SIMD.
     static constexpr bool kCst = Ctx::kCstLds;
+    // ... or (kCstAcc, the device) in the ACCUMULATOR half of the register file, by their own v_accvgpr_write / _read at the one definition and the one
+    // use per solve: gfx950 gives a one-wavefront-per-SIMD kernel 256 + 256 registers but VALU operands come from the first 256 only, and the compiler,
+    // left to park what does not fit, shuffles hundreds of registers between the halves around every phase (tools/isa_mix.py).  What is used once
+    // per solve is parked by hand: one read per use, no shuffles.
+    static constexpr bool kAcc = Ctx::kCstAcc;
     enum : int { C_SIG = 0, C_LO = 6, C_UP = 8, C_IDSF = 10, C_IDSR = 11 };
     PQP_HD double cst_get(int t, int c) const { return sh[L.cst() + c * T + t]; }
     PQP_HD void cst_set(int t, int c, double v) const { sh[L.cst() + c * T + t] = v; }
-    PQP_HD double sig_of(const Slot& S, int t, int k) const { if constexpr (kCst) return cst_get(t, C_SIG + k); else return S.sig[k]; }
-    PQP_HD void set_sig(Slot& S, int t, int k, double v) const { if constexpr (kCst) cst_set(t, C_SIG + k, v); else S.sig[k] = v; }
-    PQP_HD double idsf_of(const Slot& S, int t) const { if constexpr (kCst) return cst_get(t, C_IDSF); else return S.idsf; }
-    PQP_HD double idsr_of(const Slot& S, int t) const { if constexpr (kCst) return cst_get(t, C_IDSR); else return S.idsr; }
-    PQP_HD double lo_of(const Slot& S, int t, int j) const { if constexpr (kCst) return cst_get(t, C_LO + j); else return S.lo[j]; }
-    PQP_HD double up_of(const Slot& S, int t, int j) const { if constexpr (kCst) return cst_get(t, C_UP + j); else return S.up[j]; }
+    PQP_HD double acc_get(const Slot& S, int c) const { return Ctx::acc_read(S.acc[2 * c], S.acc[2 * c + 1]); }
+    PQP_HD void acc_set(Slot& S, int c, double v) const { Ctx::acc_write(v, S.acc[2 * c], S.acc[2 * c + 1]); }
+    PQP_HD double sig_of(const Slot& S, int t, int k) const { if constexpr (kAcc) return acc_get(S, C_SIG + k); else if constexpr (kCst) return cst_get(t, C_SIG + k); else return S.sig[k]; }
+    PQP_HD void set_sig(Slot& S, int t, int k, double v) const { if constexpr (kAcc) acc_set(S, C_SIG + k, v); else if constexpr (kCst) cst_set(t, C_SIG + k, v); else S.sig[k] = v; }
+    PQP_HD double idsf_of(const Slot& S, int t) const { if constexpr (kAcc) return acc_get(S, C_IDSF); else if constexpr (kCst) return cst_get(t, C_IDSF); else return S.idsf; }
+    PQP_HD double idsr_of(const Slot& S, int t) const { if constexpr (kAcc) return acc_get(S, C_IDSR); else if constexpr (kCst) return cst_get(t, C_IDSR); else return S.idsr; }
+    PQP_HD double lo_of(const Slot& S, int t, int j) const { if constexpr (kAcc) return acc_get(S, C_LO + j); else if constexpr (kCst) return cst_get(t, C_LO + j); else return S.lo[j]; }
+    PQP_HD double up_of(const Slot& S, int t, int j) const { if constexpr (kAcc) return acc_get(S, C_UP + j); else if constexpr (kCst) return cst_get(t, C_UP + j); else return S.up[j]; }
     PQP_HD double raw_lo(const Slot& S, int t, int k) const { return k == 0 ? ((S.flags & F_REAL) ? -kap : 0.0) : lo_of(S, t, k - 1); }
     PQP_HD double raw_up(const Slot& S, int t, int k) const { return k == 0 ? ((S.flags & F_REAL) ? kap : 0.0) : up_of(S, t, k - 1); }
     // ... and as the iteration sees it: while polishing, an active row is pinned to its bound, an inactive row is free
@@ -1193,6 +1212,7 @@ struct PathQp {
     PQP_HD void factor() {
         const pqp_params& prm = A.prm;
         factors_ += 1;
+        PQP_IT_BEGIN();
         // F1: own diagonal block + message (M, Lc) to the previous waypoint
         ctx.phase([&](int t, Lane& ln) {
             Slot& S = ln.s;
@@ -1202,7 +1222,8 @@ struct PathQp {
             const double rK = S.rhoI[0], rF = S.rhoI[1], rR = S.rhoI[2];
             const double dsf = cost_diag(prm, S.flags, 4) + sig_of(S, t, 4) + rF, dsr = cost_diag(prm, S.flags, 5) + sig_of(S, t, 5) + rR;
             const double idsf = rcp(dsf), idsr = rcp(dsr);
-            if constexpr (kCst) { cst_set(t, C_IDSF, idsf); cst_set(t, C_IDSR, idsr); } else { S.idsf = idsf; S.idsr = idsr; }
+            if constexpr (kAcc) { acc_set(S, C_IDSF, idsf); acc_set(S, C_IDSR, idsr); }
+            else if constexpr (kCst) { cst_set(t, C_IDSF, idsf); cst_set(t, C_IDSR, idsr); } else { S.idsf = idsf; S.idsr = idsr; }
             S.cF = rF * idsf; S.cR = rR * idsr;
             const double gf = rF - rF * S.cF, gr = rR - rR * S.cR;
             const double ds = S.a[5];
@@ -1238,6 +1259,7 @@ struct PathQp {
             f[5] = r1 * a12 * a12 + gup;
             _Pragma("unroll") for (int k = 0; k < 9; ++k) f[6 + k] = W.Lc[k];
         });
+        PQP_IT(8);       // F1
         // F2: receive from the next waypoint
         ctx.phase([&](int t, Lane& ln) {
             SlotSetup& W = ln.w;
@@ -1245,6 +1267,7 @@ struct PathQp {
             _Pragma("unroll") for (int k = 0; k < 6; ++k) W.Dg[k] += f[k];
             _Pragma("unroll") for (int k = 0; k < 9; ++k) W.Rc[k] = f[6 + k];
         });
+        PQP_IT(9);       // F2
         // Cyclic-reduction tree over tp = t + 1 in [1, T]: level h eliminates tp = h (mod 2h), the root is tp = T (the last
         // thread).  With this numbering the only node of a wavefront that talks to the next wavefront during the levels
         // h < 64 is its LAST lane (tp = 64m), and that node only RECEIVES until its own elimination at a level >= 64 — which
@@ -1279,6 +1302,7 @@ struct PathQp {
                     }
                 }
             });
+            PQP_IT(h == 1 ? 10 : (h <= 8 ? 11 : (h <= 32 ? 12 : 13)));       // level 1 | 2 .. 8 | 16, 32 | 64 ...
         }
     }
 
@@ -1354,6 +1378,7 @@ struct PathQp {
         const double alpha = alpha_;
         constexpr bool D = Ctx::kDpp;
         double gm[3] = {0.0, 0.0, 0.0}, qm[3] = {0.0, 0.0, 0.0}, pm[3] = {0.0, 0.0, 0.0}, xpv[3] = {0.0, 0.0, 0.0};    // kDpp: per-lane transients
+        PQP_IT_BEGIN();
         // I1: w = R z - y, reduced right-hand side pieces, message to the previous waypoint.  Wave-local: the message is read
         // by the previous lane (the last lane of a wavefront reads its neighbour's after the barrier below).
         ctx.phase_w([&](int t, Lane& ln) {
@@ -1387,11 +1412,13 @@ struct PathQp {
         // waypoint t+1 and the level messages of the nodes t + hp - and adds them after ONE barrier.  Levels h >= 64 and the
         // root use workgroup barriers.  (T = 64: no barrier at all.)
         const int hw = T < 64 ? T : 64;
+        PQP_IT(0);       // I1
         if constexpr (D) {
             forward_level_dpp<1>(gm, qm, pm);
             forward_level_dpp<2>(gm, qm, pm);
             forward_level_dpp<4>(gm, qm, pm);
             forward_level_dpp<8>(gm, qm, pm);
+            PQP_IT(1);   // forward levels 1 .. 8 (DPP)
             // level 16: its survivors are the rows' last lanes; everything they have deferred arrives now (not the wavefront's last
             // lane: it waits for the barrier below)
             ctx.phase_w([&](int t, Lane& ln) {
@@ -1441,6 +1468,7 @@ struct PathQp {
                 }
             });
         }
+        PQP_IT(2);       // forward levels 16, 32 (LDS inside the wavefront)
         ctx.phase([&](int, Lane&) {});      // the one barrier between the in-wave levels and the cross-wave part
         const bool short_tree = root_is_padding();
         for (int h = hw; h <= T; h <<= 1) {
@@ -1485,6 +1513,7 @@ struct PathQp {
                 }
             });
         }
+        PQP_IT(3);       // barrier + cross-wave levels / root
         // Backward pass: cross-wave levels with barriers, then the in-wave levels wave-locally (what they read from another
         // wavefront - the x of its last lane - was written before the last barrier).
         for (int h = T >> 1; h >= (D ? 16 : 1); h >>= 1) {
@@ -1508,6 +1537,7 @@ struct PathQp {
             };
             if (h >= 64) ctx.phase(body); else ctx.phase_w(body);
         }
+        PQP_IT(4);       // backward levels >= 16
         if constexpr (D) {
             // X~ of the previous row's last lane (solved at a level >= 16): row_bcast inside the wavefront, LDS across wavefronts
             ctx.phase_w([&](int t, Lane& ln) {
@@ -1523,6 +1553,7 @@ struct PathQp {
             backward_level_dpp<2>(xpv);
             backward_level_dpp<1>(xpv);
         }
+        PQP_IT(5);       // backward levels 8 .. 1 (DPP)
         // I3: back-substitute v, sf, sr; z~ = A x~; relaxed updates, projection, dual update.  Wave-local: a lane reads the X~ of the
         // previous one; the first lane of a wavefront reads the last lane of the previous wavefront, which wrote its X~ before
         // the last workgroup barrier of the backward pass.  iterate() therefore ENDS WITHOUT A BARRIER: the next iterate() may
@@ -1578,6 +1609,7 @@ struct PathQp {
                 }
             }
         });
+        PQP_IT(6);       // I3
     }
 
     PQP_HD void sync_after_iterate() { ctx.phase([&](int, Lane&) {}); }
@@ -2106,6 +2138,9 @@ struct PathQp {
                     tacc[7] = ctx.clock() - t_begin;
                     for (int k = 0; k < 8; ++k) f[k] = (double)tacc[k];
                     for (int k = 0; k < 8; ++k) A.out[(size_t)qp * stride * PQP_OUT_STRIDE + k] = (double)tsub_[k];     // debug build only
+#ifdef PQP_TIMING_ITER
+                    for (int k = 0; k < 16; ++k) A.out[(size_t)qp * stride * PQP_OUT_STRIDE + 12 + k] = (double)tit_[k];
+#endif
 #endif
                 }
             }

@@ -93,6 +93,22 @@ struct DevCtx {
     // DPP moves: the value of the lane H below / above in the same row of 16 lanes, of the previous row's last lane; 0 where
     // there is no such lane.  Must run with every lane enabled (a disabled source lane reads as "no lane").  (profiles/r02j_dpp_exchanges.txt)
     static constexpr bool kDpp = true;
+    // kCstAcc: twelve pass constants of a waypoint that a solve reads once live in the accumulator registers, written and read by hand
+#ifdef PQP_CST_ACC
+    static constexpr bool kCstAcc = true;
+#else
+    static constexpr bool kCstAcc = false;
+#endif
+    __device__ __forceinline__ static void acc_write(double v, int& lo, int& hi) {
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(lo) : "v"(__double2loint(v)));
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(hi) : "v"(__double2hiint(v)));
+    }
+    __device__ __forceinline__ static double acc_read(int lo, int hi) {
+        int l, h;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(l) : "a"(lo));
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(h) : "a"(hi));
+        return __hiloint2double(h, l);
+    }
     template <int CTRL, int ROW_MASK>
     __device__ __forceinline__ static double dpp0(double v) {
         const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
@@ -107,6 +123,7 @@ struct DevCtx {
     Lane lane;
     double* shp;
     __device__ __forceinline__ long long clock() const { return (long long)wall_clock64(); }     // 100 MHz
+    __device__ __forceinline__ long long cycles() const { return (long long)__builtin_amdgcn_s_memtime(); }     // shader clock
     __device__ __forceinline__ bool certificate(double* sh, int, double fl, double rl, double kap, double eps, double cscale) {
         return uniform(dev_certificate<NW>(sh, fl, rl, kap, eps, cscale));
     }
@@ -116,27 +133,30 @@ struct DevCtx {
     }
     __device__ __forceinline__ int T() const { return 64 * NW; }
     __device__ __forceinline__ double* sh() { return shp; }
+    // (round 6: an opaque lane index - asm volatile("" : "+v"(t)) per phase, so that the lane predicates "eliminated at level h" are recomputed where they
+    //  are used instead of living as spilled SGPR pairs - has fewer spills and 3 % less throughput: profiles/r06b_*)
+    __device__ __forceinline__ static int lane_index() { return (int)threadIdx.x; }
     template <class F>
     __device__ __forceinline__ void phase(F f) {
-        f((int)threadIdx.x, lane);
+        f(lane_index(), lane);
         __syncthreads();
     }
     // wave-local phase: LDS operations of one wavefront execute in program order, so lanes of the same wavefront see each
     // other's writes without a workgroup barrier; the fence only stops the compiler from moving LDS accesses across it
     template <class F>
     __device__ __forceinline__ void phase_w(F f) {
-        f((int)threadIdx.x, lane);
+        f(lane_index(), lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
     template <int K, class F>
     __device__ __forceinline__ void reduce_max(double (&out)[K], F f) {
-        f((int)threadIdx.x, lane, out);
+        f(lane_index(), lane, out);
         wg_reduce<NW, K, true>(out, shp);
     }
     template <int K, class F>
     __device__ __forceinline__ void reduce_sum(double (&out)[K], F f) {
-        f((int)threadIdx.x, lane, out);
+        f(lane_index(), lane, out);
         wg_reduce<NW, K, false>(out, shp);
     }
     // The cold operations (assemble, Ruiz, factorisation, polish bookkeeping, unpack) run inline on the same lane state: out of line, on a

@@ -33,7 +33,7 @@ namespace {
 struct HostCtx {
     // default: the device contexts' setting (Ruiz vectors parked, save area in the shared array up to 256 lanes); PQP_EMU_DIET: pass
     // constants in the shared array too, everything parked in global memory
-    static constexpr bool kCstLds = PQP_EMU_DIET != 0, kParkScale = true, kSaveLds = PQP_EMU_DIET == 0, kDpp = false;
+    static constexpr bool kCstLds = PQP_EMU_DIET != 0, kParkScale = true, kSaveLds = PQP_EMU_DIET == 0, kDpp = false, kCstAcc = false;
     static constexpr bool kFinalRefine = true;      // (the device: contexts of more than 128 lanes per QP; the parameter is 0 below that)
     int T_;
     std::vector<pqp::Lane> lanes;

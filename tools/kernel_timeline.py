@@ -17,7 +17,7 @@ def build():
     import __graft_entry__ as G
     from concurrent.futures import ThreadPoolExecutor
     G.build_hip()
-    defs = ["-DPQP_TIMING"] + ([] if MASK is None else [f"-DPQP_TIMING_MASK={MASK}"])
+    defs = ["-DPQP_TIMING"] + ([] if MASK is None else [f"-DPQP_TIMING_MASK={MASK}"]) + (["-DPQP_TIMING_ITER"] if MASK == "0x0" else [])
     odir = os.path.join(CSRC, "build", "timing" if MASK is None else f"timing_{MASK}")
     units = [(s, d + defs, o) for s, d, o in G.HIP_UNITS if s == "pqp_path_solve.hip"]
     with ThreadPoolExecutor(max_workers=4) as ex:
@@ -73,6 +73,19 @@ if __name__ == "__main__":
     print("    the 12 longest QPs (us, start): " + "  ".join(f"{dur[q]:.0f}@{st[q]:.0f}" for q in np.argsort(-dur)[:12]))
     first = np.argsort(st)[:nslot]
     print(f"    first-round QPs: duration min {dur[first].min():.0f} p10 {np.percentile(dur[first], 10):.0f} median {np.median(dur[first]):.0f}; later QPs: median {np.median(np.delete(dur, first)):.0f} p90 {np.percentile(np.delete(dur, first), 90):.0f} max {np.delete(dur, first).max():.0f}")
+    if MASK == "0x0":        # the build with shader-clock ticks inside iterate() (and nothing else timed)
+        fa = out.cpu().numpy().reshape(batch, -1)[:, 20:28]
+        it = out.cpu().numpy().reshape(batch, -1)[:, 12:20]
+        kk = info.cpu().numpy()[:, 5] if False else None
+        tot = it.sum(1).mean()
+        for k, nm in enumerate(["I1 right-hand side", "forward levels 1..8 (DPP)", "forward levels 16, 32 (in-wave)", "barrier + cross-wave levels / root", "backward levels >= 16",
+                                "backward levels 8..1 (DPP)", "I3 update"]):
+            print(f"    iterate: {nm:36s} mean {it[:, k].mean():10.0f} cycles per QP  {it[:, k].mean() / tot:5.1%}")
+        print(f"    iterate: total {tot:.0f} shader cycles per QP")
+        ftot = fa.sum(1).mean()
+        for k, nm in enumerate(["F1 own block + message", "F2 receive", "level 1", "levels 2 .. 8", "levels 16, 32", "levels >= 64"]):
+            print(f"    factor:  {nm:36s} mean {fa[:, k].mean():10.0f} cycles per QP  {fa[:, k].mean() / ftot:5.1%}")
+        print(f"    factor:  total {ftot:.0f} shader cycles per QP")
     sub = out.cpu().numpy().reshape(batch, -1)[:, :8] / 100.0      # the timing build writes the cold operations' sub-times over out[qp][0][0..7]
     for k, nm in enumerate(["load", "assemble", "ruiz", "start_transition_rows", "polish begin / apply set", "factor", "polish update set", "polish end (reject)"]):
         print(f"    cold: {nm:28s} mean {sub[:, k].mean():8.1f} us   max {sub[:, k].max():8.1f}")
