@@ -545,11 +545,12 @@ struct PathQp {
 #else
 #define PQP_SUB(k, stmt) do { stmt; } while (0)
 #endif
-// PQP_TIMING_ITER (with PQP_TIMING): shader-clock ticks of the pieces of iterate(), accumulated per QP -> out[qp][12..19] (tools/kernel_timeline.py)
+// PQP_TIMING_ITER (with PQP_TIMING): 10 ns ticks of the pieces of iterate() / factor(), accumulated per QP -> out[qp][12..27] (tools/kernel_timeline.py;
+// s_memtime instead of the 100 MHz clock costs ~6 us per read on gfx950: a QP then takes 1.3 ms)
 #if defined(PQP_TIMING) && defined(PQP_TIMING_ITER)
     long long tit_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tit_last_ = 0;      // [0..7] iterate(), [8..15] factor()
-#define PQP_IT_BEGIN() do { tit_last_ = ctx.cycles(); } while (0)
-#define PQP_IT(k) do { const long long now_ = ctx.cycles(); tit_[k] += now_ - tit_last_; tit_last_ = now_; } while (0)
+#define PQP_IT_BEGIN() do { tit_last_ = ctx.clock(); } while (0)
+#define PQP_IT(k) do { const long long now_ = ctx.clock(); tit_[k] += now_ - tit_last_; tit_last_ = now_; } while (0)
 #else
 #define PQP_IT_BEGIN() do { } while (0)
 #define PQP_IT(k) do { } while (0)
@@ -563,6 +564,19 @@ struct PathQp {
     PQP_HD static int count_of(const PathSolveArgs& a, int q) { return a.n_of ? (a.n_of[q] < a.n ? a.n_of[q] : a.n) : a.n; }
 
     PQP_HD EndRows* end_rows() const { return reinterpret_cast<EndRows*>(sh + L.end()); }
+    // The fields of the two end rows by value.  The lane that owns the rows works on them while everybody else waits at the next barrier, so its
+    // code loads what it needs in ONE batch up front (what a block does not use is never loaded: the copies are plain loads) and stores what it
+    // changed at the end; field by field inside `for (k)` with early exits every access was an LDS round trip of its own (round 6).
+    struct EndVals { double lo[2], up[2], z[2], y[2], E[2], rb[2], rho[2], rinv[2], act[2], pad[2]; };
+    PQP_HD EndVals end_vals() const {
+        const EndRows* er = end_rows();
+        EndVals v;
+        _Pragma("unroll") for (int k = 0; k < 2; ++k) {
+            v.lo[k] = er->lo[k]; v.up[k] = er->up[k]; v.z[k] = er->z[k]; v.y[k] = er->y[k]; v.E[k] = er->E[k]; v.rb[k] = er->rb[k];
+            v.rho[k] = er->rho[k]; v.rinv[k] = er->rinv[k]; v.act[k] = er->act[k]; v.pad[k] = er->pad[k];
+        }
+        return v;
+    }
     // With n < T the root of the cyclic-reduction tree (tp = T, the last lane) is a padding node, and so is everything between the last
     // waypoint and it: the couplings across the first padding lane are exact zeros, hence node T/2 hands the root nothing and needs
     // nothing from it - node T/2 IS the root of the real tree.  For T >= 128 the factorisation and the solves then stop one level
@@ -570,6 +584,7 @@ struct PathQp {
     PQP_HD bool root_is_padding() const { return T >= 128 && n < T; }
     // row `other` of an exchange buffer, or the zero block when that neighbour does not exist
     PQP_HD const double* nb(bool ok, int base, int stride, int other) const { return sh + (ok ? base + stride * other : L.zero()); }
+    PQP_HD static void ld3(double (&v)[3], const double* p) { v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; }
 
     // NOTE on style: per-lane state must stay in registers, which needs every Lane field to be written through
     // one unconditional store (values chosen with selects) or under a single branch without an else-store; only
@@ -968,10 +983,13 @@ struct PathQp {
         return rowreal ? fmax(fmax(pv, dv), 0.0) : 0.0;
     }
     PQP_HD double end_violation(const EndRows* er, int k, double ax) const {
-        if (er->rb[k] < 0.0) return 0.0;      // free row
-        const double pv = fmax(er->lo[k] - ax, ax - er->up[k]);
-        const double dv = er->act[k] < 0.0 ? er->y[k] : (er->act[k] > 0.0 ? -er->y[k] : 0.0);
-        return fmax(fmax(pv, dv), 0.0);
+        return end_violation_of(er->rb[k], er->lo[k], er->up[k], er->act[k], er->y[k], ax);
+    }
+    // ... from values (the hot callers load every field of the end rows first: no LDS round trip per field)
+    PQP_HD static double end_violation_of(double rb, double lo, double up, double act, double y, double ax) {
+        const double pv = fmax(lo - ax, ax - up);
+        const double dv = act < 0.0 ? y : (act > 0.0 ? -y : 0.0);
+        return rb < 0.0 ? 0.0 : fmax(fmax(pv, dv), 0.0);      // (rb < 0: a free row)
     }
 
     // --- polish piece 1: park the ADMM state; first guess of the active set by OSQP's rule
@@ -1005,13 +1023,14 @@ struct PathQp {
             _Pragma("unroll") for (int k = 0; k < 6; ++k) set_sig(S, t, k, sig_of(S, t, k) * sgain);
             if (S.flags & F_LAST) {
                 EndRows* er = end_rows();
-                for (int k = 0; k < 2; ++k) {
-                    er->sz[k] = er->z[k]; er->sy[k] = er->y[k];
-                    const bool fr = er->rb[k] < 0.0;
-                    const double e2 = er->E[k] * er->E[k] / cscale;
-                    const bool act_lo = !fr && ((er->z[k] - er->lo[k]) * e2 < -er->y[k]);
-                    const bool act_up = !fr && !act_lo && ((er->up[k] - er->z[k]) * e2 < er->y[k]);
-                    er->act[k] = keep_set ? (fr ? 0.0 : er->act[k]) : (act_lo ? -1.0 : (act_up ? 1.0 : 0.0));
+                const EndVals e = end_vals();
+                _Pragma("unroll") for (int k = 0; k < 2; ++k) {
+                    er->sz[k] = e.z[k]; er->sy[k] = e.y[k];
+                    const bool fr = e.rb[k] < 0.0;
+                    const double e2 = e.E[k] * e.E[k] / cscale;
+                    const bool act_lo = !fr && ((e.z[k] - e.lo[k]) * e2 < -e.y[k]);
+                    const bool act_up = !fr && !act_lo && ((e.up[k] - e.z[k]) * e2 < e.y[k]);
+                    er->act[k] = keep_set ? (fr ? 0.0 : e.act[k]) : (act_lo ? -1.0 : (act_up ? 1.0 : 0.0));
                 }
             }
         });
@@ -1043,12 +1062,13 @@ struct PathQp {
             }
             if (S.flags & F_LAST) {
                 EndRows* er = end_rows();
-                for (int k = 0; k < 2; ++k) {
-                    const bool act = er->act[k] != 0.0;
-                    const double r = act ? gain * er->E[k] * er->E[k] / cscale : 0.0;
+                const EndVals e = end_vals();
+                _Pragma("unroll") for (int k = 0; k < 2; ++k) {
+                    const bool act = e.act[k] != 0.0;
+                    const double r = act ? gain * e.E[k] * e.E[k] / cscale : 0.0;
                     er->rho[k] = r; er->rinv[k] = act ? rcp(r) : 0.0;
-                    er->y[k] = act ? er->y[k] : 0.0;
-                    er->z[k] = er->act[k] < 0.0 ? er->lo[k] : (er->act[k] > 0.0 ? er->up[k] : er->z[k]);
+                    er->y[k] = act ? e.y[k] : 0.0;
+                    er->z[k] = e.act[k] < 0.0 ? e.lo[k] : (e.act[k] > 0.0 ? e.up[k] : e.z[k]);
                 }
             }
         });
@@ -1074,9 +1094,10 @@ struct PathQp {
             }
             if (S.flags & F_LAST) {
                 EndRows* er = end_rows();
-                for (int k = 0; k < 2; ++k) {
-                    const double v = end_violation(er, k, S.x[k]);
-                    er->pad[k] = (er->act[k] == 0.0 && v > thr) ? v : 0.0;
+                const EndVals e = end_vals();
+                _Pragma("unroll") for (int k = 0; k < 2; ++k) {
+                    const double v = end_violation_of(e.rb[k], e.lo[k], e.up[k], e.act[k], e.y[k], S.x[k]);
+                    er->pad[k] = (e.act[k] == 0.0 && v > thr) ? v : 0.0;
                 }
             }
         });
@@ -1090,11 +1111,6 @@ struct PathQp {
         // ... and so are the end-state rows (offset, heading of the last waypoint) together with its two circle rows
         if (last && k >= 1) other = other && v >= end_rows()->pad[0] && v >= end_rows()->pad[1];
         return v >= l && v >= r && other;
-    }
-    PQP_HD bool polish_end_is_peak(int t, int k, double v) const {
-        const EndRows* er = end_rows();
-        const bool other = k == 0 ? v >= er->pad[1] : v > er->pad[0];
-        return other && v > sh[L.bufQ() + 3 * t + 1] && v > sh[L.bufQ() + 3 * t + 2];
     }
 
     // --- polish piece 4: primal-dual active-set step: rows failing the test by more than thr change sides
@@ -1123,14 +1139,18 @@ struct PathQp {
             S.flags = fl;
             if (S.flags & F_LAST) {
                 EndRows* er = end_rows();
-                for (int k = 0; k < 2; ++k) {
-                    const double w = end_violation(er, k, S.x[k]);
-                    if (!(w > thr) || (er->act[k] == 0.0 && !polish_end_is_peak(t, k, w))) continue;
+                const EndVals e = end_vals();
+                const double vq1 = sh[L.bufQ() + 3 * t + 1], vq2 = sh[L.bufQ() + 3 * t + 2];      // this waypoint's own published circle-row violations
+                _Pragma("unroll") for (int k = 0; k < 2; ++k) {
+                    const double w = end_violation_of(e.rb[k], e.lo[k], e.up[k], e.act[k], e.y[k], S.x[k]);
+                    // (polish_end_is_peak: the end rows and the last waypoint's circle rows over one bound are one bump)
+                    const bool peak = (k == 0 ? w >= e.pad[1] : w > e.pad[0]) && w > vq1 && w > vq2;
+                    const bool move = w > thr && (e.act[k] != 0.0 || peak);
 #ifdef PQP_EMU_DEBUG
-                    printf("      end row k=%d %s viol %.3e (x %.5f lo %.5f up %.5f y %.4e)\n", k, er->act[k] != 0.0 ? "RELEASE" : "ADD", end_violation(er, k, S.x[k]), S.x[k], er->lo[k], er->up[k], er->y[k]);
+                    if (move) printf("      end row k=%d %s viol %.3e (x %.5f lo %.5f up %.5f y %.4e)\n", k, e.act[k] != 0.0 ? "RELEASE" : "ADD", w, S.x[k], e.lo[k], e.up[k], e.y[k]);
 #endif
-                    if (er->act[k] != 0.0) er->act[k] = 0.0;
-                    else er->act[k] = (er->lo[k] - S.x[k] > S.x[k] - er->up[k]) ? -1.0 : 1.0;
+                    const double moved = e.act[k] != 0.0 ? 0.0 : ((e.lo[k] - S.x[k] > S.x[k] - e.up[k]) ? -1.0 : 1.0);
+                    er->act[k] = move ? moved : e.act[k];
                 }
             }
         });
@@ -1178,9 +1198,11 @@ struct PathQp {
             _Pragma("unroll") for (int k = 0; k < 6; ++k) set_sig(S, t, k, sig_of(S, t, k) * isgain);
             if (S.flags & F_LAST) {
                 EndRows* er = end_rows();
-                for (int k = 0; k < 2; ++k) {
-                    if (!ok) { er->z[k] = er->sz[k]; er->y[k] = reseed ? er->by[k] : er->sy[k]; }
-                    const double rb = er->rb[k];
+                double e_rb[2], e_sz[2], e_sy[2], e_by[2];
+                _Pragma("unroll") for (int k = 0; k < 2; ++k) { e_rb[k] = er->rb[k]; e_sz[k] = er->sz[k]; e_sy[k] = er->sy[k]; e_by[k] = er->by[k]; }
+                _Pragma("unroll") for (int k = 0; k < 2; ++k) {
+                    if (!ok) { er->z[k] = e_sz[k]; er->y[k] = reseed ? e_by[k] : e_sy[k]; }
+                    const double rb = e_rb[k];
                     const double r = rb < 0.0 ? -rb : rho_now * rb;
                     er->rho[k] = r; er->rinv[k] = rcp(r);
                 }
@@ -1302,7 +1324,8 @@ struct PathQp {
                     }
                 }
             });
-            PQP_IT(h == 1 ? 10 : (h <= 8 ? 11 : (h <= 32 ? 12 : 13)));       // level 1 | 2 .. 8 | 16, 32 | 64 ...
+            // level 1 | 2 .. 8 | 16, 32 | 64 ...  (constant indices: a computed one would put the solver object in scratch memory)
+            if (h == 1) PQP_IT(10); else if (h <= 8) PQP_IT(11); else if (h <= 32) PQP_IT(12); else PQP_IT(13);
         }
     }
 
@@ -1426,12 +1449,10 @@ struct PathQp {
                 const int tp = t + 1;
                 const bool surv = (tp & 15) == 0, wedge = (tp & 63) == 0;
                 const bool hr = surv && !wedge, hl = surv && (t - 8 >= 0);
-                const double* q_ = nb(hr, L.bufQ(), 3, t + 8);
-                const double* p_ = nb(hl, L.bufP(), 3, t - 8);
-                const double* g_ = nb(hr, L.bufG(), 3, t + 1);
-                const double* q1 = nb(hr, L.bufQ(), 3, t + 1);
-                const double* q2 = nb(hr, L.bufQ(), 3, t + 2);
-                const double* q4 = nb(hr, L.bufQ(), 3, t + 4);
+                double q_[3], p_[3], g_[3], q1[3], q2[3], q4[3];
+                ld3(q_, nb(hr, L.bufQ(), 3, t + 8)); ld3(p_, nb(hl, L.bufP(), 3, t - 8)); ld3(g_, nb(hr, L.bufG(), 3, t + 1));
+                ld3(q1, nb(hr, L.bufQ(), 3, t + 1)); ld3(q2, nb(hr, L.bufQ(), 3, t + 2)); ld3(q4, nb(hr, L.bufQ(), 3, t + 4));
+                ctx.join(q_, p_, g_, q1, q2, q4);
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += g_[k] + (q1[k] + q2[k] + q4[k]) + (q_[k] + p_[k]);
                 if ((tp & 31) == 16) {
                     double p[3];
@@ -1455,8 +1476,8 @@ struct PathQp {
                     const int hp = h >> 1;
                     const bool surv = (tp & (h - 1)) == 0;
                     const bool hr = surv && (t + hp < T) && !edge, hl = surv && (t - hp >= 0);
-                    const double* q_ = nb(hr, L.bufQ(), 3, t + hp);
-                    const double* p_ = nb(hl, L.bufP(), 3, t - hp);
+                    double q_[3], p_[3];
+                    ld3(q_, nb(hr, L.bufQ(), 3, t + hp)); ld3(p_, nb(hl, L.bufP(), 3, t - hp));
                     _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += q_[k] + p_[k];
                 }
                 if ((tp & (2 * h - 1)) == h) {
@@ -1478,23 +1499,30 @@ struct PathQp {
                 Slot& S = ln.s;
                 const int tp = t + 1;
                 const bool edge = (tp & 63) == 0;
-                if (h == hw && edge) {
-                    // deferred: message of waypoint t+1 and the right-hand level messages of all in-wave levels
-                    if (t + 1 < T) { _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += sh[L.bufG() + 3 * (t + 1) + k]; }
-                    for (int hp = 1; hp < (hw >> 1); hp <<= 1) {
-                        if (t + hp < T) { _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += sh[L.bufQ() + 3 * (t + hp) + k]; }
-                    }
-                }
-                if (h > 1) {
+                // this level's own messages (h > 1: T >= 64 always) - loaded BEFORE the deferred sums below, so that they travel with that batch
+                double lq[3], lp[3];
+                {
                     const int hp = h >> 1;
                     const bool surv = (tp & (h - 1)) == 0;
                     const bool hr = surv && (t + hp < T), hl = surv && (t - hp >= 0);
-                    const double* q_ = nb(hr, L.bufQ(), 3, t + hp);
-                    const double* p_ = nb(hl, L.bufP(), 3, t - hp);
-                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += q_[k] + p_[k];
-                } else if (t + 1 < T && !edge) {     // T == 1 only
-                    _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += sh[L.bufG() + 3 * (t + 1) + k];
+                    ld3(lq, nb(hr, L.bufQ(), 3, t + hp)); ld3(lp, nb(hl, L.bufP(), 3, t - hp));
                 }
+                if (h == hw && T > hw) {
+                    // deferred (the wavefront's last lane; every other lane reads the zero block): message of waypoint t+1 and the right-hand level
+                    // messages of all in-wave levels.  ALL loads first, then the sums in the old order: written as "if (in range) r += sh[..]" per
+                    // source, every source was a load -> wait -> add of its own - six LDS latencies in a row on the path both wavefronts wait for
+                    // (round 6: 0.9 us of a 3.2 us solve between the two barriers around the root)
+                    double dv[6][3];
+                    ld3(dv[0], nb(edge && t + 1 < T, L.bufG(), 3, t + 1));
+                    _Pragma("unroll") for (int j = 0; j < 5; ++j) {
+                        const int hp = 1 << j;
+                        ld3(dv[1 + j], nb(edge && hp < (hw >> 1) && t + hp < T, L.bufQ(), 3, t + hp));
+                    }
+                    ctx.join(dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], lq, lp);
+                    _Pragma("unroll") for (int j = 0; j < 6; ++j) { _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += dv[j][k]; }
+                }
+
+                _Pragma("unroll") for (int k = 0; k < 3; ++k) S.r[k] += lq[k] + lp[k];
                 if (!root_here) {
                     if ((tp & (2 * h - 1)) == h) {
                         double p[3];
@@ -1523,8 +1551,9 @@ struct PathQp {
                 const int tp = t + 1;
                 const bool act = (tp & (2 * h - 1)) == h;
                 const bool hl = act && (t - h >= 0), hr = act && (t + h < T);
-                const double* xl = nb(hl, L.xbuf(), 3, t - h);         // no neighbour: x = 0 from the zero block
-                const double* xr = nb(hr, L.xbuf(), 3, t + h);
+                double xl[3], xr[3];
+                ld3(xl, nb(hl, L.xbuf(), 3, t - h));         // no neighbour: x = 0 from the zero block
+                ld3(xr, nb(hr, L.xbuf(), 3, t + h));
                 double x3[3], p[3], pr[3];
                 sym3_vec(S.Dinv, S.r, x3);
                 mat3t_vec(S.GL, xl, p);
@@ -1591,19 +1620,26 @@ struct PathQp {
                 S.zI[k] = zn;
             }
             if (S.flags & F_LAST) {
+                // The two end rows, by the one lane that owns them while its wavefront (and, at the next barrier, the other one) waits: every field
+                // is loaded before anything is computed and nothing branches - written row by row with `if (polishing_)` inside, this was a chain
+                // of seven LDS round trips per solve (round 6: 0.25 us of 3.2)
                 EndRows* er = end_rows();
-                for (int k = 0; k < 2; ++k) {
-                    const double zh = alpha * xt[k] + (1.0 - alpha) * er->z[k];
-                    const double v = zh + er->y[k] * er->rinv[k];
-                    double elo = er->lo[k], eup = er->up[k];
-                    if (polishing_) {
-                        const double bnd = er->act[k] < 0.0 ? elo : eup;
-                        elo = er->act[k] != 0.0 ? bnd : -kInfty;
-                        eup = er->act[k] != 0.0 ? bnd : kInfty;
-                    }
+                double e_lo[2], e_up[2], e_z[2], e_y[2], e_rho[2], e_rinv[2], e_act[2];
+                _Pragma("unroll") for (int k = 0; k < 2; ++k) {
+                    e_lo[k] = er->lo[k]; e_up[k] = er->up[k]; e_z[k] = er->z[k]; e_y[k] = er->y[k];
+                    e_rho[k] = er->rho[k]; e_rinv[k] = er->rinv[k]; e_act[k] = er->act[k];
+                }
+                const bool pol = polishing_;
+                _Pragma("unroll") for (int k = 0; k < 2; ++k) {
+                    const double zh = alpha * xt[k] + (1.0 - alpha) * e_z[k];
+                    const double v = zh + e_y[k] * e_rinv[k];
+                    const double bnd = e_act[k] < 0.0 ? e_lo[k] : e_up[k];
+                    const bool pin = pol && e_act[k] != 0.0;
+                    const double elo = pin ? bnd : (pol ? -kInfty : e_lo[k]);
+                    const double eup = pin ? bnd : (pol ? kInfty : e_up[k]);
                     const double zn = fmin(fmax(v, elo), eup);
-                    const double d = er->rho[k] * (zh - zn);
-                    er->y[k] += d;
+                    const double d = e_rho[k] * (zh - zn);
+                    er->y[k] = e_y[k] + d;
                     if (CERT) er->yp[k] = d;
                     er->z[k] = zn;
                 }
@@ -1645,10 +1681,12 @@ struct PathQp {
             _Pragma("unroll") for (int k = 0; k < 3; ++k) w = fmax(w, row_violation(S, t, k, aI[k]));
             if (S.flags & F_LAST) {
                 const EndRows* er = end_rows();
-                pr = fmax(pr, fmax(fabs(S.x[0] - er->z[0]), fabs(S.x[1] - er->z[1])));
-                nz = fmax(nz, fmax(fmax(fabs(S.x[0]), fabs(er->z[0])), fmax(fabs(S.x[1]), fabs(er->z[1]))));
-                ye0 = er->y[0]; ye1 = er->y[1];
-                for (int k = 0; k < 2; ++k) w = fmax(w, end_violation(er, k, S.x[k]));
+                double e_z[2], e_y[2], e_rb[2], e_lo[2], e_up[2], e_act[2];       // (all loads first, see iterate())
+                _Pragma("unroll") for (int k = 0; k < 2; ++k) { e_z[k] = er->z[k]; e_y[k] = er->y[k]; e_rb[k] = er->rb[k]; e_lo[k] = er->lo[k]; e_up[k] = er->up[k]; e_act[k] = er->act[k]; }
+                pr = fmax(pr, fmax(fabs(S.x[0] - e_z[0]), fabs(S.x[1] - e_z[1])));
+                nz = fmax(nz, fmax(fmax(fabs(S.x[0]), fabs(e_z[0])), fmax(fabs(S.x[1]), fabs(e_z[1]))));
+                ye0 = e_y[0]; ye1 = e_y[1];
+                _Pragma("unroll") for (int k = 0; k < 2; ++k) w = fmax(w, end_violation_of(e_rb[k], e_lo[k], e_up[k], e_act[k], e_y[k], S.x[k]));
             }
             double aty[6];
             aty[0] = -S.yT[0] + gn[0] + S.yI[1] + S.yI[2] + ye0;

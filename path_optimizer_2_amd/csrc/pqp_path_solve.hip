@@ -37,10 +37,20 @@ __device__ __forceinline__ void wg_reduce(double (&v)[K], double* shp) {
         if ((threadIdx.x & 63) == 0)
             for (int k = 0; k < K; ++k) red[k * 16 + w] = v[k];
         __syncthreads();
+        // (every load before the first readfirstlane: with the uniform() inside the loop over k each value was an LDS round trip of its own -
+        //  six in a row per residual evaluation, round 6)
+        double x[K][NW];
+#pragma unroll
         for (int k = 0; k < K; ++k) {
-            double x = red[k * 16];
-            for (int j = 1; j < NW; ++j) x = MAX ? fmax(x, red[k * 16 + j]) : x + red[k * 16 + j];
-            v[k] = uniform(x);
+#pragma unroll
+            for (int j = 0; j < NW; ++j) x[k][j] = red[k * 16 + j];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double m = x[k][0];
+#pragma unroll
+            for (int j = 1; j < NW; ++j) m = MAX ? fmax(m, x[k][j]) : m + x[k][j];
+            v[k] = uniform(m);
         }
     }
     __syncthreads();
@@ -118,12 +128,25 @@ struct DevCtx {
     template <int H> __device__ __forceinline__ static double lane_below(double v) { return dpp0<0x110 + H, 0xf>(v); }     // row_shr:H
     template <int H> __device__ __forceinline__ static double lane_above(double v) { return dpp0<0x100 + H, 0xf>(v); }     // row_shl:H
     __device__ __forceinline__ static double prev_row_last(double v) { return dpp0<0x142, 0xe>(v); }                      // row_bcast:15
+    // "every one of these loaded values is needed HERE": one empty asm statement that takes them all.  The loads are then issued together and waited
+    // for once; left alone the scheduler - this kernel has no register to spare - loads a few, sums them, reuses their registers for the next
+    // few: one LDS round trip after the other on the solve's critical path (round 6: profiles/r06*_lds_round_trips.txt).  Only for batches of six
+    // and more loads: behind two loads the fence costs more than the order it enforces (profiles/r06g_*)
+    typedef double v3[3];
+    __device__ __forceinline__ static void join(v3& a, v3& b, v3& c, v3& d, v3& e, v3& f) {
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]),
+                          "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(f[0]), "+v"(f[1]), "+v"(f[2]));
+    }
+    __device__ __forceinline__ static void join(v3& a, v3& b, v3& c, v3& d, v3& e, v3& f, v3& g, v3& h) {
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]),
+                          "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(f[0]), "+v"(f[1]), "+v"(f[2]),
+                          "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(h[0]), "+v"(h[1]), "+v"(h[2]));
+    }
     __device__ __forceinline__ static double uni(double x) { return uniform(x); }      // a wave-uniform value that reaches control flow
     __device__ __forceinline__ static int uni_int(int x) { return __builtin_amdgcn_readfirstlane(x); }
     Lane lane;
     double* shp;
     __device__ __forceinline__ long long clock() const { return (long long)wall_clock64(); }     // 100 MHz
-    __device__ __forceinline__ long long cycles() const { return (long long)__builtin_amdgcn_s_memtime(); }     // shader clock
     __device__ __forceinline__ bool certificate(double* sh, int, double fl, double rl, double kap, double eps, double cscale) {
         return uniform(dev_certificate<NW>(sh, fl, rl, kap, eps, cscale));
     }

@@ -35,6 +35,7 @@ struct HostCtx {
     // constants in the shared array too, everything parked in global memory
     static constexpr bool kCstLds = PQP_EMU_DIET != 0, kParkScale = true, kSaveLds = PQP_EMU_DIET == 0, kDpp = false, kCstAcc = false;
     static constexpr bool kFinalRefine = true;      // (the device: contexts of more than 128 lanes per QP; the parameter is 0 below that)
+    template <class... A> static void join(A&...) {}      // (the device: a scheduling fence behind a batch of LDS loads)
     int T_;
     std::vector<pqp::Lane> lanes;
     std::vector<double> shm;

@@ -2,6 +2,8 @@
 (oracle/corridor_oracle.py).  Sample positions are computed in the reference's operation order with FMA contraction off, so
 the step counts of the ray search - and with them the bounds - are the oracle's; only sin/cos differ (ocml vs libm, <= 1 ulp),
 which can move a bound by one search step when a sample sits within round-off of the 0.5 m threshold."""
+import os
+
 import numpy as np
 import pytest
 

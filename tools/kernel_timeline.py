@@ -80,12 +80,12 @@ if __name__ == "__main__":
         tot = it.sum(1).mean()
         for k, nm in enumerate(["I1 right-hand side", "forward levels 1..8 (DPP)", "forward levels 16, 32 (in-wave)", "barrier + cross-wave levels / root", "backward levels >= 16",
                                 "backward levels 8..1 (DPP)", "I3 update"]):
-            print(f"    iterate: {nm:36s} mean {it[:, k].mean():10.0f} cycles per QP  {it[:, k].mean() / tot:5.1%}")
-        print(f"    iterate: total {tot:.0f} shader cycles per QP")
+            print(f"    iterate: {nm:36s} mean {it[:, k].mean() / 100.0:8.2f} us per QP  {it[:, k].mean() / tot:5.1%}")
+        print(f"    iterate: total {tot / 100.0:.1f} us per QP")
         ftot = fa.sum(1).mean()
         for k, nm in enumerate(["F1 own block + message", "F2 receive", "level 1", "levels 2 .. 8", "levels 16, 32", "levels >= 64"]):
-            print(f"    factor:  {nm:36s} mean {fa[:, k].mean():10.0f} cycles per QP  {fa[:, k].mean() / ftot:5.1%}")
-        print(f"    factor:  total {ftot:.0f} shader cycles per QP")
+            print(f"    factor:  {nm:36s} mean {fa[:, k].mean() / 100.0:8.2f} us per QP  {fa[:, k].mean() / ftot:5.1%}")
+        print(f"    factor:  total {ftot / 100.0:.1f} us per QP")
     sub = out.cpu().numpy().reshape(batch, -1)[:, :8] / 100.0      # the timing build writes the cold operations' sub-times over out[qp][0][0..7]
     for k, nm in enumerate(["load", "assemble", "ruiz", "start_transition_rows", "polish begin / apply set", "factor", "polish update set", "polish end (reject)"]):
         print(f"    cold: {nm:28s} mean {sub[:, k].mean():8.1f} us   max {sub[:, k].max():8.1f}")
