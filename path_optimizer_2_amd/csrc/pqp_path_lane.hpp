@@ -910,9 +910,10 @@ struct PathQp {
             S.flags = fl;
             if (S.flags & F_LAST) {
                 EndRows* er = end_rows();
-                for (int k = 0; k < 2; ++k) {
-                    const double e = er->E[k], e2 = e * e * ic;
-                    const double sl = e * fmax(er->lo[k], -kInfty), su = e * fmin(er->up[k], kInfty);
+                const EndVals ev = end_vals();
+                _Pragma("unroll") for (int k = 0; k < 2; ++k) {
+                    const double e = ev.E[k], e2 = e * e * ic;
+                    const double sl = e * fmax(ev.lo[k], -kInfty), su = e * fmin(ev.up[k], kInfty);
                     double rb;
                     if (sl < -kInfty * kMinScaling && su > kInfty * kMinScaling) rb = -kRhoMin * e2;
                     else if (su - sl < kRhoTol) rb = kRhoEqFactor * e2;
@@ -1046,11 +1047,13 @@ struct PathQp {
             Slot& S = ln.s;
             const bool real = S.flags & F_REAL;
             const double* w = save_slot(t);
+            const EndVals e = end_vals();                                   // (every lane, with the phase's first loads: see iterate())
+            const double w15[3] = {w[15], w[16], w[17]};                    // (one batch: read inside the loop, each was an LDS round trip of its own)
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                 const bool eq = S.flags & (F_EQ0 << k);
                 const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
                 const bool act = real && (alo || aup);
-                const double e2 = w[15 + k] * (eq ? irho_eq : irho);
+                const double e2 = w15[k] * (eq ? irho_eq : irho);
                 const double r = act ? gain * e2 : 0.0;
                 // (read every candidate into a value first: a select between two lane FIELDS becomes an address select,
                 //  i.e. dynamic indexing of the lane struct, which would push the whole struct into scratch memory)
@@ -1062,7 +1065,6 @@ struct PathQp {
             }
             if (S.flags & F_LAST) {
                 EndRows* er = end_rows();
-                const EndVals e = end_vals();
                 _Pragma("unroll") for (int k = 0; k < 2; ++k) {
                     const bool act = e.act[k] != 0.0;
                     const double r = act ? gain * e.E[k] * e.E[k] / cscale : 0.0;
@@ -1084,6 +1086,7 @@ struct PathQp {
     PQP_HD void polish_publish_adds(double thr) {
         ctx.phase([&](int t, Lane& ln) {
             const Slot& S = ln.s;
+            const EndVals e = end_vals();
             double Xp[3], aT[3], aI[3];
             { const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
             rows_of(S, Xp, S.x, aT, aI);
@@ -1094,7 +1097,6 @@ struct PathQp {
             }
             if (S.flags & F_LAST) {
                 EndRows* er = end_rows();
-                const EndVals e = end_vals();
                 _Pragma("unroll") for (int k = 0; k < 2; ++k) {
                     const double v = end_violation_of(e.rb[k], e.lo[k], e.up[k], e.act[k], e.y[k], S.x[k]);
                     er->pad[k] = (e.act[k] == 0.0 && v > thr) ? v : 0.0;
@@ -1102,15 +1104,15 @@ struct PathQp {
             }
         });
     }
-    PQP_HD bool polish_is_peak(int t, int k, double v, bool last) const {
-        const double l = t > 0 ? sh[L.bufQ() + 3 * (t - 1) + k] : 0.0;
-        const double r = t + 1 < T ? sh[L.bufQ() + 3 * (t + 1) + k] : 0.0;
+    // (from values: vl / vo / vr = the published violations of the previous, this and the next waypoint, pad = those of the end rows; the caller loads
+    //  them in one batch)
+    PQP_HD static bool polish_is_peak(int k, double v, bool last, const double (&vl)[3], const double (&vo)[3], const double (&vr)[3], const double (&pad)[2]) {
         // the front and the rear circle of one waypoint (rows 1, 2) over the same bound are one bump too: pinning both fixes
         // offset and heading there, and the two then push each other out again round after round
-        bool other = k == 0 ? true : (k == 1 ? v >= sh[L.bufQ() + 3 * t + 2] : v > sh[L.bufQ() + 3 * t + 1]);
+        bool other = k == 0 ? true : (k == 1 ? v >= vo[2] : v > vo[1]);
         // ... and so are the end-state rows (offset, heading of the last waypoint) together with its two circle rows
-        if (last && k >= 1) other = other && v >= end_rows()->pad[0] && v >= end_rows()->pad[1];
-        return v >= l && v >= r && other;
+        if (last && k >= 1) other = other && v >= pad[0] && v >= pad[1];
+        return v >= vl[k] && v >= vr[k] && other;
     }
 
     // --- polish piece 4: primal-dual active-set step: rows failing the test by more than thr change sides
@@ -1120,12 +1122,16 @@ struct PathQp {
             Slot& S = ln.s;
             double Xp[3], aT[3], aI[3];
             { const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
+            // everything the rules below read from LDS, in one batch: the published violations of the three waypoints around this one, the end rows
+            double vl[3], vo[3], vr[3];
+            ld3(vl, nb(t > 0, L.bufQ(), 3, t - 1)); ld3(vo, sh + L.bufQ() + 3 * t); ld3(vr, nb(t + 1 < T, L.bufQ(), 3, t + 1));
+            const EndVals e = end_vals();
             rows_of(S, Xp, S.x, aT, aI);
             int fl = S.flags;
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                 const bool alo = S.flags & (F_ACTLO0 << k), aup = S.flags & (F_ACTUP0 << k);
                 const double w = row_violation(S, t, k, aI[k]);
-                const bool move = w > thr && (alo || aup || polish_is_peak(t, k, w, S.flags & F_LAST));
+                const bool move = w > thr && (alo || aup || polish_is_peak(k, w, S.flags & F_LAST, vl, vo, vr, e.pad));
                 const bool add_lo = move && !alo && !aup && (raw_lo(S, t, k) - aI[k] > aI[k] - raw_up(S, t, k));
                 const bool add_up = move && !alo && !aup && !add_lo;
 #ifdef PQP_EMU_DEBUG
@@ -1139,8 +1145,7 @@ struct PathQp {
             S.flags = fl;
             if (S.flags & F_LAST) {
                 EndRows* er = end_rows();
-                const EndVals e = end_vals();
-                const double vq1 = sh[L.bufQ() + 3 * t + 1], vq2 = sh[L.bufQ() + 3 * t + 2];      // this waypoint's own published circle-row violations
+                const double vq1 = vo[1], vq2 = vo[2];      // this waypoint's own published circle-row violations
                 _Pragma("unroll") for (int k = 0; k < 2; ++k) {
                     const double w = end_violation_of(e.rb[k], e.lo[k], e.up[k], e.act[k], e.y[k], S.x[k]);
                     // (polish_end_is_peak: the end rows and the last waypoint's circle rows over one bound are one bump)
@@ -1410,12 +1415,12 @@ struct PathQp {
             double wT[3], wI[3];
             _Pragma("unroll") for (int k = 0; k < 3; ++k) wT[k] = S.rhoT[k] * S.bT[k] - S.yT[k];
             _Pragma("unroll") for (int k = 0; k < 3; ++k) wI[k] = S.rhoI[k] * S.zI[k] - S.yI[k];
-            double we0 = 0.0, we1 = 0.0;
-            if (S.flags & F_LAST) {
-                const EndRows* er = end_rows();
-                we0 = er->rho[0] * er->z[0] - er->y[0];
-                we1 = er->rho[1] * er->z[1] - er->y[1];
-            }
+            // (the end rows are loaded by EVERY lane, not under `if (F_LAST)`: the loads then leave with the phase's first instructions and their
+            //  latency is over before the one lane that uses them gets there; under the branch that lane - and everybody behind it - waits for them)
+            const EndRows* er1 = end_rows();
+            const double e_rho0 = er1->rho[0], e_rho1 = er1->rho[1], e_z0 = er1->z[0], e_z1 = er1->z[1], e_y0 = er1->y[0], e_y1 = er1->y[1];
+            const bool last1 = S.flags & F_LAST;
+            const double we0 = last1 ? e_rho0 * e_z0 - e_y0 : 0.0, we1 = last1 ? e_rho1 * e_z1 - e_y1 : 0.0;
             S.rv = sig_of(S, t, 3) * S.x[3] + S.a[5] * wT[2];
             S.rsf = sig_of(S, t, 4) * S.x[4] + wI[1];
             S.rsr = sig_of(S, t, 5) * S.x[5] + wI[2];
@@ -1589,6 +1594,15 @@ struct PathQp {
         // follow directly, anything else (residuals, cold operations) must synchronise first - sync_after_iterate().
         ctx.phase_w([&](int t, Lane& ln) {
             Slot& S = ln.s;
+            // the two end rows' fields, loaded by every lane at the top of the phase (see I1); used by the lane that owns the rows at the bottom
+            double e_lo[2], e_up[2], e_z[2], e_y[2], e_rho[2], e_rinv[2], e_act[2];
+            {
+                const EndRows* er = end_rows();
+                _Pragma("unroll") for (int k = 0; k < 2; ++k) {
+                    e_lo[k] = er->lo[k]; e_up[k] = er->up[k]; e_z[k] = er->z[k]; e_y[k] = er->y[k];
+                    e_rho[k] = er->rho[k]; e_rinv[k] = er->rinv[k]; e_act[k] = er->act[k];
+                }
+            }
             double Xp[3];
             if constexpr (D) {
                 _Pragma("unroll") for (int k = 0; k < 3; ++k) { const double b = ctx.template lane_below<1>(S.xt[k]); Xp[k] = (t & 15) ? b : xpv[k]; }
@@ -1621,14 +1635,9 @@ struct PathQp {
             }
             if (S.flags & F_LAST) {
                 // The two end rows, by the one lane that owns them while its wavefront (and, at the next barrier, the other one) waits: every field
-                // is loaded before anything is computed and nothing branches - written row by row with `if (polishing_)` inside, this was a chain
-                // of seven LDS round trips per solve (round 6: 0.25 us of 3.2)
+                // was loaded at the top of the phase and nothing branches - written row by row with loads and `if (polishing_)` inside, this was a
+                // chain of seven LDS round trips per solve (round 6: 0.25 us of 3.2)
                 EndRows* er = end_rows();
-                double e_lo[2], e_up[2], e_z[2], e_y[2], e_rho[2], e_rinv[2], e_act[2];
-                _Pragma("unroll") for (int k = 0; k < 2; ++k) {
-                    e_lo[k] = er->lo[k]; e_up[k] = er->up[k]; e_z[k] = er->z[k]; e_y[k] = er->y[k];
-                    e_rho[k] = er->rho[k]; e_rinv[k] = er->rinv[k]; e_act[k] = er->act[k];
-                }
                 const bool pol = polishing_;
                 _Pragma("unroll") for (int k = 0; k < 2; ++k) {
                     const double zh = alpha * xt[k] + (1.0 - alpha) * e_z[k];
@@ -1665,6 +1674,8 @@ struct PathQp {
         });
         ctx.template reduce_max<6>(res, [&](int t, Lane& ln, double (&v)[6]) {
             const Slot& S = ln.s;
+            double e_z[2], e_y[2], e_rb[2], e_lo[2], e_up[2], e_act[2];       // the end rows, loaded by every lane with the phase's first loads (see iterate())
+            { const EndRows* er = end_rows(); _Pragma("unroll") for (int k = 0; k < 2; ++k) { e_z[k] = er->z[k]; e_y[k] = er->y[k]; e_rb[k] = er->rb[k]; e_lo[k] = er->lo[k]; e_up[k] = er->up[k]; e_act[k] = er->act[k]; } }
             double Xp[3], gn[3];
             { const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
             { const double* gn_ = nb(t + 1 < T, L.bufG(), 3, t + 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) gn[k] = gn_[k]; }
@@ -1680,9 +1691,6 @@ struct PathQp {
             double ye0 = 0.0, ye1 = 0.0, w = 0.0;
             _Pragma("unroll") for (int k = 0; k < 3; ++k) w = fmax(w, row_violation(S, t, k, aI[k]));
             if (S.flags & F_LAST) {
-                const EndRows* er = end_rows();
-                double e_z[2], e_y[2], e_rb[2], e_lo[2], e_up[2], e_act[2];       // (all loads first, see iterate())
-                _Pragma("unroll") for (int k = 0; k < 2; ++k) { e_z[k] = er->z[k]; e_y[k] = er->y[k]; e_rb[k] = er->rb[k]; e_lo[k] = er->lo[k]; e_up[k] = er->up[k]; e_act[k] = er->act[k]; }
                 pr = fmax(pr, fmax(fabs(S.x[0] - e_z[0]), fabs(S.x[1] - e_z[1])));
                 nz = fmax(nz, fmax(fmax(fabs(S.x[0]), fabs(e_z[0])), fmax(fabs(S.x[1]), fabs(e_z[1]))));
                 ye0 = e_y[0]; ye1 = e_y[1];

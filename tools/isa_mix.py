@@ -12,7 +12,12 @@ Static counts: what the compiler emitted, not what ran (the PMC pass of tools/pm
   dpp      any VALU instruction with a DPP modifier (row_shr, row_shl, row_bcast, quad_perm ...)
   valu     every other VALU instruction (integer, fp32, bit operations)
   ds       LDS, mem: global / flat / scratch / buffer, salu: scalar ALU + s_load, wait: s_waitcnt / s_nop / s_barrier, br: branches
-A loop region is [target, branch] of a backward branch; nested regions are listed on their own (innermost first by address)."""
+A loop region is [target, branch] of a backward branch; nested regions are listed on their own (innermost first by address).
+
+    python tools/isa_mix.py --lds-trips [--lines]             # LDS round trips per barrier interval
+An LDS round trip = an s_waitcnt that completes a ds_read issued after the previous such wait: a load -> wait -> use chain.  At one wavefront per
+SIMD nothing hides them; a phase that needs k values from LDS should show ONE (all loads, one wait), not k (round 6: the root of the
+cyclic-reduction tree showed 7, the end rows 7, the workgroup reduction 6).  With --lines every interval names the source lines it spans."""
 import argparse
 import bisect
 import os
@@ -139,6 +144,32 @@ def source_functions(paths):
     return table
 
 
+def lds_trips(insns, min_insns):
+    """[(first index, last index, instructions, VALU, trips)] per interval between s_barrier instructions"""
+    from collections import deque
+    out, q, trips, start, n, valu, at = [], deque(), 0, 0, 0, 0, []
+    for i, (addr, cls, mn, ops, loc) in enumerate(insns):
+        n += 1
+        valu += cls in VALU
+        if cls == "ds":
+            q.append((trips, mn.startswith("ds_read") or "_rtn" in mn, loc))
+        elif mn.startswith("s_waitcnt") and "lgkmcnt" in ops:
+            c = int(re.search(r"lgkmcnt\((\d+)\)", ops).group(1))
+            hit = None
+            while len(q) > c:
+                g, is_read, where = q.popleft()
+                if is_read and g == trips:
+                    hit = where or ("?", 0)
+            if hit:
+                trips += 1
+                at.append(hit[1])
+        elif mn.startswith("s_barrier") or i == len(insns) - 1:
+            if n >= min_insns or trips > 1:
+                out.append((start, i, n, valu, trips, at))
+            q, trips, start, n, valu, at = deque(), 0, i + 1, 0, 0, []
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--lib", default=os.path.join(ROOT, "path_optimizer_2_amd", "csrc", "libpqp_hip.so"))
@@ -146,6 +177,7 @@ def main():
     ap.add_argument("--regions", type=int, default=16, help="loop regions to list per kernel (largest first)")
     ap.add_argument("--lines", action="store_true", help="the object carries line tables: mix per source function")
     ap.add_argument("--min-insns", type=int, default=60, help="loop regions smaller than this are not listed")
+    ap.add_argument("--lds-trips", action="store_true", help="LDS round trips (load -> wait -> use chains) per barrier interval instead of the mix")
     a = ap.parse_args()
     tmp = tempfile.mkdtemp(prefix="isa_mix_")
     try:
@@ -159,6 +191,13 @@ def main():
                 total = Counter(c for _, c, *_ in insns)
                 base = insns[0][0]
                 print(f"== {name}")
+                if a.lds_trips:
+                    rows = lds_trips(insns, a.min_insns)
+                    print(f"   {sum(r[4] for r in rows)} LDS round trips in {len(rows)} barrier intervals (static: every interval once)")
+                    for s0, s1, n, v, tr, at in rows:
+                        where = f"  loads waited for at lines {at}" if a.lines and at else ""
+                        print(f"   +{insns[s0][0] - base:#07x}..+{insns[s1][0] - base:#07x} {n:5d} insns  VALU {v:4d}  LDS round trips {tr:2d}{where}")
+                    continue
                 print(f"   whole kernel      {fmt(total)}")
                 regs, addrs = regions(insns)
                 rows = []
