@@ -47,8 +47,10 @@ class BaseSolver {
     int lastIterations() const { return iters_; }
     size_t vars() const { return vars_size_; }
     size_t cons() const { return cons_size_; }
+    size_t precisePlanningSize() const { return precise_planning_size_; }     // base_solver.cpp:25-34
 
  protected:
+    void updateSizes();
     bool run(const std::vector<SlState>& lin, bool warm, std::vector<SlState>* out);
 
     const size_t n_{};

@@ -55,9 +55,14 @@ void BaseSolver::releaseCachedHandles() { pool().clear(); }
 BaseSolver::BaseSolver(const ReferencePath& reference_path, const VehicleState& vehicle_state, const std::vector<SlState>& input_path)
     : n_(input_path.size()), reference_path_(reference_path), vehicle_state_(vehicle_state), input_path_(input_path), device_(default_device()) {
     pqp_default_params(&params_);
-    // base_solver.cpp:22-37 through the library's own size function
+    updateSizes();
+}
+
+// base_solver.cpp:22-37 through the library's own size function.  The reference reads FLAGS_rough_constraints_far_away /
+// FLAGS_precise_planning_length at construction; here they are fields of params(), so the sizes follow setParams() too
+void BaseSolver::updateSizes() {
     std::vector<double> s(n_);
-    for (size_t i = 0; i < n_; ++i) s[i] = input_path[i].s;
+    for (size_t i = 0; i < n_; ++i) s[i] = input_path_[i].s;
     pqp_sizes sz;
     if (n_ >= 2 && pqp_path_sizes(&params_, (int)n_, s.data(), &sz) == PQP_OK) {
         state_size_ = sz.state; control_size_ = sz.control; slack_size_ = sz.slack;
@@ -81,6 +86,7 @@ void BaseSolver::setDevice(int device) {
 
 void BaseSolver::setParams(const pqp_params& p) {
     params_ = p;
+    updateSizes();          // vars() / cons() / the precise planning size depend on rough_constraints_far_away and precise_planning_length
     if (handle_) pqp_set_params(handle_, &params_);
 }
 
@@ -124,7 +130,8 @@ bool BaseSolver::run(const std::vector<SlState>& lin, bool warm, std::vector<SlS
     }
     // the cold solve was launched on this handle: its warm state is this instance's own, whatever the status - the reference's solver stays
     // initialised after a solve() that ends at max_iter or infeasible, and updateProblemFormulationAndSolve still runs (base_solver.cpp:97-110)
-    solved_once_ = true;
+    // (not a QP the host entry refused - an inverted box, PRIMAL_INFEASIBLE without an iteration: nothing ran on its data)
+    solved_once_ = !(status == PQP_STATUS_PRIMAL_INFEASIBLE && iters == 0);
     if (status != PQP_STATUS_SOLVED) return false;                           // osqp-eigen: solve() true only for "solved"
     out->clear();                                                            // base_solver.cpp:266
     out->reserve(n_);

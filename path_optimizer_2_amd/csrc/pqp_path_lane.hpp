@@ -259,8 +259,15 @@ enum : int {
     F_EQ0 = 1 << 8,       // << k: inequality row k has l == u within RHO_TOL               (rho class "equality")
     F_ACTLO0 = 1 << 11,   // << k: polish: row k is taken as active at its lower bound
     F_ACTUP0 = 1 << 14,   // << k: polish: row k is taken as active at its upper bound
-    F_ROWBITS = (7 << 5) | (7 << 8) | (7 << 11) | (7 << 14)
+    F_ROWBITS = (7 << 5) | (7 << 8) | (7 << 11) | (7 << 14),
+    // the scenario of this waypoint is not a number the reference could work with: NaN / Inf among its reference state, bounds or start state, or an
+    // arclength that does not increase (the reference divides by ds, base_solver.cpp:174,180).  Such a QP ends PQP_STATUS_NUMERICAL at its first
+    // residual check with a zero output record (solve() == false, as when OSQP returns non-finite iterates); min / max arithmetic would
+    // otherwise drop a NaN bound silently and "solve" the QP without that row
+    F_BADIN = 1 << 17
 };
+// v - v is 0 for a finite v and NaN for NaN / Inf
+PQP_HD double not_finite_mark(double v) { return v - v; }
 
 // Everything a waypoint needs inside the ADMM loop (86 doubles); kept in registers.
 struct Slot {
@@ -318,6 +325,8 @@ struct ShLayout {
     PQP_HD int sk() const { return 24 * T; }                // [T][2] s, k_ref
     PQP_HD int end() const { return 26 * T; }               // EndRows (32 doubles)
     PQP_HD int red() const { return 26 * T + 32; }          // reduction scratch [8][16]
+    PQP_HD int poison() const { return 26 * T + 32 + 15; }  // (a column of the reduction scratch no wavefront uses) 1.0: the scenario of this QP is not a number (F_BADIN)
+                                                            // - zeroed in load(), set in assemble(), read once per pass behind it
     // per-waypoint pass constants that are read once per iteration (kCstLds contexts keep them here instead of in registers):
     // [12][T] sig(6) lo(2) up(2) idsf idsr, one array per constant (unit stride over the lanes: conflict-free)
     // 24 zeros (written once per workgroup): where a lane has no neighbour its read is redirected here, so the reads of a phase
@@ -495,7 +504,7 @@ struct Uni {
 enum ColdOp : int {
     COLD_BEGIN_PASS = 0,     // i0 = pass index, i1 = have_warm: [load, warm-load], assemble, Ruiz, start rows, factor
     COLD_REFACTOR = 1,       // i0 = RefactorKind, d0 = parameter: penalty change + factor
-    COLD_END_PASS = 2,       // i0 = polish accepted: [polish_end(true)], unpack
+    COLD_END_PASS = 2,       // i0 = 1: polish accepted: [polish_end(true)], unpack; i0 = 2: the pass ended PQP_STATUS_NUMERICAL: unpack writes zeros
     COLD_FINISH = 3,         // store the warm state
     COLD_CERT = 4            // primal infeasibility certificate on the last dy -> PathQp::cert_
 };
@@ -600,18 +609,22 @@ struct PathQp {
             Slot& S = ln.s;
             const int i = t;
             if (t < 24) sh[L.zero() + t] = 0.0;
+            if (t == 0) sh[L.poison()] = 0.0;
             const bool real = i < n;
             const int ic = real ? i : n - 1;
             const double* r = A.ref + ((size_t)qp * stride + ic) * PQP_REF_STRIDE;
             const double r0 = r[0], r1 = r[1];
             // base_solver.cpp:25-34: precise planning size = lower_bound(s, precise_planning_length)
             const bool precise = !prm.rough_constraints_far_away || r0 < prm.precise_planning_length;
-            S.flags = real ? (F_REAL | (i > 0 ? F_PREV : 0) | (i < n - 1 ? F_NEXT : 0) | (i == n - 1 ? F_LAST : 0) | (precise ? F_PRECISE : 0)) : 0;
             double l0 = 0.0, l1 = 0.0, l2 = r1;      // path_optimizer.cpp:128-137: (0, 0, k_ref)
             if (A.lin) {
                 const double* li = A.lin + ((size_t)qp * stride + ic) * PQP_LIN_STRIDE;
                 l0 = li[0]; l1 = li[1]; l2 = li[2];
             }
+            const double mark = not_finite_mark(r0) + not_finite_mark(r1) + not_finite_mark(r[2]) + not_finite_mark(r[3]) + not_finite_mark(r[4]) +
+                                not_finite_mark(l0) + not_finite_mark(l1) + not_finite_mark(l2);
+            S.flags = (real ? (F_REAL | (i > 0 ? F_PREV : 0) | (i < n - 1 ? F_NEXT : 0) | (i == n - 1 ? F_LAST : 0) | (precise ? F_PRECISE : 0)) : 0) |
+                      (mark == 0.0 ? 0 : F_BADIN);
             if (real) {
                 sh[L.lin() + 3 * i + 0] = l0; sh[L.lin() + 3 * i + 1] = l1; sh[L.lin() + 3 * i + 2] = l2;
                 sh[L.sk() + 2 * i + 0] = r0; sh[L.sk() + 2 * i + 1] = r1;
@@ -660,6 +673,13 @@ struct PathQp {
             soft_bounds(f_lb, f_ub, prm.expected_safety_margin, prm.min_clearance, flo, fup);
             soft_bounds(b[2], b[3], prm.expected_safety_margin, prm.min_clearance, rlo, rup);
             const double lo0 = real ? flo : 0.0, up0 = real ? fup : 0.0, lo1 = (real && precise) ? rlo : 0.0, up1 = (real && precise) ? rup : 0.0;
+            {   // F_BADIN: the bounds and the start state as numbers, the arclength increasing
+                double mark = 0.0;
+                _Pragma("unroll") for (int k = 0; k < 6; ++k) mark += not_finite_mark(b[k]) + not_finite_mark(sc[k]);
+                const bool ds_ok = !prev || sh[L.sk() + 2 * i] - sh[L.sk() + 2 * (i - 1)] > 0.0;
+                // (the QP's verdict lives in one LDS word - zeroed in load(), read by residuals() - not in a lane field of the ADMM loop)
+                if (!(mark == 0.0) || !ds_ok || (S.flags & F_BADIN)) sh[L.poison()] = 1.0;
+            }
             if constexpr (kAcc) { acc_set(S, C_LO, lo0); acc_set(S, C_LO + 1, lo1); acc_set(S, C_UP, up0); acc_set(S, C_UP + 1, up1); }
             else if constexpr (kCst) { cst_set(t, C_LO, lo0); cst_set(t, C_LO + 1, lo1); cst_set(t, C_UP, up0); cst_set(t, C_UP + 1, up1); }
             else { S.lo[0] = lo0; S.up[0] = up0; S.lo[1] = lo1; S.up[1] = up1; }
@@ -1836,7 +1856,7 @@ struct PathQp {
     // ---------------------------------------------------------------------------------------------
     // final = false (a re-linearised pass follows): only the linearisation point - the output record of this pass would be overwritten
     // by the next one, and its sincos and seven stores per waypoint are 2 % of a QP's time
-    PQP_HD void unpack(bool final) {
+    PQP_HD void unpack(bool final, bool zero = false) {
         if (!final) {
             ctx.phase([&](int t, Lane& ln) {
                 const Slot& S = ln.s;
@@ -1858,13 +1878,14 @@ struct PathQp {
                 const double new_angle = constrain_angle(angle + kPi2);
                 double sn, cn;
                 sincos_shared(new_angle, &sn, &cn);
-                o[0] = r[3] + l * cn;
-                o[1] = r[4] + l * sn;
-                o[2] = constrain_angle(angle + dpsi);
-                o[3] = l;
-                o[4] = dpsi;
-                o[5] = S.x[2];
-                o[6] = (S.flags & F_NEXT) ? sh[L.xbuf() + t + 1] : 0.0;
+                // (zero: the record of a QP that ended PQP_STATUS_NUMERICAL - its iterates are not numbers)
+                o[0] = zero ? 0.0 : r[3] + l * cn;
+                o[1] = zero ? 0.0 : r[4] + l * sn;
+                o[2] = zero ? 0.0 : constrain_angle(angle + dpsi);
+                o[3] = zero ? 0.0 : l;
+                o[4] = zero ? 0.0 : dpsi;
+                o[5] = zero ? 0.0 : S.x[2];
+                o[6] = (!zero && (S.flags & F_NEXT)) ? sh[L.xbuf() + t + 1] : 0.0;
                 // input_path_ = first solution (base_solver.cpp:100): l, d_heading, k
                 sh[L.lin() + 3 * i + 0] = l; sh[L.lin() + 3 * i + 1] = dpsi; sh[L.lin() + 3 * i + 2] = S.x[2];
             }
@@ -1894,6 +1915,7 @@ struct PathQp {
                 }
             }
             PQP_SUB(1, assemble());
+            cert_ = ctx.uni(sh[L.poison()]) != 0.0;       // (F_BADIN: the scenario is not a number - run() ends the QP before its first iteration)
             PQP_SUB(2, ruiz(/*reuse=*/(i1 & 2) != 0 && prm.polish_warm_set >= 2));
             PQP_SUB(3, start_transition_rows(have_warm));
             if (i1 & 2) {      // warm re-solve: go straight to a polish on the active set the previous pass ended with
@@ -1921,11 +1943,11 @@ struct PathQp {
             if (CERT) cert_ = primal_infeasible();
             else cert_ = primal_infeasible_late();
         } else if (op == COLD_END_PASS) {
-            if (i0) {
+            if (i0 == 1) {
                 polish_end(true);
                 polishing_ = false; alpha_ = prm.alpha;
             }
-            unpack(i1 != 0);
+            unpack(i1 != 0, /*zero=*/i0 == 2);
         } else {
             if (A.store_warm) store_warm();
         }
@@ -2002,6 +2024,7 @@ struct PathQp {
                 continue;
             }
             if (op == COLD_BEGIN_PASS) {
+                if (cert_) { cert_ = false; status = PQP_STATUS_NUMERICAL; op = COLD_END_PASS; i0 = 2; continue; }      // (F_BADIN; i0 = 2: a zero output record)
                 status = PQP_STATUS_MAX_ITER;
                 snap_valid_ = false;
                 polish_mode = false; conservative = false; end_after_reject = false;
@@ -2040,7 +2063,7 @@ struct PathQp {
                 { PQP_TIC(0x20); residuals(res); PQP_TOC(5); }
                 if (!polish_mode) {
                     bool start_polish = false;
-                    if (res[4] != 0.0) { status = PQP_STATUS_NUMERICAL; op = COLD_END_PASS; i0 = 0; break; }
+                    if (res[4] != 0.0) { status = PQP_STATUS_NUMERICAL; op = COLD_END_PASS; i0 = 2; break; }      // (i0 = 2: a zero output record)
                     if (check) {
                         const double eps_p = eps_scale * (prm.eps_abs + prm.eps_rel * res[2]);
                         const double eps_d = eps_scale * (prm.eps_abs + prm.eps_rel * res[3]);

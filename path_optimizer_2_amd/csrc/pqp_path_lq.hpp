@@ -204,7 +204,8 @@ struct Solver {
         else if (src == 1) { const double* p = a.lin + ((size_t)qp * a.n + i) * PQP_LIN_STRIDE; l = p[0]; psi = p[1]; k = p[2]; }
         else { l = 0.0; psi = 0.0; k = a.ref[((size_t)qp * a.n + i) * PQP_REF_STRIDE + 1]; }
     }
-    struct PrepIn { double l, psi, k, s, kref, b[6]; };
+    struct PrepIn { double l, psi, k, s, kref, b[6], mark; };
+    double poison;        // 0 while every number of the scenario is finite and the arclength increases; NaN otherwise (first prep of a QP)
     PQP_SWEEP void prep(int src, bool with_bounds) {
         const double* rq = a.ref + (size_t)qp * a.n * PQP_REF_STRIDE;
         const double* bq = a.bounds + (size_t)qp * a.n * PQP_BOUNDS_STRIDE;
@@ -215,8 +216,16 @@ struct Solver {
             lin_at(src, i, in.l, in.psi, in.k);
             in.s = rq[PQP_REF_STRIDE * i]; in.kref = rq[PQP_REF_STRIDE * i + 1];
             if (with_bounds) for (int k = 0; k < 6; ++k) in.b[k] = bq[PQP_BOUNDS_STRIDE * i + k];
+            // (first preparation of a QP: is every number of the scenario one? v - v is 0 for a finite v, NaN otherwise; the pose columns too - unpack() reads them)
+            if (with_bounds) in.mark = not_finite_mark(rq[PQP_REF_STRIDE * i + 2]) + not_finite_mark(rq[PQP_REF_STRIDE * i + 3]) + not_finite_mark(rq[PQP_REF_STRIDE * i + 4]);
             return in;
         }, [&](int i, const PrepIn& in) {
+            if (with_bounds) {
+                double m = in.mark + not_finite_mark(in.s) + not_finite_mark(in.kref) + not_finite_mark(in.l) + not_finite_mark(in.psi) + not_finite_mark(in.k);
+                for (int k = 0; k < 6; ++k) m += not_finite_mark(in.b[k]);
+                if (i > 0 && !(in.s - prev.s > 0.0)) m = __builtin_nan("");       // (an arclength that does not increase: the reference divides by ds)
+                poison += m;
+            }
             if (i > 0) {            // transition i - 1 -> i around the linearisation point of waypoint i - 1
                 const double l = prev.l, psi = prev.psi, k = prev.k;
                 const double t = tan(psi), cs = cos(psi);
@@ -808,7 +817,18 @@ struct Solver {
             }
         }
         ws.st(D_ACT, 0, 0.0);
+        poison = 0.0;
+        for (int k = 0; k < 6; ++k) poison += not_finite_mark(sc[k]);
         prep(a.lin ? 1 : 0, true);
+        if (!(poison == 0.0)) {
+            // NaN / Inf in the scenario, or an arclength that does not increase: not a QP the reference could solve (OSQP would return non-finite iterates and
+            // BaseSolver::solve false) - and min / max arithmetic would drop a NaN bound silently.  PQP_STATUS_NUMERICAL, a zero output record; the
+            // other lanes of the wavefront are not held up by interior-point iterations on NaNs
+            double* oq = a.out + (size_t)qp * a.n * PQP_OUT_STRIDE;
+            for (int i = 0; i < n; ++i) for (int k = 0; k < PQP_OUT_STRIDE; ++k) oq[PQP_OUT_STRIDE * i + k] = 0.0;
+            finish(PQP_STATUS_NUMERICAL, 0);
+            return;
+        }
         if (!(fabs(x0[2]) <= kl)) {
             // the start curvature violates its own box (kappa row 0 against the fixed x_0): no point satisfies the rows
             zero_point();

@@ -37,16 +37,21 @@ int main(int argc, char** argv) {
     }
     BaseSolver solver(ref, vs, input_path);
     solver.setMaxSteeringAngle(sc[5]);
-    if (argc > 1) {                                        // "polish": the engine's production setting
+    for (int a = 1; a < argc; ++a) {
         pqp_params p = solver.params();
-        p.eps_abs = p.eps_rel = 1e-4; p.polish = 1; p.polish_every = 25; p.adaptive_rho_interval = 25; p.polish_warm_set = 1; p.polish_refine_iter = 3;
+        double len = 0.0;
+        if (std::sscanf(argv[a], "rough=%lf", &len) == 1) {   // FLAGS_rough_constraints_far_away with FLAGS_precise_planning_length = len
+            p.rough_constraints_far_away = 1; p.precise_planning_length = len;
+        } else {                                           // "polish": the engine's production setting
+            p.eps_abs = p.eps_rel = 1e-4; p.polish = 1; p.polish_every = 25; p.adaptive_rho_interval = 25; p.polish_warm_set = 1; p.polish_refine_iter = 3;
+        }
         solver.setParams(p);
     }
     std::vector<SlState> final_path;
-    if (!solver.solve(&final_path)) { std::fprintf(stderr, "Pre solving failed!\n"); return 1; }
+    if (!solver.solve(&final_path)) { std::fprintf(stderr, "Pre solving failed! (status %d)\n", solver.lastStatus()); return 1; }
     const int it0 = solver.lastIterations();
     if (!solver.updateProblemFormulationAndSolve(final_path, &final_path)) { std::fprintf(stderr, "Solving failed!\n"); return 1; }
-    std::fprintf(stderr, "vars %zu cons %zu iters %d + %d\n", solver.vars(), solver.cons(), it0, solver.lastIterations());
+    std::fprintf(stderr, "vars %zu cons %zu precise %zu iters %d + %d\n", solver.vars(), solver.cons(), solver.precisePlanningSize(), it0, solver.lastIterations());
     for (const auto& p : final_path) std::printf("%.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", p.x, p.y, p.heading, p.l, p.d_heading, p.k, p.d_k);
     return 0;
 }

@@ -84,6 +84,45 @@ def test_shim_reproduces_optimize_path(shim_exe, mode):
 
 
 @pytest.mark.gpu
+def test_rough_constraints_mode_through_the_drop_in(shim_exe):
+    """FLAGS_rough_constraints_far_away (base_solver.cpp:22-37,201-205,241-247) set through setParams(): vars() / cons() / the precise planning size
+    follow the parameters (the reference reads the flag at construction), and the path is the oracle's in that mode."""
+    import re
+    b = make_batch(1, 80)
+    length = 12.0
+    r = subprocess.run([shim_exe, "polish", "rough=%r" % length], input=_scenario_text(b, 0), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"vars (\d+) cons (\d+) precise (\d+)", r.stderr)
+    n = 80
+    precise = int(np.searchsorted(b["ref"][0, :, 0], length, side="left"))          # std::lower_bound on s (base_solver.cpp:25-34)
+    assert 0 < precise < n
+    assert (int(m.group(1)), int(m.group(2)), int(m.group(3))) == (3 * n + (n - 1) + precise + n, 4 * n + precise + n + 2, precise)
+    prm = O.PathQpParams(rough_constraints_far_away=True, precise_planning_length=length)
+    want = O.solve_path(b["ref"][0], b["bounds"][0], b["scal"][0], prm=prm, st=O.OsqpSettings(eps_abs=1e-9, eps_rel=1e-9, max_iter=40000))
+    got = np.array([[float(v) for v in ln.split()] for ln in r.stdout.strip().splitlines()])
+    assert np.abs(got[:, 3:5] - want[-1]["out"][:, 3:5]).max() < 1e-6
+    # ... and the default mode reports the default sizes
+    r0 = subprocess.run([shim_exe, "polish"], input=_scenario_text(b, 0), capture_output=True, text=True)
+    m0 = re.search(r"vars (\d+) cons (\d+) precise (\d+)", r0.stderr)
+    assert (int(m0.group(1)), int(m0.group(2)), int(m0.group(3))) == (6 * n - 1, 6 * n + 2, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", ["nan_s", "equal_s", "inf_bound", "nan_start"])
+def test_a_scenario_that_is_not_a_number_makes_solve_return_false(shim_exe, what):
+    """NaN / Inf in the scenario, or an arclength that does not increase (the reference divides by ds, base_solver.cpp:174,180): solve() == false,
+    PQP_STATUS_NUMERICAL, as when OSQP hands back non-finite iterates (base_solver.cpp:80-88)."""
+    b = make_batch(1, 60)
+    if what == "nan_s": b["ref"][0, 17, 0] = np.nan
+    if what == "equal_s": b["ref"][0, 30, 0] = b["ref"][0, 29, 0]
+    if what == "inf_bound": b["bounds"][0, 5, 1] = np.inf
+    if what == "nan_start": b["scal"][0, 1] = np.nan
+    for args in ([shim_exe], [shim_exe, "polish"]):
+        r = subprocess.run(args, input=_scenario_text(b, 0), capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and "Pre solving failed" in r.stderr and "status 3" in r.stderr, r.stderr
+
+
+@pytest.mark.gpu
 def test_device_ordinal_comes_from_the_environment(shim_exe):
     """PQP_DEVICE selects the GPU of a BaseSolver (the reference has no notion of a device); an ordinal this box does not have makes
     solve() return false, like any failed set-up."""
