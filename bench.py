@@ -192,6 +192,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4], help="BASELINE.json configs[k] (default: 1 at --gpus 1, else 3)")
     ap.add_argument("--batch", type=int, default=None, help="QPs per GPU (default: the config's)")
+    ap.add_argument("--total", type=int, default=None, help="QPs of the WHOLE job, split contiguously over the ranks (shard.shard_range: the first total %% N ranks get "
+                    "one more - ragged shards); overrides --batch; the line then says \"scaling\": \"strong\" (the total stays as N grows)")
     ap.add_argument("--n", type=int, default=None, help="waypoints per path (default: the config's)")
     ap.add_argument("--profile", default=None, choices=["uniform", "varied"])
     ap.add_argument("--eps", type=float, default=1e-4, help="eps_abs = eps_rel of the ADMM termination test")
@@ -275,6 +277,14 @@ def main():
     profile = args.profile or cfg["profile"]
     preset_shape = (batch, n, profile) == (cfg["batch"], cfg["n"], cfg["profile"])
     total = batch * world
+    first_qp = rank * batch                     # this rank's contiguous shard [first_qp, first_qp + batch) of the job's QPs
+    if args.total is not None:
+        from path_optimizer_2_amd.shard import shard_range
+        if args.total < world:
+            raise SystemExit(f"bench.py: --total {args.total} is less than one QP per rank")
+        total = args.total
+        first_qp, batch = shard_range(total, world, rank)
+        preset_shape = False
     polish = not args.no_polish and not args.reference_setting
     cost_order = not args.no_cost_order
     # the handle's default PQP_OPT_STREAM_BATCH (include/pqp.h: the measured crossover of the two kernels, 20 480 x max(1, n / 80)^2 QPs):
@@ -318,13 +328,13 @@ def main():
         main_handles = [pipe.hp]
         out = pipe.buf[0]["out"]
     else:
-        host = make_batch(batch, n, profile, seed=args.seed, first_qp=rank * batch)          # this rank's shard of the global batch
+        host = make_batch(batch, n, profile, seed=args.seed, first_qp=first_qp)          # this rank's shard of the global batch
         ref = torch.from_numpy(host["ref"]).to(dev)
         n_var = max(1, args.variants)
         # variant v: the same scenarios one planning cycle later (corridor sides and start state moved by up to 5 %); the reference line stays
         var_in = []
         for v in range(n_var):
-            hv = jitter_batch(host, v, seed=args.seed, first_qp=rank * batch)
+            hv = jitter_batch(host, v, seed=args.seed, first_qp=first_qp)
             var_in.append((torch.from_numpy(hv["bounds"]).to(dev), torch.from_numpy(hv["scal"]).to(dev)))
         bounds, scal = var_in[0]
 
@@ -372,7 +382,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         full = gather_paths(coll(out), total)        # untimed: what a caller that wants every path on every rank would do
-        gathered_ok = bool(full.shape[0] == total and torch.equal(full[rank * batch:(rank + 1) * batch], coll(out)))
+        gathered_ok = bool(full.shape[0] == total and torch.equal(full[first_qp:first_qp + batch], coll(out)))
         # ... and what that RCCL all-gather over xGMI costs (outside the timed region; second call: communicators are warm)
         torch.cuda.synchronize(); dist.barrier()
         tg = time.perf_counter()
@@ -481,6 +491,11 @@ def main():
         it_np, st_np, info_np = iters.cpu().numpy(), status.cpu().numpy(), info.cpu().numpy()
         kkt_np, fac_np = info_np[:, 5], info_np[:, 6]
     out_sha = hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:16]
+    solved_all = None
+    if dist is not None:          # QPs solved over the whole job (every rank's shard): the one scalar reduction of the path (shard.reduce_stats)
+        sa = coll(torch.tensor([int((st_np == 1).sum())], dtype=torch.int64, device=dev))
+        dist.all_reduce(sa)
+        solved_all = int(sa.item())
 
     # ---------------------------------------------------------------------------------------------------------------------------
     # secondary measurements on the same inputs (N = 1, path-QP configs): index order, the literal metric, the reference's setting
@@ -810,9 +825,10 @@ def main():
         line = {
             "metric": "paths/sec (QP solves/sec) at N=80 waypoints; ADMM iters to 1e-4",
             "value": total * args.steps / dt, "unit": "paths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.total is not None else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "config_id": cfg_id, "batch_per_gpu": batch, "n_waypoints": n, "profile": profile,
+            "config": {"workload": workload, "config_id": cfg_id, "batch_per_gpu": batch, **({"total": total, "shards": "contiguous, ragged: the first total % N ranks hold one QP more (batch_per_gpu is rank 0's)"} if args.total is not None else {}),
+                       "n_waypoints": n, "profile": profile,
                        "eps_abs": args.eps, "eps_rel": args.eps, "polish": polish, "setting": setting,
                        "solver": ("lane-per-QP kernel: interior-point rounds + KKT-verifying active-set rounds on the QP as a linear-quadratic control problem "
                                   "(every path is the exact QP optimum; iterations below are interior-point iterations, not ADMM's)") if stream else
@@ -833,7 +849,7 @@ def main():
             "admm_iters": {"min": int(it_np.min()), "median": float(np.median(it_np)), "p99": float(np.percentile(it_np, 99)),
                            "max": int(it_np.max()), "mean": float(it_np.mean())},
             "out_sha1": out_sha, "gather_check": gathered_ok, "gather": gather_info, "rccl_ranks": gather_info["rccl_ranks"] if gather_info else None,
-            "solved": int((st_np == 1).sum()), "batch": batch,
+            "solved": int((st_np == 1).sum()), "batch": batch, **({"solved_all_ranks": solved_all, "total": total} if solved_all is not None else {}),
             "sustained": sustained, "secondary": secondary, "roofline": roofline, "roofline_issue": roofline_issue,
         }
         if pipe is None:

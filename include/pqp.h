@@ -168,7 +168,9 @@ typedef struct pqp_params {
                                          needs, not what the set update needs).  The accepted point is always a fully refined one. */
     int32_t polish_final_refine;      /* 0.  k: an ACCEPTED polished point gets k more refinement solves (each followed by the KKT test again).  The path QP
                                          beyond 128 waypoints runs with at least 1, beyond 256 with at least 3: residuals of 1e-9 in the transition rows - a discrete double
-                                         integrator - add up to 1e-4 in l over 300 waypoints, and a refinement solve shrinks them 100-1000x */
+                                         integrator - add up to 1e-4 in l over 300 waypoints, and a refinement solve shrinks them 100-1000x.  Honoured by the kernels of
+                                         paths beyond 128 waypoints only (the shorter paths' kernels do not compile the feature in: nothing to refine away there); in a
+                                         launch of mixed lengths (pqp_path_solve_var) this level and the three intervals above follow the launch's n_max, not the QP's own n */
     /* smoother QP weights (src/config/planning_flags.cpp:51-61) */
     double tension2_deviation_weight;        /* 0.005 */
     double tension2_curvature_weight;        /* 1     */

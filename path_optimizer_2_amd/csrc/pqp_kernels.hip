@@ -702,6 +702,7 @@ static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of,
     a.wscale = h->wscale.as<double>();
     a.store_warm = (h->opt_store_warm || h->opt_carry) ? 1 : 0;
     a.carry_tails = carry_tails;
+    a.carry_k = h->opt_carry;
     a.ticket = h->ticket.as<unsigned long long>();
     a.ticket_base = h->ticket_next;
     // inside a captured graph the launch cannot take its ticket base from a host counter that moves between replays: the graph resets the

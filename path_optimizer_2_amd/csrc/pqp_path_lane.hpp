@@ -93,6 +93,7 @@ struct PathSolveArgs {
     int32_t* cost_key;      // [batch] or nullptr: bin << 24 | rank within the bin, written at the end of every QP
     int32_t* cost_hist;     // [256] QPs per cost bin (atomically counted) + [256] = workgroups that have finished this launch
     int32_t* order_next;    // [batch] the ticket -> QP map of the NEXT launch, written by the last workgroup to finish this one
+    int carry_k;            // the handle's PQP_OPT_CARRY_CYCLES (0, 1 or k >= 2) on every launch, cold ones included: the share 1 / k behind the threshold bin
     int carry_tails;        // PQP_OPT_CARRY_CYCLES = k >= 2 (with warm == 1): only the QPs whose cost in the previous launch reached the bin
                             // cost_hist[kCostBins + 1] - the most expensive 1 / k - start from their previous optimum, the others start cold
     pqp_params prm;
@@ -1978,6 +1979,7 @@ struct PathQp {
         double eps_scale = 1.0, best = 1e300, best_any = 1e300, admm_merit = 1e300;
         int it = 0, refine_left = 0, round = 0, stall = 0, polish_gap = 0, next_polish = 0;
         int extra_refine = 0;            // extra pairs of refinement solves spent on the current polish round
+        int final_refine = 0;            // pqp_params::polish_final_refine: refinement solves an accepted point of the current round has had (contexts with kFinalRefine)
         bool lazy_look = false;          // polish_lazy: the next look at the polished point follows a single solve
         bool direct_polish = false, last_accepted = false;
         // the pending cold operation
@@ -1988,7 +1990,7 @@ struct PathQp {
         bool qp_warm = A.warm != 0;
         int keep_bin = -1;
         if (A.carry_tails && A.warm) {
-            const int prev_bin = ctx.uni_int(A.cost_key[qp] >> 24);
+            const int prev_bin = ctx.uni_int((A.cost_key[qp] >> 24) & 0xff);       // (the key is bin << 24 in an int32: bins from 128 on are negative numbers)
             qp_warm = prev_bin >= ctx.uni_int(A.cost_hist[kCostBins + 1]);
             if (qp_warm) keep_bin = prev_bin - 1;
         }
@@ -2143,12 +2145,14 @@ struct PathQp {
                     // (only in the contexts of long paths - Ctx::kFinalRefine: more than 128 lanes per QP -, so that the kernels of shorter paths compile
                     //  to what they were: their register allocation is one source line away from 20 more spilled registers and -1.5 %)
                     if constexpr (Ctx::kFinalRefine) {
-                        const bool hold = ok && extra_refine < prm.polish_final_refine;
-                        if (((!solve_ok && extra_refine < 3) || hold) && res[4] == 0.0) { extra_refine += 1; refine_left = hold ? 1 : 2; continue; }
+                        // (the final refinements have a count of their own: a point that needed extra pairs to pass still gets all of them)
+                        const bool hold = ok && final_refine < prm.polish_final_refine;
+                        if (hold && res[4] == 0.0) { final_refine += 1; refine_left = 1; continue; }
+                        if (!solve_ok && extra_refine < 3 && res[4] == 0.0) { extra_refine += 1; refine_left = 2; continue; }
                     } else {
                         if (!solve_ok && res[4] == 0.0 && extra_refine < 3) { extra_refine += 1; refine_left = 2; continue; }
                     }
-                    extra_refine = 0;
+                    extra_refine = 0; final_refine = 0;
 #ifdef PQP_EMU_DEBUG
                     printf("  polish qp %d it %d round %d: pri %.3e dua %.3e viol %.3e %s -> %s\n", qp, it, round, res[0], res[1], viol, conservative ? "(cons)" : "", ok ? "ACCEPT" : "reject");
 #endif

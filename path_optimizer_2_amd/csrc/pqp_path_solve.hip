@@ -209,10 +209,14 @@ __device__ void order_next_launch(const PathSolveArgs& args, int* start) {
     for (int b = threadIdx.x; b < kCostBins; b += nt) start[b] = __hip_atomic_load(args.cost_hist + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (threadIdx.x == 0) {                 // exclusive suffix sum over 256 bins: QPs in more expensive bins
+        // (thr: the cheapest bin b such that the QPs in bins >= b are still no more than 1 / k of the batch - a bin that would overshoot that share stays
+        //  out whole: 999 QPs in one bin and one above it carry the one, not all thousand.  k = the handle's PQP_OPT_CARRY_CYCLES on EVERY launch,
+        //  the cold first one included: the second launch's threshold is then the user's k too, not a fallback)
         int acc = 0, thr = kCostBins;
+        const long long k = args.carry_k > 1 ? args.carry_k : 8;
         for (int b = kCostBins - 1; b >= 0; --b) {
             const int c = start[b]; start[b] = acc;
-            if ((long long)(args.carry_tails > 1 ? args.carry_tails : 8) * acc < args.batch) thr = b;       // (the cheapest bin above which less than 1 / k of the batch lies)
+            if (thr == b + 1 && k * (acc + c) <= args.batch) thr = b;
             acc += c;
         }
         // PQP_OPT_CARRY_CYCLES = k >= 2: the bin from which on a QP counts as one of the launch's expensive ones (read by the next launch's QPs)

@@ -25,6 +25,12 @@ static int g_wave_order = 1;
 static const int32_t* g_n_of = nullptr;      // per-QP waypoint counts of the next pqp_emu_path_solve call (nullptr: all n)
 extern "C" void pqp_emu_set_counts(const int32_t* n_of) { g_n_of = n_of; }
 extern "C" void pqp_emu_set_wave_order(int o) { g_wave_order = o; }
+// PQP_OPT_CARRY_CYCLES = k >= 2 in the emulation: the cost keys of the "previous launch" (bin << 24), the histogram block (its entry kCostBins + 1 = the
+// threshold bin) and k for the next pqp_emu_path_solve call (nullptr: off)
+static int32_t* g_cost_key = nullptr;
+static int32_t* g_cost_hist = nullptr;
+static int g_carry_tails = 0;
+extern "C" void pqp_emu_set_carry(int32_t* cost_key, int32_t* cost_hist, int carry_tails) { g_cost_key = cost_key; g_cost_hist = cost_hist; g_carry_tails = carry_tails; }
 
 namespace {
 #ifndef PQP_EMU_DIET
@@ -126,6 +132,7 @@ extern "C" int pqp_emu_path_solve(const pqp_params* prm, int batch, int n, const
     a.prm = *prm;
     pqp::resolve_path_params(&a.prm, n);          // (as the launcher does)
     a.n_of = g_n_of;
+    a.cost_key = g_cost_key; a.cost_hist = g_cost_hist; a.carry_tails = g_cost_key ? g_carry_tails : 0; a.carry_k = a.carry_tails;
     for (int q = 0; q < batch; ++q) {
         if (pqp::PathQp<HostCtx, true>::count_of(a, q) < 2) {
             if (status) status[q] = PQP_STATUS_UNSOLVED;

@@ -60,6 +60,24 @@ def solve(prm, ref, bounds, scal, lin=None, passes=1, n_of=None):
     return dict(out=out, status=st, iters=it, info=info, wx=wx, wy=wy, wye=wye)
 
 
+def solve_carrying_tails(prm, ref, bounds, scal, prev, prev_bins, threshold_bin, k=8):
+    """The next planning cycle of a handle with PQP_OPT_CARRY_CYCLES = k >= 2, emulated: `prev` = the previous solve()'s result (its final iterates are the
+    warm state), prev_bins[q] = the QPs' cost bins in that launch, threshold_bin = the bin from which on a QP is one of the expensive ones.  Returns
+    the result and the cost keys the run left."""
+    lib = load()
+    B, n = ref.shape[0], ref.shape[1]
+    vp = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+    out = np.zeros((B, n, 7)); st = np.zeros(B, dtype=np.int32); it = np.zeros(B, dtype=np.int32); info = np.zeros((B, 8))
+    wx, wy, wye = prev["wx"].copy(), prev["wy"].copy(), prev["wye"].copy()
+    wrho = np.full(B, 0.1)
+    keys = (np.asarray(prev_bins, dtype=np.int64) << 24).astype(np.uint32).view(np.int32).copy()       # as the kernel stores them: bin << 24 in an int32
+    hist = np.zeros(258, dtype=np.int32); hist[257] = threshold_bin
+    lib.pqp_emu_set_carry(keys.ctypes.data_as(C.c_void_p), hist.ctypes.data_as(C.c_void_p), k)
+    lib.pqp_emu_path_solve(C.byref(prm), B, n, vp(ref), None, vp(bounds), vp(scal), 1, 1, vp(out), vp(st), vp(it), vp(info), vp(wx), vp(wy), vp(wye), vp(wrho))
+    lib.pqp_emu_set_carry(None, None, 0)
+    return dict(out=out, status=st, iters=it, info=info), keys
+
+
 def to_reference_order(wx, wy, wye, n, precise=None):
     """Lane layout of one QP ([n][6] primal, [n][6] dual, [2] end-row duals) -> the reference numbering."""
     precise = n if precise is None else precise

@@ -81,3 +81,26 @@ def test_two_ranks_through_the_launcher_path_on_one_gpu():
     assert abs(d["weak_scaling_efficiency"] - d["value"] / (2 * ref["shard_alone_on_one_gpu"]["value"])) < 1e-9
     assert abs(d["strong_scaling_vs_one_gpu_whole_batch"] - d["value"] / ref["whole_batch_on_one_gpu"]["value"]) < 1e-9
     assert d["scaling"] == "weak" and d["scaling_strong"] == d["strong_scaling_vs_one_gpu_whole_batch"]
+
+
+@pytest.mark.gpu
+def test_eight_ranks_with_ragged_shards_on_one_gpu():
+    """The eight-rank path nothing on a one-GPU box had ever run: `bench.py --gpus 8 --config 3 --total 8 x 251 + 3` - bench.py starts the eight ranks
+    itself, all on GPU 0 (PQP_BENCH_SHARED_GPU: gloo collectives on host copies), the total is split contiguously with the first three shards one QP
+    longer (shard.shard_range = pqp_shard_range), every rank solves its shard, the padded all-gather returns all 2011 paths to every rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PQP_BENCH_SHARED_GPU"] = "1"
+    total = 8 * 251 + 3
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "3", "--total", str(total), "--steps", "4", "--warmup", "1",
+                        "--sustain", "0", "--no-cpu-baseline", "--pmc", "off"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                        # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["gather"]["backend"] == "gloo"
+    assert d["gather_check"] is True
+    assert d["config"]["total"] == total and d["batch"] == 252 and d["total"] == total          # rank 0 holds one of the longer shards
+    assert d["solved"] == 252 and d["solved_all_ranks"] == total
+    assert d["gather"]["bytes_per_rank_received"] == total * 80 * 7 * 8
+    assert d["scaling"] == "strong" and "scaling_strong" in d and d["scaling_reference"]["whole_batch_on_one_gpu"]["batch"] == total
+    assert abs(d["value"] - total * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]

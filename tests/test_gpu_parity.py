@@ -160,7 +160,7 @@ def test_carrying_a_cycle_through_the_warm_state(hip_lib):
 def test_long_paths_whole_batches_both_kernels(hip_lib):
     """Paths of 200 and 300 waypoints, 2048 QPs each, through BOTH path-QP kernels: the batches of tools/robustness_sweep.py that held the lane-per-waypoint
     kernel's worst points before round 5 (seed 1005 / qp 1659 at 200 waypoints: 2.3e-4 off the converged oracle, seed 1015 / qp 2009 at 300: 2.6e-4 - KKT
-    residuals of 1e-9 in the transition rows add up along a long path; the acceptance test is 100x tighter beyond 128 waypoints now).  The lane-per-QP
+    residuals of 1e-9 in the transition rows add up along a long path; an accepted point gets pqp_params::polish_final_refine more refinement solves beyond 128 waypoints now - a 100x tighter acceptance test was tried and rejected, profiles/r05o).  The lane-per-QP
     kernel's roll-out satisfies those rows exactly: agreement of the two over the whole batch + the two named QPs against the C oracle."""
     import pqp_oracle_c as OC
     for n, profile, seed, q_bad in ((200, "uniform", 1005, 1659), (300, "varied", 1015, 2009)):

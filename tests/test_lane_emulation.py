@@ -238,3 +238,24 @@ def test_the_production_intervals_follow_the_path_length():
         assert k == (5 if n <= 90 else 8) and np.median(r["iters"]) == k and r["iters"].min() == k
         r8 = E.solve(E.production(adaptive_rho_interval=8, check_termination=8, polish_every=8), b["ref"], b["bounds"], b["scal"], passes=1)
         assert r8["iters"].min() == 8 and np.abs(r8["out"][:, :, 3:5] - r["out"][:, :, 3:5]).max() < 2e-6
+
+
+def test_carry_tails_reads_cost_bins_from_128_on():
+    """PQP_OPT_CARRY_CYCLES = k >= 2 carries the QPs whose cost bin in the previous launch reached the threshold.  The key is `bin << 24` in an int32, so
+    the bins of the most expensive stragglers (128 ... 255: 170 and more reduced solves) are negative numbers: read without a mask they compared as
+    bin - 256, and exactly the QPs the option is for started cold.  Here: QP 0 'was' in bin 200, QP 1 in bin 3, QP 2 in bin 130, the
+    threshold is bin 100 - QPs 0 and 2 must start from their previous optimum (a fraction of the cold solve's work), QP 1 cold (exactly the cold work),
+    all three at the same optimum; the carried ones keep their key minus one bin."""
+    from path_optimizer_2_amd.synth import make_batch
+    b = make_batch(3, 40, seed=21)
+    prm = E.production()
+    cold = E.solve(prm, b["ref"], b["bounds"], b["scal"], passes=1)
+    assert (cold["status"] == 1).all()
+    r, keys = E.solve_carrying_tails(prm, b["ref"], b["bounds"], b["scal"], cold, [200, 3, 130], threshold_bin=100)
+    assert (r["status"] == 1).all()
+    assert np.abs(r["out"] - cold["out"]).max() < 1e-6
+    work = lambda res, q: res["info"][q, 5] + 2 * res["info"][q, 6]          # reduced solves + 2 x factorisations
+    assert work(r, 1) == work(cold, 1)
+    assert work(r, 0) < 0.8 * work(cold, 0) and work(r, 2) < 0.8 * work(cold, 2)
+    bins = (keys.view(np.uint32) >> 24) & 0xff
+    assert bins[0] == 199 and bins[2] == 129 and bins[1] < 100
