@@ -318,7 +318,10 @@ struct ShLayout {
     PQP_HD int bufG() const { return 0; }                   // [T][3]  message to the previous waypoint
     PQP_HD int bufP() const { return 3 * T; }               // [T][3]  CR forward, to the right neighbour
     PQP_HD int bufQ() const { return 6 * T; }               // [T][3]  CR forward, to the left neighbour
-    PQP_HD int xbuf() const { return 9 * T; }               // [T][3]  X~ (and X for the residuals)
+    PQP_HD int xbuf() const { return 9 * T; }               // [T][3]  X~
+    // X for the residuals and the polish rules behind them: the forward pass's P buffer, which nothing reads after a solve's last workgroup barrier - so
+    // residuals() may write it while the other wavefront is still in the wave-local tail of iterate() (which reads xbuf): no barrier between the two
+    PQP_HD int xres() const { return bufP(); }
     // factor-time exchange (aliases the above): first [T][15] M(6) Lc(9), then [T][21] SL(6) SR(6) Cnew(9)
     PQP_HD int fbuf() const { return 0; }
     // persistent
@@ -1109,7 +1112,7 @@ struct PathQp {
             const Slot& S = ln.s;
             const EndVals e = end_vals();
             double Xp[3], aT[3], aI[3];
-            { const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
+            { const double* xp_ = nb(t > 0, L.xres(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
             rows_of(S, Xp, S.x, aT, aI);
             _Pragma("unroll") for (int k = 0; k < 3; ++k) {
                 const bool inactive = !(S.flags & ((F_ACTLO0 << k) | (F_ACTUP0 << k)));
@@ -1142,7 +1145,7 @@ struct PathQp {
         ctx.phase([&](int t, Lane& ln) {
             Slot& S = ln.s;
             double Xp[3], aT[3], aI[3];
-            { const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
+            { const double* xp_ = nb(t > 0, L.xres(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
             // everything the rules below read from LDS, in one batch: the published violations of the three waypoints around this one, the end rows
             double vl[3], vo[3], vr[3];
             ld3(vl, nb(t > 0, L.bufQ(), 3, t - 1)); ld3(vo, sh + L.bufQ() + 3 * t); ld3(vr, nb(t + 1 < T, L.bufQ(), 3, t + 1));
@@ -1691,14 +1694,14 @@ struct PathQp {
         ctx.phase([&](int t, Lane& ln) {
             double g[3];
             back_msg(ln.s, ln.s.yT, g);
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) { sh[L.xbuf() + 3 * t + k] = ln.s.x[k]; sh[L.bufG() + 3 * t + k] = g[k]; }
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { sh[L.xres() + 3 * t + k] = ln.s.x[k]; sh[L.bufG() + 3 * t + k] = g[k]; }
         });
         ctx.template reduce_max<6>(res, [&](int t, Lane& ln, double (&v)[6]) {
             const Slot& S = ln.s;
             double e_z[2], e_y[2], e_rb[2], e_lo[2], e_up[2], e_act[2];       // the end rows, loaded by every lane with the phase's first loads (see iterate())
             { const EndRows* er = end_rows(); _Pragma("unroll") for (int k = 0; k < 2; ++k) { e_z[k] = er->z[k]; e_y[k] = er->y[k]; e_rb[k] = er->rb[k]; e_lo[k] = er->lo[k]; e_up[k] = er->up[k]; e_act[k] = er->act[k]; } }
             double Xp[3], gn[3];
-            { const double* xp_ = nb(t > 0, L.xbuf(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
+            { const double* xp_ = nb(t > 0, L.xres(), 3, t - 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) Xp[k] = xp_[k]; }
             { const double* gn_ = nb(t + 1 < T, L.bufG(), 3, t + 1); _Pragma("unroll") for (int k = 0; k < 3; ++k) gn[k] = gn_[k]; }
             const bool real = S.flags & F_REAL;
             const double cf = coef_front(prm, S.flags), cr = coef_rear(prm, S.flags);
@@ -1725,18 +1728,18 @@ struct PathQp {
             aty[4] = S.yI[1];
             aty[5] = S.yI[2];
             const bool colreal[6] = {real, real, real, (S.flags & F_PREV) != 0, real, real && (S.flags & F_PRECISE)};
-            double du = 0.0, nd = 0.0, bad = 0.0;
+            double du = 0.0, nd = 0.0, xsum = 0.0;
             _Pragma("unroll") for (int k = 0; k < 6; ++k) {
                 const double px = cost_diag(prm, S.flags, k) * S.x[k];
                 du = fmax(du, colreal[k] ? fabs(px + aty[k]) : 0.0);
                 nd = fmax(nd, colreal[k] ? fmax(fabs(px), fabs(aty[k])) : 0.0);
-                bad = (fabs(S.x[k]) <= 1e300) ? bad : 1.0;   // NaN / Inf guard
+                xsum += S.x[k];
             }
             v[0] = real ? pr : 0.0;
             v[1] = du;
             v[2] = real ? nz : 0.0;
             v[3] = nd;
-            v[4] = bad;
+            v[4] = (fabs(xsum) <= 1e300) ? 0.0 : 1.0;   // NaN / Inf guard: a sum of six iterates is finite iff (up to overflow near 1e300) each of them is
             v[5] = w;
         });
     }
@@ -2061,7 +2064,7 @@ struct PathQp {
                     if (!polish_mode && it >= prm.max_iter) { sync_after_iterate(); op = COLD_END_PASS; i0 = 0; break; }
                     continue;
                 }
-                sync_after_iterate();
+                // (no barrier between the solve and the residuals: residuals() publishes into buffers the tail of iterate() does not touch - ShLayout::xres)
                 { PQP_TIC(0x20); residuals(res); PQP_TOC(5); }
                 if (!polish_mode) {
                     bool start_polish = false;
