@@ -159,7 +159,7 @@ def pmc_child(argv_core, kernel_substr, timeout_s, steps=6, passes=None):
     FETCH_SIZE / WRITE_SIZE in a pass each: they do not fit one) of a short child run of bench.py, --kernel-trace only
     beside --pmc (MI355X_MICROARCH.md, rocprofv3 PMC section).  Returns per-launch averages or None (never raises)."""
     passes = passes or ["SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU",
-                        "FETCH_SIZE GRBM_GUI_ACTIVE", "WRITE_SIZE SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU"]
+                        "FETCH_SIZE GRBM_GUI_ACTIVE", "WRITE_SIZE SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64"]
     acc, cnt = {}, {}
     try:
         for pmc in passes:
@@ -817,6 +817,11 @@ def main():
                               "scalar_active_frac": pmc.get("SQ_ACTIVE_INST_SCA", 0.0) / wc, "any_active_frac": pmc.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
                               "wait_frac": pmc.get("SQ_WAIT_ANY", 0.0) / wc, "valu_instructions_per_launch": pmc.get("SQ_INSTS_VALU"),
                               "waves_per_launch": pmc.get("SQ_WAVES"), "kernel_cycles": kernel_cycles,
+                              # the dynamic instruction mix (round 6): what share of the VALU instructions that RAN is fp64 arithmetic - the rest moves
+                              # registers (AGPR <-> VGPR copies, lane moves of spilled SGPRs, selects, DPP exchanges); tools/isa_mix.py gives the static view
+                              "fp64_share_of_valu_instructions": (sum(pmc.get(f"SQ_INSTS_VALU_{k}_F64", 0.0) for k in ("ADD", "MUL", "FMA", "TRANS")) / pmc["SQ_INSTS_VALU"])
+                                                                 if pmc.get("SQ_INSTS_VALU") and "SQ_INSTS_VALU_FMA_F64" in pmc else None,
+                              "wait_inst_frac": pmc.get("SQ_WAIT_INST_ANY", 0.0) / wc,
                               "source": f"rocprofv3 --pmc child pass of this command, {pmc['_launches']} launches averaged"}
 
     if rank == 0:
