@@ -83,7 +83,12 @@ typedef enum pqp_status {
     PQP_STATUS_SOLVED = 1,         /* both residual tests passed (and, with polish on, the KKT-verified polish
                                       was accepted or ADMM reached 1e-10)             -> solve() == true  */
     PQP_STATUS_MAX_ITER = 2,       /* max_iter reached                                  -> solve() == false */
-    PQP_STATUS_NUMERICAL = 3,      /* NaN/Inf in the iterates                           -> solve() == false */
+    PQP_STATUS_NUMERICAL = 3,      /* NaN/Inf in the iterates, or a scenario that is not a number: NaN / Inf among its reference states,
+                                      bounds, linearisation point or start state, or an arclength s that does not increase (the reference
+                                      divides by ds, base_solver.cpp:174,180).  Checked inside both path kernels (host- and device-pointer
+                                      entry points alike): such a QP ends here before its first iteration, its output record is all
+                                      zeros, the other QPs of the batch are not affected.  An absent bound is +-1e30 (OSQP_INFTY),
+                                      not an IEEE infinity                              -> solve() == false */
     PQP_STATUS_PRIMAL_INFEASIBLE = 4   /* OSQP's primal infeasibility certificate holds  -> solve() == false */
 } pqp_status;
 

@@ -20,7 +20,8 @@ import json,sys
 ls=[l for l in sys.stdin.readlines() if l.startswith('{\"metric\"')]
 if not ls: print('$1: no bench line'); sys.exit(0)
 d=json.loads(ls[-1])
-print('%-44s %9.0f paths/s  step %.4f ms  solved %d  kkt %.1f (max %.0f)  fac %.1f (max %.0f)  sha %s' % ('$1', d['value'], d['ms_per_step'], d['solved'], d['kkt_solves']['mean'], d['kkt_solves']['max'], d['factorisations']['mean'], d['factorisations']['max'], d['out_sha1'][:10]))"; }
+k, f = d.get('kkt_solves') or d.get('riccati_sweeps') or {}, d.get('factorisations') or d.get('active_set_rounds') or {}
+print('%-44s %9.0f paths/s  step %.4f ms  solved %d  kkt %.1f (max %.0f)  fac %.1f (max %.0f)  sha %s' % ('$1', d['value'], d['ms_per_step'], d['solved'], k.get('mean', 0), k.get('max', 0), f.get('mean', 0), f.get('max', 0), d['out_sha1'][:10]))"; }
 for sec in "$@"; do case $sec in
 tests)
   (timeout 1800 python -m pytest tests -m gpu -q -x 2>&1 | grep -v "$F" | tail -15) > ${o}_pytest.log 2>&1; tail -5 ${o}_pytest.log ;;
