@@ -259,3 +259,29 @@ def test_carry_tails_reads_cost_bins_from_128_on():
     assert work(r, 0) < 0.8 * work(cold, 0) and work(r, 2) < 0.8 * work(cold, 2)
     bins = (keys.view(np.uint32) >> 24) & 0xff
     assert bins[0] == 199 and bins[2] == 129 and bins[1] < 100
+
+
+@pytest.mark.parametrize("what", ["nan_s", "inf_k", "nan_bound", "inf_bound", "nan_start", "equal_s", "decreasing_s", "nan_pose"])
+def test_a_scenario_that_is_not_a_number_ends_numerical_with_a_zero_record(what):
+    """The in-kernel input check of the lane-per-waypoint solver (the same source on the host): NaN / Inf anywhere in a scenario, or an arclength that
+    does not increase (the reference divides by ds, base_solver.cpp:174,180), end that QP PQP_STATUS_NUMERICAL before its first iteration with an
+    all-zero output record; its neighbours in the batch are what they are without it.  (On the GPU, through both kernels and both kinds of entry
+    point: tests/test_gpu_hostile_inputs.py.)"""
+    b = make_batch(3, 40, seed=31)
+    prm = E.production()
+    clean = E.solve(prm, b["ref"], b["bounds"], b["scal"], passes=1)
+    h = {k: v.copy() for k, v in b.items()}
+    if what == "nan_s": h["ref"][1, 10, 0] = np.nan
+    if what == "inf_k": h["ref"][1, 20, 1] = np.inf
+    if what == "nan_bound": h["bounds"][1, 5, 0] = np.nan
+    if what == "inf_bound": h["bounds"][1, 33, 3] = np.inf
+    if what == "nan_start": h["scal"][1, 2] = np.nan
+    if what == "equal_s": h["ref"][1, 30, 0] = h["ref"][1, 29, 0]
+    if what == "decreasing_s": h["ref"][1, 25, 0] = h["ref"][1, 23, 0]
+    if what == "nan_pose": h["ref"][1, 39, 4] = np.nan
+    r = E.solve(prm, h["ref"], h["bounds"], h["scal"], passes=1)
+    assert r["status"][1] == 3 and r["iters"][1] == 0 and np.all(r["out"][1] == 0.0)
+    for q in (0, 2):
+        assert r["status"][q] == 1 and np.array_equal(r["out"][q], clean["out"][q])
+    ref_setting = E.solve(E.params(), h["ref"], h["bounds"], h["scal"], passes=1)          # the reference's ADMM setting, certificate inside the loop
+    assert ref_setting["status"][1] == 3 and np.all(ref_setting["out"][1] == 0.0)

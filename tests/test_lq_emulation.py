@@ -237,3 +237,20 @@ def test_start_curvature_outside_its_box_by_less_than_the_tolerance():
     sc[0, 2] = 0.9                                   # far outside: no point satisfies the rows
     assert E.solve(b["ref"], b["bounds"], sc)["status"][0] == 4
 
+
+@pytest.mark.parametrize("what", ["nan_s", "nan_bound", "inf_start", "equal_s", "nan_pose"])
+def test_a_scenario_that_is_not_a_number_ends_numerical_with_a_zero_record(what):
+    """the lane-per-QP solver's input check (first preparation sweep): PQP_STATUS_NUMERICAL, zero record, no interior-point iteration on NaNs"""
+    from path_optimizer_2_amd.synth import make_batch
+    b = make_batch(3, 40, seed=31)
+    clean = E.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+    h = {k: v.copy() for k, v in b.items()}
+    if what == "nan_s": h["ref"][1, 10, 0] = np.nan
+    if what == "nan_bound": h["bounds"][1, 5, 0] = np.nan
+    if what == "inf_start": h["scal"][1, 1] = np.inf
+    if what == "equal_s": h["ref"][1, 30, 0] = h["ref"][1, 29, 0]
+    if what == "nan_pose": h["ref"][1, 39, 4] = np.nan
+    r = E.solve(h["ref"], h["bounds"], h["scal"], passes=1)
+    assert r["status"][1] == 3 and r["iters"][1] == 0 and np.all(r["out"][1] == 0.0)
+    for q in (0, 2):
+        assert r["status"][q] == 1 and np.array_equal(r["out"][q], clean["out"][q])
