@@ -166,7 +166,7 @@ def pmc_child(argv_core, kernel_substr, timeout_s, steps=6, passes=None):
             with tempfile.TemporaryDirectory(dir="/tmp") as d:
                 cmd = ["rocprofv3", "--kernel-trace", "--pmc", *pmc.split(), "-f", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
                        *argv_core, "--steps", str(steps), "--warmup", "3", "--no-cpu-baseline", "--no-secondary", "--pmc", "off", "--sustain", "0",
-                       "--inflight", "1"]          # (one kernel at a time: the counters of a launch are its own)
+                       "--inflight", "1", "--prewarm", "0"]          # (one kernel at a time: the counters of a launch are its own)
                 env = dict(os.environ, TMPDIR="/tmp")
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
                 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -190,6 +190,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000, help="timed steps (default: 0.65 s of configs[1] steps, so that the timed region is visible to a 10 Hz sampler)")
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--prewarm", type=float, default=0.25, help="seconds of untimed steps before the W warm-up steps (clocks, start order); 0: none")
     ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4], help="BASELINE.json configs[k] (default: 1 at --gpus 1, else 3)")
     ap.add_argument("--batch", type=int, default=None, help="QPs per GPU (default: the config's)")
     ap.add_argument("--total", type=int, default=None, help="QPs of the WHOLE job, split contiguously over the ranks (shard.shard_range: the first total %% N ranks get "
@@ -361,6 +362,14 @@ def main():
                 hh.sync()
 
     torch.cuda.synchronize()          # the inputs were produced on torch's stream; the handles launch on their own (non-blocking) streams
+    # Untimed, before the W warm-up steps: the same step for --prewarm seconds.  A fresh process finds the GPU at its idle clocks and the handles
+    # without a start order; W = 3 ... 5 steps are ~1.5 ms of work - the K steps behind them would measure the ramp, not the kernel.
+    if args.prewarm > 0:
+        t_pw = time.perf_counter()
+        while time.perf_counter() - t_pw < args.prewarm:
+            for _ in range(16):
+                step()
+            sync_all()
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -848,7 +857,7 @@ def main():
                        "passes": "cold solve + 1 re-linearised warm re-solve (PathOptimizer::optimizePath)",
                        "qp_start_order": "most expensive first by the previous step's cost (PQP_OPT_ORDER_BY_COST)" if cost_order else "index order",
                        "parallelism": f"{world} independent shard(s), no collective in the timed region" + (" - TEST MODE: all ranks share GPU 0 (PQP_BENCH_SHARED_GPU), numbers meaningless" if shared_gpu else ""),
-                       "batches_in_flight": max(args.inflight, 1),
+                       "batches_in_flight": max(args.inflight, 1), "prewarm_s": args.prewarm,
                        **({"smoother": "TensionSmoother2 QP (equality rows only) " + ("as the reference runs it: ADMM to eps 1e-3" if args.reference_setting else
                                        "solved exactly by one Riccati sweep per scenario (pqp_params.polish = 2: tension2_exact_kernel, no ADMM iterations)")} if pipe is not None else {})},
             "admm_iters": {"min": int(it_np.min()), "median": float(np.median(it_np)), "p99": float(np.percentile(it_np, 99)),

@@ -48,7 +48,7 @@ valumix)
              "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU" \
              "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_WAVES"; do
     i=$((i+1)); rm -rf /tmp/vm_$i
-    rocprofv3 --kernel-trace --pmc $pmc -f csv -d /tmp/vm_$i -- python $root/bench.py $Q --steps 10 --warmup 3 ${VALUMIX_ARGS} > /tmp/vm_$i.log 2>&1 || tail -3 /tmp/vm_$i.log
+    rocprofv3 --kernel-trace --pmc $pmc -f csv -d /tmp/vm_$i -- python $root/bench.py $Q --prewarm 0 --steps 10 --warmup 3 ${VALUMIX_ARGS} > /tmp/vm_$i.log 2>&1 || tail -3 /tmp/vm_$i.log
   done
   cd $root
   mkdir -p /tmp/vm && rm -rf /tmp/vm/* && for k in 1 2 3; do [ -d /tmp/vm_$k ] && cp -r /tmp/vm_$k /tmp/vm/pmc_$k; done

@@ -5,7 +5,7 @@ tag=$1; bargs=$2; shift 2
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-cmd="python $root/bench.py --no-cpu-baseline --no-secondary --pmc off --sustain 0 --steps 10 --warmup 3 $bargs"
+cmd="python $root/bench.py --no-cpu-baseline --no-secondary --pmc off --sustain 0 --prewarm 0 --steps 10 --warmup 3 $bargs"
 i=0
 for pmc in "$@"; do
   i=$((i+1))
