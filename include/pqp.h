@@ -141,9 +141,8 @@ typedef struct pqp_params {
                                          with iters = 0 where the QP's structure allows: TensionSmoother2's (equality rows only: a linear-
                                          quadratic control problem) by one Riccati sweep per scenario; with polish == 1 postSmooth's (a box
                                          QP in the offsets) and TensionSmoother's (a box QP in the lateral shifts) by a KKT-verified
-                                         active-set solve, one wavefront per scenario (up to 1024 layers / points; beyond: the generic
-                                         core's active-set solve from the cold start, with ADMM + KKT-verified polish attempts as the
-                                         fallback).  With polish == 2 QPs with inequality rows run the plain ADMM.  The path QP treats 2
+                                         active-set solve, one wavefront per scenario (any count of layers / points: up to 1024 in the
+                                         wavefront's registers, beyond with the lane state in an HBM workspace).  With polish == 2 QPs with inequality rows run the plain ADMM.  The path QP treats 2
                                          like 1 */
     int32_t polish_refine_iter;       /* 4     */
     int32_t polish_every;             /* 0: only when the residual test passes; k: also try every k iterations; < 0: see adaptive_rho_interval */
@@ -378,9 +377,10 @@ int pqp_smooth_tension2_device(pqp_handle* h, int batch, int n, const double* x_
                                int32_t* status, int32_t* iters, double* info);
 /* TensionSmoother::osqpSmooth    src/reference_path_smoother/tension_smoother.cpp:49-100; clearance = Map::getObstacleDistance
  * at each input point (the distance-map lookup itself, tension_smoother.cpp:168, stays on the caller's side; pqp_clearance_device does it).
- * 4 <= n <= 1024 points (the reference: unbounded, one point per metre of line).  Up to ~166 points a handle in the reference's ADMM setting (polish == 0) runs OSQP's iteration on the 9 x 9-block
- * core; beyond that core's LDS capacity - and for polish == 1 at any size - the QP is solved exactly (iters = 0), which meets OSQP's
- * termination test at any eps. */
+ * n >= 4 points, no upper bound (as the reference: one point per metre of line).  Up to ~166 points a handle in the reference's ADMM setting
+ * (polish == 0) runs OSQP's iteration on the 9 x 9-block core; beyond that core's LDS capacity - and for polish == 1 at any size - the QP is
+ * solved exactly (iters = 0), which meets OSQP's termination test at any eps.  The same rule holds for the other two smoothers: where the
+ * generic core cannot hold the QP (TensionSmoother2: more than 256 points; postSmooth: more than ~340 layers) every handle gets the exact kernel. */
 int pqp_smooth_tension(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list,
                        const double* clearance, double* out_x, double* out_y, double* out_s, int32_t* status, int32_t* iters);
 int pqp_smooth_tension_device(pqp_handle* h, int batch, int n, const double* x_list, const double* y_list, const double* angle_list,
@@ -566,7 +566,9 @@ typedef enum pqp_chain_stage {
 typedef enum pqp_smoothing_method { PQP_SMOOTHING_TENSION2 = 0, PQP_SMOOTHING_TENSION = 1 } pqp_smoothing_method;
 typedef struct pqp_chain_config {
     int32_t raw_max, sample_max, layer_max, n_max;   /* capacities per scenario: raw-line points (bSpline, about one per metre), 1 m samples of
-                                                        the smoother QP (<= 256), DP layers (1.5 m, <= 341), waypoints of the path (<= 512) */
+                                                        the smoother QP, DP layers (1.5 m), waypoints of the path.  No upper bounds (the reference
+                                                        has none); a line of more than ~2000 spline knots exceeds the LDS staging of the corridor
+                                                        steps (PQP_ERR_CAPACITY from that step) */
     double output_spacing;               /* 0.3   FLAGS_output_spacing, planning_flags.cpp:106 */
     int32_t dynamic_segmentation;        /* 1     FLAGS_enable_dynamic_segmentation, :110 */
     double max_steering_angle;           /* 35 degrees, :22 */

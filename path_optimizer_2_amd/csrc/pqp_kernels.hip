@@ -986,6 +986,13 @@ int sm_solve(pqp_handle* h, int type, int batch, int n, int32_t* status, int32_t
     return PQP_OK;
 }
 
+// does the generic banded core hold a smoother QP of this size (its vectors, factor rows and row data in one CU's LDS, one lane per padded variable)?
+bool sm_generic_fits(int type, int n) {
+    const SmShape sh = sm_shape(type, n);
+    const pqp::BqLayout lay{sh.nv, sh.nc, sh.bw};
+    return (size_t)lay.total(false) * 8 <= 160 * 1024 && 64 * ((lay.nbb() + 63) / 64) <= 1024;
+}
+
 int sm_alloc(pqp_handle* h, int type, int batch, int n) {
     const SmShape sh = sm_shape(type, n);
     int rc;
@@ -1005,8 +1012,9 @@ static int smooth_tension2_impl(pqp_handle* h, int batch, int n, const int32_t* 
         return fail(PQP_ERR_INVALID, "pqp_smooth_tension2: bad argument");
     PQP_HIP(hipSetDevice(h->device));
     int rc;
-    if (h->prm.polish != 0) {
-        // exact optima asked for: the QP has equality rows only - its optimum by one Riccati sweep per scenario (tension2_exact_kernel)
+    if (h->prm.polish != 0 || !sm_generic_fits(SM_TENSION2, n)) {
+        // exact optima asked for (or more points than the generic core holds: 4 n variables on at most 1024 lanes, tension_smoother_2.cpp:20-72 has
+        // no cap): the QP has equality rows only - its optimum by one Riccati sweep per scenario (tension2_exact_kernel)
         if (!status) return fail(PQP_ERR_INVALID, "pqp_smooth_tension2: status is null");
         if ((rc = h->b_pband.ensure((size_t)batch * n * 5 * 8)) || (rc = h->b_aval.ensure((size_t)batch * n * 6 * 8))) return rc;
         hipLaunchKernelGGL(pqp::tension2_stage_kernel, dim3((batch * n + 255) / 256), dim3(256), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, k_list,
@@ -1060,10 +1068,8 @@ static int smooth_tension_impl(pqp_handle* h, int batch, int n, const int32_t* n
     // point per metre of line).  Beyond it, also a handle in the reference's ADMM setting gets the exact kernel's optimum: a point with
     // zero residuals meets OSQP's termination test at any eps, so it IS a valid result of that setting (iters = 0; OSQP itself would
     // stop at a less accurate one).
-    const SmShape sh9 = sm_shape(SM_TENSION, n);
-    const pqp::BqLayout lay9{sh9.nv, sh9.nc, sh9.bw};
-    const bool generic_fits = (size_t)lay9.total(false) * 8 <= 160 * 1024 && 64 * ((lay9.nbb() + 63) / 64) <= 1024;
-    if ((h->prm.polish == 1 || !generic_fits) && n <= 1024) {
+    const bool generic_fits = sm_generic_fits(SM_TENSION, n);
+    if (h->prm.polish == 1 || !generic_fits) {
         // exact optima asked for (or the only kernel that holds the QP): the box QP in the lateral shifts alone, one wavefront per scenario (tension_exact_kernel)
         if (!status) return fail(PQP_ERR_INVALID, "pqp_smooth_tension: status is null");
         h->next_event_pair();
@@ -1079,15 +1085,20 @@ static int smooth_tension_impl(pqp_handle* h, int batch, int n, const int32_t* n
             carry = (h->sm_act_batch[0] == batch && h->sm_act_n[0] == n && before == h->sm_act[0].p) ? 1 : 0;
             h->sm_act_batch[0] = batch; h->sm_act_n[0] = n;
         }
-        if (n <= 64) hipLaunchKernelGGL(pqp::tension_exact_kernel<1>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
-        else if (n <= 128) hipLaunchKernelGGL(pqp::tension_exact_kernel<2>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
-        else if (n <= 256) hipLaunchKernelGGL(pqp::tension_exact_kernel<4>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
-        else if (n <= 384) hipLaunchKernelGGL(pqp::tension_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
-        else if (n <= 512) hipLaunchKernelGGL(pqp::tension_exact_kernel<8>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
+        if (n <= 64) hipLaunchKernelGGL(pqp::tension_exact_kernel<1>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry, nullptr);
+        else if (n <= 128) hipLaunchKernelGGL(pqp::tension_exact_kernel<2>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry, nullptr);
+        else if (n <= 256) hipLaunchKernelGGL(pqp::tension_exact_kernel<4>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry, nullptr);
+        else if (n <= 384) hipLaunchKernelGGL(pqp::tension_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry, nullptr);
+        else if (n <= 512) hipLaunchKernelGGL(pqp::tension_exact_kernel<8>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry, nullptr);
         // (twelve / sixteen points per lane: the lane state no longer fits the registers - 1.8 / 3.3 KB of scratch per lane - but lines that long are
         //  rare, a point per metre of reference line, and the recursion down the lanes, not the spills, is what their time goes to)
-        else if (n <= 768) hipLaunchKernelGGL(pqp::tension_exact_kernel<12>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
-        else hipLaunchKernelGGL(pqp::tension_exact_kernel<16>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry);
+        else if (n <= 768) hipLaunchKernelGGL(pqp::tension_exact_kernel<12>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry, nullptr);
+        else if (n <= 1024) hipLaunchKernelGGL(pqp::tension_exact_kernel<16>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry, nullptr);
+        else {
+            // any longer line (the reference has no cap: tension_smoother.cpp:49-100): the same kernel with its arrays in HBM (SmHbm)
+            if ((rc = h->b_pband.ensure((size_t)batch * pqp::kTensionExactArrays * (64 * (((size_t)n + 63) / 64)) * 8))) return rc;
+            hipLaunchKernelGGL(pqp::tension_exact_kernel<0>, dim3(batch), dim3(64), 0, h->stream, batch, n, n_of, x_list, y_list, angle_list, clearance, wk, wdk, wdev, tol, out_x, out_y, out_s, status, iters, info, act_io, carry, h->b_pband.as<double>());
+        }
         PQP_HIP(hipGetLastError());
         if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
         h->timed = true;
@@ -1122,7 +1133,8 @@ static int post_smooth_impl(pqp_handle* h, int batch, int m, const int32_t* m_of
                             const double* vehicle_l, double* out_l, int32_t* status, int32_t* iters, double* info) {
     if (!h || !layers_s || !lb || !ub || !vehicle_l || !out_l || batch < 1 || m < 4) return fail(PQP_ERR_INVALID, "pqp_post_smooth: bad argument (m >= 4, reference_path_smoother.cpp:528)");
     PQP_HIP(hipSetDevice(h->device));
-    if (h->prm.polish == 1 && m <= 1024) {
+    // (beyond what the generic core holds in a CU's LDS also a handle in the reference's ADMM setting gets the exact kernel's optimum, as in smooth_tension_impl)
+    if (h->prm.polish == 1 || !sm_generic_fits(SM_POST, m)) {
         // exact optima asked for: the box QP in the offsets alone, one wavefront per scenario (post_exact_kernel)
         if (!status) return fail(PQP_ERR_INVALID, "pqp_post_smooth: status is null");
         h->next_event_pair();
@@ -1138,13 +1150,19 @@ static int post_smooth_impl(pqp_handle* h, int batch, int m, const int32_t* m_of
             carry = (h->sm_act_batch[1] == batch && h->sm_act_n[1] == m && before == h->sm_act[1].p) ? 1 : 0;
             h->sm_act_batch[1] = batch; h->sm_act_n[1] = m;
         }
-        if (m <= 64) hipLaunchKernelGGL(pqp::post_exact_kernel<1>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
-        else if (m <= 128) hipLaunchKernelGGL(pqp::post_exact_kernel<2>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
-        else if (m <= 256) hipLaunchKernelGGL(pqp::post_exact_kernel<4>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
-        else if (m <= 384) hipLaunchKernelGGL(pqp::post_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
-        else if (m <= 512) hipLaunchKernelGGL(pqp::post_exact_kernel<8>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
-        else if (m <= 768) hipLaunchKernelGGL(pqp::post_exact_kernel<12>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
-        else hipLaunchKernelGGL(pqp::post_exact_kernel<16>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry);
+        if (m <= 64) hipLaunchKernelGGL(pqp::post_exact_kernel<1>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry, nullptr);
+        else if (m <= 128) hipLaunchKernelGGL(pqp::post_exact_kernel<2>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry, nullptr);
+        else if (m <= 256) hipLaunchKernelGGL(pqp::post_exact_kernel<4>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry, nullptr);
+        else if (m <= 384) hipLaunchKernelGGL(pqp::post_exact_kernel<6>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry, nullptr);
+        else if (m <= 512) hipLaunchKernelGGL(pqp::post_exact_kernel<8>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry, nullptr);
+        else if (m <= 768) hipLaunchKernelGGL(pqp::post_exact_kernel<12>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry, nullptr);
+        else if (m <= 1024) hipLaunchKernelGGL(pqp::post_exact_kernel<16>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry, nullptr);
+        else {
+            // any longer corridor (reference_path_smoother.cpp:526-580 has no cap): the same kernel with its arrays in HBM (SmHbm)
+            int rc_w;
+            if ((rc_w = h->b_pband.ensure((size_t)batch * pqp::kPostExactArrays * (64 * (((size_t)m + 63) / 64)) * 8))) return rc_w;
+            hipLaunchKernelGGL(pqp::post_exact_kernel<0>, dim3(batch), dim3(64), 0, h->stream, batch, m, m_of, layers_s, lb, ub, vehicle_l, tol, out_l, status, iters, info, act_io, carry, h->b_pband.as<double>());
+        }
         PQP_HIP(hipGetLastError());
         if (!h->capturing) PQP_HIP(hipEventRecord(h->ev1, h->stream));
         h->timed = true;
@@ -1261,7 +1279,14 @@ int pqp_corridor_bounds_device(pqp_handle* h, int batch, int n, int m, const dou
     if (threads > 1024) threads = 1024;
     h->next_event_pair();
     if (!h->capturing) PQP_HIP(hipEventRecord(h->ev0, h->stream));
-    const size_t lds = pqp::CorridorLds{m, n}.total_bytes();
+    // a whole scenario's probes in LDS when they fit (9 m + 33 n doubles), tiles of waypoints otherwise: any path length
+    a.tile = n;
+    if (pqp::CorridorLds{m, n}.total_bytes() > 160 * 1024) {
+        const long long room = 160 * 1024 - (long long)pqp::CorridorLds{m, 0}.total_bytes(), per_waypoint = (long long)(pqp::CorridorLds{m, 1}.total_bytes() - pqp::CorridorLds{m, 0}.total_bytes());
+        if (room < 16 * per_waypoint) return fail(PQP_ERR_CAPACITY, "pqp_corridor_bounds: the line's spline table (9 m doubles) does not leave room for the probes in one CU's LDS");
+        a.tile = (int)(room / per_waypoint);
+    }
+    const size_t lds = pqp::CorridorLds{m, a.tile}.total_bytes();
     if (lds > 160 * 1024) return fail(PQP_ERR_CAPACITY, "pqp_corridor_bounds: scenario too large for one CU's LDS (about 9 m + 31 n doubles)");
     if (lds > 48 * 1024) PQP_HIP(hipFuncSetAttribute((const void*)pqp::corridor_bounds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     threads = 512;                   // the sample loops are strided; 512 lanes per scenario keep the most gathers in flight per CU (measured at batch

@@ -119,6 +119,31 @@ def test_configs0_the_demo_s_single_path(hip_lib):
     h.close(); hs.close()
 
 
+def test_capacities_beyond_the_register_kernels(hip_lib):
+    """pqp_chain_config has no upper bounds (the reference has none): 300 samples are more than TensionSmoother2's generic core holds (256),
+    400 layers more than postSmooth's (341), 600 waypoints more than the lane-per-waypoint kernel's (512 - the handle is created for them;
+    a line this short still runs there).  Same paths as with the default capacities; a smoother handle in the reference's ADMM setting gets
+    the exact kernels where the generic core does not fit instead of PQP_ERR_CAPACITY."""
+    sc = _scenarios(3, n_maps=2, seed=33)
+    h = capi.Handle(capi.production_params(), max_batch=3, max_n=600)
+    hs = capi.Handle(_smoother_params(), max_batch=3, max_n=400)
+    big_cfg = h.chain_config(raw_max=400, sample_max=300, layer_max=400, n_max=600)
+    for method in (capi.SMOOTHING_TENSION2, capi.SMOOTHING_TENSION):
+        cfg0 = h.chain_config(smoothing_method=method)
+        cfg1 = h.chain_config(raw_max=400, sample_max=300, layer_max=400, n_max=600, smoothing_method=method)
+        a = h.optimize_path(sc["pts"], sc["n_pts"], sc["start"], sc["target"], sc["dist"], sc["geom"], map_of=sc["map_of"], smoother=hs, cfg=cfg0)
+        b = h.optimize_path(sc["pts"], sc["n_pts"], sc["start"], sc["target"], sc["dist"], sc["geom"], map_of=sc["map_of"], smoother=hs, cfg=cfg1)
+        assert (a["stage"] == 0).all() and (b["stage"] == 0).all() and (b["status"] == 1).all()
+        assert np.array_equal(a["n_out"], b["n_out"])
+        for q in range(3):
+            nv = int(a["n_out"][q])
+            assert np.abs(a["out"][q, :nv] - b["out"][q, :nv]).max() < 1e-7, (method, q)
+    plain = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3), max_batch=3, max_n=400)       # the reference's smoother setting
+    c = h.optimize_path(sc["pts"], sc["n_pts"], sc["start"], sc["target"], sc["dist"], sc["geom"], map_of=sc["map_of"], smoother=plain, cfg=big_cfg)
+    assert (c["stage"] == 0).all() and (c["status"] == 1).all()
+    h.close(); hs.close(); plain.close()
+
+
 def test_the_tension_smoothing_method(hip_lib):
     """FLAGS_smoothing_method = TENSION (planning_flags.cpp:27, ReferencePathSmoother::create reference_path_smoother.cpp:18-29): the chain
     looks the clearance of the raw line's samples up on the device and runs TensionSmoother's QP (tension_smoother.cpp:49-177) in place of

@@ -63,6 +63,30 @@ def test_batch_with_one_map_per_scenario_and_a_blocked_road(handle):
     assert nv[2] < 35 and nv[0] == 60
 
 
+def test_paths_longer_than_the_lds_go_through_in_tiles(handle):
+    """corridor_bounds_kernel keeps the line's spline table and the probes of its waypoints in one CU's LDS (9 m + 33 n doubles); where a
+    scenario does not fit the waypoints go through in tiles.  Forced here with a table of 2150 knots (the same line, refitted through a
+    dense resampling), which leaves room for 33 waypoints at a time: 80 waypoints in three tiles, a wall in the third; against the oracle's
+    walk on the same dense splines."""
+    c = U.build(seed=8, n=80)
+    s_end = c["scene"]["knots_s"][-1]
+    ks = np.linspace(0.0, s_end, 2150)
+    dx = K.spline_fit(ks, np.array([K.spline_eval(c["sx"], v) for v in ks]))
+    dy = K.spline_fit(ks, np.array([K.spline_eval(c["sy"], v) for v in ks]))
+    tab, ext = K.pack_spline(dx, dy)
+    assert tab.shape[-1] == 2150
+    g = c["geom"]
+    d2 = c["dist"].copy()
+    x_wall = c["ref"][72, 3]
+    for i in range(g.rows):
+        x, _ = K.grid_cell_position(g, i, 0)
+        d2[i, :] = np.minimum(d2[i, :], np.float32(abs(x - x_wall)))
+    for dist in (c["dist"], d2):
+        got, nv = handle.corridor_bounds(c["ref"][None], tab[None], ext[None], dist, _geom(g))
+        _compare(got[0], int(nv[0]), dict(ref=c["ref"], sx=dx, sy=dy, dist=dist, geom=g))
+    assert 36 <= int(nv[0]) < 72
+
+
 def test_non_default_vehicle_parameters(handle):
     c = U.build(seed=11, n=50)
     prm_o = K.CorridorParams(front_length=3.2, rear_length=-0.8, car_width=1.8, safety_margin=0.2)

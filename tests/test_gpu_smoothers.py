@@ -4,6 +4,7 @@ assemble kernel + banded ADMM core + finish kernel against the oracle's restatem
 import numpy as np
 import pytest
 import scipy.sparse as sp
+from scipy.sparse.linalg import spsolve
 
 import pqp_oracle as O
 from path_optimizer_2_amd import capi
@@ -115,6 +116,43 @@ def test_tension_sizes_beyond_the_9x9_formulation(hip_lib):
     # the certificate is not vacuous: a point moved off the optimum fails it by orders of magnitude
     bad = _tension_kkt_certificate(x[0], y[0], ang[0], cl[0], r["x"][0] + 1e-3 * np.cos(ang[0] + np.pi / 2) * np.sin(np.arange(n)), r["y"][0] + 1e-3 * np.sin(ang[0] + np.pi / 2) * np.sin(np.arange(n)))
     assert bad > 1e-3
+
+
+def test_tension_lines_of_any_length(hip_lib):
+    """Beyond 1024 points (the reference has no cap: tension_smoother.cpp:49-100; a point per metre of raw reference) the exact kernel keeps its
+    arrays in HBM (tension_exact_kernel<0>, SmHbm) instead of registers: the same iteration, checked by the KKT conditions of the oracle's
+    matrices - both handle settings, a point count per line across the 64-point chunks, and the previous cycle's active set carried."""
+    for n, seeds in ((1025, (21,)), (1600, (22, 23)), (2500, (24,))):
+        cases = [tension_inputs(n, seed=sd) for sd in seeds]
+        x, y, ang, cl = (np.stack([c[k] for c in cases]) for k in (0, 1, 2, 5))
+        for prm in (_polished(), capi.default_params(eps_abs=1e-3, eps_rel=1e-3)):
+            h = capi.Handle(prm, max_batch=len(seeds), max_n=n)
+            r = h.smooth_tension(x, y, ang, cl, info=True)
+            assert (r["status"] == 1).all() and (r["iters"] == 0).all()
+            assert (r["info"][:, 5] <= 40).all(), r["info"][:, 5]               # factorisations: 10-12 interior iterations + 1-3 rounds at every size
+            for b in range(len(seeds)):
+                assert _tension_kkt_certificate(x[b], y[b], ang[b], cl[b], r["x"][b], r["y"][b]) < 1e-6, (n, b)
+                np.testing.assert_allclose(r["s"][b], _chord(r["x"][b], r["y"][b]), atol=1e-10)
+            h.close()
+    # a point count per line: the chunk boundaries (1088 = 17 * 64), short lines in a long batch, the tail repeats the last point
+    n = 1700
+    counts = np.array([1700, 1087, 1088, 1089, 5, 64, 1025, 1699], dtype=np.int32)
+    B = len(counts)
+    x = np.zeros((B, n)); y = np.zeros((B, n)); ang = np.zeros((B, n)); cl = np.ones((B, n))
+    for b, c in enumerate(counts):
+        cx, cy, ca, _, _, cc = tension_inputs(int(c), seed=300 + b)
+        x[b, :c], y[b, :c], ang[b, :c], cl[b, :c] = cx, cy, ca, cc
+    h = capi.Handle(_polished(), max_batch=B, max_n=n)
+    h.set_option(capi.OPT_CARRY_CYCLES, 1)
+    first = h.smooth_tension_var(x, y, ang, cl, counts)
+    again = h.smooth_tension_var(x, y, ang, cl, counts)               # from the carried set: the same optimum in one or two rounds
+    h.close()
+    for r in (first, again):
+        assert (r["status"] == 1).all()
+        for b, c in enumerate(counts):
+            assert _tension_kkt_certificate(x[b, :c], y[b, :c], ang[b, :c], cl[b, :c], r["x"][b, :c], r["y"][b, :c]) < 1e-6, b
+            assert np.all(r["x"][b, c:] == r["x"][b, c - 1]) and np.all(r["s"][b, c:] == r["s"][b, c - 1])
+    assert np.abs(first["x"] - again["x"]).max() < 1e-7
 
 
 def test_exact_tension_kernel_is_bounded_from_the_cold_start(hip_lib):
@@ -303,6 +341,67 @@ def test_post_smooth_exact_kernel_on_long_corridors(hip_lib, m):
     assert want["status"][0] == 1 and want["iters"][0] > 0
     assert np.abs(want["l"][0] - r["l"][b, :c]).max() < 1e-6
     g.close()
+
+
+def test_post_smooth_corridors_of_any_length(hip_lib):
+    """Beyond 1024 layers (reference_path_smoother.cpp:526-580 has no cap) post_exact_kernel<0> keeps its arrays in HBM; beyond what the generic
+    core holds (3 m variables on at most 1024 lanes) also a handle in the reference's ADMM setting gets the exact optimum."""
+    for m in (1025, 2200):
+        counts = np.array([m, 1024, m - 1, 4, 1088 if m > 1088 else 65, (m + 1024) // 2], dtype=np.int32)
+        B = len(counts)
+        rng = np.random.default_rng(m)
+        s = np.full((B, m), np.nan); lb = np.full((B, m), np.nan); ub = np.full((B, m), np.nan); l0 = np.zeros(B)
+        for b in range(B):
+            c = int(counts[b])
+            sb, lbb, ubb, v = post_inputs(c, seed=900 + 7 * b + m)
+            if b % 3 == 1:
+                half = rng.uniform(0.02, 0.15, size=c); mid = 0.5 * (lbb + ubb); lbb, ubb = mid - half, mid + half
+            s[b, :c], lb[b, :c], ub[b, :c], l0[b] = sb, lbb, ubb, v
+        for prm in (_polished(), capi.default_params(eps_abs=1e-3, eps_rel=1e-3)):
+            h = capi.Handle(prm, max_batch=B, max_n=m)
+            r = h.post_smooth_var(s, lb, ub, l0, counts, info=True)
+            h.close()
+            assert (r["status"] == 1).all() and (r["iters"] == 0).all()
+            for b in range(B):
+                c = int(counts[b])
+                assert _post_reduced_kkt(s[b, :c], lb[b, :c], ub[b, :c], l0[b], r["l"][b, :c]) < 5e-7, (m, b)
+                assert np.all(r["l"][b, c:] == 0.0)
+    # hostile corridors end as they do in registers: abscissae that do not increase -> NUMERICAL, an inverted box -> PRIMAL_INFEASIBLE, zero offsets
+    m = 1300
+    sb, lbb, ubb, v = post_inputs(m, seed=5)
+    s2 = np.stack([sb, sb, sb]); lb2 = np.stack([lbb, lbb, lbb]); ub2 = np.stack([ubb, ubb, ubb])
+    s2[1, 1200] = s2[1, 1199]
+    lb2[2, 1100], ub2[2, 1100] = 0.5, -0.5
+    h = capi.Handle(_polished(), max_batch=3, max_n=m)
+    r = h.post_smooth(s2, lb2, ub2, np.full(3, v))
+    h.close()
+    assert list(r["status"]) == [1, 3, 4] and np.all(r["l"][1:] == 0.0)
+
+
+def test_tension2_beyond_the_generic_core_in_the_reference_setting(hip_lib):
+    """TensionSmoother2's 4 n variables fill the generic core's 1024 lanes at 256 points; tension_smoother_2.cpp:20-72 has no cap.  Beyond it a
+    handle in the reference's ADMM setting gets the Riccati sweep's optimum (zero residuals: solved at any eps) instead of PQP_ERR_CAPACITY."""
+    n = 700
+    cases = [tension_inputs(n, seed=40 + b) for b in range(2)]
+    arr = [np.stack([c[k] for c in cases]) for k in range(5)]
+    h = capi.Handle(capi.default_params(eps_abs=1e-3, eps_rel=1e-3), max_batch=2, max_n=n)
+    r = h.smooth_tension2(arr[0], arr[1], arr[2], arr[3], arr[4])
+    h.close()
+    g = capi.Handle(_polished(), max_batch=2, max_n=n)
+    want = g.smooth_tension2(arr[0], arr[1], arr[2], arr[3], arr[4])
+    g.close()
+    assert (r["status"] == 1).all() and (want["status"] == 1).all()
+    assert np.array_equal(r["x"], want["x"]) and np.array_equal(r["y"], want["y"]) and np.array_equal(r["s"], want["s"])
+    for b in range(2):
+        x, y, ang, k, s, _ = cases[b]
+        P, q, A, lo, up = O.assemble_tension2(x, y, ang, k, s)
+        # equality rows only: the optimum is the solution of the KKT system of the oracle's matrices
+        nv, nc = P.shape[0], A.shape[0]
+        kkt = sp.bmat([[sp.csc_matrix(P), sp.csc_matrix(A).T], [sp.csc_matrix(A), None]], format="csc")
+        sol = spsolve(kkt, np.concatenate([-q, lo]))
+        assert np.abs(lo - up).max() == 0.0
+        np.testing.assert_allclose(r["x"][b], sol[:n], atol=1e-7)
+        np.testing.assert_allclose(r["y"][b], sol[n:2 * n], atol=1e-7)
 
 
 def test_tension2_exact_kernel_with_a_point_count_per_scenario(hip_lib):
