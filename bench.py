@@ -78,22 +78,39 @@ def algorithmic_bytes(n, kkt_solves, admm_iters, factors, setups):
 # bytes per waypoint of one sweep of path_stream_kernel (fields read + written, fp64 problem data / gains / point,
 # fp32 interior-point state); "1": a pass linearised around (0, 0, k_ref) streams 3 of the 8 transition doubles, "2": a re-linearised pass all 8
 STREAM_BYTES = {"prep1": 184, "init": 232, "ipm1": 368, "ipm2": 448, "guess1": 172, "guess2": 212, "fset1": 144, "fset2": 184,
-                "bset1": 104, "bset2": 144, "prep2": 104, "warm": 128, "unpack": 136}
+                "bset1": 104, "bset2": 144, "prep2": 104, "warm": 128, "unpack": 136, "stash": 80}
 
 
-def stream_algorithmic_bytes(n, info):
+STREAM_DIRECT_ROUNDS = 3        # lq::kDirectRounds (csrc/pqp_path_lq.hpp)
+
+
+def stream_direct_rounds(info):
+    """Was this a sorted launch of the lane-per-QP kernel (its re-linearised passes began with active-set rounds on the first pass's set)?  Only there does a QP
+    end its second pass without an interior-point iteration: a pass started from the previous optimum runs at least one."""
+    return STREAM_DIRECT_ROUNDS if ((info[:, 4] >= 2) & (info[:, 3] - info[:, 2] == 0)).any() else 0
+
+
+def stream_algorithmic_bytes(n, info, direct=0):
     """Workspace + I/O bytes the lane-per-QP kernel's algorithm moves for the sweeps each QP actually ran (info rows of pqp_path_solve:
     [2] interior-point iterations of the first pass, [3] of both, [5] active-set rounds of the first pass, [7] of both).  Every byte is HBM
     (or Infinity-Cache) traffic by construction: nothing is kept on chip between two sweeps.  A wavefront also moves the lines of lanes that
-    have finished while a neighbour in the same 128-byte line has not, so measured traffic is 1.2-1.35x this."""
+    have finished while a neighbour in the same 128-byte line has not, so measured traffic is 1.0-1.35x this.
+    direct = k > 0: a sorted launch (PQP_OPT_ORDER_BY_COST with a map) - the re-linearised pass keeps the first pass's optimum aside ("stash": 40 bytes
+    read + 40 written per waypoint) and runs up to k active-set rounds on its set (one backward + one forward sweep each); a QP whose set was
+    confirmed ran no interior-point iteration in that pass, the others ran k rounds and then the pass of an unsorted launch."""
     B = STREAM_BYTES
     it1, it = info[:, 2], info[:, 3]
     s1, st = info[:, 5], info[:, 7]
     it2, s2 = it - it1, st - s1
-    two = (info[:, 4] >= 2) | (it2 > 0)
-    per_wp = (B["prep1"] + B["init"] + it1 * B["ipm1"] + B["guess1"] + s1 * B["fset1"] + np.maximum(s1 - 1, 0) * B["bset1"] + B["unpack"]
-              + two * (B["prep2"] + B["warm"] + B["guess2"]) + it2 * B["ipm2"] + s2 * B["fset2"] + np.maximum(s2 - 1, 0) * B["bset2"])
-    return float(np.sum(per_wp) * n)
+    two = (info[:, 4] >= 2) | (it2 > 0) | (s2 > 0)
+    first = B["prep1"] + B["init"] + it1 * B["ipm1"] + B["guess1"] + s1 * B["fset1"] + np.maximum(s1 - 1, 0) * B["bset1"] + B["unpack"]
+    from_ipm = lambda rounds: B["warm"] + B["guess2"] + it2 * B["ipm2"] + rounds * B["fset2"] + np.maximum(rounds - 1, 0) * B["bset2"]
+    if direct > 0:
+        hit = two & (it2 == 0)
+        second = B["prep2"] + B["stash"] + np.where(hit, s2 * (B["bset2"] + B["fset2"]), direct * (B["bset2"] + B["fset2"]) + from_ipm(np.maximum(s2 - direct, 0)))
+    else:
+        second = B["prep2"] + from_ipm(s2)
+    return float(np.sum(first + two * second) * n)
 
 
 def fetch_calibration():
@@ -716,7 +733,7 @@ def main():
                         del var_b
                         hh.solve_device(bb, 80, t_ref, t_b, t_s, o, passes=1, status=stt, info=inf)
                         hh.sync()
-                        ab = stream_algorithmic_bytes(80, inf.cpu().numpy())
+                        ab = stream_algorithmic_bytes(80, inf.cpu().numpy(), direct=stream_direct_rounds(inf.cpu().numpy()))
                         res_w[name]["roofline"] = {"bound": "hbm", "kernel": "path_stream_kernel", "algorithmic_bytes_per_launch": ab, "achieved": ab / (kms * 1e-3) / 1e9,
                                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                                    "note": "bytes the algorithm streams through its HBM workspace for the sweeps each QP ran (DESIGN.md 3b) / kernel time; "
@@ -755,7 +772,7 @@ def main():
         setups = 2.0
         kernel_name = "path_stream_kernel" if stream else "path_solve_kernel"
         if stream:
-            abytes = stream_algorithmic_bytes(n, info_np)
+            abytes = stream_algorithmic_bytes(n, info_np, direct=stream_direct_rounds(info_np))
             abytes_admm = abytes_ext = abytes
         else:
             abytes, abytes_admm, abytes_ext = algorithmic_bytes(n, kkt_np, it_np, fac_np, setups)

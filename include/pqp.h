@@ -229,6 +229,12 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      active-set rounds per pass in the handle's previous solve of the shape - a wavefront runs every phase as often as its slowest lane:
  *                                      65 536 QPs 10.5 -> 9.7 ms with the identical batch's counts, 11.2 -> 10.4 ms on jittered planning cycles, 98 304 QPs 17.5 -> 13.0 ms
  *                                      (profiles/r05g_stream_sorted_probe.txt, r05i_*); HBM traffic 1.31x -> 1.03x the algorithmic bytes.
+ *                                      Round 6: in such a sorted launch (the second solve of a shape onwards) a re-linearised pass first tries the previous pass's
+ *                                      active set on the new transition rows - up to three active-set rounds, a confirmed set being the KKT test of that pass's
+ *                                      QP - before the interior-point rounds get their turn (98 % of the bench's QPs confirm: 14.0 instead of 17.5 sweeps per path,
+ *                                      65 536 QPs 7.7 -> 9.0 M paths/s with two launches in flight, profiles/r06ae_*).  The optimum is the same one; reached through other
+ *                                      arithmetic it agrees with an unsorted launch's to the rounds' tolerances (< 5e-7 in l, psi, kappa), and a sorted launch
+ *                                      reproduces the previous sorted launch bit for bit.
  *   PQP_OPT_CARRY_CYCLES (default 0)   a cold call (warm == 0, lin == NULL) starts the FIRST pass of QP k from the optimum QP k had in the handle's
  *                                      previous solve of the same batch and n instead of cold (lane-per-waypoint kernel: from the warm state it then keeps
  *                                      - final iterate, equilibration, active set, kept per waypoint: counts per QP may change between the calls; lane-per-QP kernel: from its workspace) - a planner re-solves

@@ -49,6 +49,19 @@ constexpr double kMuWarm = 1e-3;        // complementarity a re-linearised pass 
 constexpr double kEqWidth = 1e-6;       // a collision box narrower than this is an equality row (weight w_s at its upper bound)
 constexpr int kIpmMaxIter = 100;
 constexpr int kPolishMaxRounds = 12;
+// A re-linearised pass of a launch whose wavefronts are sorted by their phase counts (Args::order) first tries the previous pass's active set on the new
+// transition rows: this many active-set rounds before the interior-point rounds get their turn (round 6).  Of the bench's QPs 60 % confirm their set in
+// the first round, 93 % within two, 98 % within three (tools/lq_direct_probe.py) - 2 x 328 bytes per waypoint instead of 3.9 interior-point iterations of
+// 448 and the hand-over.  Only in sorted launches: a wavefront runs its phases as often as its slowest lane, and of 64 unsorted lanes one nearly always
+// falls back (0.977^64 = 0.22) - the rounds would be paid on top of the iterations.
+#ifndef PQP_LQ_DIRECT_ROUNDS
+#define PQP_LQ_DIRECT_ROUNDS 3
+#endif
+constexpr int kDirectRounds = PQP_LQ_DIRECT_ROUNDS;
+// where the direct rounds keep the previous pass's optimum (point, set, multiplier: five doubles per waypoint) for the interior-point rounds to start
+// from should the set not be confirmed: the fp32 fields of the waypoint, which only the interior-point rounds use - and initialise
+constexpr int kStash = kFieldsD;
+static_assert(kFieldsF / 2 >= 5 && D_X1 == D_X0 + 1 && D_X2 == D_X0 + 2, "five doubles per waypoint fit the fp32 fields; the point's fields are consecutive");
 
 // reciprocal: the hardware seed (4.6e-8, tools/probes/rcp_probe.hip) + ONE Newton step = 2.2e-15 relative - a third fewer instructions than
 // pqp::rcp's two steps in a kernel whose row arithmetic is mostly reciprocals (two steps: -2 %, profiles/r03a_stream_first.txt)
@@ -490,7 +503,18 @@ struct Solver {
     }
     // a re-linearised pass: the interior-point state out of the previous pass's optimum, its active set and multipliers
     struct WarmIn { double xl, xp, xk, act, lam; Box b; };
-    PQP_SWEEP void warm_init() {
+    // before the direct rounds of a re-linearised pass overwrite them: the previous pass's point, set and multiplier of every waypoint into the stash
+    struct StashIn { double v[5]; };
+    PQP_SWEEP void stash() {
+        sweep_up<kDepth, StashIn>(1, n, [&](int j) {
+            StashIn in;
+            in.v[0] = ws.ld(D_X0, j); in.v[1] = ws.ld(D_X1, j); in.v[2] = ws.ld(D_X2, j); in.v[3] = ws.ld(D_ACT, j); in.v[4] = ws.ld(D_LAM, j);
+            return in;
+        }, [&](int j, const StashIn& in) {
+            for (int k = 0; k < 5; ++k) ws.st(kStash + k, j, in.v[k]);
+        });
+    }
+    PQP_SWEEP void warm_init(bool stashed) {
         const double mu_w = kMuWarm, sq = sqrt(kMuWarm);
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         auto start = [&](double v, double y, double lo, double up, bool slack) {
@@ -504,10 +528,11 @@ struct Solver {
             acc.res = fmax(acc.res, fmax(fabs(r.g - lo - r.tl), fabs(up - r.g - r.tu)));
             return r;
         };
-        const double x_end_l = ws.ld(D_X0, n - 1), x_end_p = ws.ld(D_X1, n - 1);
+        const int fx = stashed ? kStash : D_X0, fa = stashed ? kStash + 3 : D_ACT, fl = stashed ? kStash + 4 : D_LAM;
+        const double x_end_l = ws.ld(fx, n - 1), x_end_p = ws.ld(fx + 1, n - 1);
         sweep_up<kDepth, WarmIn>(1, n, [&](int j) {
             WarmIn in;
-            in.xl = ws.ld(D_X0, j); in.xp = ws.ld(D_X1, j); in.xk = ws.ld(D_X2, j); in.act = ws.ld(D_ACT, j); in.lam = ws.ld(D_LAM, j); in.b = load_box(j);
+            in.xl = ws.ld(fx, j); in.xp = ws.ld(fx + 1, j); in.xk = ws.ld(fx + 2, j); in.act = ws.ld(fa, j); in.lam = ws.ld(fl, j); in.b = load_box(j);
             return in;
         }, [&](int j, const WarmIn& in) {
             const int code = (int)in.act;
@@ -695,52 +720,69 @@ struct Solver {
     // Returns PQP_STATUS_SOLVED, or why not.  A QP whose hard rows cannot all hold (an end box out of the controls' reach, say) shows in
     // the interior-point rounds as steps that shrink to nothing while the row residual stays: PQP_STATUS_PRIMAL_INFEASIBLE - the
     // verdict OSQP's certificate gives the lane-per-waypoint kernel on the same QP.
-    PQP_HD int solve_pass(bool warm) {
+    PQP_HD int solve_pass(bool warm, int direct = 0) {
         // attempts: (from the previous optimum,) cold to complementarity 1e-6, cold to 1e-9.  A warm start that fails - the slot's previous QP may
         // have nothing to do with this one - is no verdict on the QP: the cold attempts follow.
+        // In a sorted launch a re-linearised pass begins with attempt -1: the previous pass's set on this pass's transition rows (kDirectRounds) - a round that asks
+        // for no change is the KKT test of THIS pass's QP.  What those rounds overwrite - point, sets, multipliers, the end rows' state - is what the
+        // interior-point rounds of attempt 0 start from should the set not be confirmed: kept aside (stash()).
         int verdict = PQP_STATUS_MAX_ITER;
-        for (int attempt = warm ? 0 : 1; attempt < 3; ++attempt) {
+        bool stashed = false;
+        int k_el = 0, k_ep = 0;
+        double k_lel = 0.0, k_lep = 0.0;
+        for (int attempt = (warm && direct > 0) ? -1 : (warm ? 0 : 1); attempt < 3; ++attempt) {
             const bool from_previous = attempt == 0;
-            const double mu_stop = attempt < 2 ? kMuStop : 1e-9;
-            if (from_previous) warm_init();
-            else { backward<MODE_INIT>(0.0); forward_init(); }
-            bool first = true;
-            int it = 0, stall = 0;
-            int slow = 0;          // iterations in a row with a step below 1e-3 although the rows are feasible: complementarity has stopped falling
-            const double res0 = res;
-            // (a QP whose hard rows start far outside their boxes - an end heading a radian off what the curvature limit can reach early on the
-            //  line - crawls: 2 % of residual per iteration.  Every QP of the bench distributions is feasible within 12 iterations; one that
-            //  has not shed 90 % of its initial residual after 30 gives up as PQP_STATUS_MAX_ITER instead of holding its wavefront for 100)
-            while (!(mu < mu_stop && res < 1e-6) && it < kIpmMaxIter && stall < 6 && slow < 3 && !(it >= 30 && res > 0.1 * res0 && res > 1e-6)) {
-                const double sigma = (first || alpha <= 0.9) ? 0.2 : 0.05;
-                const double sm = sigma * mu;
-                backward<MODE_IPM>(sm);
-                forward_ipm(sm);
-                stall = (alpha < 1e-3 && res > 1e-6) ? stall + 1 : 0;
-                slow = (alpha < 1e-3 && res <= 1e-6) ? slow + 1 : 0;
+            bool rounds = false;          // the attempt has a set for the active-set rounds
+            if (attempt < 0) {
+                k_el = act_el; k_ep = act_ep; k_lel = lam_el; k_lep = lam_ep;
+                stash();
+                rounds = true;
+            } else {
+                const double mu_stop = attempt < 2 ? kMuStop : 1e-9;
+                if (from_previous) warm_init(stashed);
+                else { backward<MODE_INIT>(0.0); forward_init(); }
+                bool first = true;
+                int it = 0, stall = 0;
+                int slow = 0;          // iterations in a row with a step below 1e-3 although the rows are feasible: complementarity has stopped falling
+                const double res0 = res;
+                // (a QP whose hard rows start far outside their boxes - an end heading a radian off what the curvature limit can reach early on the
+                //  line - crawls: 2 % of residual per iteration.  Every QP of the bench distributions is feasible within 12 iterations; one that
+                //  has not shed 90 % of its initial residual after 30 gives up as PQP_STATUS_MAX_ITER instead of holding its wavefront for 100)
+                while (!(mu < mu_stop && res < 1e-6) && it < kIpmMaxIter && stall < 6 && slow < 3 && !(it >= 30 && res > 0.1 * res0 && res > 1e-6)) {
+                    const double sigma = (first || alpha <= 0.9) ? 0.2 : 0.05;
+                    const double sm = sigma * mu;
+                    backward<MODE_IPM>(sm);
+                    forward_ipm(sm);
+                    stall = (alpha < 1e-3 && res > 1e-6) ? stall + 1 : 0;
+                    slow = (alpha < 1e-3 && res <= 1e-6) ? slow + 1 : 0;
 #if defined(PQP_LQ_DEBUG) && !defined(__HIP_DEVICE_COMPILE__)
-                std::fprintf(stderr, "  qp %d attempt %d it %d: sigma %.2f alpha %.3e mu %.3e res %.3e\n", qp, attempt, it, sigma, alpha, mu, res);
+                    std::fprintf(stderr, "  qp %d attempt %d it %d: sigma %.2f alpha %.3e mu %.3e res %.3e\n", qp, attempt, it, sigma, alpha, mu, res);
 #endif
-                first = false;
-                it += 1;
+                    first = false;
+                    it += 1;
+                }
+                ipm_iters += it;
+                if (!(mu == mu)) verdict = PQP_STATUS_NUMERICAL;
+                else if (!(res < 1e-6)) verdict = stall >= 6 ? PQP_STATUS_PRIMAL_INFEASIBLE : PQP_STATUS_MAX_ITER;
+                else if (!(mu < 1e-3)) verdict = PQP_STATUS_MAX_ITER;      // (short of mu_stop but below 1e-3: the active-set rounds get their chance)
+                else rounds = true;
             }
-            ipm_iters += it;
-            if (!(mu == mu)) verdict = PQP_STATUS_NUMERICAL;
-            else if (!(res < 1e-6)) verdict = stall >= 6 ? PQP_STATUS_PRIMAL_INFEASIBLE : PQP_STATUS_MAX_ITER;
-            else if (!(mu < 1e-3)) verdict = PQP_STATUS_MAX_ITER;      // (short of mu_stop but below 1e-3: the active-set rounds get their chance)
-            else {
-                backward<MODE_GUESS>(0.0);
+            if (rounds) {
                 // (the last attempt: guarded rounds once the plain ones have had their chance)
-                const int max_rounds = attempt == 2 ? 5 * kPolishMaxRounds : kPolishMaxRounds;
-                for (int r = 0; r < max_rounds; ++r) {
+                const int max_rounds = attempt < 0 ? direct : (attempt == 2 ? 5 * kPolishMaxRounds : kPolishMaxRounds);
+                for (int r = 0; ; ++r) {
+                    if (attempt < 0 && r == max_rounds) break;
+                    // (one call site per sweep: each is inlined into the kernel body)
+                    if (r == 0 && attempt >= 0) backward<MODE_GUESS>(0.0); else backward<MODE_SET>(0.0);
+                    if (r == max_rounds) break;
                     if (r < kPolishMaxRounds) { if (forward_set<false>()) return PQP_STATUS_SOLVED; }
                     else {
                         // (x_N confirms its set: one plain roll-out of the same gains puts it into D_X*, which a guarded one leaves at x)
                         if (forward_set<true>()) { if (forward_set<false>()) return PQP_STATUS_SOLVED; }
                         else settle();
                     }
-                    backward<MODE_SET>(0.0);
                 }
+                if (attempt < 0) { act_el = k_el; act_ep = k_ep; lam_el = k_lel; lam_ep = k_lep; stashed = true; }
                 verdict = PQP_STATUS_MAX_ITER;
                 continue;                                              // the set was not confirmed: the next attempt
             }
@@ -842,7 +884,7 @@ struct Solver {
         if (st == PQP_STATUS_SOLVED) solved += 1;
         for (int pass = 0; st == PQP_STATUS_SOLVED && pass < a.passes; ++pass) {
             prep(2, false);
-            st = solve_pass(true);
+            st = solve_pass(true, a.order ? kDirectRounds : 0);
             if (st == PQP_STATUS_SOLVED) solved += 1;
         }
         if (solved == 0) zero_point();          // (no active-set round ever ran: F_X* hold nothing)

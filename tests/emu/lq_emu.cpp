@@ -48,6 +48,27 @@ void pqp_emu_lq_solve(const pqp_params* prm, int batch, int n, const int32_t* n_
     }
 }
 
+// the same with Args::order set, as a launch has it whose wavefronts are sorted by their phase counts (PQP_OPT_ORDER_BY_COST from the second launch on): the solver
+// itself only asks WHETHER the launch is sorted (the re-linearised pass then starts with active-set rounds on the previous pass's set)
+void pqp_emu_lq_solve_sorted(const pqp_params* prm, int batch, int n, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
+                             const double* scal, int passes, double* out, int32_t* status, int32_t* iters, double* info) {
+    pqp::lq::Args a;
+    std::memset(&a, 0, sizeof(a));
+    static const int32_t sorted_marker = 0;
+    a.batch = batch; a.n = n; a.passes = passes; a.n_of = n_of; a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
+    a.status = status; a.iters = iters; a.info = info; a.prm = *prm; a.order = &sorted_marker;
+#pragma omp parallel
+    {
+        std::vector<double> ws((size_t)n * pqp::lq::kBlockDoubles);
+#pragma omp for schedule(dynamic, 16)
+        for (int q = 0; q < batch; ++q) {
+            std::fill(ws.begin(), ws.end(), 0.0);
+            pqp::lq::Solver<pqp::lq::StridedWs> s(a, q, pqp::lq::StridedWs{ws.data(), 0, 1});
+            s.run();
+        }
+    }
+}
+
 int pqp_emu_lq_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -33,7 +33,7 @@ def production(**over):
     return p
 
 
-def solve(ref, bounds, scal, passes=1, n_of=None, lin=None, prm=None):
+def solve(ref, bounds, scal, passes=1, n_of=None, lin=None, prm=None, sorted_launch=False):
     lib = load()
     B, n = ref.shape[:2]
     prm = prm or production()
@@ -43,7 +43,8 @@ def solve(ref, bounds, scal, passes=1, n_of=None, lin=None, prm=None):
     scal = np.ascontiguousarray(scal, dtype=np.float64)
     lin = None if lin is None else np.ascontiguousarray(lin, dtype=np.float64)
     n_of = None if n_of is None else np.ascontiguousarray(n_of, dtype=np.int32)
-    lib.pqp_emu_lq_solve(C.byref(prm), B, n, vp(n_of), vp(ref), vp(lin), vp(bounds), vp(scal), passes, vp(out), vp(st), vp(it), vp(info))
+    # sorted_launch: as in a launch with Args::order (the re-linearised pass starts with active-set rounds on the previous pass's set)
+    (lib.pqp_emu_lq_solve_sorted if sorted_launch else lib.pqp_emu_lq_solve)(C.byref(prm), B, n, vp(n_of), vp(ref), vp(lin), vp(bounds), vp(scal), passes, vp(out), vp(st), vp(it), vp(info))
     return dict(out=out, status=st, iters=it, info=info)
 
 

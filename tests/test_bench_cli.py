@@ -34,6 +34,17 @@ def test_stream_kernel_bytes_follow_the_sweep_counts():
     assert a == B["prep1"] + B["init"] + 9 * B["ipm1"] + B["guess1"] + B["fset1"] + B["unpack"] + B["prep2"] + B["warm"] + B["guess2"] + 5 * B["ipm2"] + B["fset2"]
     b = bench.stream_algorithmic_bytes(80, info[1:]) / 80
     assert b == B["prep1"] + B["init"] + 9 * B["ipm1"] + B["guess1"] + B["fset1"] + B["unpack"]
+    # a sorted launch (round 6): the second pass keeps the first pass's optimum aside and runs active-set rounds on its set - confirmed after two rounds
+    # (no interior-point iteration), or not within three: then the pass of an unsorted launch follows
+    info = np.zeros((2, 8))
+    info[0] = [0, 0, 9, 9, 2, 1, 14, 3]
+    info[1] = [0, 0, 9, 13, 2, 1, 30, 6]          # three direct rounds, four iterations, two more rounds
+    assert bench.stream_direct_rounds(info) == bench.STREAM_DIRECT_ROUNDS == 3 and bench.stream_direct_rounds(info[1:]) == 0
+    first = B["prep1"] + B["init"] + 9 * B["ipm1"] + B["guess1"] + B["fset1"] + B["unpack"]
+    a = bench.stream_algorithmic_bytes(80, info[:1], direct=3) / 80
+    assert a == first + B["prep2"] + B["stash"] + 2 * (B["bset2"] + B["fset2"])
+    b = bench.stream_algorithmic_bytes(80, info[1:], direct=3) / 80
+    assert b == first + B["prep2"] + B["stash"] + 3 * (B["bset2"] + B["fset2"]) + B["warm"] + B["guess2"] + 4 * B["ipm2"] + 2 * B["fset2"] + B["bset2"]
 
 
 def test_gpus_n_without_a_launcher_starts_n_ranks_or_fails_loudly():

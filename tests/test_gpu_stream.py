@@ -190,25 +190,35 @@ def test_stream_kernel_on_the_whole_of_configs_3(hip_lib):
     h.close()
     assert (st.cpu().numpy() == 1).all()
     assert shas[0] == shas[1]
-    # PQP_OPT_ORDER_BY_COST on this kernel (round 5): from the second solve on the wavefronts hold QPs that ran the same phases in the previous one.
-    # The same paths bit for bit (a QP's arithmetic does not depend on its slot) - also on a jittered batch, whose map comes from another batch's
-    # counts - every QP solved exactly once, and the wavefronts' lock-step phase maxima come down from ~25 to ~17 per wavefront
+    # PQP_OPT_ORDER_BY_COST on this kernel (round 5): from the second solve on the wavefronts hold QPs that ran the same phases in the previous one - also on a
+    # jittered batch, whose map comes from another batch's counts - every QP solved exactly once, and the wavefronts' lock-step phase maxima come down
+    # from ~25 to ~17 per wavefront.  Round 6: in such a sorted launch the re-linearised pass first tries the first pass's active set (lq::kDirectRounds
+    # active-set rounds before the interior-point rounds), so a sorted launch's path is the same optimum through other arithmetic: within the rounds'
+    # tolerances of the unsorted launch's, bit for bit the same from one sorted launch to the next (a QP's arithmetic does not depend on its slot), and
+    # ~98 % of the QPs end their second pass without an interior-point iteration.
     from path_optimizer_2_amd.synth import jitter_batch
     ho = _handle(capi, batch, n)
     ho.set_option(capi.OPT_ORDER_BY_COST, 1)
     hv = jitter_batch(b, 1)
     bounds_v, scal_v = torch.from_numpy(hv["bounds"]).to(dev), torch.from_numpy(hv["scal"]).to(dev)
-
-    def phases(inf):        # what the wavefronts of an index-ordered launch would run for these per-QP counts
-        ph = np.stack([inf[:, 2], inf[:, 5], inf[:, 3] - inf[:, 2], inf[:, 7] - inf[:, 5]], axis=1)
-        return ph
+    sorted_shas = []
     for k, (bb, ss) in enumerate(((bounds, scal), (bounds, scal), (bounds_v, scal_v), (bounds, scal))):
-        out.zero_(); st.zero_()
+        out.zero_(); st.zero_(); info.zero_()
         ho.solve_device(batch, n, ref, bb, ss, out, passes=1, status=st, info=info)
         ho.sync()
         assert (st.cpu().numpy() == 1).all(), k
-        if k in (0, 1, 3):
-            assert hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest() == shas[0], k
+        ok = out.cpu().numpy()
+        inf = info.cpu().numpy()
+        if k == 0:          # no map yet: the unsorted launch
+            assert hashlib.sha1(ok.tobytes()).hexdigest() == shas[0]
+            assert (inf[:, 3] - inf[:, 2] > 0).all()
+        elif k in (1, 3):
+            sorted_shas.append(hashlib.sha1(ok.tobytes()).hexdigest())
+            assert np.abs(ok - o)[:, :, 3:6].max() < 5e-7
+            assert np.abs(ok - o)[:, :, 0:2].max() < 5e-7
+            hit = inf[:, 3] - inf[:, 2] == 0
+            assert 0.95 < hit.mean() < 1.0, hit.mean()
+    assert sorted_shas[0] == sorted_shas[1]
     ho.close()
     # properties of an optimum that need no oracle: start state, curvature box, end box, x / y consistent with l
     assert np.abs(o[:, 0, 3] - b["scal"][:, 0]).max() < 1e-12 and np.abs(o[:, 0, 5] - b["scal"][:, 2]).max() < 1e-12
@@ -219,6 +229,52 @@ def test_stream_kernel_on_the_whole_of_configs_3(hip_lib):
     idx = np.linspace(0, batch - 1, 24).astype(int)
     want = _oracle({k: v[idx] for k, v in b.items()}, 24)
     assert np.abs(o[idx][:, :, 3:5] - want[:, :, 3:5]).max() < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,profile", [(200, "varied"), (120, "varied")])
+def test_sorted_launches_of_other_shapes(hip_lib, n, profile):
+    """The re-linearised pass of a sorted launch (PQP_OPT_ORDER_BY_COST, 768 wavefronts or more) on longer, varied and ragged paths: fewer sets survive the
+    re-linearisation (93 % at 120 waypoints, 86 % at 200), the others fall back to the interior-point rounds from the kept-aside optimum.  Same
+    statuses as the unsorted launch, the same optimum, and against the device emulation's counts QP by QP on a sample."""
+    import torch
+    import lq_emu_util as E
+    from path_optimizer_2_amd import capi
+    from path_optimizer_2_amd.synth import make_batch
+    batch = 49152
+    b = make_batch(batch, n, profile, seed=31)
+    n_of = np.full(batch, n, dtype=np.int32)
+    n_of[::7] = n - 13; n_of[3::11] = max(n // 2, 2)
+    b["scal"][n_of < n, 4] = 1.0                                 # a road cut short is blocked: no end-heading row (base_solver.cpp:254)
+    dev = torch.device("cuda", 0)
+    ref, bounds, scal, nof = (torch.from_numpy(v).to(dev) for v in (b["ref"], b["bounds"], b["scal"], n_of))
+    h = _handle(capi, batch, n)
+    h.set_option(capi.OPT_ORDER_BY_COST, 1)
+    res = []
+    for k in range(3):
+        out = torch.zeros((batch, n, 7), dtype=torch.float64, device=dev)
+        st = torch.zeros(batch, dtype=torch.int32, device=dev)
+        info = torch.zeros((batch, 8), dtype=torch.float64, device=dev)
+        h.solve_var_device(batch, n, nof, ref, bounds, scal, out, passes=1, status=st, info=info)
+        h.sync()
+        res.append((out.cpu().numpy(), st.cpu().numpy(), info.cpu().numpy()))
+    h.close()
+    (o0, s0, i0), (o1, s1, i1), (o2, s2, i2) = res
+    assert (s0 == s1).all() and (s1 == s2).all() and (s0 == 1).mean() > 0.999
+    ok = s0 == 1
+    assert np.abs(o1[ok] - o0[ok])[:, :, 3:6].max() < 5e-7
+    assert (o1 == o2).all() and (i1 == i2).all()
+    assert (i0[ok, 3] - i0[ok, 2] > 0).all()                    # the unsorted launch: every second pass ran interior-point iterations
+    hit = i1[ok, 3] - i1[ok, 2] == 0
+    assert 0.75 < hit.mean() < 0.99, hit.mean()
+    # the same source on the host, sorted launch: the same counts per QP
+    k = 256
+    r = E.solve(b["ref"][:k], b["bounds"][:k], b["scal"][:k], passes=1, n_of=n_of[:k], sorted_launch=True)
+    assert (r["status"] == s1[:k]).all()
+    same = (r["info"][:, 2:8] == i1[:k, 2:8]).all(axis=1)
+    assert same.mean() > 0.97, same.mean()                      # (FMA contraction differs between the two compilers: a borderline row may flip a count)
+    sel = r["status"] == 1
+    assert np.abs(r["out"][sel] - o1[:k][sel])[:, :, 3:6].max() < 5e-7
 
 
 def test_paths_of_more_than_512_waypoints(hip_lib):

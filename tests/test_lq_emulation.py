@@ -63,6 +63,41 @@ def test_kkt_certificate_of_the_returned_point():
         kkt_certificate_of_the_last_pass(b["ref"][q], b["bounds"][q], b["scal"][q], r0["out"][q], r1["out"][q])
 
 
+def test_sorted_launch_starts_the_second_pass_from_the_first_pass_s_set():
+    """In a launch whose wavefronts are sorted by their phase counts (Args::order) the re-linearised pass first tries the previous pass's active set on the
+    new transition rows (lq::kDirectRounds rounds); a confirmed set IS the KKT test, an unconfirmed one falls back to the interior-point rounds started
+    from the kept-aside optimum - with the same iteration counts as an unsorted launch.  Same statuses, the same optimum within the rounds' tolerances."""
+    fallbacks = 0
+    for n, profile, batch, seed in ((80, "uniform", 1024, 21), (200, "varied", 256, 22), (9, "varied", 256, 23), (300, "varied", 96, 24)):
+        b = make_batch(batch, n, profile, seed=seed)
+        r0 = E.solve(b["ref"], b["bounds"], b["scal"], passes=1)
+        r1 = E.solve(b["ref"], b["bounds"], b["scal"], passes=1, sorted_launch=True)
+        assert (r0["status"] == r1["status"]).all()
+        ok = r0["status"] == 1
+        assert np.abs(r0["out"][ok] - r1["out"][ok])[:, :, 3:6].max() < 5e-7
+        # the first pass is the same computation
+        assert (r0["info"][:, 2] == r1["info"][:, 2]).all() and (r0["info"][:, 5] == r1["info"][:, 5]).all()
+        it2_0, it2_1 = r0["info"][ok, 3] - r0["info"][ok, 2], r1["info"][ok, 3] - r1["info"][ok, 2]
+        hit = it2_1 == 0
+        assert hit.mean() > (0.9 if n <= 120 else 0.5), hit.mean()            # most sets survive the re-linearisation
+        # a fallback is the unsorted launch's second pass (same start, same iterations) behind the rounds that did not confirm
+        assert (it2_1[~hit] == it2_0[~hit]).all()
+        fallbacks += int((~hit).sum())
+        k = min(batch, 16)
+        want = OC.solve_batch(OC.params(**TIGHT_C), b["ref"][:k], b["bounds"][:k], b["scal"][:k], passes=1)["out"]
+        sel = ok[:k]
+        assert np.abs(r1["out"][:k][sel] - want[sel])[:, :, 3:5].max() < 2e-5
+    assert fallbacks >= 20          # (the fallback was exercised)
+
+
+def test_kkt_certificate_of_a_sorted_launch_s_point():
+    b = make_batch(6, 60, "varied", seed=12)
+    r0 = E.solve(b["ref"], b["bounds"], b["scal"], passes=0)
+    r1 = E.solve(b["ref"], b["bounds"], b["scal"], passes=1, sorted_launch=True)
+    for q in range(6):
+        kkt_certificate_of_the_last_pass(b["ref"][q], b["bounds"][q], b["scal"][q], r0["out"][q], r1["out"][q])
+
+
 # QPs on which the plain active-set rounds cycle - from the interior point of every attempt - until the rounds run out (found by
 # tools/lq_robustness_sweep.py-style sweeps of 16 384 ... 131 072 QPs per size; none at 300 waypoints or fewer): (n, profile, seed, QP)
 CYCLING = [(512, "varied", None, 5742), (1000, "varied", 3001, 1450), (1000, "uniform", 3007, 3912)]
