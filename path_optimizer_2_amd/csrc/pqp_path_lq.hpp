@@ -54,10 +54,7 @@ constexpr int kPolishMaxRounds = 12;
 // the first round, 93 % within two, 98 % within three (tools/lq_direct_probe.py) - 2 x 328 bytes per waypoint instead of 3.9 interior-point iterations of
 // 448 and the hand-over.  Only in sorted launches: a wavefront runs its phases as often as its slowest lane, and of 64 unsorted lanes one nearly always
 // falls back (0.977^64 = 0.22) - the rounds would be paid on top of the iterations.
-#ifndef PQP_LQ_DIRECT_ROUNDS
-#define PQP_LQ_DIRECT_ROUNDS 3
-#endif
-constexpr int kDirectRounds = PQP_LQ_DIRECT_ROUNDS;
+constexpr int kDirectRounds = 3;
 // where the direct rounds keep the previous pass's optimum (point, set, multiplier: five doubles per waypoint) for the interior-point rounds to start
 // from should the set not be confirmed: the fp32 fields of the waypoint, which only the interior-point rounds use - and initialise
 constexpr int kStash = kFieldsD;
@@ -472,7 +469,9 @@ struct Solver {
     }
     // after the initial solve: the interior-point state of every row, strictly inside its box where the row has a slack
     PQP_SWEEP void forward_init() {
-        const double theta = 0.05, mu0 = 0.1;
+        // (theta: how far inside its box a row with a slack starts, as a share of the box's width.  0.05 until round 6; 0.2 costs a bench QP 9.2 instead of 10.2
+        //  iterations, -6 ... -9 % of a sorted wavefront's bytes at 60 ... 1000 waypoints - profiles/r06ag_lq_constant_sweep_emulation.txt)
+        const double theta = 0.2, mu0 = 0.1;
         double x[3] = {x0[0], x0[1], x0[2]};
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         auto start = [&](double v, double lo, double up, bool slack) {
