@@ -601,6 +601,9 @@ def main():
             "plain_admm_eps_1e-4": dict(timed(capi.default_params(eps_abs=1e-4, eps_rel=1e-4), False, max(3, sec_steps // 8)),
                                         setting="the literal metric: OSQP termination at eps_abs = eps_rel = 1e-4, OSQP defaults, no polish "
                                                 "(pqp_default_params); paths 1e-5..2e-3 from the optimum"),
+            "plain_admm_eps_1e-4_as_the_headline_runs": dict(timed(capi.default_params(eps_abs=1e-4, eps_rel=1e-4), cost_order, max(6, sec_steps // 8), inflight=nfl),
+                                        setting="the literal metric under the headline's launch conditions: two batches in flight, QPs started most-expensive-first by the "
+                                                "previous step's cost (a launch of 1024 QPs on 512 slots otherwise lasts as long as its slowest QP: 1100 iterations against 247 on average)") if nfl > 1 else None,
             "reference_setting_eps_2e-3": dict(timed(capi.default_params(), False, max(3, sec_steps // 4)),
                                                setting="what base_solver.cpp:61-62 runs: eps 2e-3, OSQP defaults, no polish; paths 2e-4..2e-2 from the optimum"),
         }
@@ -686,6 +689,8 @@ def main():
                     res_w[name] = {"value": bb / tb, "unit": "paths/s", "ms_per_step": tb * 1e3, "kernel_ms": kms, "solved": int((stt == 1).sum().item()),
                                    "out_sha1": hashlib.sha1(o.cpu().numpy().tobytes()).hexdigest()[:16]}
                     if thr:
+                        inf_timed = inf.cpu().numpy()          # the counts of the last TIMED launch (a sorted one): the roofline's bytes below belong to kms
+                        res_w[name]["riccati_sweeps_mean"] = float(inf_timed[:, 6].mean())
                         # the same with PQP_OPT_CARRY_CYCLES over 4 jittered variants of the batch (the scenarios one planning cycle later)
                         var_b = []
                         for v in range(4):
@@ -733,7 +738,7 @@ def main():
                         del var_b
                         hh.solve_device(bb, 80, t_ref, t_b, t_s, o, passes=1, status=stt, info=inf)
                         hh.sync()
-                        ab = stream_algorithmic_bytes(80, inf.cpu().numpy(), direct=stream_direct_rounds(inf.cpu().numpy()))
+                        ab = stream_algorithmic_bytes(80, inf_timed, direct=stream_direct_rounds(inf_timed))
                         res_w[name]["roofline"] = {"bound": "hbm", "kernel": "path_stream_kernel", "algorithmic_bytes_per_launch": ab, "achieved": ab / (kms * 1e-3) / 1e9,
                                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                                    "note": "bytes the algorithm streams through its HBM workspace for the sweeps each QP ran (DESIGN.md 3b) / kernel time; "
