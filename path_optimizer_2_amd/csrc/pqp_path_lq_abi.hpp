@@ -51,7 +51,8 @@ struct Args {
     // iterations / active-set rounds per pass in the previous solve: the 64 lanes of a wavefront run the maxima of their phases in lock-step) or nullptr;
     // what the launch records for the next one: every QP's phase key, the key histogram (+ [kOrderBins]: wavefronts finished), and the next map -
     // written by the last wavefront to finish (pqp_path_stream.hip)
-    const int32_t* order;       // [batch] or nullptr
+    const int32_t* order;       // [batch] or nullptr.  The solver also asks WHETHER the launch is sorted: its re-linearised passes then begin with active-set rounds on the
+                                // previous pass's set (lq::kDirectRounds, pqp_path_lq.hpp) - the phase key's third field keeps the QPs that fall back in wavefronts of their own
     int32_t* key_out;           // [batch] or nullptr
     int32_t* hist;              // [kOrderBins + 1]
     int32_t* order_next;        // [batch]
