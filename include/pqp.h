@@ -242,6 +242,8 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      (path_optimizer.cpp:138).  The optimum returned is the same (unique; it agrees with the cold solve to the
  *                                      1e-7 of the KKT test); on scenarios that moved by 5 %: configs[1] 4.0 M instead of 3.1 M paths/s and no stragglers
  *                                      (profiles/r03n_seed_sweep.txt, r03y_seed_sweep.txt); lane-per-QP kernel 14 -> 9 interior-point iterations per path.
+ *                                      (On that kernel the option switches the sorted launches of PQP_OPT_ORDER_BY_COST off - a slot's workspace belongs to the QP that sat there - and
+ *                                      since round 6 those are the faster of the two from 768 wavefronts on: 65 536 QPs 7.8 M paths/s sorted against 6.6 M carried, profiles/r06am_bench_n1.json.)
  *                                      A QP that differs wildly from its slot's previous one is still solved (the start is then merely poor).
  *                                      Value k = 2..64 ("tails", lane-per-waypoint kernel, needs PQP_OPT_ORDER_BY_COST): only the QPs that were among the most
  *                                      expensive 1 / k of the handle's previous solve of the shape start from their previous optimum, all others start
