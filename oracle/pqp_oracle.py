@@ -7,6 +7,8 @@ through robotology/osqp-eigen (install_deps.sh:116).  Neither is present in this
 results instead: uniqueness of the QP optimum + a solver-independent KKT certificate
 (`kkt_certificate` below) + agreement of two independent formulations (this file: full quasi-definite
 KKT via sparse LU; oracle/pqp_oracle.c: reduced banded Cholesky).
+Round 6: the OPTIMUM (not OSQP's iterates) is pinned against a third-party solver - HiGHS's QP solver as bundled
+with scipy, oracle/highs_qp.py, tests/test_highs_pin.py: every variable of every QP assembled here to 2e-7.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 Nothing in the product path (path_optimizer_2_amd/, include/) may.
