@@ -168,6 +168,26 @@ def cpu_baseline(make_sample, n, eps, budget_s):
         base["same_algorithm_on_host"] = LE.timed_rate(make_sample, n, 0.3 * budget_s)
     except Exception as e:
         base["same_algorithm_on_host"] = {"error": f"{type(e).__name__}: {e}"}
+    # a third line, for scale: a third-party production QP solver on the reference's QPs (HiGHS's active-set QP solver as bundled with scipy,
+    # oracle/highs_qp.py - the solver tests/test_highs_pin.py pins the optimum against), one thread, both passes of optimizePath, exact optimum
+    try:
+        import highs_qp as HQ
+        import pqp_oracle as ON
+        if HQ.available():
+            smp = make_sample(6)
+            t0 = time.perf_counter()
+            for q in range(6):
+                lin = ON.first_linearization(smp["ref"][q])
+                for _ in range(2):
+                    Pd, A, lo, up, sz = ON.assemble_path_qp(smp["ref"][q], lin, smp["bounds"][q], smp["scal"][q])
+                    xq, _, _ = HQ.solve_qp(Pd, np.zeros(sz["vars"]), A, lo, up)
+                    lin = ON.unpack_path(xq, smp["ref"][q])[:, 3:6].copy()
+            dtq = time.perf_counter() - t0
+            base["third_party_qp_solver_single_thread"] = {"value": 6 / dtq, "unit": "paths/s", "cores": 1, "solver": HQ.version() + ", active-set QP solver",
+                                                           "sample": f"6 paths (N={n}) in {dtq:.1f} s: the oracle's line-by-line assembly of the reference's QP (numpy, included in the time) + HiGHS, "
+                                                                     "two passes per path, exact optimum"}
+    except Exception as e:
+        base["third_party_qp_solver_single_thread"] = {"error": f"{type(e).__name__}: {e}"}
     return base
 
 
