@@ -10,6 +10,10 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "pqp_oracle.c")
 LIB = os.path.join(HERE, "libpqp_oracle.so")
+# PQP_SANITIZED_LIBS=<dir>: load a prebuilt (-fsanitize=address,undefined) library from there instead (tools/sanitize_cpu.sh)
+_SANITIZED = os.environ.get("PQP_SANITIZED_LIBS")
+if _SANITIZED:
+    LIB = os.path.join(_SANITIZED, "libpqp_oracle.so")
 
 
 class PqoParams(C.Structure):
@@ -29,7 +33,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB) or os.path.getmtime(SRC) > os.path.getmtime(LIB):
+    if not _SANITIZED and (not os.path.exists(LIB) or os.path.getmtime(SRC) > os.path.getmtime(LIB)):
         subprocess.run(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-o", LIB, SRC, "-lm"], check=True)
     _lib = C.CDLL(LIB)
     return _lib

@@ -13,6 +13,9 @@ SRC = os.path.join(HERE, "emu", "lane_emu.cpp")
 # PQP_EMU_DIET=1: the emulation of the register-diet contexts (pass constants in the shared-memory array, Ruiz vectors parked)
 DIET = os.environ.get("PQP_EMU_DIET", "0") == "1"
 LIB = os.path.join(HERE, "emu", "liblane_emu_diet.so" if DIET else "liblane_emu.so")
+# PQP_SANITIZED_LIBS=<dir>: load a prebuilt (-fsanitize=address,undefined) library from there instead (tools/sanitize_cpu.sh)
+if os.environ.get("PQP_SANITIZED_LIBS"):
+    LIB = os.path.join(os.environ["PQP_SANITIZED_LIBS"], "liblane_emu.so")
 _DEPS = [SRC, os.path.join(ROOT, "path_optimizer_2_amd", "csrc", "pqp_path_lane.hpp"), os.path.join(ROOT, "path_optimizer_2_amd", "csrc", "pqp_banded_qp.hpp"),
          os.path.join(ROOT, "path_optimizer_2_amd", "csrc", "pqp_defaults.hpp"), os.path.join(ROOT, "include", "pqp.h")]
 _lib = None
@@ -22,7 +25,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in _DEPS):
+    if not os.environ.get("PQP_SANITIZED_LIBS") and (not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in _DEPS)):
         subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", f"-DPQP_EMU_DIET={1 if DIET else 0}", "-o", LIB, SRC], check=True)
     _lib = C.CDLL(LIB)
     return _lib

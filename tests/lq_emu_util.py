@@ -11,6 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "emu", "lq_emu.cpp")
 LIB = os.path.join(HERE, "emu", "liblq_emu.so")
+# PQP_SANITIZED_LIBS=<dir>: load a prebuilt (-fsanitize=address,undefined) library from there instead (tools/sanitize_cpu.sh)
+if os.environ.get("PQP_SANITIZED_LIBS"):
+    LIB = os.path.join(os.environ["PQP_SANITIZED_LIBS"], "liblq_emu.so")
 _DEPS = [SRC] + [os.path.join(ROOT, "path_optimizer_2_amd", "csrc", f) for f in ("pqp_path_lq.hpp", "pqp_path_lane.hpp", "pqp_defaults.hpp")] + \
         [os.path.join(ROOT, "include", "pqp.h")]
 _lib = None
@@ -19,7 +22,7 @@ _lib = None
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in _DEPS):
+        if not os.environ.get("PQP_SANITIZED_LIBS") and (not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in _DEPS)):
             subprocess.run(["g++", "-O3", "-march=native", "-fopenmp", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC], check=True)
         _lib = C.CDLL(LIB)
     return _lib
