@@ -199,13 +199,28 @@ struct Solver {
 
     PQP_HD Solver(const Args& a_, int qp_, WS ws_) : a(a_), ws(ws_), qp(qp_) {}
 
-    PQP_HD Stage load_stage(int i) const {
+    // where a sweep's per-waypoint record is read from: the workspace itself, or the wavefront's LDS slot the record was staged into ahead of time
+    // (WS::kStageDepth > 0: pqp_path_stream.hip).  A slot is laid out like a workspace block, so a field keeps its index whatever waypoint it came from.
+    struct FromWs {
+        const WS w;
+        PQP_HD double ld(int f, int i) const { return w.ld(f, i); }
+        PQP_HD float ldf(int f, int i) const { return w.ldf(f, i); }
+    };
+    struct FromSlot {
+        const WS w;
+        int slot;
+        PQP_HD double ld(int f, int) const { return w.slot_ld(slot, f); }
+        PQP_HD float ldf(int f, int) const { return w.slot_ldf(slot, f); }
+    };
+    template <class Src>
+    PQP_HD Stage load_stage(const Src& src, int i) const {
         Stage s;
-        s.m10 = ws.ld(D_M10, i); s.c1 = ws.ld(D_C1, i); s.ds = ws.ld(D_DS, i);
+        s.m10 = src.ld(D_M10, i); s.c1 = src.ld(D_C1, i); s.ds = src.ld(D_DS, i);
         if (lin0) { s.m00 = 1.0; s.m01 = s.ds; s.m11 = 1.0; s.m12 = s.ds; s.c0 = 0.0; }      // (3 of the 8 doubles: the first pass's share of the traffic)
-        else { s.m00 = ws.ld(D_M00, i); s.m01 = ws.ld(D_M01, i); s.m11 = ws.ld(D_M11, i); s.m12 = ws.ld(D_M12, i); s.c0 = ws.ld(D_C0, i); }
+        else { s.m00 = src.ld(D_M00, i); s.m01 = src.ld(D_M01, i); s.m11 = src.ld(D_M11, i); s.m12 = src.ld(D_M12, i); s.c0 = src.ld(D_C0, i); }
         return s;
     }
+    PQP_HD Stage load_stage(int i) const { return load_stage(FromWs{ws}, i); }
 
     // ---- stage data of a pass: the transition rows around the linearisation point (base_solver.cpp:165-186) -----------------------
     // src 0: (0, 0, k_ref) (path_optimizer.cpp:128-137), 1: a.lin, 2: the previous pass's optimum (F_X*)
@@ -306,6 +321,43 @@ struct Solver {
         }
     }
     static constexpr int kDepth = 1;         // (2 / 3 / 4 / 6 waypoints ahead: slower at every depth - spills; profiles/r03a_stream_first.txt)
+    // The same pipelines with the records staged in LDS (round 6): `stage(slot, i)` issues the copies of waypoint i's record into a slot, `load(slot, i)`
+    // reads it from there when its turn has come - D waypoints ahead without a register held for them.  Before a record is read the wavefront
+    // waits until at most the copies issued AFTER that record's are outstanding (vector memory returns in order): C per later record.
+    template <int D, int C, int S, class In, class Stg, class Load, class Body>
+    PQP_HD void sweep_down_staged(int i0, int i_last, Stg stage, Load load, Body body) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) if (i0 - k >= i_last) stage(k, i0 - k);
+        for (int i = i0; i >= i_last; i -= D) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const int ii = i - k;
+                if (ii >= i_last) {
+                    ws.template staged_wait<C, S>(ii - i_last < D - 1 ? ii - i_last : D - 1);
+                    const In cur = load(k, ii);
+                    if (ii - D >= i_last) stage(k, ii - D);
+                    body(ii, cur);
+                }
+            }
+        }
+    }
+    template <int D, int C, int S, class In, class Stg, class Load, class Body>
+    PQP_HD void sweep_up_staged(int i0, int i_end, Stg stage, Load load, Body body) {          // i0 <= i < i_end
+#pragma unroll
+        for (int k = 0; k < D; ++k) if (i0 + k < i_end) stage(k, i0 + k);
+        for (int i = i0; i < i_end; i += D) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const int ii = i + k;
+                if (ii < i_end) {
+                    ws.template staged_wait<C, S>(i_end - 1 - ii < D - 1 ? i_end - 1 - ii : D - 1);
+                    const In cur = load(k, ii);
+                    if (ii + D < i_end) stage(k, ii + D);
+                    body(ii, cur);
+                }
+            }
+        }
+    }
 
     // what a sweep reads per waypoint
     struct Box { double lof, upf, lor, upr; };
@@ -313,13 +365,16 @@ struct Solver {
     struct BackIn { Stage s; Box b; IpmRows r; float dgf, dgr, dgk; double act, lam; };
     struct FwdIn { Stage s; double K0, K1, K2, kk; Box b; IpmRows r; double act, lam; double xo[3]; };     // stage / gains of transition i, rows of waypoint i + 1
 
-    PQP_HD Box load_box(int i) const { Box b; b.lof = ws.ld(D_LOF, i); b.upf = ws.ld(D_UPF, i); b.lor = ws.ld(D_LOR, i); b.upr = ws.ld(D_UPR, i); return b; }
-    PQP_HD IpmRows load_rows(int i) const {
+    template <class Src>
+    PQP_HD Box load_box(const Src& src, int i) const { Box b; b.lof = src.ld(D_LOF, i); b.upf = src.ld(D_UPF, i); b.lor = src.ld(D_LOR, i); b.upr = src.ld(D_UPR, i); return b; }
+    PQP_HD Box load_box(int i) const { return load_box(FromWs{ws}, i); }
+    template <class Src>
+    PQP_HD IpmRows load_rows(const Src& src, int i) const {
         IpmRows r;
-        r.tlf = ws.ldf(S_TLF, i); r.tuf = ws.ldf(S_TUF, i); r.zlf = ws.ldf(S_ZLF, i); r.zuf = ws.ldf(S_ZUF, i);
-        r.tlr = ws.ldf(S_TLR, i); r.tur = ws.ldf(S_TUR, i); r.zlr = ws.ldf(S_ZLR, i); r.zur = ws.ldf(S_ZUR, i);
-        r.tlk = ws.ldf(S_TLK, i); r.tuk = ws.ldf(S_TUK, i); r.zlk = ws.ldf(S_ZLK, i); r.zuk = ws.ldf(S_ZUK, i);
-        r.gk = ws.ld(D_GK, i);
+        r.tlf = src.ldf(S_TLF, i); r.tuf = src.ldf(S_TUF, i); r.zlf = src.ldf(S_ZLF, i); r.zuf = src.ldf(S_ZUF, i);
+        r.tlr = src.ldf(S_TLR, i); r.tur = src.ldf(S_TUR, i); r.zlr = src.ldf(S_ZLR, i); r.zur = src.ldf(S_ZUR, i);
+        r.tlk = src.ldf(S_TLK, i); r.tuk = src.ldf(S_TUK, i); r.zlk = src.ldf(S_ZLK, i); r.zuk = src.ldf(S_ZUK, i);
+        r.gk = src.ld(D_GK, i);
         return r;
     }
     // a collision row's state: its value is lo + t_l by definition (the slack absorbs the rest), t_u carries its own rounding
@@ -328,27 +383,75 @@ struct Solver {
     PQP_HD void store_f(int i, const Row& r) const { ws.stf(S_TLF, i, r.tl); ws.stf(S_TUF, i, r.tu); ws.stf(S_ZLF, i, r.zl); ws.stf(S_ZUF, i, r.zu); }
     PQP_HD void store_r(int i, const Row& r) const { ws.stf(S_TLR, i, r.tl); ws.stf(S_TUR, i, r.tu); ws.stf(S_ZLR, i, r.zl); ws.stf(S_ZUR, i, r.zu); }
     PQP_HD void store_k(int i, const Row& r) const { ws.st(D_GK, i, r.g); ws.stf(S_TLK, i, r.tl); ws.stf(S_TUK, i, r.tu); ws.stf(S_ZLK, i, r.zl); ws.stf(S_ZUK, i, r.zu); }
-    template <int MODE>
-    PQP_HD BackIn load_back(int i) const {           // transition i (i < n - 1) and the rows of waypoint i (i > 0)
+    template <int MODE, class Src>
+    PQP_HD BackIn load_back(const Src& src, int i) const {           // transition i (i < n - 1) and the rows of waypoint i (i > 0)
         BackIn in;
-        if (i < n - 1) in.s = load_stage(i);
+        if (i < n - 1) in.s = load_stage(src, i);
         if (i > 0) {
-            in.b = load_box(i);
-            if (MODE == MODE_IPM || MODE == MODE_GUESS) { in.r = load_rows(i); in.dgf = ws.ldf(S_DGF, i); in.dgr = ws.ldf(S_DGR, i); in.dgk = ws.ldf(S_DGK, i); }
-            if (MODE == MODE_SET) { in.act = ws.ld(D_ACT, i); in.lam = ws.ld(D_LAM, i); }
+            in.b = load_box(src, i);
+            if (MODE == MODE_IPM || MODE == MODE_GUESS) { in.r = load_rows(src, i); in.dgf = src.ldf(S_DGF, i); in.dgr = src.ldf(S_DGR, i); in.dgk = src.ldf(S_DGK, i); }
+            if (MODE == MODE_SET) { in.act = src.ld(D_ACT, i); in.lam = src.ld(D_LAM, i); }
         }
         return in;
     }
-    template <int MODE>
-    PQP_HD FwdIn load_fwd(int i) const {
+    template <int MODE, class Src>
+    PQP_HD FwdIn load_fwd(const Src& src, int i) const {
         FwdIn in;
-        in.s = load_stage(i);
-        in.K0 = ws.ld(D_K0, i); in.K1 = ws.ld(D_K1, i); in.K2 = ws.ld(D_K2, i); in.kk = ws.ld(D_KK, i);
-        in.b = load_box(i + 1);
-        if (MODE == MODE_IPM) in.r = load_rows(i + 1);
-        if (MODE == MODE_SET || MODE == MODE_SET_GUARDED) { in.act = ws.ld(D_ACT, i + 1); in.lam = ws.ld(D_LAM, i + 1); }
-        if (MODE == MODE_SET_GUARDED) { in.xo[0] = ws.ld(D_X0, i + 1); in.xo[1] = ws.ld(D_X1, i + 1); in.xo[2] = ws.ld(D_X2, i + 1); }      // the point the set was taken from
+        in.s = load_stage(src, i);
+        in.K0 = src.ld(D_K0, i); in.K1 = src.ld(D_K1, i); in.K2 = src.ld(D_K2, i); in.kk = src.ld(D_KK, i);
+        in.b = load_box(src, i + 1);
+        if (MODE == MODE_IPM) in.r = load_rows(src, i + 1);
+        if (MODE == MODE_SET || MODE == MODE_SET_GUARDED) { in.act = src.ld(D_ACT, i + 1); in.lam = src.ld(D_LAM, i + 1); }
+        if (MODE == MODE_SET_GUARDED) { in.xo[0] = src.ld(D_X0, i + 1); in.xo[1] = src.ld(D_X1, i + 1); in.xo[2] = src.ld(D_X2, i + 1); }      // the point the set was taken from
         return in;
+    }
+    // ---- staging (WS::kStageDepth > 0) ----------------------------------------------------------------------------------------------
+    // What load_back / load_fwd read, as 16-byte-per-lane chunks of a workspace block (chunk c = double fields 2c, 2c + 1; the float fields fill
+    // doubles 22 .. 29) copied into LDS slot `slot` by LDS-direct loads: no register is tied up while they are in flight, so the records of
+    // kStageDepth waypoints ahead can be.  A forward record takes its transition and gains from block i and its rows from block i + 1 -
+    // different fields, so one slot holds both.  kBackChunks / kFwdChunks: copies per record (a lower bound: it sizes the wait).
+    //   chunks: 0-3 transition (the first pass: 1 and 3), 4-5 boxes, 6-7 gains, 8 X0 X1, 9 X2 GK, 10 ACT LAM, 11-14 the float fields
+    PQP_HD void stage_transition(int slot, int i) const {
+        if (!lin0) { ws.stage_chunk(slot, 0, i); ws.stage_chunk(slot, 2, i); }
+        ws.stage_chunk(slot, 1, i); ws.stage_chunk(slot, 3, i);
+    }
+    template <int MODE> static constexpr int back_chunks() { return 2 + 2 + ((MODE == MODE_IPM || MODE == MODE_GUESS) ? 5 : 0) + (MODE == MODE_SET ? 1 : 0); }
+    template <int MODE>
+    PQP_HD void stage_back(int slot, int i) const {
+        stage_transition(slot, i);
+        ws.stage_chunk(slot, 4, i); ws.stage_chunk(slot, 5, i);
+        if (MODE == MODE_IPM || MODE == MODE_GUESS) { ws.stage_chunk(slot, 9, i); for (int c = 11; c <= 14; ++c) ws.stage_chunk(slot, c, i); }
+        if (MODE == MODE_SET) ws.stage_chunk(slot, 10, i);
+    }
+    template <int MODE> static constexpr int fwd_chunks() { return 2 + 2 + 2 + (MODE == MODE_IPM ? 5 : 0) + ((MODE == MODE_SET || MODE == MODE_SET_GUARDED) ? 1 : 0) + (MODE == MODE_SET_GUARDED ? 2 : 0); }
+    template <int MODE>
+    PQP_HD void stage_fwd(int slot, int i) const {
+        stage_transition(slot, i);
+        ws.stage_chunk(slot, 6, i); ws.stage_chunk(slot, 7, i);
+        ws.stage_chunk(slot, 4, i + 1); ws.stage_chunk(slot, 5, i + 1);
+        if (MODE == MODE_IPM) { ws.stage_chunk(slot, 9, i + 1); for (int c = 11; c <= 14; ++c) ws.stage_chunk(slot, c, i + 1); }
+        if (MODE == MODE_SET || MODE == MODE_SET_GUARDED) ws.stage_chunk(slot, 10, i + 1);
+        if (MODE == MODE_SET_GUARDED) { ws.stage_chunk(slot, 8, i + 1); ws.stage_chunk(slot, 9, i + 1); }
+    }
+    // EXPERIMENT (PQP_LAX_WAIT): the stores a body issues when every row of its waypoint is live - NOT a lower bound
+    template <int MODE> static constexpr int back_stores() { return MODE == MODE_IPM ? 17 : (MODE == MODE_GUESS ? 6 : 4); }
+    template <int MODE> static constexpr int fwd_stores() { return MODE == MODE_INIT ? 13 : (MODE == MODE_IPM ? 3 : 5); }
+    // a sweep over staged records: the one function the sweeps below call
+    template <int MODE, class Body>
+    PQP_HD void sweep_back(Body body) {
+        if constexpr (WS::kStageDepth > 0)
+            sweep_down_staged<WS::kStageDepth, back_chunks<MODE>(), back_stores<MODE>(), BackIn>(n - 1, 0, [&](int slot, int i) { stage_back<MODE>(slot, i); },
+                                                                           [&](int slot, int i) { return load_back<MODE>(FromSlot{ws, slot}, i); }, body);
+        else
+            sweep_down<kDepth, BackIn>(n - 1, 0, [&](int i) { return load_back<MODE>(FromWs{ws}, i); }, body);
+    }
+    template <int MODE, class Body>
+    PQP_HD void sweep_fwd(Body body) {
+        if constexpr (WS::kStageDepth > 0)
+            sweep_up_staged<WS::kStageDepth, fwd_chunks<MODE>(), fwd_stores<MODE>(), FwdIn>(0, n - 1, [&](int slot, int i) { stage_fwd<MODE>(slot, i); },
+                                                                       [&](int slot, int i) { return load_fwd<MODE>(FromSlot{ws, slot}, i); }, body);
+        else
+            sweep_up<kDepth, FwdIn>(0, n - 1, [&](int i) { return load_fwd<MODE>(FromWs{ws}, i); }, body);
     }
 
     // ---- one backward sweep -------------------------------------------------------------------------------------------------------
@@ -446,7 +549,7 @@ struct Solver {
         Value v;
         for (int k = 0; k < 6; ++k) v.P[k] = 0.0;
         v.p[0] = v.p[1] = v.p[2] = 0.0;
-        sweep_down<kDepth, BackIn>(n - 1, 0, [&](int i) { return load_back<MODE>(i); }, [&](int i, const BackIn& in) {
+        sweep_back<MODE>([&](int i, const BackIn& in) {
             if (i < n - 1) {
                 double K[3], kk;
                 riccati_step(in.s, w_u, v, K, kk);
@@ -487,7 +590,7 @@ struct Solver {
             acc.res = fmax(acc.res, fmax(fabs(r.g - lo - r.tl), fabs(up - r.g - r.tu)));
             return r;
         };
-        sweep_up<kDepth, FwdIn>(0, n - 1, [&](int i) { return load_fwd<MODE_INIT>(i); }, [&](int i, const FwdIn& in) {
+        sweep_fwd<MODE_INIT>([&](int i, const FwdIn& in) {
             advance(in, x);
             const int j = i + 1;
             const double lof = in.b.lof, upf = in.b.upf, lor = in.b.lor, upr = in.b.upr;
@@ -556,7 +659,7 @@ struct Solver {
     PQP_SWEEP void forward_ipm(double sm) {
         double x[3] = {x0[0], x0[1], x0[2]};
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        sweep_up<kDepth, FwdIn>(0, n - 1, [&](int i) { return load_fwd<MODE_IPM>(i); }, [&](int i, const FwdIn& in) {
+        sweep_fwd<MODE_IPM>([&](int i, const FwdIn& in) {
             advance(in, x);
             const int j = i + 1;
             const double lof = in.b.lof, upf = in.b.upf, lor = in.b.lor, upr = in.b.upr;
@@ -641,7 +744,7 @@ struct Solver {
                 slope[c] += w_s * (truth - model) * dv;
             }
         };
-        sweep_up<kDepth, FwdIn>(0, n - 1, [&](int i) { return load_fwd<GUARDED ? MODE_SET_GUARDED : MODE_SET>(i); }, [&](int i, const FwdIn& in) {
+        sweep_fwd<GUARDED ? MODE_SET_GUARDED : MODE_SET>([&](int i, const FwdIn& in) {
             advance(in, x);
             const int j = i + 1;
             if (!GUARDED) { ws.st(D_X0, j, x[0]); ws.st(D_X1, j, x[1]); ws.st(D_X2, j, x[2]); }
@@ -897,14 +1000,16 @@ struct Solver {
 
 // a lane's view of its wavefront's workspace block (layout: pqp_path_lq_abi.hpp)
 struct StridedWs {
+    static constexpr int kStageDepth = 0;      // records are prefetched into registers (the host emulation; the device: StagedWs, pqp_path_stream.hip)
     double* block;          // the wavefront's block
     int lane;
     int lanes;              // lanes per block: 64 on the device, 1 in the host emulation
-    PQP_HD double ld(int f, int i) const { return block[((size_t)i * kBlockDoubles + f) * lanes + lane]; }
-    PQP_HD void st(int f, int i, double v) const { block[((size_t)i * kBlockDoubles + f) * lanes + lane] = v; }
-    PQP_HD float* floats(int i) const { return reinterpret_cast<float*>(block + ((size_t)i * kBlockDoubles + kFieldsD) * lanes); }
-    PQP_HD float ldf(int f, int i) const { return floats(i)[(size_t)f * lanes + lane]; }
-    PQP_HD void stf(int f, int i, double v) const { floats(i)[(size_t)f * lanes + lane] = (float)v; }
+    PQP_HD size_t chunk_at(int c, int i) const { return (((size_t)i * kBlockChunks + c) * lanes + lane) * 2; }       // this lane's 16 bytes of chunk c, in doubles
+    PQP_HD double ld(int f, int i) const { return block[chunk_at(f >> 1, i) + (f & 1)]; }
+    PQP_HD void st(int f, int i, double v) const { block[chunk_at(f >> 1, i) + (f & 1)] = v; }
+    PQP_HD float* floats(int f, int i) const { return reinterpret_cast<float*>(block + chunk_at(kFieldsD / 2 + (f >> 2), i)) + (f & 3); }
+    PQP_HD float ldf(int f, int i) const { return *floats(f, i); }
+    PQP_HD void stf(int f, int i, double v) const { *floats(f, i) = (float)v; }
 };
 
 }  // namespace lq

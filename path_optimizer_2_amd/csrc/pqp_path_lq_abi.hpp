@@ -8,8 +8,11 @@
 namespace pqp {
 namespace lq {
 
-// Workspace: per waypoint and lane kFieldsD doubles followed by kFieldsF floats; element (waypoint i, field f) of lane j of a
-// wavefront's block sits at block[(i * kBlockDoubles + f) * 64 + j] (doubles) resp. ((float*)(block + (i * kBlockDoubles + kFieldsD) * 64))[f * 64 + j].
+// Workspace: per waypoint and lane kFieldsD doubles followed by kFieldsF floats, in 16-byte CHUNKS (two doubles / four floats) that stay together:
+// chunk c of (waypoint i, lane j) of a wavefront's block sits at block[((i * kBlockChunks + c) * 64 + j) * 2 .. + 1] - double field f is part f & 1 of
+// chunk f >> 1, float field f is float f & 3 of chunk kFieldsD / 2 + (f >> 2).  A wavefront's access to a chunk is one contiguous kilobyte, and a
+// lane's share of it is one 16-byte piece: what an LDS-direct load (global_load_lds_dwordx4) copies per lane, whatever waypoint each lane is at
+// (round 6; before: [field][lane], 8-byte pieces).
 // fp64: everything an ACTIVE-SET round reads or writes (problem data, gains, the point) - those rounds return the result.  fp32: what only
 // the interior-point rounds exchange between their sweeps (slacks, multipliers, row steps): they only have to predict the active set.
 enum FieldD {
@@ -29,7 +32,8 @@ enum FieldF {
     kFieldsF
 };
 constexpr int kBlockDoubles = kFieldsD + kFieldsF / 2;            // 30 doubles = 240 bytes per waypoint and QP
-static_assert(kFieldsF % 2 == 0, "the float fields fill whole doubles");
+constexpr int kBlockChunks = kBlockDoubles / 2;                   // 15 chunks of 16 bytes
+static_assert(kFieldsD % 2 == 0 && kFieldsF % 4 == 0, "the fields fill whole 16-byte chunks");
 
 // phase key of a QP: interior-point iterations of the first pass (5 bits), active-set rounds of the first pass (3), iterations (4) and rounds (3) of the
 // re-linearised pass - what a wavefront runs in lock-step, most significant first
