@@ -25,8 +25,8 @@ enum FieldD {
     kFieldsD
 };
 enum FieldF {
-    S_DGF = 0, S_DGR, S_DGK,                                       // row steps of the last interior-point roll-out
-    S_TLF, S_TUF, S_ZLF, S_ZUF, S_TLR, S_TUR, S_ZLR, S_ZUR, S_TLK, S_TUK, S_ZLK, S_ZUK,     // slacks and multipliers of the three rows
+    S_TLF = 0, S_TUF, S_ZLF, S_ZUF, S_TLR, S_TUR, S_ZLR, S_ZUR, S_TLK, S_TUK, S_ZLK, S_ZUK,     // slacks and multipliers of the three rows: one 16-byte chunk per row
+    S_DGF, S_DGR, S_DGK,                                           // row steps of the last interior-point roll-out
     S_PAD,      // (the gains stay fp64 in every round: an fp32 gain times a state of order 1 is 1e-8 of noise in a row value, more than the slack
                 // of a tightly active row near the end of the interior-point rounds - the steps then shrink to nothing)
     kFieldsF
