@@ -52,7 +52,7 @@ def _solve_once(P, q, A, lo, up, tol):
     h.run()
     status = h.modelStatusToString(h.getModelStatus())
     if status != "Optimal":
-        raise RuntimeError(f"HiGHS: {status}")
+        return None, None, status
     sol = h.getSolution()
     # HiGHS: row dual = d objective / d row activity bound (>= 0 at a lower bound for a minimisation); OSQP's y is its negative
     return np.array(sol.col_value), -np.array(sol.row_dual), h.getObjectiveValue()
@@ -68,15 +68,18 @@ def solve_qp(P, q, A, lo, up, tol=1e-9, tries=6):
     P = sp.csc_matrix(sp.diags(np.asarray(P, dtype=np.float64)) if np.ndim(P) == 1 else sp.csc_matrix(P))
     q = np.asarray(q, dtype=np.float64); lo = np.asarray(lo, dtype=np.float64); up = np.asarray(up, dtype=np.float64)
     rng = np.random.default_rng(20260926)
-    worst = None
+    worst = float("nan")
     for t in range(tries):
         rp = np.arange(m) if t == 0 else rng.permutation(m)
         cp = np.arange(n) if t == 0 else rng.permutation(n)
         x2, y2, obj = _solve_once(sp.csc_matrix(P[cp][:, cp]), q[cp], sp.csc_matrix(A[rp][:, cp]), lo[rp], up[rp], tol)
+        if x2 is None:          # (its active-set solver gave up in this ordering - seen once in ~200 path QPs: "Unknown" - the next ordering)
+            worst = obj
+            continue
         x = np.empty(n); x[cp] = x2
         y = np.empty(m); y[rp] = y2
         Ax = A @ x
         worst = float(np.maximum(lo - Ax, Ax - up).max())
         if worst <= 100.0 * tol:
             return x, y, obj
-    raise RuntimeError(f"HiGHS: no feasible 'Optimal' point in {tries} orderings (rows missed by {worst:.1e})")
+    raise RuntimeError(f"HiGHS: no feasible 'Optimal' point in {tries} orderings (last: {worst if isinstance(worst, str) else 'rows missed by %.1e' % worst})")
