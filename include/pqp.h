@@ -253,6 +253,12 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      (profiles/r05c_*).
  *                                      The exact TensionSmoother / postSmooth kernels (polish == 1) honour it too: a line's active-set rounds start from
  *                                      the set its slot ended with in the previous solve of the shape (16-31 rounds from the cold start, 2-3 from there).
+ *   PQP_OPT_STREAM_STAGED (default -1 = by launch size)
+ *                                      the lane-per-QP kernel has two forms.  A launch that fills the chip (768 wavefronts = 49 152 QPs or more) is bound by HBM's throughput:
+ *                                      its workspace is laid out [field][lane], every access one contiguous line, a sweep's records prefetched one waypoint ahead in registers.
+ *                                      A launch that leaves SIMDs idle waits for its loads: its workspace is laid out in 16-byte chunks per lane and the sweeps' records are staged in
+ *                                      LDS two waypoints ahead by LDS-direct loads (global_load_lds_dwordx4) - +29 ... 33 % at 24 576 / 32 768 QPs of 80 waypoints one launch at a
+ *                                      time, -3 ... 4 % where the chip is full (profiles/r06au_*).  Same arithmetic, same paths.  0 / 1 force one form (tests, measurements).
  *   PQP_OPT_CHAIN_GRAPH (default 0)    pqp_optimize_path_device replays a captured hipGraph: the third call with the same arguments (pointers, sizes, configuration,
  *                                      parameters of both handles) captures its ~25 launches on the handles' streams, later calls with those arguments are ONE
  *                                      hipGraphLaunch - the gaps between the launches were 13 % of the chain.  Results are bit-identical; any (re)allocation inside
@@ -260,7 +266,7 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      A replay runs on the path handle's stream; it is fenced against the smoother handle's stream on both sides
  *                                      (work the caller enqueues there stays ordered as with plain launches).  Value 2: no fences (-3.6 % time) -
  *                                      the caller guarantees that the smoother handle's stream carries no other work while chains are in flight. */
-typedef enum pqp_option { PQP_OPT_STORE_WARM = 1, PQP_OPT_ORDER_BY_COST = 2, PQP_OPT_RESERVE_CUS = 3, PQP_OPT_STREAM_BATCH = 4, PQP_OPT_CARRY_CYCLES = 5, PQP_OPT_CHAIN_GRAPH = 6 } pqp_option;
+typedef enum pqp_option { PQP_OPT_STORE_WARM = 1, PQP_OPT_ORDER_BY_COST = 2, PQP_OPT_RESERVE_CUS = 3, PQP_OPT_STREAM_BATCH = 4, PQP_OPT_CARRY_CYCLES = 5, PQP_OPT_CHAIN_GRAPH = 6, PQP_OPT_STREAM_STAGED = 7 } pqp_option;
 int pqp_set_option(pqp_handle* h, int option, int value);
 int pqp_get_stream(pqp_handle* h, void** hip_stream);   /* hipStream_t */
 /* The handle's stream is created non-blocking: work the caller enqueued on ANOTHER stream (the inputs of a *_device call produced by

@@ -208,7 +208,7 @@ def _ptr(a):
     return C.c_void_p(int(a))      # raw device pointer (e.g. torch.Tensor.data_ptr())
 
 
-OPT_STORE_WARM, OPT_ORDER_BY_COST, OPT_RESERVE_CUS, OPT_STREAM_BATCH, OPT_CARRY_CYCLES, OPT_CHAIN_GRAPH = 1, 2, 3, 4, 5, 6
+OPT_STORE_WARM, OPT_ORDER_BY_COST, OPT_RESERVE_CUS, OPT_STREAM_BATCH, OPT_CARRY_CYCLES, OPT_CHAIN_GRAPH, OPT_STREAM_STAGED = 1, 2, 3, 4, 5, 6, 7
 def path_interval(value, n):
     """What pqp_params.adaptive_rho_interval / check_termination / polish_every mean for paths of n waypoints: negative values (the production
     setting) stand for "by path length" (csrc/pqp_defaults.hpp path_interval: 5 iterations up to 90 waypoints, 8 beyond)."""

@@ -323,7 +323,7 @@ struct Solver {
     // The same pipelines with the records staged in LDS (round 6): `stage(slot, i)` issues the copies of waypoint i's record into a slot, `load(slot, i)`
     // reads it from there when its turn has come - D waypoints ahead without a register held for them.  Before a record is read the wavefront
     // waits until at most the copies issued AFTER that record's are outstanding (vector memory returns in order): C per later record.
-    template <int D, int C, int S, class In, class Stg, class Load, class Body>
+    template <int D, int C, class In, class Stg, class Load, class Body>
     PQP_HD void sweep_down_staged(int i0, int i_last, Stg stage, Load load, Body body) {
 #pragma unroll
         for (int k = 0; k < D; ++k) if (i0 - k >= i_last) stage(k, i0 - k);
@@ -332,7 +332,7 @@ struct Solver {
             for (int k = 0; k < D; ++k) {
                 const int ii = i - k;
                 if (ii >= i_last) {
-                    ws.template staged_wait<C, S>(ii - i_last < D - 1 ? ii - i_last : D - 1);
+                    ws.template staged_wait<C>(ii - i_last < D - 1 ? ii - i_last : D - 1);
                     const In cur = load(k, ii);
                     if (ii - D >= i_last) stage(k, ii - D);
                     body(ii, cur);
@@ -340,7 +340,7 @@ struct Solver {
             }
         }
     }
-    template <int D, int C, int S, class In, class Stg, class Load, class Body>
+    template <int D, int C, class In, class Stg, class Load, class Body>
     PQP_HD void sweep_up_staged(int i0, int i_end, Stg stage, Load load, Body body) {          // i0 <= i < i_end
 #pragma unroll
         for (int k = 0; k < D; ++k) if (i0 + k < i_end) stage(k, i0 + k);
@@ -349,7 +349,7 @@ struct Solver {
             for (int k = 0; k < D; ++k) {
                 const int ii = i + k;
                 if (ii < i_end) {
-                    ws.template staged_wait<C, S>(i_end - 1 - ii < D - 1 ? i_end - 1 - ii : D - 1);
+                    ws.template staged_wait<C>(i_end - 1 - ii < D - 1 ? i_end - 1 - ii : D - 1);
                     const In cur = load(k, ii);
                     if (ii + D < i_end) stage(k, ii + D);
                     body(ii, cur);
@@ -432,14 +432,11 @@ struct Solver {
         if (MODE == MODE_SET || MODE == MODE_SET_GUARDED) ws.stage_chunk(slot, 10, i + 1);
         if (MODE == MODE_SET_GUARDED) { ws.stage_chunk(slot, 8, i + 1); ws.stage_chunk(slot, 9, i + 1); }
     }
-    // EXPERIMENT (PQP_LAX_WAIT): the stores a body issues when every row of its waypoint is live - NOT a lower bound
-    template <int MODE> static constexpr int back_stores() { return MODE == MODE_IPM ? 17 : (MODE == MODE_GUESS ? 6 : 4); }
-    template <int MODE> static constexpr int fwd_stores() { return MODE == MODE_INIT ? 13 : (MODE == MODE_IPM ? 3 : 5); }
     // a sweep over staged records: the one function the sweeps below call
     template <int MODE, class Body>
     PQP_HD void sweep_back(Body body) {
         if constexpr (WS::kStageDepth > 0)
-            sweep_down_staged<WS::kStageDepth, back_chunks<MODE>(), back_stores<MODE>(), BackIn>(n - 1, 0, [&](int slot, int i) { stage_back<MODE>(slot, i); },
+            sweep_down_staged<WS::kStageDepth, back_chunks<MODE>(), BackIn>(n - 1, 0, [&](int slot, int i) { stage_back<MODE>(slot, i); },
                                                                            [&](int slot, int i) { return load_back<MODE>(FromSlot{ws, slot}, i); }, body);
         else
             sweep_down<kDepth, BackIn>(n - 1, 0, [&](int i) { return load_back<MODE>(FromWs{ws}, i); }, body);
@@ -447,7 +444,7 @@ struct Solver {
     template <int MODE, class Body>
     PQP_HD void sweep_fwd(Body body) {
         if constexpr (WS::kStageDepth > 0)
-            sweep_up_staged<WS::kStageDepth, fwd_chunks<MODE>(), fwd_stores<MODE>(), FwdIn>(0, n - 1, [&](int slot, int i) { stage_fwd<MODE>(slot, i); },
+            sweep_up_staged<WS::kStageDepth, fwd_chunks<MODE>(), FwdIn>(0, n - 1, [&](int slot, int i) { stage_fwd<MODE>(slot, i); },
                                                                        [&](int slot, int i) { return load_fwd<MODE>(FromSlot{ws, slot}, i); }, body);
         else
             sweep_up<kDepth, FwdIn>(0, n - 1, [&](int i) { return load_fwd<MODE>(FromWs{ws}, i); }, body);
@@ -994,12 +991,29 @@ struct Solver {
     }
 };
 
-// a lane's view of its wavefront's workspace block (layout: pqp_path_lq_abi.hpp)
+// a lane's view of its wavefront's workspace block, in either of the two layouts of pqp_path_lq_abi.hpp
+// [field][lane]: every access of a wavefront is one contiguous line of 8 (4) bytes per lane - the launches that fill the chip (and the host emulation)
 struct StridedWs {
-    static constexpr int kStageDepth = 0;      // records are prefetched into registers (the host emulation; the device: StagedWs, pqp_path_stream.hip)
+    static constexpr int kStageDepth = 0;      // records are prefetched into registers, one waypoint ahead
     double* block;          // the wavefront's block
     int lane;
     int lanes;              // lanes per block: 64 on the device, 1 in the host emulation
+    PQP_HD double ld(int f, int i) const { return block[((size_t)i * kBlockDoubles + f) * lanes + lane]; }
+    PQP_HD void st(int f, int i, double v) const { block[((size_t)i * kBlockDoubles + f) * lanes + lane] = v; }
+    PQP_HD float* floats(int i) const { return reinterpret_cast<float*>(block + ((size_t)i * kBlockDoubles + kFieldsD) * lanes); }
+    PQP_HD float ldf(int f, int i) const { return floats(i)[(size_t)f * lanes + lane]; }
+    PQP_HD void stf(int f, int i, double v) const { floats(i)[(size_t)f * lanes + lane] = (float)v; }
+    // (fields that are written together: one access per field here, one per 16-byte chunk in ChunkWs)
+    PQP_HD void st2(int f, int i, double v0, double v1) const { st(f, i, v0); st(f + 1, i, v1); }
+    PQP_HD void stf4(int f, int i, double v0, double v1, double v2, double v3) const { stf(f, i, v0); stf(f + 1, i, v1); stf(f + 2, i, v2); stf(f + 3, i, v3); }
+};
+// [chunk][lane][16 bytes]: what LDS-direct loads can stage (StagedWs, pqp_path_stream.hip) - the launches that leave SIMDs idle, whose sweeps wait for
+// their loads rather than for HBM's throughput
+struct ChunkWs {
+    static constexpr int kStageDepth = 0;
+    double* block;
+    int lane;
+    int lanes;
     PQP_HD size_t chunk_at(int c, int i) const { return (((size_t)i * kBlockChunks + c) * lanes + lane) * 2; }       // this lane's 16 bytes of chunk c, in doubles
     PQP_HD double ld(int f, int i) const { return block[chunk_at(f >> 1, i) + (f & 1)]; }
     PQP_HD void st(int f, int i, double v) const { block[chunk_at(f >> 1, i) + (f & 1)] = v; }

@@ -8,11 +8,12 @@
 namespace pqp {
 namespace lq {
 
-// Workspace: per waypoint and lane kFieldsD doubles followed by kFieldsF floats, in 16-byte CHUNKS (two doubles / four floats) that stay together:
-// chunk c of (waypoint i, lane j) of a wavefront's block sits at block[((i * kBlockChunks + c) * 64 + j) * 2 .. + 1] - double field f is part f & 1 of
-// chunk f >> 1, float field f is float f & 3 of chunk kFieldsD / 2 + (f >> 2).  A wavefront's access to a chunk is one contiguous kilobyte, and a
-// lane's share of it is one 16-byte piece: what an LDS-direct load (global_load_lds_dwordx4) copies per lane, whatever waypoint each lane is at
-// (round 6; before: [field][lane], 8-byte pieces).
+// Workspace: per waypoint and lane kFieldsD doubles followed by kFieldsF floats, in one of two layouts chosen per launch (Args::staged):
+//   [field][lane] (lq::StridedWs): element (waypoint i, field f) of lane j of a wavefront's block sits at block[(i * kBlockDoubles + f) * 64 + j] (doubles) resp.
+//     ((float*)(block + (i * kBlockDoubles + kFieldsD) * 64))[f * 64 + j] - every load / store instruction of a wavefront is one contiguous 512 (256) bytes;
+//   [chunk][lane][16 bytes] (lq::ChunkWs): the fields in 16-byte CHUNKS (two doubles / four floats) that stay together - chunk c of (waypoint i, lane j) sits at
+//     block[((i * kBlockChunks + c) * 64 + j) * 2 .. + 1], double field f is part f & 1 of chunk f >> 1, float field f is float f & 3 of chunk
+//     kFieldsD / 2 + (f >> 2).  A lane's share of a chunk is what an LDS-direct load (global_load_lds_dwordx4) copies per lane, whatever waypoint each lane is at.
 // fp64: everything an ACTIVE-SET round reads or writes (problem data, gains, the point) - those rounds return the result.  fp32: what only
 // the interior-point rounds exchange between their sweeps (slacks, multipliers, row steps): they only have to predict the active set.
 enum FieldD {
@@ -60,6 +61,7 @@ struct Args {
     int32_t* key_out;           // [batch] or nullptr
     int32_t* hist;              // [kOrderBins + 1]
     int32_t* order_next;        // [batch]
+    int staged;                 // 1: the [chunk][lane] layout, the sweeps' records staged in LDS two waypoints ahead (launches that leave SIMDs idle: pqp_kernels.hip)
     int carry;                  // 1: the workspace still holds what this very launch shape left there last time (PQP_OPT_CARRY_CYCLES): a QP's first pass
                                 // starts its interior-point rounds from its slot's previous optimum - the same scenario one planning cycle earlier
     pqp_params prm;

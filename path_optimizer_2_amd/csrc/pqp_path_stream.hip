@@ -10,6 +10,8 @@
 // Replaces: the OSQP solves called at src/solver/base_solver.cpp:88,110 for batches that fill the chip's 65 536 lanes.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "pqp_path_lq.hpp"
 
 namespace pqp {
@@ -23,7 +25,7 @@ namespace pqp {
 // copies may still be in flight; whatever else the wavefront issued in between (its stores) only makes the wait longer, never too short.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"      // (M0 is reserved, and named as clobbered: the compiler then restores its own uses)
-struct StagedWs : lq::StridedWs {
+struct StagedWs : lq::ChunkWs {
     static constexpr int kStageDepth = 2;
     const double* lds;        // the wavefront's slots [kStageDepth][kBlockDoubles][64]
     unsigned lds_addr;        // their LDS byte address
@@ -37,12 +39,8 @@ struct StagedWs : lq::StridedWs {
     __device__ __forceinline__ float slot_ldf(int slot, int f) const { return reinterpret_cast<const float*>(slot_chunk(slot, lq::kFieldsD / 2 + (f >> 2)))[f & 3]; }
     template <int N> __device__ __forceinline__ static void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N < 63 ? N : 63) : "memory"); }
     // before a record is read: at most the copies of `later` (0 .. kStageDepth - 1) records issued after it may be outstanding, C copies each
-    template <int C, int S> __device__ __forceinline__ void staged_wait(int later) const {
-#if defined(PQP_LAX_WAIT)
-        if (later >= 1) wait_vm<C + 2 * S>(); else wait_vm<S>();
-#else
+    template <int C> __device__ __forceinline__ void staged_wait(int later) const {
         if (later >= 1) wait_vm<C>(); else wait_vm<0>();
-#endif
         static_assert(kStageDepth == 2, "one case per depth");
     }
 };
@@ -88,29 +86,35 @@ __device__ void stream_order_next(const lq::Args& a) {
 
 // (one wavefront per SIMD: the whole 512-register budget; two / four per SIMD spill and lose, half-filled wavefronts two per SIMD lose 1.5x -
 //  profiles/r03a_stream_first.txt)
+// STAGED: the [chunk][lane] workspace with the sweeps' records staged in LDS (launches that leave SIMDs idle); else the [field][lane] workspace with the
+// register prefetch (launches that fill the chip) - Args::staged, chosen by the launcher
+template <bool STAGED>
 __global__ void __launch_bounds__(64, 1) path_stream_kernel(const lq::Args a_by_value) {
-    __shared__ __attribute__((aligned(16))) double stage_lds[StagedWs::kStageDepth * lq::kBlockDoubles * 64];      // 30 KB: four wavefronts per CU keep 120 of its 160 KB
+    using Ws = typename std::conditional<STAGED, StagedWs, lq::StridedWs>::type;
     const int lanes = 64;
     // Wavefronts of similar work (a.order, PQP_OPT_ORDER_BY_COST): the 64 lanes of a wavefront run every phase - interior-point iterations and active-set
     // rounds of each pass - as often as their slowest lane.  Sorting by the TOTAL sweeps of the previous solve changes nothing (round 3: 11 % less
     // traffic, the same 10.7 ms - profiles/r03d_stream_ordered.txt); sorting by the four phase counts, first pass first, does: 25.4 -> 16.8 lock-step
     // phases per wavefront for 16.5 per lane, 11.1 -> 9.4 ms at 65 536 QPs with the counts of the identical batch, 10.3 ms with those of the previous
     // planning cycle (profiles/r05g_stream_sorted_probe.txt).
-    // (the argument block is read where the launch put it: a reference to the by-value parameter becomes a private copy as soon as the function holds a
+    // (STAGED: the argument block is read where the launch put it - a reference to the by-value parameter becomes a private copy as soon as the function holds a
     //  statement that may write memory - the LDS copies are such statements - and the solver would read pqp_params from scratch)
+    const lq::Args* ap = &a_by_value;
 #if defined(__HIP_DEVICE_COMPILE__)
-    const lq::Args& a = *(const lq::Args*)__builtin_amdgcn_kernarg_segment_ptr();
-#else
-    const lq::Args& a = a_by_value;
+    if constexpr (STAGED) ap = (const lq::Args*)__builtin_amdgcn_kernarg_segment_ptr();
 #endif
+    const lq::Args& a = *ap;
     const int slot = blockIdx.x * lanes + threadIdx.x;
     const bool live = slot < a.batch;
     if (live) {
         const int qp = a.order ? a.order[slot] : slot;
-        StagedWs ws;
+        Ws ws;
         ws.block = a.ws + (size_t)blockIdx.x * a.n * lq::kBlockDoubles * lanes; ws.lane = (int)threadIdx.x; ws.lanes = lanes;
-        ws.lds = stage_lds; ws.lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) double*)stage_lds;
-        lq::Solver<StagedWs> s(a, qp, ws);
+        if constexpr (STAGED) {
+            __shared__ __attribute__((aligned(16))) double stage_lds[StagedWs::kStageDepth * lq::kBlockDoubles * 64];      // 30 KB: four wavefronts per CU keep 120 of its 160 KB
+            ws.lds = stage_lds; ws.lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) double*)stage_lds;
+        }
+        lq::Solver<Ws> s(a, qp, ws);
         s.run();
         if (a.key_out) {
             const int it1 = s.ipm_iters_first < 31 ? s.ipm_iters_first : 31, s1 = s.set_rounds_first < 7 ? s.set_rounds_first : 7;
@@ -138,6 +142,7 @@ __global__ void __launch_bounds__(64, 1) path_stream_kernel(const lq::Args a_by_
 extern "C" hipError_t pqp_stream_launch(const pqp::lq::Args* a, int waves, void* stream) {
     (void)waves;
     const int lanes = 64;
-    hipLaunchKernelGGL(pqp::path_stream_kernel, dim3((a->batch + lanes - 1) / lanes), dim3(lanes), 0, (hipStream_t)stream, *a);
+    if (a->staged) hipLaunchKernelGGL(pqp::path_stream_kernel<true>, dim3((a->batch + lanes - 1) / lanes), dim3(lanes), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(pqp::path_stream_kernel<false>, dim3((a->batch + lanes - 1) / lanes), dim3(lanes), 0, (hipStream_t)stream, *a);
     return hipGetLastError();
 }
