@@ -174,6 +174,7 @@ def test_the_two_forms_of_the_kernel_agree(hip_lib, n, profile, batch):
     counts equal, the paths equal up to the fused multiply-adds the compiler picks in the two instantiations; ragged paths; run twice (a record read before its
     copy has landed would show as a run-to-run difference)."""
     from path_optimizer_2_amd import capi
+    from path_optimizer_2_amd.synth import make_batch
     b = make_batch(batch, n, profile, seed=41)
     n_of = np.full(batch, n, dtype=np.int32)
     n_of[::5] = max(n - 7, 2); n_of[2::9] = max(n // 2, 2); n_of[1] = 2
