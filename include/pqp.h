@@ -212,9 +212,9 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *   PQP_OPT_RESERVE_CUS (default 0)    compute units the path QP's persistent workgroups leave free.  Their wavefronts own a SIMD's whole
  *                                      register file, so kernels of another stream (the smoother chain of the next batch, configs[4]) only
  *                                      get onto the chip when a unit is left to them.
- *   PQP_OPT_STREAM_BATCH (default -1 = by measurement: 20 480 x max(1, n / 80)^2 - the measured crossover of the two kernels on one MI355X,
- *                                      18.7 k QPs at 80 waypoints, ~45 k at 120, profiles/r05a_crossover_*; 64 n beyond 256 waypoints,
- *                                      profiles/r05t_crossover_long_paths.txt; 0: never)
+ *   PQP_OPT_STREAM_BATCH (default -1 = by measurement: pqp_stream_batch_default(n) - the measured crossover of the two kernels on one MI355X, one launch after the
+ *                                      other: 15 360 x max(1, n / 80)^1.5 up to 128 waypoints (15 k QPs at 80, 29 k at 120), 0.75 n^2 up to 256 (where the lane-per-
+ *                                      waypoint kernel runs half as many QPs at a time), 48 n beyond; profiles/r06ay_*, r06az_*; 0: never)
  *                                      cold solves (warm == 0) of at least this many QPs on a handle with polish != 0 and
  *                                      PQP_OPT_STORE_WARM off run on the lane-per-QP kernel (one QP per lane, 64 per wavefront, the
  *                                      per-waypoint state streamed through a batch-interleaved workspace of 240 n bytes per QP in HBM;
@@ -411,6 +411,8 @@ int pqp_post_smooth_device(pqp_handle* h, int batch, int m, const double* layers
  * pqp_path_kernel, 0 before the first solve; < 0: error. */
 typedef enum pqp_path_kernel { PQP_KERNEL_NONE = 0, PQP_KERNEL_LANE_PER_WAYPOINT = 1, PQP_KERNEL_LANE_PER_QP = 2 } pqp_path_kernel;
 int pqp_last_path_kernel(pqp_handle* h);
+/* PQP_OPT_STREAM_BATCH's default for paths of n waypoints (above). */
+int pqp_stream_batch_default(int n);
 /* GPU time (ms, hipEvent) of the handle's last solve / assemble launch. */
 int pqp_last_kernel_ms(pqp_handle* h, float* ms);
 /* the same for the last `count` launches of this handle (oldest first; at most 256): the events are recorded on the handle's stream

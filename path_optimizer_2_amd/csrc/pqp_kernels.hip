@@ -619,12 +619,17 @@ const void* pqp_path_solve_fn_nw4(int cert);
 const void* pqp_path_solve_fn_nw8(int cert);
 }
 
+// PQP_OPT_STREAM_BATCH's default: where the lane-per-QP kernel overtakes the lane-per-waypoint kernel, one launch after the other on one MI355X, remeasured on
+// round 6's kernels (profiles/r06ay_crossover_hybrid.txt, r06az_crossover_other_n.txt).  The lane-per-waypoint kernel's rate steps down with its workgroup width
+// (3.5 M paths/s up to 128 waypoints, ~1.1 M up to 256, 0.2 M beyond), a lone wavefront of the other takes sweeps x n waypoint steps: measured crossovers
+// 15 k QPs at 80 waypoints, 20 k at 100, 29 k at 120 | 13 k at 160, 34 k at 200, 49 k at 256 | 11.5 k at 300, 24.5 k at 512.
 static int stream_batch_auto(int n) {
-    if (n > 256) return 64 * n;
+    if (n > 256) return 48 * n;
+    if (n > 128) return (int)(0.75 * n * n);
     const double r = n > 80 ? (double)n / 80.0 : 1.0;
-    const double t = 20480.0 * r * r;
-    return t < 1.0e9 ? (int)t : 1000000000;
+    return (int)(15360.0 * r * sqrt(r));
 }
+extern "C" int pqp_stream_batch_default(int n) { return n < 2 ? 0 : stream_batch_auto(n); }
 
 static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
                            const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters, double* info) {
