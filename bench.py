@@ -15,7 +15,7 @@ still one pass over one whole batch, and K steps are timed); --inflight 1 and it
 Consecutive steps solve SIMILAR, not identical, batches (--variants 8: the scenarios one planning cycle later, synth.jitter_batch: corridor
 sides and start state scaled by 1 +- 5 %), so that the most-expensive-first start order (previous step's cost) has no perfect foresight;
 `secondary.identical_batch_every_step` is round 2's headline (the same batch re-solved every step).
-Batches of at least 20 480 x max(1, N / 80)^2 QPs (PQP_OPT_STREAM_BATCH, the measured crossover) run on the lane-per-QP kernel (path_stream_kernel: HBM-streaming, its roofline is
+Batches of at least pqp_stream_batch_default(N) QPs (PQP_OPT_STREAM_BATCH: the measured crossover, 15 360 at N = 80) run on the lane-per-QP kernel (path_stream_kernel: HBM-streaming, its roofline is
 measured traffic): `--config 3 --batch 65536` is configs[3]'s whole batch on one GPU, timed in every default run under
 `secondary.configs3_whole_batch_one_gpu_stream_kernel`.
 Solver setting: the engine's production setting (pqp_production_params: ADMM to eps 1e-4 + KKT-verified polish — every returned path
@@ -325,9 +325,9 @@ def main():
         preset_shape = False
     polish = not args.no_polish and not args.reference_setting
     cost_order = not args.no_cost_order
-    # the handle's default PQP_OPT_STREAM_BATCH (include/pqp.h: the measured crossover of the two kernels, 20 480 x max(1, n / 80)^2 QPs):
+    # the handle's default PQP_OPT_STREAM_BATCH (include/pqp.h: the measured crossover of the two kernels, pqp_stream_batch_default):
     # from here on the lane-per-QP kernel runs
-    STREAM_BATCH = int(20480.0 * max(1.0, n / 80.0) ** 2)
+    STREAM_BATCH = capi.stream_batch_default(n)
     stream = polish and cfg_id != 4 and batch >= STREAM_BATCH
 
     def production(**over):
@@ -847,7 +847,7 @@ def main():
                                  "= x kernels running at a time (two launches in flight share the chip).  A MODEL, not traffic: the iterates of path_solve_kernel are "
                                  "register / LDS resident, it is bound by fp64 VALU issue + LDS latency (roofline_issue); what HBM really moved is `traffic`, "
                                  "hbm_measured_frac = traffic / kernel time / 8 TB/s.  The kernel whose roofline IS measured traffic is path_stream_kernel "
-                                 "(batches >= 20 480 at N = 80: secondary.configs3_whole_batch_one_gpu, `bench.py --config 3 --batch 65536`)")
+                                 "(batches >= 15 360 at N = 80: secondary.configs3_whole_batch_one_gpu, `bench.py --config 3 --batch 65536`)")
         if secondary and secondary.get("plain_admm_eps_1e-4") and not stream:
             # what the model says about the solver the metric names: OSQP's plain ADMM streaming its data from HBM every iteration
             its = secondary["plain_admm_eps_1e-4"]["admm_iters"]["mean"]

@@ -212,9 +212,9 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *   PQP_OPT_RESERVE_CUS (default 0)    compute units the path QP's persistent workgroups leave free.  Their wavefronts own a SIMD's whole
  *                                      register file, so kernels of another stream (the smoother chain of the next batch, configs[4]) only
  *                                      get onto the chip when a unit is left to them.
- *   PQP_OPT_STREAM_BATCH (default -1 = by measurement: 20 480 x max(1, n / 80)^2 - the measured crossover of the two kernels on one MI355X,
- *                                      18.7 k QPs at 80 waypoints, ~45 k at 120, profiles/r05a_crossover_*; 64 n beyond 256 waypoints,
- *                                      profiles/r05t_crossover_long_paths.txt; 0: never)
+ *   PQP_OPT_STREAM_BATCH (default -1 = by measurement: pqp_stream_batch_default(n) - the measured crossover of the two kernels on one MI355X, one launch after the
+ *                                      other: 15 360 x max(1, n / 80)^1.5 up to 128 waypoints (15 k QPs at 80, 29 k at 120), 0.75 n^2 up to 256 (where the lane-per-
+ *                                      waypoint kernel runs half as many QPs at a time), 48 n beyond; profiles/r06ay_*, r06az_*; 0: never)
  *                                      cold solves (warm == 0) of at least this many QPs on a handle with polish != 0 and
  *                                      PQP_OPT_STORE_WARM off run on the lane-per-QP kernel (one QP per lane, 64 per wavefront, the
  *                                      per-waypoint state streamed through a batch-interleaved workspace of 240 n bytes per QP in HBM;
@@ -253,6 +253,12 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      (profiles/r05c_*).
  *                                      The exact TensionSmoother / postSmooth kernels (polish == 1) honour it too: a line's active-set rounds start from
  *                                      the set its slot ended with in the previous solve of the shape (16-31 rounds from the cold start, 2-3 from there).
+ *   PQP_OPT_STREAM_STAGED (default -1 = by launch size)
+ *                                      the lane-per-QP kernel has two forms.  A launch that fills the chip (768 wavefronts = 49 152 QPs or more) is bound by HBM's throughput:
+ *                                      its workspace is laid out [field][lane], every access one contiguous line, a sweep's records prefetched one waypoint ahead in registers.
+ *                                      A launch that leaves SIMDs idle waits for its loads: its workspace is laid out in 16-byte chunks per lane and the sweeps' records are staged in
+ *                                      LDS two waypoints ahead by LDS-direct loads (global_load_lds_dwordx4) - +29 ... 33 % at 24 576 / 32 768 QPs of 80 waypoints one launch at a
+ *                                      time, -3 ... 4 % where the chip is full (profiles/r06au_*).  Same arithmetic, same paths.  0 / 1 force one form (tests, measurements).
  *   PQP_OPT_CHAIN_GRAPH (default 0)    pqp_optimize_path_device replays a captured hipGraph: the third call with the same arguments (pointers, sizes, configuration,
  *                                      parameters of both handles) captures its ~25 launches on the handles' streams, later calls with those arguments are ONE
  *                                      hipGraphLaunch - the gaps between the launches were 13 % of the chain.  Results are bit-identical; any (re)allocation inside
@@ -260,7 +266,7 @@ int pqp_set_params(pqp_handle* h, const pqp_params* params);
  *                                      A replay runs on the path handle's stream; it is fenced against the smoother handle's stream on both sides
  *                                      (work the caller enqueues there stays ordered as with plain launches).  Value 2: no fences (-3.6 % time) -
  *                                      the caller guarantees that the smoother handle's stream carries no other work while chains are in flight. */
-typedef enum pqp_option { PQP_OPT_STORE_WARM = 1, PQP_OPT_ORDER_BY_COST = 2, PQP_OPT_RESERVE_CUS = 3, PQP_OPT_STREAM_BATCH = 4, PQP_OPT_CARRY_CYCLES = 5, PQP_OPT_CHAIN_GRAPH = 6 } pqp_option;
+typedef enum pqp_option { PQP_OPT_STORE_WARM = 1, PQP_OPT_ORDER_BY_COST = 2, PQP_OPT_RESERVE_CUS = 3, PQP_OPT_STREAM_BATCH = 4, PQP_OPT_CARRY_CYCLES = 5, PQP_OPT_CHAIN_GRAPH = 6, PQP_OPT_STREAM_STAGED = 7 } pqp_option;
 int pqp_set_option(pqp_handle* h, int option, int value);
 int pqp_get_stream(pqp_handle* h, void** hip_stream);   /* hipStream_t */
 /* The handle's stream is created non-blocking: work the caller enqueued on ANOTHER stream (the inputs of a *_device call produced by
@@ -405,6 +411,8 @@ int pqp_post_smooth_device(pqp_handle* h, int batch, int m, const double* layers
  * pqp_path_kernel, 0 before the first solve; < 0: error. */
 typedef enum pqp_path_kernel { PQP_KERNEL_NONE = 0, PQP_KERNEL_LANE_PER_WAYPOINT = 1, PQP_KERNEL_LANE_PER_QP = 2 } pqp_path_kernel;
 int pqp_last_path_kernel(pqp_handle* h);
+/* PQP_OPT_STREAM_BATCH's default for paths of n waypoints (above). */
+int pqp_stream_batch_default(int n);
 /* GPU time (ms, hipEvent) of the handle's last solve / assemble launch. */
 int pqp_last_kernel_ms(pqp_handle* h, float* ms);
 /* the same for the last `count` launches of this handle (oldest first; at most 256): the events are recorded on the handle's stream

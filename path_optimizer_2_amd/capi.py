@@ -64,7 +64,7 @@ EXPORTS = [
     "pqp_chain_default_config", "pqp_optimize_path_device", "pqp_clearance_device", "pqp_smooth_tension2_var_device", "pqp_smooth_tension_var_device", "pqp_post_smooth_var_device", "pqp_spline_fit_var_device",
     "pqp_shard_range", "pqp_multi_create", "pqp_multi_destroy", "pqp_multi_shards", "pqp_multi_handle", "pqp_multi_set_option", "pqp_multi_path_solve", "pqp_multi_gather_paths", "pqp_multi_gather_ranks", "pqp_sync", "pqp_path_sizes", "pqp_path_pattern", "pqp_path_assemble",
     "pqp_path_assemble_device", "pqp_path_solve", "pqp_path_solve_device", "pqp_path_solve_var_device", "pqp_path_solve_var", "pqp_path_get_solution",
-    "pqp_last_kernel_ms", "pqp_last_path_kernel", "pqp_kernel_ms_history", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
+    "pqp_last_kernel_ms", "pqp_last_path_kernel", "pqp_stream_batch_default", "pqp_kernel_ms_history", "pqp_smooth_tension2", "pqp_smooth_tension2_device", "pqp_smooth_tension", "pqp_smooth_tension_device",
     "pqp_post_smooth", "pqp_post_smooth_device", "pqp_corridor_default_params", "pqp_corridor_bounds", "pqp_corridor_bounds_device",
     "pqp_reference_states", "pqp_reference_states_device", "pqp_spline_fit", "pqp_spline_fit_device", "pqp_dp_default_params",
     "pqp_dp_corridor", "pqp_dp_corridor_device", "pqp_segment_raw_reference", "pqp_segment_raw_reference_device", "pqp_bspline_resample", "pqp_bspline_resample_device", "pqp_reference_length", "pqp_reference_length_device", "pqp_offsets_to_points", "pqp_offsets_to_points_device",
@@ -208,7 +208,14 @@ def _ptr(a):
     return C.c_void_p(int(a))      # raw device pointer (e.g. torch.Tensor.data_ptr())
 
 
-OPT_STORE_WARM, OPT_ORDER_BY_COST, OPT_RESERVE_CUS, OPT_STREAM_BATCH, OPT_CARRY_CYCLES, OPT_CHAIN_GRAPH = 1, 2, 3, 4, 5, 6
+OPT_STORE_WARM, OPT_ORDER_BY_COST, OPT_RESERVE_CUS, OPT_STREAM_BATCH, OPT_CARRY_CYCLES, OPT_CHAIN_GRAPH, OPT_STREAM_STAGED = 1, 2, 3, 4, 5, 6, 7
+def stream_batch_default(n, lib=None):
+    """pqp_stream_batch_default: from how many QPs of n waypoints on a cold call runs on the lane-per-QP kernel (PQP_OPT_STREAM_BATCH's default)."""
+    lib = lib or load_library()
+    lib.pqp_stream_batch_default.restype = C.c_int
+    return int(lib.pqp_stream_batch_default(C.c_int(n)))
+
+
 def path_interval(value, n):
     """What pqp_params.adaptive_rho_interval / check_termination / polish_every mean for paths of n waypoints: negative values (the production
     setting) stand for "by path length" (csrc/pqp_defaults.hpp path_interval: 5 iterations up to 90 waypoints, 8 beyond)."""

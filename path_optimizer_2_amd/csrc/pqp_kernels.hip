@@ -320,7 +320,7 @@ struct pqp_handle {
     unsigned long long ticket_next = 0;
     long long solves = 0;                       // solve launches so far (parity selects the cost histogram being filled)
     int hist_batch = 0, hist_n = 0;             // shape of the solve whose costs cost_key / cost_hist hold (0: none)
-    int opt_store_warm = 1, opt_order_by_cost = 0, opt_reserve_cus = 0, opt_stream_batch = -1, opt_carry = 0;      // (opt_stream_batch < 0: stream_batch_auto(n))
+    int opt_store_warm = 1, opt_order_by_cost = 0, opt_reserve_cus = 0, opt_stream_batch = -1, opt_carry = 0, opt_stream_staged = -1;      // (opt_stream_batch < 0: stream_batch_auto(n))
     int stream_last_batch = 0, stream_last_n = 0;      // shape of the last path_stream_kernel launch (what its workspace still holds)
     int last_path_kernel = 0;                          // pqp_path_kernel of the last pqp_path_solve* launch (pqp_last_path_kernel)
     DevBuf sm_act[2];                                  // final active sets of the exact TensionSmoother / postSmooth kernels (PQP_OPT_CARRY_CYCLES)
@@ -417,6 +417,7 @@ int pqp_set_option(pqp_handle* h, int option, int value) {
         case PQP_OPT_ORDER_BY_COST: h->opt_order_by_cost = value ? 1 : 0; h->hist_batch = 0; h->stream_order_batch = 0; return PQP_OK;
         case PQP_OPT_RESERVE_CUS: h->opt_reserve_cus = value < 0 ? 0 : value; return PQP_OK;
         case PQP_OPT_STREAM_BATCH: h->opt_stream_batch = value < 0 ? -1 : value; return PQP_OK;
+        case PQP_OPT_STREAM_STAGED: h->opt_stream_staged = value < 0 ? -1 : (value ? 1 : 0); h->stream_last_batch = 0; return PQP_OK;      // (another layout: nothing to carry)
         case PQP_OPT_CARRY_CYCLES: h->opt_carry = value < 0 ? 0 : (value > 64 ? 64 : value); h->stream_last_batch = 0; h->sm_act_batch[0] = h->sm_act_batch[1] = 0; return PQP_OK;
         case PQP_OPT_CHAIN_GRAPH: h->opt_chain_graph = value == 2 ? 2 : (value ? 1 : 0); return PQP_OK;
         default: return fail(PQP_ERR_INVALID, "pqp_set_option: unknown option");
@@ -565,6 +566,11 @@ static int path_stream_impl(pqp_handle* h, int batch, int n, const int32_t* n_of
     std::memset(&a, 0, sizeof(a));
     a.batch = batch; a.n = n; a.passes = passes; a.n_of = n_of; a.ref = ref; a.lin = lin; a.bounds = bounds; a.scal = scal; a.out = out;
     a.status = status; a.iters = iters; a.info = info; a.ws = h->stream_ws.as<double>(); a.prm = h->prm;
+    // Which of the kernel's two workspace layouts (pqp_path_lq_abi.hpp): a launch that leaves SIMDs idle - fewer than 768 wavefronts - waits for its loads, not for
+    // HBM's throughput: the sweeps' records staged in LDS two waypoints ahead, +29 ... 33 % at 24 576 / 32 768 QPs of 80 waypoints; a launch that fills the chip
+    // loses 3-4 % with them (profiles/r06au_*) and keeps the [field][lane] layout and the register prefetch.  A function of the shape alone: what PQP_OPT_CARRY_CYCLES
+    // finds in the workspace was left there in the same layout.
+    a.staged = h->opt_stream_staged >= 0 ? h->opt_stream_staged : (waves < 3 * h->num_cu ? 1 : 0);
     // PQP_OPT_CARRY_CYCLES: the workspace still holds, slot by slot, the optimum of the previous launch of this very shape
     a.carry = (h->opt_carry && !lin && h->stream_last_batch == batch && h->stream_last_n == n && h->stream_ws.p == ws_before) ? 1 : 0;       // (lin == NULL: pqp.h)
     // PQP_OPT_ORDER_BY_COST: wavefronts of QPs that ran the same phases in the handle's previous solve of the shape.  Only where it pays - batches that
@@ -613,12 +619,17 @@ const void* pqp_path_solve_fn_nw4(int cert);
 const void* pqp_path_solve_fn_nw8(int cert);
 }
 
+// PQP_OPT_STREAM_BATCH's default: where the lane-per-QP kernel overtakes the lane-per-waypoint kernel, one launch after the other on one MI355X, remeasured on
+// round 6's kernels (profiles/r06ay_crossover_hybrid.txt, r06az_crossover_other_n.txt).  The lane-per-waypoint kernel's rate steps down with its workgroup width
+// (3.5 M paths/s up to 128 waypoints, ~1.1 M up to 256, 0.2 M beyond), a lone wavefront of the other takes sweeps x n waypoint steps: measured crossovers
+// 15 k QPs at 80 waypoints, 20 k at 100, 29 k at 120 | 13 k at 160, 34 k at 200, 49 k at 256 | 11.5 k at 300, 24.5 k at 512.
 static int stream_batch_auto(int n) {
-    if (n > 256) return 64 * n;
+    if (n > 256) return 48 * n;
+    if (n > 128) return (int)(0.75 * n * n);
     const double r = n > 80 ? (double)n / 80.0 : 1.0;
-    const double t = 20480.0 * r * r;
-    return t < 1.0e9 ? (int)t : 1000000000;
+    return (int)(15360.0 * r * sqrt(r));
 }
+extern "C" int pqp_stream_batch_default(int n) { return n < 2 ? 0 : stream_batch_auto(n); }
 
 static int path_solve_impl(pqp_handle* h, int batch, int n, const int32_t* n_of, const double* ref, const double* lin, const double* bounds,
                            const double* scal, int passes, int warm, double* out, int32_t* status, int32_t* iters, double* info) {

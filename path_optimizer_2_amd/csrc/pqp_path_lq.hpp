@@ -199,13 +199,28 @@ struct Solver {
 
     PQP_HD Solver(const Args& a_, int qp_, WS ws_) : a(a_), ws(ws_), qp(qp_) {}
 
-    PQP_HD Stage load_stage(int i) const {
+    // where a sweep's per-waypoint record is read from: the workspace itself, or the wavefront's LDS slot the record was staged into ahead of time
+    // (WS::kStageDepth > 0: pqp_path_stream.hip).  A slot is laid out like a workspace block, so a field keeps its index whatever waypoint it came from.
+    struct FromWs {
+        const WS w;
+        PQP_HD double ld(int f, int i) const { return w.ld(f, i); }
+        PQP_HD float ldf(int f, int i) const { return w.ldf(f, i); }
+    };
+    struct FromSlot {
+        const WS w;
+        int slot;
+        PQP_HD double ld(int f, int) const { return w.slot_ld(slot, f); }
+        PQP_HD float ldf(int f, int) const { return w.slot_ldf(slot, f); }
+    };
+    template <class Src>
+    PQP_HD Stage load_stage(const Src& src, int i) const {
         Stage s;
-        s.m10 = ws.ld(D_M10, i); s.c1 = ws.ld(D_C1, i); s.ds = ws.ld(D_DS, i);
+        s.m10 = src.ld(D_M10, i); s.c1 = src.ld(D_C1, i); s.ds = src.ld(D_DS, i);
         if (lin0) { s.m00 = 1.0; s.m01 = s.ds; s.m11 = 1.0; s.m12 = s.ds; s.c0 = 0.0; }      // (3 of the 8 doubles: the first pass's share of the traffic)
-        else { s.m00 = ws.ld(D_M00, i); s.m01 = ws.ld(D_M01, i); s.m11 = ws.ld(D_M11, i); s.m12 = ws.ld(D_M12, i); s.c0 = ws.ld(D_C0, i); }
+        else { s.m00 = src.ld(D_M00, i); s.m01 = src.ld(D_M01, i); s.m11 = src.ld(D_M11, i); s.m12 = src.ld(D_M12, i); s.c0 = src.ld(D_C0, i); }
         return s;
     }
+    PQP_HD Stage load_stage(int i) const { return load_stage(FromWs{ws}, i); }
 
     // ---- stage data of a pass: the transition rows around the linearisation point (base_solver.cpp:165-186) -----------------------
     // src 0: (0, 0, k_ref) (path_optimizer.cpp:128-137), 1: a.lin, 2: the previous pass's optimum (F_X*)
@@ -243,24 +258,23 @@ struct Solver {
                 const double df10 = -k * k / cs, df11 = (1 - k * l) * k * t / cs, df12 = (1 - k * l) / cs;
                 const double ds = in.s - prev.s;
                 const double f0 = (1 - k * l) * t, f1 = (1 - k * l) * k / cs - prev.kref;
-                ws.st(D_M00, i - 1, ds * df00 + 1.0); ws.st(D_M01, i - 1, ds * df01);
-                ws.st(D_M10, i - 1, ds * df10); ws.st(D_M11, i - 1, ds * df11 + 1.0); ws.st(D_M12, i - 1, ds * df12);
-                ws.st(D_C0, i - 1, ds * (f0 - (df00 * l + df01 * psi)));
-                ws.st(D_C1, i - 1, ds * (f1 - (df10 * l + df11 * psi + df12 * k)));
-                ws.st(D_DS, i - 1, ds);
+                ws.st2(D_M00, i - 1, ds * df00 + 1.0, ds * df01);
+                ws.st2(D_M10, i - 1, ds * df10, ds * df11 + 1.0);
+                ws.st2(D_M12, i - 1, ds * df12, ds * (f0 - (df00 * l + df01 * psi)));
+                ws.st2(D_C1, i - 1, ds * (f1 - (df10 * l + df11 * psi + df12 * k)), ds);
             }
             if (with_bounds) {
                 const bool rough = a.prm.rough_constraints_far_away && !(in.s < a.prm.precise_planning_length);
                 double lo, up;
                 if (!rough) {
                     soft_bounds(in.b[0], in.b[1], a.prm.expected_safety_margin, a.prm.min_clearance, lo, up);
-                    ws.st(D_LOF, i, lo); ws.st(D_UPF, i, up);
+                    ws.st2(D_LOF, i, lo, up);
                     soft_bounds(in.b[2], in.b[3], a.prm.expected_safety_margin, a.prm.min_clearance, lo, up);
-                    ws.st(D_LOR, i, lo); ws.st(D_UPR, i, up);
+                    ws.st2(D_LOR, i, lo, up);
                 } else {            // base_solver.cpp:201-205,241-247: one row on l alone with the centre circle's box
                     soft_bounds(in.b[4], in.b[5], a.prm.expected_safety_margin, a.prm.min_clearance, lo, up);
-                    ws.st(D_LOF, i, lo); ws.st(D_UPF, i, up);
-                    ws.st(D_LOR, i, -kInfty); ws.st(D_UPR, i, kInfty);
+                    ws.st2(D_LOF, i, lo, up);
+                    ws.st2(D_LOR, i, -kInfty, kInfty);
                 }
             }
             prev = in;
@@ -306,6 +320,43 @@ struct Solver {
         }
     }
     static constexpr int kDepth = 1;         // (2 / 3 / 4 / 6 waypoints ahead: slower at every depth - spills; profiles/r03a_stream_first.txt)
+    // The same pipelines with the records staged in LDS (round 6): `stage(slot, i)` issues the copies of waypoint i's record into a slot, `load(slot, i)`
+    // reads it from there when its turn has come - D waypoints ahead without a register held for them.  Before a record is read the wavefront
+    // waits until at most the copies issued AFTER that record's are outstanding (vector memory returns in order): C per later record.
+    template <int D, int C, class In, class Stg, class Load, class Body>
+    PQP_HD void sweep_down_staged(int i0, int i_last, Stg stage, Load load, Body body) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) if (i0 - k >= i_last) stage(k, i0 - k);
+        for (int i = i0; i >= i_last; i -= D) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const int ii = i - k;
+                if (ii >= i_last) {
+                    ws.template staged_wait<C>(ii - i_last < D - 1 ? ii - i_last : D - 1);
+                    const In cur = load(k, ii);
+                    if (ii - D >= i_last) stage(k, ii - D);
+                    body(ii, cur);
+                }
+            }
+        }
+    }
+    template <int D, int C, class In, class Stg, class Load, class Body>
+    PQP_HD void sweep_up_staged(int i0, int i_end, Stg stage, Load load, Body body) {          // i0 <= i < i_end
+#pragma unroll
+        for (int k = 0; k < D; ++k) if (i0 + k < i_end) stage(k, i0 + k);
+        for (int i = i0; i < i_end; i += D) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const int ii = i + k;
+                if (ii < i_end) {
+                    ws.template staged_wait<C>(i_end - 1 - ii < D - 1 ? i_end - 1 - ii : D - 1);
+                    const In cur = load(k, ii);
+                    if (ii + D < i_end) stage(k, ii + D);
+                    body(ii, cur);
+                }
+            }
+        }
+    }
 
     // what a sweep reads per waypoint
     struct Box { double lof, upf, lor, upr; };
@@ -313,42 +364,90 @@ struct Solver {
     struct BackIn { Stage s; Box b; IpmRows r; float dgf, dgr, dgk; double act, lam; };
     struct FwdIn { Stage s; double K0, K1, K2, kk; Box b; IpmRows r; double act, lam; double xo[3]; };     // stage / gains of transition i, rows of waypoint i + 1
 
-    PQP_HD Box load_box(int i) const { Box b; b.lof = ws.ld(D_LOF, i); b.upf = ws.ld(D_UPF, i); b.lor = ws.ld(D_LOR, i); b.upr = ws.ld(D_UPR, i); return b; }
-    PQP_HD IpmRows load_rows(int i) const {
+    template <class Src>
+    PQP_HD Box load_box(const Src& src, int i) const { Box b; b.lof = src.ld(D_LOF, i); b.upf = src.ld(D_UPF, i); b.lor = src.ld(D_LOR, i); b.upr = src.ld(D_UPR, i); return b; }
+    PQP_HD Box load_box(int i) const { return load_box(FromWs{ws}, i); }
+    template <class Src>
+    PQP_HD IpmRows load_rows(const Src& src, int i) const {
         IpmRows r;
-        r.tlf = ws.ldf(S_TLF, i); r.tuf = ws.ldf(S_TUF, i); r.zlf = ws.ldf(S_ZLF, i); r.zuf = ws.ldf(S_ZUF, i);
-        r.tlr = ws.ldf(S_TLR, i); r.tur = ws.ldf(S_TUR, i); r.zlr = ws.ldf(S_ZLR, i); r.zur = ws.ldf(S_ZUR, i);
-        r.tlk = ws.ldf(S_TLK, i); r.tuk = ws.ldf(S_TUK, i); r.zlk = ws.ldf(S_ZLK, i); r.zuk = ws.ldf(S_ZUK, i);
-        r.gk = ws.ld(D_GK, i);
+        r.tlf = src.ldf(S_TLF, i); r.tuf = src.ldf(S_TUF, i); r.zlf = src.ldf(S_ZLF, i); r.zuf = src.ldf(S_ZUF, i);
+        r.tlr = src.ldf(S_TLR, i); r.tur = src.ldf(S_TUR, i); r.zlr = src.ldf(S_ZLR, i); r.zur = src.ldf(S_ZUR, i);
+        r.tlk = src.ldf(S_TLK, i); r.tuk = src.ldf(S_TUK, i); r.zlk = src.ldf(S_ZLK, i); r.zuk = src.ldf(S_ZUK, i);
+        r.gk = src.ld(D_GK, i);
         return r;
     }
     // a collision row's state: its value is lo + t_l by definition (the slack absorbs the rest), t_u carries its own rounding
     PQP_HD static Row soft_row(float tl, float tu, float zl, float zu, double lo) { Row r; r.tl = tl; r.tu = tu; r.zl = zl; r.zu = zu; r.g = lo + r.tl; return r; }
     PQP_HD static Row hard_row(double g, float tl, float tu, float zl, float zu) { Row r; r.g = g; r.tl = tl; r.tu = tu; r.zl = zl; r.zu = zu; return r; }
-    PQP_HD void store_f(int i, const Row& r) const { ws.stf(S_TLF, i, r.tl); ws.stf(S_TUF, i, r.tu); ws.stf(S_ZLF, i, r.zl); ws.stf(S_ZUF, i, r.zu); }
-    PQP_HD void store_r(int i, const Row& r) const { ws.stf(S_TLR, i, r.tl); ws.stf(S_TUR, i, r.tu); ws.stf(S_ZLR, i, r.zl); ws.stf(S_ZUR, i, r.zu); }
-    PQP_HD void store_k(int i, const Row& r) const { ws.st(D_GK, i, r.g); ws.stf(S_TLK, i, r.tl); ws.stf(S_TUK, i, r.tu); ws.stf(S_ZLK, i, r.zl); ws.stf(S_ZUK, i, r.zu); }
-    template <int MODE>
-    PQP_HD BackIn load_back(int i) const {           // transition i (i < n - 1) and the rows of waypoint i (i > 0)
+    PQP_HD void store_f(int i, const Row& r) const { ws.stf4(S_TLF, i, r.tl, r.tu, r.zl, r.zu); }
+    PQP_HD void store_r(int i, const Row& r) const { ws.stf4(S_TLR, i, r.tl, r.tu, r.zl, r.zu); }
+    PQP_HD void store_k(int i, const Row& r) const { ws.st(D_GK, i, r.g); ws.stf4(S_TLK, i, r.tl, r.tu, r.zl, r.zu); }
+    template <int MODE, class Src>
+    PQP_HD BackIn load_back(const Src& src, int i) const {           // transition i (i < n - 1) and the rows of waypoint i (i > 0)
         BackIn in;
-        if (i < n - 1) in.s = load_stage(i);
+        if (i < n - 1) in.s = load_stage(src, i);
         if (i > 0) {
-            in.b = load_box(i);
-            if (MODE == MODE_IPM || MODE == MODE_GUESS) { in.r = load_rows(i); in.dgf = ws.ldf(S_DGF, i); in.dgr = ws.ldf(S_DGR, i); in.dgk = ws.ldf(S_DGK, i); }
-            if (MODE == MODE_SET) { in.act = ws.ld(D_ACT, i); in.lam = ws.ld(D_LAM, i); }
+            in.b = load_box(src, i);
+            if (MODE == MODE_IPM || MODE == MODE_GUESS) { in.r = load_rows(src, i); in.dgf = src.ldf(S_DGF, i); in.dgr = src.ldf(S_DGR, i); in.dgk = src.ldf(S_DGK, i); }
+            if (MODE == MODE_SET) { in.act = src.ld(D_ACT, i); in.lam = src.ld(D_LAM, i); }
         }
         return in;
     }
-    template <int MODE>
-    PQP_HD FwdIn load_fwd(int i) const {
+    template <int MODE, class Src>
+    PQP_HD FwdIn load_fwd(const Src& src, int i) const {
         FwdIn in;
-        in.s = load_stage(i);
-        in.K0 = ws.ld(D_K0, i); in.K1 = ws.ld(D_K1, i); in.K2 = ws.ld(D_K2, i); in.kk = ws.ld(D_KK, i);
-        in.b = load_box(i + 1);
-        if (MODE == MODE_IPM) in.r = load_rows(i + 1);
-        if (MODE == MODE_SET || MODE == MODE_SET_GUARDED) { in.act = ws.ld(D_ACT, i + 1); in.lam = ws.ld(D_LAM, i + 1); }
-        if (MODE == MODE_SET_GUARDED) { in.xo[0] = ws.ld(D_X0, i + 1); in.xo[1] = ws.ld(D_X1, i + 1); in.xo[2] = ws.ld(D_X2, i + 1); }      // the point the set was taken from
+        in.s = load_stage(src, i);
+        in.K0 = src.ld(D_K0, i); in.K1 = src.ld(D_K1, i); in.K2 = src.ld(D_K2, i); in.kk = src.ld(D_KK, i);
+        in.b = load_box(src, i + 1);
+        if (MODE == MODE_IPM) in.r = load_rows(src, i + 1);
+        if (MODE == MODE_SET || MODE == MODE_SET_GUARDED) { in.act = src.ld(D_ACT, i + 1); in.lam = src.ld(D_LAM, i + 1); }
+        if (MODE == MODE_SET_GUARDED) { in.xo[0] = src.ld(D_X0, i + 1); in.xo[1] = src.ld(D_X1, i + 1); in.xo[2] = src.ld(D_X2, i + 1); }      // the point the set was taken from
         return in;
+    }
+    // ---- staging (WS::kStageDepth > 0) ----------------------------------------------------------------------------------------------
+    // What load_back / load_fwd read, as 16-byte-per-lane chunks of a workspace block (chunk c = double fields 2c, 2c + 1; the float fields fill
+    // doubles 22 .. 29) copied into LDS slot `slot` by LDS-direct loads: no register is tied up while they are in flight, so the records of
+    // kStageDepth waypoints ahead can be.  A forward record takes its transition and gains from block i and its rows from block i + 1 -
+    // different fields, so one slot holds both.  kBackChunks / kFwdChunks: copies per record (a lower bound: it sizes the wait).
+    //   chunks: 0-3 transition (the first pass: 1 and 3), 4-5 boxes, 6-7 gains, 8 X0 X1, 9 X2 GK, 10 ACT LAM, 11-13 the three rows' slacks and multipliers, 14 their steps
+    PQP_HD void stage_transition(int slot, int i) const {
+        if (!lin0) { ws.stage_chunk(slot, 0, i); ws.stage_chunk(slot, 2, i); }
+        ws.stage_chunk(slot, 1, i); ws.stage_chunk(slot, 3, i);
+    }
+    template <int MODE> static constexpr int back_chunks() { return 2 + 2 + ((MODE == MODE_IPM || MODE == MODE_GUESS) ? 5 : 0) + (MODE == MODE_SET ? 1 : 0); }
+    template <int MODE>
+    PQP_HD void stage_back(int slot, int i) const {
+        stage_transition(slot, i);
+        ws.stage_chunk(slot, 4, i); ws.stage_chunk(slot, 5, i);
+        if (MODE == MODE_IPM || MODE == MODE_GUESS) { ws.stage_chunk(slot, 9, i); for (int c = 11; c <= 14; ++c) ws.stage_chunk(slot, c, i); }
+        if (MODE == MODE_SET) ws.stage_chunk(slot, 10, i);
+    }
+    template <int MODE> static constexpr int fwd_chunks() { return 2 + 2 + 2 + (MODE == MODE_IPM ? 4 : 0) + ((MODE == MODE_SET || MODE == MODE_SET_GUARDED) ? 1 : 0) + (MODE == MODE_SET_GUARDED ? 2 : 0); }
+    template <int MODE>
+    PQP_HD void stage_fwd(int slot, int i) const {
+        stage_transition(slot, i);
+        ws.stage_chunk(slot, 6, i); ws.stage_chunk(slot, 7, i);
+        ws.stage_chunk(slot, 4, i + 1); ws.stage_chunk(slot, 5, i + 1);
+        if (MODE == MODE_IPM) { ws.stage_chunk(slot, 9, i + 1); for (int c = 11; c <= 13; ++c) ws.stage_chunk(slot, c, i + 1); }
+        if (MODE == MODE_SET || MODE == MODE_SET_GUARDED) ws.stage_chunk(slot, 10, i + 1);
+        if (MODE == MODE_SET_GUARDED) { ws.stage_chunk(slot, 8, i + 1); ws.stage_chunk(slot, 9, i + 1); }
+    }
+    // a sweep over staged records: the one function the sweeps below call
+    template <int MODE, class Body>
+    PQP_HD void sweep_back(Body body) {
+        if constexpr (WS::kStageDepth > 0)
+            sweep_down_staged<WS::kStageDepth, back_chunks<MODE>(), BackIn>(n - 1, 0, [&](int slot, int i) { stage_back<MODE>(slot, i); },
+                                                                           [&](int slot, int i) { return load_back<MODE>(FromSlot{ws, slot}, i); }, body);
+        else
+            sweep_down<kDepth, BackIn>(n - 1, 0, [&](int i) { return load_back<MODE>(FromWs{ws}, i); }, body);
+    }
+    template <int MODE, class Body>
+    PQP_HD void sweep_fwd(Body body) {
+        if constexpr (WS::kStageDepth > 0)
+            sweep_up_staged<WS::kStageDepth, fwd_chunks<MODE>(), FwdIn>(0, n - 1, [&](int slot, int i) { stage_fwd<MODE>(slot, i); },
+                                                                       [&](int slot, int i) { return load_fwd<MODE>(FromSlot{ws, slot}, i); }, body);
+        else
+            sweep_up<kDepth, FwdIn>(0, n - 1, [&](int i) { return load_fwd<MODE>(FromWs{ws}, i); }, body);
     }
 
     // ---- one backward sweep -------------------------------------------------------------------------------------------------------
@@ -401,8 +500,7 @@ struct Solver {
         const int ar = !on_r ? 0 : (!live_r ? 1 : (rr.zu > rr.tu ? 1 : (rr.zl > rr.tl ? -1 : 0)));
         const int ak = rk.zu > rk.tu ? 1 : (rk.zl > rk.tl ? -1 : 0);
         const double lam = ak > 0 ? rk.zu : (ak < 0 ? -rk.zl : 0.0);
-        ws.st(D_ACT, i, (double)((af + 1) + 3 * (ar + 1) + 9 * (ak + 1)));
-        ws.st(D_LAM, i, lam);
+        ws.st2(D_ACT, i, (double)((af + 1) + 3 * (ar + 1) + 9 * (ak + 1)), lam);
         if (af != 0) add_lpsi_term(v, w_s, L0, af > 0 ? upf : lof);
         if (ar != 0) add_lpsi_term(v, w_s, Lr, ar > 0 ? upr : lor);
         if (ak != 0) { const double w = kInvDelta; v.P[5] += w; v.p[2] -= w * (ak * kl - kDelta * lam); }
@@ -446,11 +544,11 @@ struct Solver {
         Value v;
         for (int k = 0; k < 6; ++k) v.P[k] = 0.0;
         v.p[0] = v.p[1] = v.p[2] = 0.0;
-        sweep_down<kDepth, BackIn>(n - 1, 0, [&](int i) { return load_back<MODE>(i); }, [&](int i, const BackIn& in) {
+        sweep_back<MODE>([&](int i, const BackIn& in) {
             if (i < n - 1) {
                 double K[3], kk;
                 riccati_step(in.s, w_u, v, K, kk);
-                ws.st(D_K0, i, K[0]); ws.st(D_K1, i, K[1]); ws.st(D_K2, i, K[2]); ws.st(D_KK, i, kk);
+                ws.st2(D_K0, i, K[0], K[1]); ws.st2(D_K2, i, K[2], kk);
                 if (i > 0) stage_cost<MODE>(i, in, sm, v);
             } else {
                 stage_cost<MODE>(i, in, sm, v);
@@ -487,7 +585,7 @@ struct Solver {
             acc.res = fmax(acc.res, fmax(fabs(r.g - lo - r.tl), fabs(up - r.g - r.tu)));
             return r;
         };
-        sweep_up<kDepth, FwdIn>(0, n - 1, [&](int i) { return load_fwd<MODE_INIT>(i); }, [&](int i, const FwdIn& in) {
+        sweep_fwd<MODE_INIT>([&](int i, const FwdIn& in) {
             advance(in, x);
             const int j = i + 1;
             const double lof = in.b.lof, upf = in.b.upf, lor = in.b.lor, upr = in.b.upr;
@@ -510,7 +608,7 @@ struct Solver {
             in.v[0] = ws.ld(D_X0, j); in.v[1] = ws.ld(D_X1, j); in.v[2] = ws.ld(D_X2, j); in.v[3] = ws.ld(D_ACT, j); in.v[4] = ws.ld(D_LAM, j);
             return in;
         }, [&](int j, const StashIn& in) {
-            for (int k = 0; k < 5; ++k) ws.st(kStash + k, j, in.v[k]);
+            ws.st2(kStash, j, in.v[0], in.v[1]); ws.st2(kStash + 2, j, in.v[2], in.v[3]); ws.st(kStash + 4, j, in.v[4]);
         });
     }
     PQP_SWEEP void warm_init(bool stashed) {
@@ -556,32 +654,31 @@ struct Solver {
     PQP_SWEEP void forward_ipm(double sm) {
         double x[3] = {x0[0], x0[1], x0[2]};
         Acc acc = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        sweep_up<kDepth, FwdIn>(0, n - 1, [&](int i) { return load_fwd<MODE_IPM>(i); }, [&](int i, const FwdIn& in) {
+        sweep_fwd<MODE_IPM>([&](int i, const FwdIn& in) {
             advance(in, x);
             const int j = i + 1;
             const double lof = in.b.lof, upf = in.b.upf, lor = in.b.lor, upr = in.b.upr;
             const double L0 = lor <= -kBig ? 0.0 : Lf;
+            double dgf = 0.0, dgr = 0.0;          // (the step of a row that is not live is never read)
             if (upf - lof > kEqWidth) {
                 const Row r = soft_row(in.r.tlf, in.r.tuf, in.r.zlf, in.r.zuf, lof);
                 double d, tgt;
                 row_weight(r, lof, upf, sm, d, tgt);
                 const double v = x[0] + L0 * x[1];
-                const double dg = as_stored(v - d * rcpq(w_s + d) * (v - tgt) - r.g);           // (+ the slack of the Newton point)
-                ws.stf(S_DGF, j, dg);
-                row_accumulate(r, row_step(r, lof, upf, sm, dg), lof, upf, acc, false);
+                dgf = as_stored(v - d * rcpq(w_s + d) * (v - tgt) - r.g);           // (+ the slack of the Newton point)
+                row_accumulate(r, row_step(r, lof, upf, sm, dgf), lof, upf, acc, false);
             }
             if (upr < kBig && upr - lor > kEqWidth) {
                 const Row r = soft_row(in.r.tlr, in.r.tur, in.r.zlr, in.r.zur, lor);
                 double d, tgt;
                 row_weight(r, lor, upr, sm, d, tgt);
                 const double v = x[0] + Lr * x[1];
-                const double dg = as_stored(v - d * rcpq(w_s + d) * (v - tgt) - r.g);
-                ws.stf(S_DGR, j, dg);
-                row_accumulate(r, row_step(r, lor, upr, sm, dg), lor, upr, acc, false);
+                dgr = as_stored(v - d * rcpq(w_s + d) * (v - tgt) - r.g);
+                row_accumulate(r, row_step(r, lor, upr, sm, dgr), lor, upr, acc, false);
             }
             const Row r = hard_row(in.r.gk, in.r.tlk, in.r.tuk, in.r.zlk, in.r.zuk);
             const double dg = as_stored(x[2] - r.g);
-            ws.stf(S_DGK, j, dg);
+            ws.stf4(S_DGF, j, dgf, dgr, dg, 0.0);          // (one chunk: the three steps; S_PAD only means something at waypoint 0, and j >= 1)
             row_accumulate(r, row_step(r, -kl, kl, sm, dg), -kl, kl, acc);
         });
         gp_el = x[0]; gp_ep = x[1];
@@ -611,7 +708,7 @@ struct Solver {
         bool asks = false;          // x_N asks for another set than the one it was computed with
         double pin = 0.0;
         double dhd = 0.0, slope[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, dk_prev = 0.0, dl = 0.0, dp = 0.0;
-        if (!GUARDED) { ws.st(D_X0, 0, x[0]); ws.st(D_X1, 0, x[1]); ws.st(D_X2, 0, x[2]); }
+        if (!GUARDED) { ws.st2(D_X0, 0, x[0], x[1]); ws.st(D_X2, 0, x[2]); }
         auto soft = [&](int act, double v, double lo, double up) {
             // consistent within the tolerance: keep; else what the point asks for
             const bool keep = (act == 1 && v >= up - kSetTol) || (act == -1 && v <= lo + kSetTol) || (act == 0 && v <= up + kSetTol && v >= lo - kSetTol);
@@ -641,10 +738,10 @@ struct Solver {
                 slope[c] += w_s * (truth - model) * dv;
             }
         };
-        sweep_up<kDepth, FwdIn>(0, n - 1, [&](int i) { return load_fwd<GUARDED ? MODE_SET_GUARDED : MODE_SET>(i); }, [&](int i, const FwdIn& in) {
+        sweep_fwd<GUARDED ? MODE_SET_GUARDED : MODE_SET>([&](int i, const FwdIn& in) {
             advance(in, x);
             const int j = i + 1;
-            if (!GUARDED) { ws.st(D_X0, j, x[0]); ws.st(D_X1, j, x[1]); ws.st(D_X2, j, x[2]); }
+            if (!GUARDED) { ws.st2(D_X0, j, x[0], x[1]); ws.st(D_X2, j, x[2]); }
             const double lof = in.b.lof, upf = in.b.upf, lor = in.b.lor, upr = in.b.upr;
             const double L0 = lor <= -kBig ? 0.0 : Lf;
             const int code = (int)in.act;
@@ -664,14 +761,13 @@ struct Solver {
                 dl = x[0] - in.xo[0]; dp = x[1] - in.xo[1];
                 const double dk = x[2] - in.xo[2], du = (dk - dk_prev) * rcpq(in.s.ds);
                 dk_prev = dk;
-                ws.stf(S_DGF, j, dl); ws.stf(S_DGR, j, dp); ws.stf(S_DGK, j, dk);
+                ws.stf4(S_DGF, j, dl, dp, dk, 0.0);
                 dhd += w_l * dl * dl + (w_k + (ak != 0 ? kInvDelta : 0.0)) * dk * dk + w_u * du * du;
                 if (live_f) along(af, in.xo[0] + L0 * in.xo[1], dl + L0 * dp, lof, upf); else dhd += w_s * (dl + L0 * dp) * (dl + L0 * dp);
                 if (live_r) along(ar, in.xo[0] + Lr * in.xo[1], dl + Lr * dp, lor, upr); else if (on_r) dhd += w_s * (dl + Lr * dp) * (dl + Lr * dp);
                 nf = af; nr = ar;           // (settle() takes the collision rows' sides from where the step arrives)
             }
-            ws.st(D_ACT, j, (double)((nf + 1) + 3 * (nr + 1) + 9 * (nk + 1)));
-            ws.st(D_LAM, j, lam);
+            ws.st2(D_ACT, j, (double)((nf + 1) + 3 * (nr + 1) + 9 * (nk + 1)), lam);
         });
         if (GUARDED) dhd += kInvDelta * ((act_el != 0 ? dl * dl : 0.0) + (act_ep != 0 ? dp * dp : 0.0));
         const int ne = hard(act_el, lam_el, x[0], -a.prm.end_l_bound, a.prm.end_l_bound);
@@ -703,7 +799,7 @@ struct Solver {
             return in;
         }, [&](int j, const SettleIn& in) {
             const double l = in.x0 + t * (double)in.d0, psi = in.x1 + t * (double)in.d1;
-            ws.st(D_X0, j, l); ws.st(D_X1, j, psi); ws.st(D_X2, j, in.x2 + t * (double)in.d2);
+            ws.st2(D_X0, j, l, psi); ws.st(D_X2, j, in.x2 + t * (double)in.d2);
             const double lof = in.b.lof, upf = in.b.upf, lor = in.b.lor, upr = in.b.upr;
             const double L0 = lor <= -kBig ? 0.0 : Lf;
             const int code = (int)in.act;
@@ -895,8 +991,10 @@ struct Solver {
     }
 };
 
-// a lane's view of its wavefront's workspace block (layout: pqp_path_lq_abi.hpp)
+// a lane's view of its wavefront's workspace block, in either of the two layouts of pqp_path_lq_abi.hpp
+// [field][lane]: every access of a wavefront is one contiguous line of 8 (4) bytes per lane - the launches that fill the chip (and the host emulation)
 struct StridedWs {
+    static constexpr int kStageDepth = 0;      // records are prefetched into registers, one waypoint ahead
     double* block;          // the wavefront's block
     int lane;
     int lanes;              // lanes per block: 64 on the device, 1 in the host emulation
@@ -905,6 +1003,30 @@ struct StridedWs {
     PQP_HD float* floats(int i) const { return reinterpret_cast<float*>(block + ((size_t)i * kBlockDoubles + kFieldsD) * lanes); }
     PQP_HD float ldf(int f, int i) const { return floats(i)[(size_t)f * lanes + lane]; }
     PQP_HD void stf(int f, int i, double v) const { floats(i)[(size_t)f * lanes + lane] = (float)v; }
+    // (fields that are written together: one access per field here, one per 16-byte chunk in ChunkWs)
+    PQP_HD void st2(int f, int i, double v0, double v1) const { st(f, i, v0); st(f + 1, i, v1); }
+    PQP_HD void stf4(int f, int i, double v0, double v1, double v2, double v3) const { stf(f, i, v0); stf(f + 1, i, v1); stf(f + 2, i, v2); stf(f + 3, i, v3); }
+};
+// [chunk][lane][16 bytes]: what LDS-direct loads can stage (StagedWs, pqp_path_stream.hip) - the launches that leave SIMDs idle, whose sweeps wait for
+// their loads rather than for HBM's throughput
+struct ChunkWs {
+    static constexpr int kStageDepth = 0;
+    double* block;
+    int lane;
+    int lanes;
+    PQP_HD size_t chunk_at(int c, int i) const { return (((size_t)i * kBlockChunks + c) * lanes + lane) * 2; }       // this lane's 16 bytes of chunk c, in doubles
+    PQP_HD double ld(int f, int i) const { return block[chunk_at(f >> 1, i) + (f & 1)]; }
+    PQP_HD void st(int f, int i, double v) const { block[chunk_at(f >> 1, i) + (f & 1)] = v; }
+    PQP_HD float* floats(int f, int i) const { return reinterpret_cast<float*>(block + chunk_at(kFieldsD / 2 + (f >> 2), i)) + (f & 3); }
+    PQP_HD float ldf(int f, int i) const { return *floats(f, i); }
+    PQP_HD void stf(int f, int i, double v) const { *floats(f, i) = (float)v; }
+    // a whole chunk in one 16-byte access: the two doubles of an even field pair, the four floats of a row
+    struct alignas(16) D2 { double a, b; };
+    struct alignas(16) F4 { float a, b, c, d; };
+    PQP_HD void st2(int f, int i, double v0, double v1) const { *reinterpret_cast<D2*>(block + chunk_at(f >> 1, i)) = D2{v0, v1}; }
+    PQP_HD void stf4(int f, int i, double v0, double v1, double v2, double v3) const {
+        *reinterpret_cast<F4*>(block + chunk_at(kFieldsD / 2 + (f >> 2), i)) = F4{(float)v0, (float)v1, (float)v2, (float)v3};
+    }
 };
 
 }  // namespace lq

@@ -8,8 +8,12 @@
 namespace pqp {
 namespace lq {
 
-// Workspace: per waypoint and lane kFieldsD doubles followed by kFieldsF floats; element (waypoint i, field f) of lane j of a
-// wavefront's block sits at block[(i * kBlockDoubles + f) * 64 + j] (doubles) resp. ((float*)(block + (i * kBlockDoubles + kFieldsD) * 64))[f * 64 + j].
+// Workspace: per waypoint and lane kFieldsD doubles followed by kFieldsF floats, in one of two layouts chosen per launch (Args::staged):
+//   [field][lane] (lq::StridedWs): element (waypoint i, field f) of lane j of a wavefront's block sits at block[(i * kBlockDoubles + f) * 64 + j] (doubles) resp.
+//     ((float*)(block + (i * kBlockDoubles + kFieldsD) * 64))[f * 64 + j] - every load / store instruction of a wavefront is one contiguous 512 (256) bytes;
+//   [chunk][lane][16 bytes] (lq::ChunkWs): the fields in 16-byte CHUNKS (two doubles / four floats) that stay together - chunk c of (waypoint i, lane j) sits at
+//     block[((i * kBlockChunks + c) * 64 + j) * 2 .. + 1], double field f is part f & 1 of chunk f >> 1, float field f is float f & 3 of chunk
+//     kFieldsD / 2 + (f >> 2).  A lane's share of a chunk is what an LDS-direct load (global_load_lds_dwordx4) copies per lane, whatever waypoint each lane is at.
 // fp64: everything an ACTIVE-SET round reads or writes (problem data, gains, the point) - those rounds return the result.  fp32: what only
 // the interior-point rounds exchange between their sweeps (slacks, multipliers, row steps): they only have to predict the active set.
 enum FieldD {
@@ -22,14 +26,15 @@ enum FieldD {
     kFieldsD
 };
 enum FieldF {
-    S_DGF = 0, S_DGR, S_DGK,                                       // row steps of the last interior-point roll-out
-    S_TLF, S_TUF, S_ZLF, S_ZUF, S_TLR, S_TUR, S_ZLR, S_ZUR, S_TLK, S_TUK, S_ZLK, S_ZUK,     // slacks and multipliers of the three rows
+    S_TLF = 0, S_TUF, S_ZLF, S_ZUF, S_TLR, S_TUR, S_ZLR, S_ZUR, S_TLK, S_TUK, S_ZLK, S_ZUK,     // slacks and multipliers of the three rows: one 16-byte chunk per row
+    S_DGF, S_DGR, S_DGK,                                           // row steps of the last interior-point roll-out
     S_PAD,      // (the gains stay fp64 in every round: an fp32 gain times a state of order 1 is 1e-8 of noise in a row value, more than the slack
                 // of a tightly active row near the end of the interior-point rounds - the steps then shrink to nothing)
     kFieldsF
 };
 constexpr int kBlockDoubles = kFieldsD + kFieldsF / 2;            // 30 doubles = 240 bytes per waypoint and QP
-static_assert(kFieldsF % 2 == 0, "the float fields fill whole doubles");
+constexpr int kBlockChunks = kBlockDoubles / 2;                   // 15 chunks of 16 bytes
+static_assert(kFieldsD % 2 == 0 && kFieldsF % 4 == 0, "the fields fill whole 16-byte chunks");
 
 // phase key of a QP: interior-point iterations of the first pass (5 bits), active-set rounds of the first pass (3), iterations (4) and rounds (3) of the
 // re-linearised pass - what a wavefront runs in lock-step, most significant first
@@ -56,6 +61,7 @@ struct Args {
     int32_t* key_out;           // [batch] or nullptr
     int32_t* hist;              // [kOrderBins + 1]
     int32_t* order_next;        // [batch]
+    int staged;                 // 1: the [chunk][lane] layout, the sweeps' records staged in LDS two waypoints ahead (launches that leave SIMDs idle: pqp_kernels.hip)
     int carry;                  // 1: the workspace still holds what this very launch shape left there last time (PQP_OPT_CARRY_CYCLES): a QP's first pass
                                 // starts its interior-point rounds from its slot's previous optimum - the same scenario one planning cycle earlier
     pqp_params prm;

@@ -2,14 +2,49 @@
 // large function and compiles in seconds instead of the 90 s of pqp_kernels.hip.
 //
 // One wavefront = 64 QPs in lock-step, every per-waypoint quantity streamed through the batch-interleaved workspace
-// [wavefront][waypoint][field][lane]: each load / store instruction of a wavefront is one contiguous 512-byte line.  No LDS, no
-// cross-lane traffic: HBM (or the Infinity Cache, while the workspace of 240 n bytes per QP fits its 256 MiB) bandwidth bounds it.
+// [wavefront][waypoint][field][lane]: each load / store instruction of a wavefront is one contiguous 512-byte line.  No cross-lane
+// traffic: HBM (or the Infinity Cache, while the workspace of 240 n bytes per QP fits its 256 MiB) bandwidth bounds it - once its latency
+// is hidden: one wavefront per SIMD, nothing else to switch to, and a sweep is a dependency chain that wants a waypoint's record every
+// ~0.8 us of arithmetic while a load takes ~2 us to come back.  Round 6: the sweeps' records are copied workspace -> LDS by LDS-direct
+// loads (global_load_lds_dwordx4: no destination registers, so kStageDepth waypoints ahead cost none - in registers every depth beyond 1 spilled and lost).
 // Replaces: the OSQP solves called at src/solver/base_solver.cpp:88,110 for batches that fill the chip's 65 536 lanes.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "pqp_path_lq.hpp"
 
 namespace pqp {
+
+// ---- the workspace view of the device: StridedWs + LDS staging of the sweeps' records --------------------------------------------------
+// A slot = one workspace block ([chunk][lane][16 bytes], lq::kBlockChunks KB); one global_load_lds_dwordx4 copies chunk c of every lane's OWN
+// waypoint into it (16 bytes per lane from the lane's address, LDS address = M0 + 16 * lane) - lanes of a wavefront may be at different
+// waypoints (ragged batches) or masked off (their QP's rounds are over): each lane's copy only feeds that lane.
+// The copies are inline assembly: through the builtin the compiler knows that an LDS-direct load writes LDS and waits for ALL outstanding ones
+// (s_waitcnt vmcnt(0)) before every LDS read - the pipeline's depth would be gone.  Here the wait is staged_wait(): at most `later` records'
+// copies may still be in flight; whatever else the wavefront issued in between (its stores) only makes the wait longer, never too short.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // (M0 is reserved, and named as clobbered: the compiler then restores its own uses)
+struct StagedWs : lq::ChunkWs {
+    static constexpr int kStageDepth = 2;
+    const double* lds;        // the wavefront's slots [kStageDepth][kBlockDoubles][64]
+    unsigned lds_addr;        // their LDS byte address
+    __device__ __forceinline__ void stage_chunk(int slot, int chunk, int i) const {
+        const double* g = block + chunk_at(chunk, i);
+        const unsigned to = lds_addr + (unsigned)((slot * lq::kBlockChunks + chunk) * 1024);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(to) : "memory", "m0");
+    }
+    __device__ __forceinline__ const double* slot_chunk(int slot, int chunk) const { return lds + ((slot * lq::kBlockChunks + chunk) * 64 + lane) * 2; }
+    __device__ __forceinline__ double slot_ld(int slot, int f) const { return slot_chunk(slot, f >> 1)[f & 1]; }
+    __device__ __forceinline__ float slot_ldf(int slot, int f) const { return reinterpret_cast<const float*>(slot_chunk(slot, lq::kFieldsD / 2 + (f >> 2)))[f & 3]; }
+    template <int N> __device__ __forceinline__ static void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N < 63 ? N : 63) : "memory"); }
+    // before a record is read: at most the copies of `later` (0 .. kStageDepth - 1) records issued after it may be outstanding, C copies each
+    template <int C> __device__ __forceinline__ void staged_wait(int later) const {
+        if (later >= 1) wait_vm<C>(); else wait_vm<0>();
+        static_assert(kStageDepth == 2, "one case per depth");
+    }
+};
+#pragma clang diagnostic pop
 
 // slot -> QP of the NEXT launch, heaviest phase keys first: a counting sort over the 32 768 key bins, run by the last wavefront of the launch to finish (all
 // keys and bin counts are complete then; no separate kernel: with a second launch in flight a tiny ordering kernel waits for a free SIMD behind its 1024
@@ -51,19 +86,35 @@ __device__ void stream_order_next(const lq::Args& a) {
 
 // (one wavefront per SIMD: the whole 512-register budget; two / four per SIMD spill and lose, half-filled wavefronts two per SIMD lose 1.5x -
 //  profiles/r03a_stream_first.txt)
-__global__ void __launch_bounds__(64, 1) path_stream_kernel(const lq::Args a) {
+// STAGED: the [chunk][lane] workspace with the sweeps' records staged in LDS (launches that leave SIMDs idle); else the [field][lane] workspace with the
+// register prefetch (launches that fill the chip) - Args::staged, chosen by the launcher
+template <bool STAGED>
+__global__ void __launch_bounds__(64, 1) path_stream_kernel(const lq::Args a_by_value) {
+    using Ws = typename std::conditional<STAGED, StagedWs, lq::StridedWs>::type;
     const int lanes = 64;
     // Wavefronts of similar work (a.order, PQP_OPT_ORDER_BY_COST): the 64 lanes of a wavefront run every phase - interior-point iterations and active-set
     // rounds of each pass - as often as their slowest lane.  Sorting by the TOTAL sweeps of the previous solve changes nothing (round 3: 11 % less
     // traffic, the same 10.7 ms - profiles/r03d_stream_ordered.txt); sorting by the four phase counts, first pass first, does: 25.4 -> 16.8 lock-step
     // phases per wavefront for 16.5 per lane, 11.1 -> 9.4 ms at 65 536 QPs with the counts of the identical batch, 10.3 ms with those of the previous
     // planning cycle (profiles/r05g_stream_sorted_probe.txt).
+    // (STAGED: the argument block is read where the launch put it - a reference to the by-value parameter becomes a private copy as soon as the function holds a
+    //  statement that may write memory - the LDS copies are such statements - and the solver would read pqp_params from scratch)
+    const lq::Args* ap = &a_by_value;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (STAGED) ap = (const lq::Args*)__builtin_amdgcn_kernarg_segment_ptr();
+#endif
+    const lq::Args& a = *ap;
     const int slot = blockIdx.x * lanes + threadIdx.x;
     const bool live = slot < a.batch;
     if (live) {
         const int qp = a.order ? a.order[slot] : slot;
-        lq::StridedWs ws{a.ws + (size_t)blockIdx.x * a.n * lq::kBlockDoubles * lanes, (int)threadIdx.x, lanes};
-        lq::Solver<lq::StridedWs> s(a, qp, ws);
+        Ws ws;
+        ws.block = a.ws + (size_t)blockIdx.x * a.n * lq::kBlockDoubles * lanes; ws.lane = (int)threadIdx.x; ws.lanes = lanes;
+        if constexpr (STAGED) {
+            __shared__ __attribute__((aligned(16))) double stage_lds[StagedWs::kStageDepth * lq::kBlockDoubles * 64];      // 30 KB: four wavefronts per CU keep 120 of its 160 KB
+            ws.lds = stage_lds; ws.lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) double*)stage_lds;
+        }
+        lq::Solver<Ws> s(a, qp, ws);
         s.run();
         if (a.key_out) {
             const int it1 = s.ipm_iters_first < 31 ? s.ipm_iters_first : 31, s1 = s.set_rounds_first < 7 ? s.set_rounds_first : 7;
@@ -91,6 +142,7 @@ __global__ void __launch_bounds__(64, 1) path_stream_kernel(const lq::Args a) {
 extern "C" hipError_t pqp_stream_launch(const pqp::lq::Args* a, int waves, void* stream) {
     (void)waves;
     const int lanes = 64;
-    hipLaunchKernelGGL(pqp::path_stream_kernel, dim3((a->batch + lanes - 1) / lanes), dim3(lanes), 0, (hipStream_t)stream, *a);
+    if (a->staged) hipLaunchKernelGGL(pqp::path_stream_kernel<true>, dim3((a->batch + lanes - 1) / lanes), dim3(lanes), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(pqp::path_stream_kernel<false>, dim3((a->batch + lanes - 1) / lanes), dim3(lanes), 0, (hipStream_t)stream, *a);
     return hipGetLastError();
 }

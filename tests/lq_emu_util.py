@@ -36,7 +36,7 @@ def production(**over):
     return p
 
 
-def solve(ref, bounds, scal, passes=1, n_of=None, lin=None, prm=None, sorted_launch=False):
+def solve(ref, bounds, scal, passes=1, n_of=None, lin=None, prm=None, sorted_launch=False, chunk_layout=False):
     lib = load()
     B, n = ref.shape[:2]
     prm = prm or production()
@@ -47,6 +47,9 @@ def solve(ref, bounds, scal, passes=1, n_of=None, lin=None, prm=None, sorted_lau
     lin = None if lin is None else np.ascontiguousarray(lin, dtype=np.float64)
     n_of = None if n_of is None else np.ascontiguousarray(n_of, dtype=np.int32)
     # sorted_launch: as in a launch with Args::order (the re-linearised pass starts with active-set rounds on the previous pass's set)
+    if chunk_layout:          # the solver over lq::ChunkWs (the workspace layout of the device's staged form)
+        lib.pqp_emu_lq_solve_chunk_layout(C.byref(prm), B, n, vp(n_of), vp(ref), vp(lin), vp(bounds), vp(scal), passes, vp(out), vp(st), vp(it), vp(info), 1 if sorted_launch else 0)
+        return dict(out=out, status=st, iters=it, info=info)
     (lib.pqp_emu_lq_solve_sorted if sorted_launch else lib.pqp_emu_lq_solve)(C.byref(prm), B, n, vp(n_of), vp(ref), vp(lin), vp(bounds), vp(scal), passes, vp(out), vp(st), vp(it), vp(info))
     return dict(out=out, status=st, iters=it, info=info)
 

@@ -166,6 +166,39 @@ def test_stream_kernel_rough_constraints_far_away(hip_lib):
         assert np.abs(r["out"][q, :, 3:5] - want[:, 3:5]).max() < 2e-5, q
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,profile,batch", [(80, "uniform", 4096), (120, "varied", 2048), (300, "varied", 192), (9, "varied", 1000)])
+def test_the_two_forms_of_the_kernel_agree(hip_lib, n, profile, batch):
+    """PQP_OPT_STREAM_STAGED: the [field][lane] workspace with the register prefetch (launches that fill the chip) against the [chunk][lane] workspace whose records
+    are staged in LDS two waypoints ahead by LDS-direct loads (launches that leave SIMDs idle) - the same solver over other addresses: every QP's status and
+    counts equal, the paths equal up to the fused multiply-adds the compiler picks in the two instantiations; ragged paths; run twice (a record read before its
+    copy has landed would show as a run-to-run difference)."""
+    from path_optimizer_2_amd import capi
+    from path_optimizer_2_amd.synth import make_batch
+    b = make_batch(batch, n, profile, seed=41)
+    n_of = np.full(batch, n, dtype=np.int32)
+    n_of[::5] = max(n - 7, 2); n_of[2::9] = max(n // 2, 2); n_of[1] = 2
+    b["scal"][n_of < n, 4] = 1.0
+    res = {}
+    for form in (0, 1):
+        h = _handle(capi, batch, n)
+        h.set_option(capi.OPT_STREAM_STAGED, form)
+        runs = [h.solve_var(n_of, b["ref"], b["bounds"], b["scal"], passes=1) for _ in range(2)]
+        assert h.last_path_kernel() == capi.KERNEL_LANE_PER_QP
+        h.close()
+        assert np.array_equal(runs[0]["out"], runs[1]["out"]) and np.array_equal(runs[0]["info"], runs[1]["info"]), form
+        res[form] = runs[0]
+    assert np.array_equal(res[0]["status"], res[1]["status"])
+    same = (res[0]["info"][:, 2:8] == res[1]["info"][:, 2:8]).all(axis=1)
+    assert same.mean() > 0.99, same.mean()                 # (a borderline row may flip a count between two compilations of the arithmetic)
+    ok = (res[0]["status"] == 1) & same
+    d = 0.0
+    for q in np.nonzero(ok)[0]:
+        m = int(n_of[q])
+        d = max(d, float(np.abs(res[0]["out"][q, :m] - res[1]["out"][q, :m]).max()))
+    assert d < 1e-6, d                                       # (1.7e-7 seen at 120 and 300 waypoints: the flat direction of the lateral offsets, weight_l = 0)
+
+
 def test_stream_kernel_on_the_whole_of_configs_3(hip_lib):
     """BASELINE configs[3] at its full 65 536 QPs of 80 waypoints on ONE GPU: every QP verified, deterministic run to run, and a sample
     of the paths against the converged oracle."""

@@ -56,13 +56,15 @@ def test_path_solve_kernel_of_512_lanes_spills_no_more_than_today(kernels, cert)
     assert r["VGPRs"] <= 256 and r["Occupancy"] >= 2
 
 
-def test_path_stream_kernel_register_budget(kernels):
-    """the lane-per-QP kernel at its default prefetch depth: one wavefront per SIMD, all 512 registers, at most a few spill slots of the
-    once-per-pass code (0-360 B from build to build: the allocator's noise at this size; depth 2 and more spill 500-2900 B and are slower,
-    profiles/r03a_stream_first.txt)"""
-    r = _find(kernels, "path_stream_kernel")
+@pytest.mark.parametrize("staged", [0, 1])
+def test_path_stream_kernel_register_budget(kernels, staged):
+    """the lane-per-QP kernel in both of its forms (register prefetch one waypoint ahead / records staged in LDS two ahead): one wavefront per SIMD, all 512
+    registers, at most a few spill slots of the once-per-pass code (0-360 B from build to build: the allocator's noise at this size; two waypoints ahead IN
+    REGISTERS spill 500-2900 B and are slower, profiles/r03a_stream_first.txt); the staged form's 30 KB of LDS leave room for four workgroups per CU"""
+    r = _find(kernels, "path_stream_kernel", f"ILb{staged}E")
     assert r["ScratchSize"] <= 512, r
     assert r["Occupancy"] >= 1
+    assert r["LDS Size"] == (30720 if staged else 0), r
 
 
 @pytest.mark.parametrize("b,maxt,stage", [(3, 256, 1), (4, 256, 1), (9, 256, 1), (3, 512, 1), (4, 512, 1), (3, 512, 0), (4, 512, 0)])

@@ -90,6 +90,20 @@ def test_sorted_launch_starts_the_second_pass_from_the_first_pass_s_set():
     assert fallbacks >= 20          # (the fallback was exercised)
 
 
+def test_the_chunk_layout_is_the_same_solver():
+    """lq::ChunkWs ([chunk][lane][16 bytes], whole-chunk stores: the workspace of the device kernel's staged form) against lq::StridedWs ([field][lane]): other
+    addresses, the same arithmetic on the same values - the same counts for every QP, ragged paths and sorted launches included, and the same paths up to what
+    the compiler's choice of fused multiply-adds in the two instantiations moves (a few 1e-9)."""
+    for n, profile, batch, seed in ((80, "uniform", 256, 31), (37, "varied", 128, 32), (200, "varied", 48, 33)):
+        b = make_batch(batch, n, profile, seed=seed)
+        n_of = np.full(batch, n, dtype=np.int32); n_of[::3] = max(n - 11, 2); n_of[1] = 2
+        for srt in (False, True):
+            r0 = E.solve(b["ref"], b["bounds"], b["scal"], passes=1, n_of=n_of, sorted_launch=srt)
+            r1 = E.solve(b["ref"], b["bounds"], b["scal"], passes=1, n_of=n_of, sorted_launch=srt, chunk_layout=True)
+            assert np.array_equal(r0["status"], r1["status"]) and np.array_equal(r0["info"][:, 2:], r1["info"][:, 2:])
+            assert np.abs(r0["out"] - r1["out"]).max() < 5e-8
+
+
 def test_kkt_certificate_of_a_sorted_launch_s_point():
     b = make_batch(6, 60, "varied", seed=12)
     r0 = E.solve(b["ref"], b["bounds"], b["scal"], passes=0)
