@@ -26,7 +26,7 @@ def version():
     return f"HiGHS {c._Highs().githash()} (scipy {scipy.__version__})"
 
 
-def _solve_once(P, q, A, lo, up, tol):
+def _solve_once(P, q, A, lo, up, tol, time_limit=None):
     from scipy.optimize._highspy import _core as c
     m, n = A.shape
     Pl = sp.csc_matrix(sp.tril(P))
@@ -47,6 +47,8 @@ def _solve_once(P, q, A, lo, up, tol):
     h = c._Highs()
     h.setOptionValue("output_flag", False)
     h.setOptionValue("primal_feasibility_tolerance", tol); h.setOptionValue("dual_feasibility_tolerance", tol)
+    if time_limit is not None:
+        h.setOptionValue("time_limit", float(time_limit))          # (an ordering its active-set solver cycles on: status "Time limit reached", the next ordering)
     if h.passModel(model) == c.HighsStatus.kError:          # (kWarning: e.g. coefficients below its small-matrix-value threshold were dropped)
         raise RuntimeError("HiGHS refused the model")
     h.run()
@@ -58,7 +60,7 @@ def _solve_once(P, q, A, lo, up, tol):
     return np.array(sol.col_value), -np.array(sol.row_dual), h.getObjectiveValue()
 
 
-def solve_qp(P, q, A, lo, up, tol=1e-9, tries=6):
+def solve_qp(P, q, A, lo, up, tol=1e-9, tries=6, time_limit=None):
     """Returns (x, row duals y in OSQP's sign convention, objective).  P: dense / sparse symmetric PSD or a 1-D diagonal; A: dense / sparse.
     HiGHS's active-set QP solver now and then calls a point "Optimal" that misses two equality rows by ~5e-5 (one in ten path QPs in the reference's
     row / column order; its row activities drift over the iterations).  The point it returns is therefore checked against the rows here, and a QP it
@@ -72,7 +74,7 @@ def solve_qp(P, q, A, lo, up, tol=1e-9, tries=6):
     for t in range(tries):
         rp = np.arange(m) if t == 0 else rng.permutation(m)
         cp = np.arange(n) if t == 0 else rng.permutation(n)
-        x2, y2, obj = _solve_once(sp.csc_matrix(P[cp][:, cp]), q[cp], sp.csc_matrix(A[rp][:, cp]), lo[rp], up[rp], tol)
+        x2, y2, obj = _solve_once(sp.csc_matrix(P[cp][:, cp]), q[cp], sp.csc_matrix(A[rp][:, cp]), lo[rp], up[rp], tol, time_limit)
         if x2 is None:          # (its active-set solver gave up in this ordering - seen once in ~200 path QPs: "Unknown" - the next ordering)
             worst = obj
             continue
