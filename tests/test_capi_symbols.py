@@ -51,3 +51,15 @@ def test_no_device_fails_loudly(hip_lib):
     rc = hip_lib.pqp_create(C.byref(h), C.byref(p), 0, 8, 80)
     assert rc != 0 and not h.value
     assert b"no HIP device" in hip_lib.pqp_last_error() or rc == -3
+
+
+def test_stream_batch_default_is_the_measured_crossover(hip_lib):
+    """PQP_OPT_STREAM_BATCH's default (pure host logic): from how many QPs of n waypoints on a cold call runs on the lane-per-QP kernel - the crossover of the two
+    path kernels measured on one MI355X (profiles/r06ay_crossover_hybrid.txt, r06az_crossover_other_n.txt: 15 k at 80 waypoints, 20 k at 100, 29 k at 120,
+    49 k at 256, 11.5 k at 300, 24.5 k at 512); an 8192-QP shard of configs[3] stays on the lane-per-waypoint kernel at every length up to 128 waypoints."""
+    f = lambda n: capi.stream_batch_default(n, hip_lib)
+    assert f(80) == 15360 and f(60) == 15360 and f(1) == 0
+    assert 21000 < f(100) < 22000 and 28000 < f(120) < 28500 and f(128) > 30000
+    assert f(200) == 30000 and f(256) == 49152
+    assert f(300) == 14400 and f(512) == 24576
+    assert all(f(n) > 8192 for n in range(2, 129))
