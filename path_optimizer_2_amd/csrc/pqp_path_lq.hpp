@@ -334,6 +334,7 @@ struct Solver {
                 if (ii >= i_last) {
                     ws.template staged_wait<C>(ii - i_last < D - 1 ? ii - i_last : D - 1);
                     const In cur = load(k, ii);
+                    ws.reads_done();          // (the copies below overwrite the slot just read)
                     if (ii - D >= i_last) stage(k, ii - D);
                     body(ii, cur);
                 }
@@ -351,6 +352,7 @@ struct Solver {
                 if (ii < i_end) {
                     ws.template staged_wait<C>(i_end - 1 - ii < D - 1 ? i_end - 1 - ii : D - 1);
                     const In cur = load(k, ii);
+                    ws.reads_done();
                     if (ii + D < i_end) stage(k, ii + D);
                     body(ii, cur);
                 }

@@ -37,6 +37,9 @@ struct StagedWs : lq::ChunkWs {
     __device__ __forceinline__ const double* slot_chunk(int slot, int chunk) const { return lds + ((slot * lq::kBlockChunks + chunk) * 64 + lane) * 2; }
     __device__ __forceinline__ double slot_ld(int slot, int f) const { return slot_chunk(slot, f >> 1)[f & 1]; }
     __device__ __forceinline__ float slot_ldf(int slot, int f) const { return reinterpret_cast<const float*>(slot_chunk(slot, lq::kFieldsD / 2 + (f >> 2)))[f & 3]; }
+    // A slot is read (ds_read) and then refilled by the copies of the record two waypoints on.  The reads are issued first, and a copy's data comes back a memory
+    // round trip later - but nothing in the ISA orders an LDS read against a later LDS-direct write: the reads are waited for before the slot is handed over.
+    __device__ __forceinline__ void reads_done() const { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); }
     template <int N> __device__ __forceinline__ static void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N < 63 ? N : 63) : "memory"); }
     // before a record is read: at most the copies of `later` (0 .. kStageDepth - 1) records issued after it may be outstanding, C copies each
     template <int C> __device__ __forceinline__ void staged_wait(int later) const {
