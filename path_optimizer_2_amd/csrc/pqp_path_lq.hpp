@@ -362,7 +362,7 @@ struct Solver {
 
     // what a sweep reads per waypoint
     struct Box { double lof, upf, lor, upr; };
-    struct IpmRows { float tlf, tuf, zlf, zuf, tlr, tur, zlr, zur, tlk, tuk, zlk, zuk; double gk; };
+    struct IpmRows { float tlf, tuf, zlf, zuf, tlr, tur, zlr, zur, tlk, tuk, zlk, zuk; double gk, x2; };      // (x2: the other half of GK's chunk, staged form only)
     struct BackIn { Stage s; Box b; IpmRows r; float dgf, dgr, dgk; double act, lam; };
     struct FwdIn { Stage s; double K0, K1, K2, kk; Box b; IpmRows r; double act, lam; double xo[3]; };     // stage / gains of transition i, rows of waypoint i + 1
 
@@ -376,6 +376,7 @@ struct Solver {
         r.tlr = src.ldf(S_TLR, i); r.tur = src.ldf(S_TUR, i); r.zlr = src.ldf(S_ZLR, i); r.zur = src.ldf(S_ZUR, i);
         r.tlk = src.ldf(S_TLK, i); r.tuk = src.ldf(S_TUK, i); r.zlk = src.ldf(S_ZLK, i); r.zuk = src.ldf(S_ZUK, i);
         r.gk = src.ld(D_GK, i);
+        if constexpr (WS::kStageDepth > 0) r.x2 = src.ld(D_X2, i);          // (the same 16 bytes of the slot)
         return r;
     }
     // a collision row's state: its value is lo + t_l by definition (the slack absorbs the rest), t_u carries its own rounding
@@ -492,7 +493,11 @@ struct Solver {
             else add_lpsi_term(v, w_s, L0, upf);
             if (live_r) { store_r(i, rr); rr = soft_row((float)rr.tl, (float)rr.tu, (float)rr.zl, (float)rr.zu, lor); row_weight(rr, lor, upr, sm, d, tgt); add_lpsi_term(v, w_s * d * rcpq(w_s + d), Lr, tgt); }
             else if (on_r) add_lpsi_term(v, w_s, Lr, upr);
-            store_k(i, rk); rk = hard_row(rk.g, (float)rk.tl, (float)rk.tu, (float)rk.zl, (float)rk.zu);
+            // (staged form: GK goes out with the X2 it shares its 16-byte chunk with - read from the slot, written back as it was: a store of 8 bytes per lane at a
+            //  stride of 16 leaves every line half written)
+            if constexpr (WS::kStageDepth > 0) { static_assert(D_GK == D_X2 + 1 && D_X2 % 2 == 0, "X2 and GK share a chunk"); ws.st2(D_X2, i, in.r.x2, rk.g); ws.stf4(S_TLK, i, rk.tl, rk.tu, rk.zl, rk.zu); }
+            else store_k(i, rk);
+            rk = hard_row(rk.g, (float)rk.tl, (float)rk.tu, (float)rk.zl, (float)rk.zu);
             row_weight(rk, -kl, kl, sm, d, tgt);
             v.P[5] += d; v.p[2] -= d * tgt;
             return;
