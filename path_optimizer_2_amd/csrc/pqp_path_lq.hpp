@@ -413,27 +413,24 @@ struct Solver {
     // kStageDepth waypoints ahead can be.  A forward record takes its transition and gains from block i and its rows from block i + 1 -
     // different fields, so one slot holds both.  kBackChunks / kFwdChunks: copies per record (a lower bound: it sizes the wait).
     //   chunks: 0-3 transition (the first pass: 1 and 3), 4-5 boxes, 6-7 gains, 8 X0 X1, 9 X2 GK, 10 ACT LAM, 11-13 the three rows' slacks and multipliers, 14 their steps
-    PQP_HD void stage_transition(int slot, int i) const {
-        if (!lin0) { ws.stage_chunk(slot, 0, i); ws.stage_chunk(slot, 2, i); }
-        ws.stage_chunk(slot, 1, i); ws.stage_chunk(slot, 3, i);
-    }
+    // (chunks of one waypoint go out in groups around a centre chunk - StagedWs::stage_group: one address, one M0 per group)
     template <int MODE> static constexpr int back_chunks() { return 2 + 2 + ((MODE == MODE_IPM || MODE == MODE_GUESS) ? 5 : 0) + (MODE == MODE_SET ? 1 : 0); }
     template <int MODE>
     PQP_HD void stage_back(int slot, int i) const {
-        stage_transition(slot, i);
-        ws.stage_chunk(slot, 4, i); ws.stage_chunk(slot, 5, i);
-        if (MODE == MODE_IPM || MODE == MODE_GUESS) { ws.stage_chunk(slot, 9, i); for (int c = 11; c <= 14; ++c) ws.stage_chunk(slot, c, i); }
-        if (MODE == MODE_SET) ws.stage_chunk(slot, 10, i);
+        if (!lin0) ws.template stage_group<4, 0, 2>(slot, i);
+        ws.template stage_group<4, 1, 3, 4, 5>(slot, i);                                                                   // transition, boxes
+        if (MODE == MODE_IPM || MODE == MODE_GUESS) ws.template stage_group<12, 9, 11, 12, 13, 14>(slot, i);              // GK, the rows' states and steps
+        if (MODE == MODE_SET) ws.template stage_group<12, 10>(slot, i);
     }
     template <int MODE> static constexpr int fwd_chunks() { return 2 + 2 + 2 + (MODE == MODE_IPM ? 4 : 0) + ((MODE == MODE_SET || MODE == MODE_SET_GUARDED) ? 1 : 0) + (MODE == MODE_SET_GUARDED ? 2 : 0); }
     template <int MODE>
     PQP_HD void stage_fwd(int slot, int i) const {
-        stage_transition(slot, i);
-        ws.stage_chunk(slot, 6, i); ws.stage_chunk(slot, 7, i);
-        ws.stage_chunk(slot, 4, i + 1); ws.stage_chunk(slot, 5, i + 1);
-        if (MODE == MODE_IPM) { ws.stage_chunk(slot, 9, i + 1); for (int c = 11; c <= 13; ++c) ws.stage_chunk(slot, c, i + 1); }
-        if (MODE == MODE_SET || MODE == MODE_SET_GUARDED) ws.stage_chunk(slot, 10, i + 1);
-        if (MODE == MODE_SET_GUARDED) { ws.stage_chunk(slot, 8, i + 1); ws.stage_chunk(slot, 9, i + 1); }
+        if (!lin0) ws.template stage_group<4, 0, 2>(slot, i);
+        ws.template stage_group<4, 1, 3, 6, 7>(slot, i);                                                                   // transition, gains
+        if (MODE == MODE_IPM) { ws.template stage_group<4, 4, 5>(slot, i + 1); ws.template stage_group<12, 9, 11, 12, 13>(slot, i + 1); }       // boxes | GK, the rows' states
+        else if (MODE == MODE_SET) ws.template stage_group<8, 4, 5, 10>(slot, i + 1);
+        else if (MODE == MODE_SET_GUARDED) ws.template stage_group<8, 4, 5, 8, 9, 10>(slot, i + 1);
+        else ws.template stage_group<4, 4, 5>(slot, i + 1);
     }
     // a sweep over staged records: the one function the sweeps below call
     template <int MODE, class Body>

@@ -34,6 +34,24 @@ struct StagedWs : lq::ChunkWs {
         const unsigned to = lds_addr + (unsigned)((slot * lq::kBlockChunks + chunk) * 1024);
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(to) : "memory", "m0");
     }
+    // Several chunks of ONE waypoint in one statement: the instruction's 13-bit signed offset moves the source address AND the LDS destination (measured:
+    // tools/probes/glds_offset_probe.hip), and a slot is laid out like a workspace block - so the chunks within -4 ... +3 of a centre chunk share one address
+    // register pair and one M0: two VALU and two SALU instructions less per chunk after a group's first.
+    template <int CENTER, int... CS> __device__ __forceinline__ void stage_group(int slot, int i) const {
+        constexpr int n = sizeof...(CS);
+        constexpr int o[] = {(CS - CENTER) * 1024 ...};
+        static_assert(n >= 1 && n <= 5, "one asm string per count");
+        static_assert(((CS - CENTER >= -4 && CS - CENTER <= 3) && ...), "the offset field holds -4096 ... 4095");
+        const double* g = block + chunk_at(CENTER, i);
+        const unsigned to = lds_addr + (unsigned)((slot * lq::kBlockChunks + CENTER) * 1024);
+#define PQP_GLDS "\n\tglobal_load_lds_dwordx4 %0, off offset:"
+        if constexpr (n == 1) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0" PQP_GLDS "%2" : : "v"(g), "s"(to), "n"(o[0]) : "memory", "m0");
+        if constexpr (n == 2) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0" PQP_GLDS "%2" PQP_GLDS "%3" : : "v"(g), "s"(to), "n"(o[0]), "n"(o[n > 1 ? 1 : 0]) : "memory", "m0");
+        if constexpr (n == 3) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0" PQP_GLDS "%2" PQP_GLDS "%3" PQP_GLDS "%4" : : "v"(g), "s"(to), "n"(o[0]), "n"(o[n > 1 ? 1 : 0]), "n"(o[n > 2 ? 2 : 0]) : "memory", "m0");
+        if constexpr (n == 4) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0" PQP_GLDS "%2" PQP_GLDS "%3" PQP_GLDS "%4" PQP_GLDS "%5" : : "v"(g), "s"(to), "n"(o[0]), "n"(o[n > 1 ? 1 : 0]), "n"(o[n > 2 ? 2 : 0]), "n"(o[n > 3 ? 3 : 0]) : "memory", "m0");
+        if constexpr (n == 5) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0" PQP_GLDS "%2" PQP_GLDS "%3" PQP_GLDS "%4" PQP_GLDS "%5" PQP_GLDS "%6" : : "v"(g), "s"(to), "n"(o[0]), "n"(o[n > 1 ? 1 : 0]), "n"(o[n > 2 ? 2 : 0]), "n"(o[n > 3 ? 3 : 0]), "n"(o[n > 4 ? 4 : 0]) : "memory", "m0");
+#undef PQP_GLDS
+    }
     __device__ __forceinline__ const double* slot_chunk(int slot, int chunk) const { return lds + ((slot * lq::kBlockChunks + chunk) * 64 + lane) * 2; }
     __device__ __forceinline__ double slot_ld(int slot, int f) const { return slot_chunk(slot, f >> 1)[f & 1]; }
     __device__ __forceinline__ float slot_ldf(int slot, int f) const { return reinterpret_cast<const float*>(slot_chunk(slot, lq::kFieldsD / 2 + (f >> 2)))[f & 3]; }
